@@ -1,0 +1,156 @@
+"""ctypes binding of csrc/libinstarevive_hip.so (the C ABI declared in include/instarevive_hip.h).
+
+There is deliberately no fallback: if the shared library is missing or a call fails, an exception is raised.
+PyTorch is used only as the owner of device memory / streams; tensors cross the ABI as raw device pointers.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libinstarevive_hip.so")
+
+# every symbol include/instarevive_hip.h declares (tests check that the library exports all of them)
+SYMBOLS = [
+    "ir_abi_version", "ir_init", "ir_destroy", "ir_last_error", "ir_upload", "ir_has_tensor",
+    "ir_swinir_configure", "ir_vae_configure", "ir_dit_configure", "ir_dit_set_prompt", "ir_workspace_bytes",
+    "ir_swinir_forward", "ir_vae_encode", "ir_dit_forward", "ir_dit_step", "ir_vae_decode", "ir_color_fix",
+    "ir_pipeline", "ir_u8_to_nchw", "ir_nchw_to_u8",
+    "ir_op_conv", "ir_op_linear", "ir_op_groupnorm", "ir_op_layernorm", "ir_op_attention", "ir_op_swin_attention",
+    "ir_op_softmax_rows",
+]
+
+STAGE_SWINIR, STAGE_VAE_ENCODE, STAGE_DIT, STAGE_VAE_DECODE, STAGE_PIPELINE, STAGE_COLORFIX = range(6)
+FLAG_NO_PREPROCESS, FLAG_TILED, FLAG_FIX_WAVELET, FLAG_FIX_ADAIN = 1, 2, 4, 8
+ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_LRELU, ACT_SILU = range(5)
+
+_lib = None
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def load_library():
+    """Load the HIP library; raises NativeLibraryError when it has not been built (no CPU fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            f"{LIB_PATH} not found: build it with `python -m instarevive_amd.build` (hipcc, gfx950). "
+            "There is no CPU fallback for the MI355X path.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i, f, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+    lib.ir_abi_version.restype = i
+    lib.ir_init.argtypes = [i, C.POINTER(vp)]
+    lib.ir_destroy.argtypes = [vp]
+    lib.ir_destroy.restype = None
+    lib.ir_last_error.argtypes = [vp]
+    lib.ir_last_error.restype = C.c_char_p
+    lib.ir_upload.argtypes = [vp, C.c_char_p, vp, sz]
+    lib.ir_has_tensor.argtypes = [vp, C.c_char_p]
+    lib.ir_swinir_configure.argtypes = [vp, i, i, C.POINTER(i), i, i, i, f, C.POINTER(f)]
+    lib.ir_vae_configure.argtypes = [vp, i, i, C.POINTER(i), i, i, i]
+    lib.ir_dit_configure.argtypes = [vp, i, i, i, i, i, i]
+    lib.ir_dit_set_prompt.argtypes = [vp, vp, vp, vp, i]
+    lib.ir_workspace_bytes.argtypes = [vp, i, i, i, i, i, i, i]
+    lib.ir_workspace_bytes.restype = sz
+    lib.ir_swinir_forward.argtypes = [vp, vp, vp, vp, i, i, i, vp, sz]
+    lib.ir_vae_encode.argtypes = [vp, vp, vp, vp, i, i, i, vp, sz]
+    lib.ir_dit_forward.argtypes = [vp, vp, vp, f, vp, i, i, i, vp, sz]
+    lib.ir_dit_step.argtypes = [vp, vp, vp, vp, i, i, i, f, f, vp, sz]
+    lib.ir_vae_decode.argtypes = [vp, vp, vp, vp, i, i, i, vp, sz]
+    lib.ir_color_fix.argtypes = [vp, vp, i, vp, vp, vp, i, i, i, vp, sz]
+    lib.ir_pipeline.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, f, f, f, vp, sz]
+    lib.ir_u8_to_nchw.argtypes = [vp, vp, vp, vp, i, i, i]
+    lib.ir_nchw_to_u8.argtypes = [vp, vp, vp, vp, i, i, i]
+    lib.ir_op_conv.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, i, i, i, f, vp, i, i]
+    lib.ir_op_linear.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, i, vp, vp, i, i, f]
+    lib.ir_op_groupnorm.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, f, i, vp, sz]
+    lib.ir_op_layernorm.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, f]
+    lib.ir_op_attention.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, i, f, vp, vp, sz]
+    lib.ir_op_swin_attention.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, f]
+    lib.ir_op_softmax_rows.argtypes = [vp, vp, vp, vp, i, i]
+    for name in SYMBOLS:
+        fn = getattr(lib, name)
+        if fn.restype is C.c_int and name not in ("ir_abi_version",):
+            pass
+    _lib = lib
+    return lib
+
+
+def ptr(t):
+    """Device (or host) pointer of a contiguous tensor, or None."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "tensors crossing the C ABI must be contiguous"
+    return C.c_void_p(t.data_ptr())
+
+
+def bf16_bits(t: torch.Tensor) -> torch.Tensor:
+    """fp32 tensor -> raw bf16 bit pattern (round-to-nearest-even) as int16 view, same device."""
+    return t.to(torch.bfloat16).contiguous().view(torch.int16)
+
+
+def from_bf16_bits(t: torch.Tensor) -> torch.Tensor:
+    return t.view(torch.bfloat16).to(torch.float32)
+
+
+class Context:
+    """One ir_ctx on one GPU. Owns uploaded weights; not thread safe (mirrors the reference's single host loop)."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise NativeLibraryError("no GPU visible: the MI355X path cannot run (and has no CPU fallback)")
+        self.device = torch.device("cuda", device if isinstance(device, int) else (device.index or 0))
+        h = C.c_void_p()
+        rc = self.lib.ir_init(self.device.index, C.byref(h))
+        if rc != 0:
+            raise NativeLibraryError(f"ir_init failed ({rc})")
+        self.h = h
+        self._ws = None
+        self._names = set()
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.ir_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # ---- helpers
+    def check(self, rc, what):
+        if rc != 0:
+            msg = self.lib.ir_last_error(self.h)
+            raise RuntimeError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+    def stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def upload(self, name, t: torch.Tensor):
+        """Copy a HOST tensor (any dtype, contiguous) into the named device buffer of the context."""
+        t = t.detach().cpu().contiguous()
+        self.check(self.lib.ir_upload(self.h, name.encode(), C.c_void_p(t.data_ptr()), t.numel() * t.element_size()),
+                   f"ir_upload({name})")
+        self._names.add(name)
+
+    def upload_all(self, tensors: dict):
+        for k, v in tensors.items():
+            self.upload(k, v)
+
+    def has(self, name):
+        return bool(self.lib.ir_has_tensor(self.h, name.encode()))
+
+    def workspace(self, nbytes):
+        """Grow-only scratch buffer owned by torch's allocator; handed to the C ABI as caller-owned workspace."""
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = None
+            self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def ws_bytes(self, stage, n, h, w, flags=0, tile_size=0, tile_stride=0):
+        return int(self.lib.ir_workspace_bytes(self.h, stage, n, h, w, flags, tile_size, tile_stride))

@@ -1,0 +1,441 @@
+// Attention kernels for gfx950 (bf16 MFMA 32x32x16, fp32 softmax state).
+//
+//  flash_attn_kernel<DQK,DV> : multi-head softmax(Q K^T * scale + key_bias) V, online softmax, never materialises
+//      the score matrix. Used for the PixArt-DiT self-attention (16 heads x 72; reference
+//      diffusion/model/nets/PixArt_blocks.py:123-158 == diffusers Attention/SDPA) and its cross-attention to the
+//      300 caption tokens with an additive per-key bias (PixArt_blocks.py:43-58; diffusers semantics: the raw
+//      0/1 mask is ADDED).
+//      Layout trick (CDNA4): scores are computed transposed, S^T = K Q^T, so a query lives on a lane and its keys
+//      in that lane's accumulator registers -> row max / row sum are in-register plus one cross-half shuffle, and
+//      the S^T accumulators are directly the B operand of the second product O^T = V^T P^T. K rows are fetched
+//      with bits 2/3 of the row index swapped so that the V^T operand is a plain 16-byte LDS read.
+//  transpose_v_kernel        : V[token][head*D+d] -> V^T[batch][head][DV][Tpad] (zero padded), HBM-bound helper.
+//  swin_window_attn_kernel   : SwinIR (S)W-MSA, 8x8 windows, 6 heads x 30 (padded 32), relative-position bias and
+//      shifted-window mask generated in-kernel (reference diffusion/model/swinir.py:125-156,227-248,259-283).
+//  softmax_rows_kernel       : fp32 row softmax -> bf16, for the materialised VAE mid-block attention
+//      (reference ldm/modules/diffusionmodules/model.py:181-205).
+#include "common.h"
+#include "kernels.h"
+
+IR_DEVINL int swap23(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }
+
+template <int DQK, int DV>
+__global__ __launch_bounds__(256) void flash_attn_kernel(AttnParams p) {
+    constexpr int QS = DQK + 8;   // LDS row stride of Q/K tiles (bf16 elements); odd number of 16-B chunks
+    constexpr int VS = 64 + 8;    // LDS row stride of V^T tiles
+    constexpr int KCH = DQK / 8;  // 16-B chunks per Q/K row
+    constexpr int NKS = DQK / 16;
+    constexpr int NDT = DV / 32;
+    constexpr int OS = DV + 8;    // O staging row stride
+    constexpr int K_ITEMS = (64 * KCH + 255) / 256;
+    constexpr int V_ITEMS = (DV * 8 + 255) / 256;
+    constexpr int Q_ITEMS = (128 * KCH + 255) / 256;
+    constexpr int KV_ELEMS = 2 * 64 * QS + 2 * DV * VS;
+    constexpr int O_ELEMS = 128 * OS;
+    constexpr int TAIL = KV_ELEMS > O_ELEMS ? KV_ELEMS : O_ELEMS;
+    __shared__ __attribute__((aligned(16))) bf16_t smem[128 * QS + TAIL];
+    bf16_t* Qs = smem;
+    bf16_t* Ks = smem + 128 * QS;
+    bf16_t* Vs = Ks + 2 * 64 * QS;
+    bf16_t* Os = Ks;  // reused after the KV loop
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int q0 = blockIdx.x * 128, head = blockIdx.y, b = blockIdx.z;
+    const int dch = p.D >> 3;  // real 16-B chunks per row
+
+    const bf16_t* qp = p.q + (long)b * p.q_bs + (long)head * p.q_hs;
+    const bf16_t* kp = p.k + (long)b * p.k_bs + (long)head * p.k_hs;
+    const bf16_t* vtp = p.vt + (long)b * p.vt_bs + (long)head * DV * p.Tk_pad;
+    const float* kb = p.key_bias ? p.key_bias + (long)b * p.kb_bs : nullptr;
+
+    // ---- stage Q
+#pragma unroll
+    for (int i = 0; i < Q_ITEMS; ++i) {
+        int c = tid + i * 256;
+        if (c < 128 * KCH) {
+            int row = c / KCH, ch = c - row * KCH;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (q0 + row < p.Tq && ch < dch) v = *reinterpret_cast<const uint4*>(qp + (long)(q0 + row) * p.q_rs + ch * 8);
+            *reinterpret_cast<uint4*>(&Qs[row * QS + ch * 8]) = v;
+        }
+    }
+    uint4 kreg[K_ITEMS], vreg[V_ITEMS];
+    auto load_kv = [&](int t) {
+        const int key0 = t * 64;
+#pragma unroll
+        for (int i = 0; i < K_ITEMS; ++i) {
+            int c = tid + i * 256;
+            if (c < 64 * KCH) {
+                int row = c / KCH, ch = c - row * KCH;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (key0 + row < p.Tk && ch < dch) v = *reinterpret_cast<const uint4*>(kp + (long)(key0 + row) * p.k_rs + ch * 8);
+                kreg[i] = v;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < V_ITEMS; ++i) {
+            int c = tid + i * 256;
+            if (c < DV * 8) {
+                int row = c >> 3, ch = c & 7;
+                vreg[i] = *reinterpret_cast<const uint4*>(vtp + (long)row * p.Tk_pad + key0 + ch * 8);
+            }
+        }
+    };
+    auto store_kv = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < K_ITEMS; ++i) {
+            int c = tid + i * 256;
+            if (c < 64 * KCH) {
+                int row = c / KCH, ch = c - row * KCH;
+                *reinterpret_cast<uint4*>(&Ks[(buf * 64 + row) * QS + ch * 8]) = kreg[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < V_ITEMS; ++i) {
+            int c = tid + i * 256;
+            if (c < DV * 8) {
+                int row = c >> 3, ch = c & 7;
+                *reinterpret_cast<uint4*>(&Vs[(buf * DV + row) * VS + ch * 8]) = vreg[i];
+            }
+        }
+    };
+    load_kv(0);
+    store_kv(0);
+    __syncthreads();
+
+    bf16x8 qf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(&Qs[(wid * 32 + r) * QS + ks * 16 + h * 8]);
+
+    f32x16 o[NDT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) o[dt][g] = 0.f;
+    float m_i = -1e30f, l_i = 0.f;
+    const int NT = (p.Tk + 63) >> 6;
+    const int kr = swap23(r);
+    int cur = 0;
+    for (int t = 0; t < NT; ++t) {
+        const bool more = t + 1 < NT;
+        if (more) load_kv(t + 1);
+        // ---- S^T = K Q^T (two 32-key tiles)
+        f32x16 s[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) s[kt][g] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                bf16x8 a = *reinterpret_cast<const bf16x8*>(&Ks[(cur * 64 + kt * 32 + kr) * QS + ks * 16 + h * 8]);
+                s[kt] = mfma32(a, qf[ks], s[kt]);
+            }
+        }
+        // ---- softmax update; this lane's keys for (kt, g): t*64 + kt*32 + 16*(g>>3) + 8*h + (g&7)
+        float mx = -INFINITY, m_new, alpha, rs = 0.f;
+        if (kb || (t == NT - 1 && (p.Tk & 63))) {  // wave-uniform: additive key bias and/or ragged last tile
+            const int kbase = t * 64 + 8 * h;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int key = kbase + kt * 32 + 16 * (g >> 3) + (g & 7);
+                    float v = s[kt][g] * p.scale_log2;
+                    if (kb) v += kb[key < p.Tk ? key : 0] * 1.44269504088896340736f;
+                    v = key < p.Tk ? v : -INFINITY;
+                    s[kt][g] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            m_new = fmaxf(m_i, mx);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const float pv = __builtin_amdgcn_exp2f(s[kt][g] - m_new);
+                    s[kt][g] = pv;
+                    rs += pv;
+                }
+        } else {  // hot path: scale folded into the exponent's fma, max taken on raw scores (scale > 0)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) mx = fmaxf(mx, s[kt][g]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            m_new = fmaxf(m_i, mx * p.scale_log2);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][g], p.scale_log2, -m_new));
+                    s[kt][g] = pv;
+                    rs += pv;
+                }
+        }
+        alpha = __builtin_amdgcn_exp2f(m_i - m_new);
+        rs += __shfl_xor(rs, 32);
+        l_i = l_i * alpha + rs;
+        m_i = m_new;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) o[dt][g] *= alpha;
+        // ---- P^T fragments (B operand): registers 8*s2 .. 8*s2+7 of tile kt
+        bf16x8 pb[2][2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pb[kt][s2][e] = (__bf16)s[kt][s2 * 8 + e];
+        // ---- O^T += V^T P^T
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    bf16x8 a = *reinterpret_cast<const bf16x8*>(&Vs[(cur * DV + dt * 32 + r) * VS + kt * 32 + s2 * 16 + h * 8]);
+                    o[dt] = mfma32(a, pb[kt][s2], o[dt]);
+                }
+        if (more) store_kv(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    // ---- finalise: O^T[d][q] / l -> LDS [q][d] -> 16-byte row stores
+    const float inv = 1.0f / l_i;
+    bf16_t* ow = Os + wid * 32 * OS;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) {
+            uint2 w = make_uint2(pack2bf(o[dt][4 * gg] * inv, o[dt][4 * gg + 1] * inv),
+                                 pack2bf(o[dt][4 * gg + 2] * inv, o[dt][4 * gg + 3] * inv));
+            *reinterpret_cast<uint2*>(&ow[r * OS + dt * 32 + 8 * gg + 4 * h]) = w;
+        }
+    __syncthreads();
+    bf16_t* op = p.o + (long)b * p.o_bs + (long)head * p.o_hs;
+    for (int c = lane; c < 32 * dch; c += 64) {
+        int row = c / dch, ch = c - row * dch;
+        int q = q0 + wid * 32 + row;
+        if (q < p.Tq) *reinterpret_cast<uint4*>(op + (long)q * p.o_rs + ch * 8) = *reinterpret_cast<const uint4*>(&ow[row * OS + ch * 8]);
+    }
+}
+
+int ir_launch_flash_attn(const AttnParams& p, hipStream_t s) {
+    if (p.Tq <= 0 || p.Tk <= 0 || p.B <= 0 || p.Hh <= 0) return -2;
+    if ((p.D & 7) || (p.q_rs & 7) || (p.k_rs & 7) || (p.o_rs & 7) || (p.q_hs & 7) || (p.k_hs & 7) || (p.o_hs & 7) ||
+        (p.q_bs & 7) || (p.k_bs & 7) || (p.o_bs & 7))
+        return -3;
+    if ((p.Tk_pad & 63) || p.Tk_pad < ((p.Tk + 63) & ~63)) return -4;
+    dim3 grid((p.Tq + 127) / 128, p.Hh, p.B);
+    if (p.D == 72)
+        hipLaunchKernelGGL((flash_attn_kernel<80, 96>), grid, dim3(256), 0, s, p);
+    else if (p.D == 32)
+        hipLaunchKernelGGL((flash_attn_kernel<32, 32>), grid, dim3(256), 0, s, p);
+    else if (p.D == 64)
+        hipLaunchKernelGGL((flash_attn_kernel<64, 64>), grid, dim3(256), 0, s, p);
+    else
+        return -5;
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// V[b][t][head*D + d] (row stride v_rs) -> Vt[b][head][DV][Tpad]; rows d >= D and columns t >= T are zero.
+// grid = (Tpad/64, Hh, B), block 256. LDS tile [64 tokens][DV].
+__global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t* __restrict__ v, bf16_t* __restrict__ vt, long v_bs, int v_rs,
+                                                          int v_hs, int T, int Tpad, int D, int DV, int Hh) {
+    __shared__ bf16_t tile[64][128 + 2];
+    const int t0 = blockIdx.x * 64, head = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+    const bf16_t* src = v + (long)b * v_bs + (long)head * v_hs;
+    for (int i = tid; i < 64 * DV; i += 256) {
+        int tok = i / DV, d = i - tok * DV;
+        bf16_t x = 0;
+        if (d < D && t0 + tok < T) x = src[(long)(t0 + tok) * v_rs + d];
+        tile[tok][d] = x;
+    }
+    __syncthreads();
+    bf16_t* dst = vt + ((long)b * Hh + head) * (long)DV * Tpad + t0;
+    for (int i = tid; i < DV * 64; i += 256) {
+        int d = i >> 6, tok = i & 63;
+        dst[(long)d * Tpad + tok] = tile[tok][d];
+    }
+}
+
+int ir_launch_transpose_v(const bf16_t* v, bf16_t* vt, long v_bs, int v_rs, int v_hs, int B, int Hh, int T, int Tpad, int D,
+                          int DV, hipStream_t s) {
+    if (DV > 128 || D > DV || (Tpad & 63) || Tpad < T) return -2;
+    hipLaunchKernelGGL(transpose_v_kernel, dim3(Tpad / 64, Hh, B), dim3(256), 0, s, v, vt, v_bs, v_rs, v_hs, T, Tpad, D, DV, Hh);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// ---------------------------------------------------------------- SwinIR window attention
+// qkv: [B][H*W][ld] bf16 with columns [q: heads*32 | k: heads*32 | v: heads*32] (head dim 30 zero-padded to 32).
+// out: [B][H*W][ldo] bf16, columns head*32 + d. One block (2 waves) per (window, head); wave = 32-query half.
+// biasT: [heads][64 keys][64 queries] fp32, relative-position bias already multiplied by log2(e).
+__global__ __launch_bounds__(128) void swin_window_attn_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                               const float* __restrict__ biasT, int H, int W, int heads, int ld,
+                                                               int ldo, int shift, float scale_log2) {
+    __shared__ __attribute__((aligned(16))) bf16_t Qs[64][40];
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[64][40];
+    __shared__ __attribute__((aligned(16))) bf16_t Vt[32][72];
+    __shared__ int tok_idx[64];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int nwx = W >> 3, nwy = H >> 3;
+    int wlin = blockIdx.x;
+    const int head = wlin % heads; wlin /= heads;
+    const int wx = wlin % nwx; wlin /= nwx;
+    const int wy = wlin % nwy;
+    const int b = wlin / nwy;
+    if (tid < 64) {
+        int iy = tid >> 3, ix = tid & 7;
+        int y = wy * 8 + iy + shift, x = wx * 8 + ix + shift;  // shifted-frame (Y,X) -> source pixel (Y+s)%H
+        if (y >= H) y -= H;
+        if (x >= W) x -= W;
+        tok_idx[tid] = y * W + x;
+    }
+    __syncthreads();
+    const bf16_t* base = qkv + (long)b * H * W * ld;
+    // 64 tokens x 3 tensors x 4 chunks (16 B) = 768 chunks
+    for (int c = tid; c < 768; c += 128) {
+        int tok = c / 12, rem = c - tok * 12;
+        int which = rem >> 2, ch = rem & 3;
+        uint4 v = *reinterpret_cast<const uint4*>(base + (long)tok_idx[tok] * ld + which * heads * 32 + head * 32 + ch * 8);
+        if (which == 0)
+            *reinterpret_cast<uint4*>(&Qs[tok][ch * 8]) = v;
+        else if (which == 1)
+            *reinterpret_cast<uint4*>(&Ks[tok][ch * 8]) = v;
+        else {
+            uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                Vt[ch * 8 + 2 * e][tok] = (bf16_t)(w[e] & 0xffff);
+                Vt[ch * 8 + 2 * e + 1][tok] = (bf16_t)(w[e] >> 16);
+            }
+        }
+    }
+    __syncthreads();
+    bf16x8 qf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(&Qs[wid * 32 + r][ks * 16 + h * 8]);
+    const int kr = swap23(r);
+    f32x16 s[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) s[kt][g] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a = *reinterpret_cast<const bf16x8*>(&Ks[kt * 32 + kr][ks * 16 + h * 8]);
+            s[kt] = mfma32(a, qf[ks], s[kt]);
+        }
+    }
+    // bias + shifted-window mask (regions in the shifted frame, swinir.py:227-248)
+    const int qi = wid * 32 + r;
+    auto region = [&](int idx) {
+        int Y = wy * 8 + (idx >> 3), X = wx * 8 + (idx & 7);
+        int rh = Y < H - 8 ? 0 : (Y < H - shift ? 1 : 2);
+        int rw = X < W - 8 ? 0 : (X < W - shift ? 1 : 2);
+        return rh * 3 + rw;
+    };
+    const int rq = shift ? region(qi) : 0;
+    const float* bt = biasT + (long)head * 4096 + qi;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const int key = kt * 32 + 16 * (g >> 3) + 8 * h + (g & 7);
+            float v = s[kt][g] * scale_log2 + bt[key * 64];
+            if (shift && region(key) != rq) v += -100.0f * 1.44269504088896340736f;
+            s[kt][g] = v;
+            mx = fmaxf(mx, v);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float rs = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const float pv = __builtin_amdgcn_exp2f(s[kt][g] - mx);
+            s[kt][g] = pv;
+            rs += pv;
+        }
+    rs += __shfl_xor(rs, 32);
+    f32x16 o;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) o[g] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            bf16x8 pb;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pb[e] = (__bf16)s[kt][s2 * 8 + e];
+            bf16x8 a = *reinterpret_cast<const bf16x8*>(&Vt[r][kt * 32 + s2 * 16 + h * 8]);
+            o = mfma32(a, pb, o);
+        }
+    const float inv = 1.0f / rs;
+    bf16_t* op = out + ((long)b * H * W + tok_idx[qi]) * ldo + head * 32;
+#pragma unroll
+    for (int gg = 0; gg < 4; ++gg) {
+        uint2 w = make_uint2(pack2bf(o[4 * gg] * inv, o[4 * gg + 1] * inv), pack2bf(o[4 * gg + 2] * inv, o[4 * gg + 3] * inv));
+        *reinterpret_cast<uint2*>(op + 8 * gg + 4 * h) = w;
+    }
+}
+
+int ir_launch_swin_attn(const bf16_t* qkv, bf16_t* out, const float* biasT, int B, int H, int W, int heads, int ld, int ldo,
+                        int shift, float scale, hipStream_t s) {
+    if ((H & 7) || (W & 7) || (ld & 7) || (ldo & 3) || shift < 0 || shift >= 8) return -2;
+    if (ld < 3 * heads * 32 || ldo < heads * 32) return -3;
+    const long blocks = (long)B * (H >> 3) * (W >> 3) * heads;
+    if (blocks <= 0 || blocks > 0x7fffffffL) return -4;
+    hipLaunchKernelGGL(swin_window_attn_kernel, dim3((unsigned)blocks), dim3(128), 0, s, qkv, out, biasT, H, W, heads, ld, ldo,
+                       shift, scale * 1.44269504088896340736f);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// ---------------------------------------------------------------- fp32 row softmax -> bf16 (one block per row)
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int cols, long ldx,
+                                                           long ldy) {
+    __shared__ float red[8];
+    const long row = blockIdx.x;
+    const float* xr = x + row * ldx;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const float L2E = 1.44269504088896340736f;
+    float m = -INFINITY, l = 0.f;  // online max / sum over this thread's elements (float4 steps)
+    for (int c = tid * 4; c < cols; c += 1024) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+        float vm = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+        float mn = fmaxf(m, vm);
+        l = l * __builtin_amdgcn_exp2f((m - mn) * L2E);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) l += __builtin_amdgcn_exp2f((v[e] - mn) * L2E);
+        m = mn;
+    }
+    float wm = wave_max(m);
+    l *= __builtin_amdgcn_exp2f((m - wm) * L2E);
+    l = wave_sum(l);
+    if (lane == 0) { red[wid] = wm; red[4 + wid] = l; }
+    __syncthreads();
+    float gm = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float gl = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) gl += red[4 + i] * __builtin_amdgcn_exp2f((red[i] - gm) * L2E);
+    const float inv = 1.0f / gl;
+    bf16_t* yr = y + row * ldy;
+    for (int c = tid * 4; c < cols; c += 1024) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+        float pz[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pz[e] = __builtin_amdgcn_exp2f((v[e] - gm) * L2E) * inv;
+        *reinterpret_cast<uint2*>(yr + c) = make_uint2(pack2bf(pz[0], pz[1]), pack2bf(pz[2], pz[3]));
+    }
+}
+
+int ir_launch_softmax_rows(const float* x, bf16_t* y, long rows, int cols, long ldx, long ldy, hipStream_t s) {
+    if ((cols & 3) || (ldx & 3) || (ldy & 3) || rows <= 0 || rows > 0x7fffffffL) return -2;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, s, x, y, cols, ldx, ldy);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}

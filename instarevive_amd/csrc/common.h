@@ -1,0 +1,56 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of the InstaRevive one-step path.
+// Wave = 64 lanes; MFMA = v_mfma_f32_32x32x16_bf16 (A/B: 8 bf16 per lane, C/D: 16 f32 per lane).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // raw bf16 bits; storage type for every activation / weight tensor
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define IR_DEVINL __device__ __forceinline__
+
+// f32 -> bf16 round-to-nearest-even through the hardware convert (keeps NaN a NaN).
+IR_DEVINL bf16_t f2bf(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, b);
+}
+IR_DEVINL float bf2f(bf16_t b) {
+    uint32_t u = ((uint32_t)b) << 16;
+    return __builtin_bit_cast(float, u);
+}
+IR_DEVINL uint32_t pack2bf(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+IR_DEVINL float bflo(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
+IR_DEVINL float bfhi(uint32_t u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+
+IR_DEVINL f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// C/D fragment of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+IR_DEVINL int mfma_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+IR_DEVINL float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+IR_DEVINL float gelu_tanh(float x) {
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    float u = k0 * (x + k1 * x * x * x);
+    return 0.5f * x * (1.0f + tanhf(u));
+}
+IR_DEVINL float silu(float x) { return x / (1.0f + __expf(-x)); }
+
+IR_DEVINL float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+IR_DEVINL float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// activation codes shared by host and device
+enum { IR_ACT_NONE = 0, IR_ACT_GELU_ERF = 1, IR_ACT_GELU_TANH = 2, IR_ACT_LRELU = 3, IR_ACT_SILU = 4 };

@@ -1,0 +1,106 @@
+// Internal launcher interface between the C-ABI layer (api.cpp) and the HIP kernels. Not part of the public ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;
+
+// ---- implicit GEMM (igemm.hip)
+struct IGemmParams {
+    // A operand: NHWC bf16 activations. taps==1: row m at in + m*in_cs. taps==9: 3x3 window around output pixel.
+    const bf16_t* in;
+    int NB, H, W;   // input batch / height / width (before the optional nearest-2x upsample)
+    int Cin;        // channels reduced over per tap (multiple of 32; zero-padded channels are fine)
+    int in_cs;      // elements between consecutive pixels / rows of `in`
+    int Ho, Wo;     // output height / width
+    int taps;       // 1 or 9
+    int stride;     // 1 or 2
+    int pad;        // 1: symmetric "same" pad; 0: pad only bottom/right (the VAE's (0,1,0,1) stride-2 downsample)
+    int up;         // 1: conv runs on the nearest-2x upsampled input (2H x 2W), folded into addressing
+    // B operand
+    const bf16_t* wgt;  // [Cout_pad][taps*Cin] bf16, K contiguous
+    int Cout, Cout_pad, M;
+    // epilogue: v = act(acc + bias) * out_scale; v *= gate; v += res; store
+    const float* bias;  // [Cout_pad] or null
+    int act;
+    float slope;
+    float out_scale;
+    const float* gate;  // gate[(m / rows_per_batch) * gate_stride + n] or null
+    int gate_stride, rows_per_batch;
+    const void* res;    // residual [.][res_cs], row index m (or m % res_mod when res_mod > 0)
+    int res_f32, res_cs, res_mod;
+    void* out;
+    int out_f32, out_cs;
+    bf16_t* out2;       // optional extra bf16 copy of the result
+    int out2_cs;
+    int vec;            // set by the launcher: all strides/pointers allow 4-element vector I/O
+};
+int ir_launch_igemm(const IGemmParams& p, hipStream_t s);
+
+// ---- norms (norm.hip)
+static inline int ir_gn_chunks(long HW) {
+    long c = HW / 2048;
+    if (c < 1) c = 1;
+    if (c > 1024) c = 1024;
+    return (int)c;
+}
+// workspace floats needed by ir_launch_groupnorm
+static inline long ir_gn_ws_floats(int N, long HW, int C) { return (long)N * ir_gn_chunks(HW) * 2 * C + 2L * N * C; }
+int ir_launch_groupnorm(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, float* ws, int N, long HW, int C,
+                        int G, float eps, int do_silu, hipStream_t s);
+// y (bf16, may be null) and yf (fp32, may be null) both receive xn*a + b; columns C..ldy-1 are written as zero.
+int ir_launch_layernorm(const float* x, bf16_t* y, float* yf, const float* a, const float* b, long rows, int C, int ldx, int ldy,
+                        float eps, long rows_per_batch, int ab_stride, hipStream_t s);
+int ir_launch_gemv_f32(const float* w, const float* x, const float* b, float* out, int N, int K, int act, hipStream_t s);
+
+// ---- attention (attention.hip)
+struct AttnParams {
+    const bf16_t *q, *k, *vt;  // q/k: [B][T][..] rows with head slices; vt: [B][Hh][DV][Tk_pad]
+    bf16_t* o;
+    long q_bs, k_bs, o_bs;     // batch strides (elements)
+    long vt_bs;                // batch stride of vt (0: one K/V set shared by the whole batch); head stride = DV*Tk_pad
+    int q_rs, k_rs, o_rs;      // token strides
+    int q_hs, k_hs, o_hs;      // head strides
+    int B, Hh, Tq, Tk, Tk_pad, D;
+    float scale_log2;          // softmax scale * log2(e)
+    const float* key_bias;     // optional additive bias per key [B][kb_bs] (natural-log domain)
+    long kb_bs;
+};
+int ir_launch_flash_attn(const AttnParams& p, hipStream_t s);
+int ir_launch_transpose_v(const bf16_t* v, bf16_t* vt, long v_bs, int v_rs, int v_hs, int B, int Hh, int T, int Tpad, int D,
+                          int DV, hipStream_t s);
+int ir_launch_swin_attn(const bf16_t* qkv, bf16_t* out, const float* biasT, int B, int H, int W, int heads, int ld, int ldo,
+                        int shift, float scale, hipStream_t s);
+int ir_launch_softmax_rows(const float* x, bf16_t* y, long rows, int cols, long ldx, long ldy, hipStream_t s);
+static inline int ir_attn_dv(int D) { return (D + 31) & ~31; }
+
+// ---- layout / elementwise (elementwise.hip)
+int ir_launch_u8_to_nchw(const uint8_t* in, float* out, int N, int H, int W, hipStream_t s);
+int ir_launch_swin_prep(const float* x_nchw, bf16_t* out, int N, int H, int W, const float* mean3, float img_range, hipStream_t s);
+int ir_launch_nhwc_to_nchw(const float* in, int in_cs, float* out, int N, int C, long HW, float scale, float shift, int clamp01,
+                           hipStream_t s);
+int ir_launch_nchw_to_nhwc_bf16(const float* in, bf16_t* out, int N, int C, long HW, int Cpad, float scale, float shift,
+                                hipStream_t s);
+int ir_launch_nhwc_f32_to_bf16pad(const float* in, int in_cs, bf16_t* out, long npix, int C, int Cpad, float scale, float shift,
+                                  hipStream_t s);
+int ir_launch_quant_mean(const float* h8, int h_cs, const float* wq, const float* bq, float* lat_nchw, int N, long HW, float scale,
+                         hipStream_t s);
+int ir_launch_latent_prep(const float* lat_nchw, const float* wpq, const float* bpq, bf16_t* out, int N, long HW, int Cpad,
+                          float in_scale, hipStream_t s);
+int ir_launch_patchify(const float* lat_nchw, bf16_t* out, int N, int h, int w, int Cpad, hipStream_t s);
+int ir_launch_unpatchify(const float* tok, float* out_nchw, int N, int h, int w, hipStream_t s);
+int ir_launch_eps_to_x0(const float* tok, const float* lat_in, float* lat_out, int N, int h, int w, float sqrt_acp,
+                        float sqrt_1macp, float out_scale, hipStream_t s);
+int ir_launch_nhwc_to_u8(const float* in, int in_cs, uint8_t* out, long npix, float scale, float shift, hipStream_t s);
+int ir_launch_nchw_to_u8(const float* in, uint8_t* out, int N, long HW, hipStream_t s);
+int ir_launch_tile_add(float* dst, const float* src, int N, int C, int H, int W, int th, int tw, int y0, int x0, hipStream_t s);
+int ir_launch_tile_div(float* dst, int N, int C, int H, int W, int th, int tw, int sy, int sx, hipStream_t s);
+int ir_launch_crop_nchw(const float* src, float* dst, int N, int C, int H, int W, int y0, int x0, int th, int tw, float scale,
+                        hipStream_t s);
+int ir_launch_wavelet_fix(const float* content, const float* style, float* out, float* tmp, int N, int H, int W, hipStream_t s);
+int ir_launch_adain_fix(const float* content, const float* style, float* out, float* ws, int N, int H, int W, hipStream_t s);
+int ir_launch_silu_f32(const float* in, float* out, long n, hipStream_t s);
+int ir_launch_timestep_embed(float* out, float t, int dim, hipStream_t s);
+int ir_launch_f32_to_bf16(const float* in, bf16_t* out, long n, hipStream_t s);
+int ir_launch_modtab(const float* t, const float* sst, float* out, int L, int R, int C, int t_stride, int scale_mask, hipStream_t s);
+int ir_launch_add_bias_rows(float* x, const float* b, long n, int C, hipStream_t s);

@@ -1,0 +1,221 @@
+// HBM-bound normalisation kernels (gfx950): GroupNorm(32)+SiLU for the VAE, LayerNorm (+affine or
+// adaLN-single modulate) for SwinIR / PixArt-DiT. All statistics accumulate in fp32 (finalised in fp64).
+//
+// GroupNorm follows reference ldm/modules/diffusionmodules/model.py:43-49 (Normalize = GroupNorm(32,
+// eps=1e-6, affine) followed by x*sigmoid(x)); it is split in three launches:
+//   gn_partial  : per (image, pixel-chunk) per-channel sum / sum-of-squares        (1 read of x)
+//   gn_finalize : per (image, group) mean / rstd in fp64 -> per (image, channel) scale & shift
+//   gn_apply    : y = silu(x * scale + shift), 16-byte vectors                      (1 read, 1 write)
+// LayerNorm follows swinir.py:210,216,256,288,769 (affine, eps 1e-5) and PixArtMS.py:58,64,74-77 +
+// PixArt_blocks.py:24-25 (no affine, eps 1e-6, then x*(1+scale)+shift).
+#include "common.h"
+#include "kernels.h"
+
+// ---------------------------------------------------------------- GroupNorm
+// x: [N][HW][C] bf16 (C multiple of 8, C <= 512). grid = (chunks, N), block = 256.
+// part: [N][chunks][2][C] fp32.
+__global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restrict__ x, float* __restrict__ part,
+                                                         int HW, int C, int chunks) {
+    __shared__ float s_sum[2][512];
+    const int n = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const int vpp = C >> 3;             // 16-byte vectors per pixel
+    const int ppi = 256 / vpp;          // pixels per block iteration (C=128:16, 256:8, 512:4)
+    const int cv = tid % vpp, pl = tid / vpp;
+    const long per = (HW + chunks - 1) / chunks;
+    const long p0 = (long)chunk * per;
+    const long p1 = p0 + per < HW ? p0 + per : HW;
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
+    if (pl < ppi) {
+        const bf16_t* base = x + (long)n * HW * C + cv * 8;
+        for (long pix = p0 + pl; pix < p1; pix += ppi) {
+            uint4 v = *reinterpret_cast<const uint4*>(base + pix * C);
+            uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a = bflo(w[e]), b = bfhi(w[e]);
+                s[2 * e] += a; q[2 * e] += a * a;
+                s[2 * e + 1] += b; q[2 * e + 1] += b * b;
+            }
+        }
+    }
+    // reduce over the ppi pixel lanes that share a channel vector
+    for (int i = tid; i < 2 * 512; i += 256) (&s_sum[0][0])[i] = 0.f;
+    __syncthreads();
+    if (pl < ppi) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            atomicAdd(&s_sum[0][cv * 8 + e], s[e]);
+            atomicAdd(&s_sum[1][cv * 8 + e], q[e]);
+        }
+    }
+    __syncthreads();
+    float* out = part + ((long)n * chunks + chunk) * 2 * C;
+    for (int c = tid; c < C; c += 256) {
+        out[c] = s_sum[0][c];
+        out[C + c] = s_sum[1][c];
+    }
+}
+
+// grid = N, block = 256. scale/shift: [N][C] fp32. gamma/beta: [C] fp32.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ scale,
+                                                          float* __restrict__ shift, int HW, int C, int G, int chunks,
+                                                          float eps) {
+    __shared__ double s_mean[64], s_rstd[64];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int cpg = C / G;
+    // one wave-quarter (8 lanes) per group would be enough; keep it simple: thread g handles group g.
+    if (tid < G) {
+        double s = 0.0, q = 0.0;
+        for (int ch = 0; ch < chunks; ++ch) {
+            const float* pp = part + ((long)n * chunks + ch) * 2 * C;
+            for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
+                s += (double)pp[c];
+                q += (double)pp[C + c];
+            }
+        }
+        const double cnt = (double)HW * cpg;
+        const double mean = s / cnt;
+        double var = q / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        s_mean[tid] = mean;
+        s_rstd[tid] = 1.0 / sqrt(var + (double)eps);
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        const int g = c / cpg;
+        const double a = s_rstd[g] * (double)gamma[c];
+        scale[(long)n * C + c] = (float)a;
+        shift[(long)n * C + c] = (float)((double)beta[c] - s_mean[g] * a);
+    }
+}
+
+// y = act(x*scale + shift); x,y: [N][HW][C] bf16; grid-stride over 16-byte vectors.
+__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       long HW, int C, long nvec, int do_silu) {
+    const int vpp = C >> 3;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+        const long pix = i / vpp;
+        const int cv = (int)(i - pix * vpp);
+        const int n = (int)(pix / HW);
+        uint4 v = *reinterpret_cast<const uint4*>(x + i * 8);
+        const float* sc = scale + (long)n * C + cv * 8;
+        const float* sh = shift + (long)n * C + cv * 8;
+        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float a = bflo(w[e]) * sc[2 * e] + sh[2 * e];
+            float b = bfhi(w[e]) * sc[2 * e + 1] + sh[2 * e + 1];
+            if (do_silu) { a = silu(a); b = silu(b); }
+            o[e] = pack2bf(a, b);
+        }
+        *reinterpret_cast<uint4*>(y + i * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+int ir_launch_groupnorm(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, float* ws, int N, long HW, int C,
+                        int G, float eps, int do_silu, hipStream_t s) {
+    if (C % 8 || C > 512 || G > 64 || C % G || 256 % (C / 8)) return -2;
+    if (HW >= (1L << 31)) return -3;
+    int chunks = ir_gn_chunks(HW);
+    float* part = ws;                                  // [N][chunks][2][C]
+    float* scale = ws + (long)N * chunks * 2 * C;      // [N][C]
+    float* shift = scale + (long)N * C;                // [N][C]
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, N), dim3(256), 0, s, x, part, (int)HW, C, chunks);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), 0, s, part, gamma, beta, scale, shift, (int)HW, C, G, chunks, eps);
+    const long nvec = (long)N * HW * C / 8;
+    long blocks = (nvec + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, y, scale, shift, HW, C, nvec, do_silu);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// ---------------------------------------------------------------- LayerNorm
+// x: [rows][ldx] fp32 (first C entries normalised), y: [rows][ldy] bf16, y[c] = xn*a[c] + b[c] for c < C,
+// 0 for C <= c < ldy. a/b: fp32 [C] (+ batch*ab_stride). One wave per row; VPL = values per lane.
+template <int VPL>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, float* __restrict__ yf,
+                                                        const float* __restrict__ a, const float* __restrict__ b, long rows,
+                                                        int C, int ldx, int ldy, float eps, long rows_per_batch, int ab_stride) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * ldx;
+    float v[VPL];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = i * 64 + lane;
+        v[i] = c < C ? xr[c] : 0.f;
+        sum += v[i];
+    }
+    const float mean = wave_sum(sum) / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = i * 64 + lane;
+        const float d = c < C ? v[i] - mean : 0.f;
+        sq += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+    const long batch = row / rows_per_batch;
+    const float* ap = a ? a + batch * ab_stride : nullptr;
+    const float* bp = b ? b + batch * ab_stride : nullptr;
+    bf16_t* yr = y ? y + row * ldy : nullptr;
+    float* yfr = yf ? yf + row * ldy : nullptr;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int c = i * 64 + lane;
+        if (c < ldy) {
+            float o = 0.f;
+            if (c < C) {
+                o = (v[i] - mean) * rstd;
+                if (ap) o *= ap[c];
+                if (bp) o += bp[c];
+            }
+            if (yr) yr[c] = f2bf(o);
+            if (yfr) yfr[c] = o;
+        }
+    }
+}
+
+int ir_launch_layernorm(const float* x, bf16_t* y, float* yf, const float* a, const float* b, long rows, int C, int ldx, int ldy,
+                        float eps, long rows_per_batch, int ab_stride, hipStream_t s) {
+    if (rows <= 0) return 0;
+    if (C > ldx || C > ldy || ldy > 1152) return -2;
+    if (rows_per_batch <= 0) return -3;
+    const unsigned grid = (unsigned)((rows + 3) / 4);
+    if (ldy <= 192)
+        hipLaunchKernelGGL((layernorm_kernel<3>), dim3(grid), dim3(256), 0, s, x, y, yf, a, b, rows, C, ldx, ldy, eps, rows_per_batch, ab_stride);
+    else if (ldy <= 1152)
+        hipLaunchKernelGGL((layernorm_kernel<18>), dim3(grid), dim3(256), 0, s, x, y, yf, a, b, rows, C, ldx, ldy, eps, rows_per_batch, ab_stride);
+    else
+        return -2;
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// ---------------------------------------------------------------- fp32 GEMV (conditioning path, run once per timestep)
+// out[n] = act(b[n] + sum_k w[n][k] * x[k]); one wave per output row. Used for the timestep MLP and adaLN-single
+// linear (PixArt_blocks.py:336-358, PixArtMS.py:134-137) where bf16 rounding of a [1,K] operand would bias every token.
+__global__ __launch_bounds__(256) void gemv_f32_kernel(const float* __restrict__ w, const float* __restrict__ x,
+                                                       const float* __restrict__ b, float* __restrict__ out, int N, int K, int act) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= N) return;
+    const float* wr = w + (long)row * K;
+    float acc = 0.f;
+    for (int k = lane; k < K; k += 64) acc += wr[k] * x[k];
+    acc = wave_sum(acc);
+    if (lane == 0) {
+        float v = acc + (b ? b[row] : 0.f);
+        if (act == IR_ACT_SILU) v = silu(v);
+        out[row] = v;
+    }
+}
+int ir_launch_gemv_f32(const float* w, const float* x, const float* b, float* out, int N, int K, int act, hipStream_t s) {
+    hipLaunchKernelGGL(gemv_f32_kernel, dim3((N + 3) / 4), dim3(256), 0, s, w, x, b, out, N, K, act);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}

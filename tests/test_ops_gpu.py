@@ -1,0 +1,255 @@
+"""Kernel-level parity: every HIP kernel is called through the C ABI and compared with a plain PyTorch fp32
+restatement of the same op on the same (bf16-rounded) inputs. Tolerances are stated per test: inputs/outputs are
+bf16 (8 mantissa bits, rel. 2^-9 per rounding), accumulation is fp32."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from instarevive_amd import _lib as L
+
+pytestmark = pytest.mark.gpu
+
+
+def rb(t):  # round to bf16 and back (fp32, cpu)
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def dev_bf16(t):
+    return L.bf16_bits(t).cuda()
+
+
+def close(got, ref, rtol, atol, what=""):
+    err = (got - ref).abs()
+    bad = err > (atol + rtol * ref.abs())
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} off, max abs err {err.max():.4g}, ref max {ref.abs().max():.4g}"
+
+
+def pack_conv(w, cin_pad, cout_pad):
+    """[Cout][Cin][kh][kw] -> [Cout_pad][kh*kw][Cin_pad] (tap-major, channel-minor), fp32."""
+    co, ci, kh, kw = w.shape
+    p = torch.zeros(cout_pad, kh * kw, cin_pad)
+    p[:co, :, :ci] = w.permute(0, 2, 3, 1).reshape(co, kh * kw, ci)
+    return p.reshape(cout_pad, kh * kw * cin_pad)
+
+
+@pytest.mark.parametrize("m,k,n", [(128, 32, 128), (300, 96, 192), (1000, 1152, 64), (77, 64, 32), (256, 4608, 1152)])
+def test_linear(ctx, m, k, n):
+    g = torch.Generator().manual_seed(m + k + n)
+    x = rb(torch.randn(m, k, generator=g))
+    w = rb(torch.randn(n, k, generator=g) / math.sqrt(k))
+    b = torch.randn(n, generator=g)
+    ref = x @ w.t() + b
+    out = torch.empty(m, n, dtype=torch.float32, device="cuda")
+    xd, wd, bd = dev_bf16(x), dev_bf16(w), b.cuda()
+    ctx.check(ctx.lib.ir_op_linear(ctx.h, ctx.stream(), L.ptr(xd), L.ptr(wd), L.ptr(bd), L.ptr(out), m, k, n, n, L.ACT_NONE,
+                                   None, None, 0, 1, 1.0), "linear")
+    torch.cuda.synchronize()
+    close(out.cpu(), ref, 1e-4, 2e-4 * math.sqrt(k), "linear f32")  # fp32 accumulate of exact bf16 products
+
+
+def test_linear_epilogues(ctx):
+    g = torch.Generator().manual_seed(5)
+    m, k, n = 260, 128, 96
+    x = rb(torch.randn(m, k, generator=g))
+    w = rb(torch.randn(n, k, generator=g) / math.sqrt(k))
+    b = torch.randn(n, generator=g)
+    gate = torch.randn(n, generator=g)
+    res = torch.randn(m, n, generator=g)
+    xd, wd = dev_bf16(x), dev_bf16(w)
+    # gelu-tanh, bf16 out
+    out = torch.empty(m, n, dtype=torch.int16, device="cuda")
+    ctx.check(ctx.lib.ir_op_linear(ctx.h, ctx.stream(), L.ptr(xd), L.ptr(wd), L.ptr(b.cuda()), L.ptr(out), m, k, n, n,
+                                   L.ACT_GELU_TANH, None, None, 0, 0, 1.0), "linear gelu")
+    ref = F.gelu(x @ w.t() + b, approximate="tanh")
+    close(L.from_bf16_bits(out).cpu(), ref, 2 ** -7, 1e-3, "gelu tanh bf16")
+    # gelu-erf
+    ctx.check(ctx.lib.ir_op_linear(ctx.h, ctx.stream(), L.ptr(xd), L.ptr(wd), L.ptr(b.cuda()), L.ptr(out), m, k, n, n,
+                                   L.ACT_GELU_ERF, None, None, 0, 0, 1.0), "linear gelu erf")
+    close(L.from_bf16_bits(out).cpu(), F.gelu(x @ w.t() + b), 2 ** -7, 1e-3, "gelu erf bf16")
+    # gate * (acc+b) + fp32 residual, fp32 out, in place on the residual buffer
+    resd = res.cuda().clone()
+    ctx.check(ctx.lib.ir_op_linear(ctx.h, ctx.stream(), L.ptr(xd), L.ptr(wd), L.ptr(b.cuda()), L.ptr(resd), m, k, n, n,
+                                   L.ACT_NONE, L.ptr(gate.cuda()), L.ptr(resd), 1, 1, 1.0), "linear gate res")
+    close(resd.cpu(), res + gate * (x @ w.t() + b), 1e-4, 1e-3, "gate+residual")
+    # bf16 residual, bf16 out, out_scale
+    rbf = rb(res)
+    ctx.check(ctx.lib.ir_op_linear(ctx.h, ctx.stream(), L.ptr(xd), L.ptr(wd), None, L.ptr(out), m, k, n, n, L.ACT_NONE, None,
+                                   L.ptr(dev_bf16(rbf)), 0, 0, 0.5), "linear res bf16")
+    close(L.from_bf16_bits(out).cpu(), rbf + 0.5 * (x @ w.t()), 2 ** -7, 1e-3, "bf16 residual + out_scale")
+
+
+CONV_CASES = [
+    # n, h, w, cin, cout, stride, pad, up
+    (1, 16, 16, 32, 64, 1, 1, 0),
+    (2, 24, 40, 64, 128, 1, 1, 0),
+    (1, 16, 24, 32, 32, 2, 0, 0),   # VAE Downsample: pad (0,1,0,1), stride 2
+    (1, 12, 20, 64, 64, 1, 1, 1),   # nearest x2 folded in
+    (1, 32, 32, 128, 256, 1, 1, 0),
+    (1, 20, 28, 64, 3, 1, 1, 0),    # Cout=3 (padded to 32), scalar store path
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv3x3(ctx, case):
+    n, h, w, cin, cout, stride, pad, up = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = rb(torch.randn(n, cin, h, w, generator=g))
+    wt = rb(torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin))
+    b = torch.randn(cout, generator=g)
+    xin = F.interpolate(x, scale_factor=2.0, mode="nearest") if up else x
+    if stride == 2:
+        ref = F.conv2d(F.pad(xin, (0, 1, 0, 1)), wt, b, stride=2)
+    else:
+        ref = F.conv2d(xin, wt, b, padding=1)
+    cout_pad = (cout + 31) // 32 * 32
+    wp = pack_conv(wt, cin, cout_pad)
+    bp = torch.zeros(cout_pad)
+    bp[:cout] = b
+    ho, wo = ref.shape[-2:]
+    out = torch.empty(n, ho, wo, cout, dtype=torch.float32, device="cuda")
+    xd = dev_bf16(x.permute(0, 2, 3, 1).contiguous())
+    ctx.check(ctx.lib.ir_op_conv(ctx.h, ctx.stream(), L.ptr(xd), L.ptr(dev_bf16(wp)), L.ptr(bp.cuda()), L.ptr(out), n, h, w, cin, cout,
+                                 cout_pad, 9, stride, pad, up, L.ACT_NONE, 0.0, None, 0, 1), "conv")
+    torch.cuda.synchronize()
+    close(out.cpu().permute(0, 3, 1, 2), ref, 1e-4, 1e-3, f"conv {case}")
+
+
+def test_conv_lrelu_residual_bf16(ctx):
+    g = torch.Generator().manual_seed(11)
+    n, h, w, cin, cout = 1, 16, 16, 64, 64
+    x = rb(torch.randn(n, cin, h, w, generator=g))
+    wt = rb(torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin))
+    b = torch.randn(cout, generator=g)
+    res = rb(torch.randn(n, cout, h, w, generator=g))
+    y = F.conv2d(x, wt, b, padding=1)
+    ref = F.leaky_relu(y, 0.2) + res
+    out = torch.empty(n, h, w, cout, dtype=torch.int16, device="cuda")
+    ctx.check(ctx.lib.ir_op_conv(ctx.h, ctx.stream(), L.ptr(dev_bf16(x.permute(0, 2, 3, 1).contiguous())), L.ptr(dev_bf16(pack_conv(wt, cin, cout))),
+                                 L.ptr(b.cuda()), L.ptr(out), n, h, w, cin, cout, cout, 9, 1, 1, 0, L.ACT_LRELU, 0.2,
+                                 L.ptr(dev_bf16(res.permute(0, 2, 3, 1).contiguous())), 0, 0), "conv lrelu")
+    close(L.from_bf16_bits(out).cpu().permute(0, 3, 1, 2), ref, 2 ** -7, 2e-3, "conv lrelu + residual")
+
+
+@pytest.mark.parametrize("n,hw,c,silu", [(1, 64 * 64, 128, 1), (2, 40 * 24, 256, 1), (1, 16 * 16, 512, 0), (1, 100 * 100, 32, 1)])
+def test_groupnorm(ctx, n, hw, c, silu):
+    g = torch.Generator().manual_seed(c + hw)
+    x = rb(torch.randn(n, hw, c, generator=g) * 2 + 0.5)
+    gamma, beta = torch.randn(c, generator=g), torch.randn(c, generator=g)
+    ref = F.group_norm(x.permute(0, 2, 1), 32, gamma, beta, eps=1e-6).permute(0, 2, 1)
+    if silu:
+        ref = F.silu(ref)
+    y = torch.empty(n, hw, c, dtype=torch.int16, device="cuda")
+    ws = torch.empty(8 << 20, dtype=torch.uint8, device="cuda")
+    ctx.check(ctx.lib.ir_op_groupnorm(ctx.h, ctx.stream(), L.ptr(dev_bf16(x)), L.ptr(y), L.ptr(gamma.cuda()), L.ptr(beta.cuda()), n, hw, c,
+                                      32, 1e-6, silu, L.ptr(ws), ws.numel()), "groupnorm")
+    close(L.from_bf16_bits(y).cpu(), ref, 2 ** -7, 4e-3, "groupnorm")
+
+
+@pytest.mark.parametrize("rows,c,ld", [(1000, 180, 192), (513, 1152, 1152), (64, 60, 192)])
+def test_layernorm(ctx, rows, c, ld):
+    g = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, ld, generator=g) * 3 + 1
+    a, b = torch.randn(c, generator=g), torch.randn(c, generator=g)
+    eps = 1e-5
+    ref = torch.zeros(rows, ld)
+    ref[:, :c] = F.layer_norm(x[:, :c], (c,), None, None, eps) * a + b
+    y = torch.full((rows, ld), 0x7fff, dtype=torch.int16, device="cuda")
+    ctx.check(ctx.lib.ir_op_layernorm(ctx.h, ctx.stream(), L.ptr(x.cuda()), L.ptr(y), L.ptr(a.cuda()), L.ptr(b.cuda()), rows, c, ld, ld, eps),
+              "layernorm")
+    close(L.from_bf16_bits(y).cpu(), ref, 2 ** -7, 2e-3, "layernorm")
+
+
+@pytest.mark.parametrize("b,heads,tq,tk,d,bias", [
+    (1, 2, 128, 128, 72, False), (2, 3, 200, 200, 72, False), (1, 16, 1024, 1024, 72, False),
+    (2, 2, 130, 300, 72, True), (1, 2, 64, 64, 32, False), (1, 1, 256, 192, 64, True)])
+def test_flash_attention(ctx, b, heads, tq, tk, d, bias):
+    g = torch.Generator().manual_seed(tq + tk + d)
+    q = rb(torch.randn(b, tq, heads, d, generator=g))
+    k = rb(torch.randn(b, tk, heads, d, generator=g))
+    v = rb(torch.randn(b, tk, heads, d, generator=g))
+    kb = torch.randn(b, tk, generator=g) if bias else None
+    scale = d ** -0.5
+    mask = kb[:, None, None, :] if bias else None
+    ref = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), attn_mask=mask, scale=scale).transpose(1, 2)
+    o = torch.empty(b, tq, heads, d, dtype=torch.int16, device="cuda")
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    ctx.check(ctx.lib.ir_op_attention(ctx.h, ctx.stream(), L.ptr(dev_bf16(q)), L.ptr(dev_bf16(k)), L.ptr(dev_bf16(v)), L.ptr(o), b, heads, tq, tk,
+                                      d, scale, L.ptr(kb.cuda()) if bias else None, L.ptr(ws), ws.numel()), "attention")
+    # P is rounded to bf16 before PV and O is stored in bf16: tolerance a few bf16 ulps of |v|~1 averages
+    close(L.from_bf16_bits(o).cpu(), ref, 2 ** -6, 6e-3, "flash attention")
+
+
+def test_flash_attention_spike(ctx):
+    """Force the online-softmax rescale: a late key dominates one query (max jumps in the last tile)."""
+    g = torch.Generator().manual_seed(3)
+    b, heads, t, d = 1, 1, 256, 72
+    q = rb(torch.randn(b, t, heads, d, generator=g))
+    k = rb(torch.randn(b, t, heads, d, generator=g))
+    v = rb(torch.randn(b, t, heads, d, generator=g))
+    k[0, 250, 0] = q[0, 7, 0] * 4.0
+    k = rb(k)
+    scale = d ** -0.5
+    ref = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), scale=scale).transpose(1, 2)
+    o = torch.empty(b, t, heads, d, dtype=torch.int16, device="cuda")
+    ws = torch.empty(8 << 20, dtype=torch.uint8, device="cuda")
+    ctx.check(ctx.lib.ir_op_attention(ctx.h, ctx.stream(), L.ptr(dev_bf16(q)), L.ptr(dev_bf16(k)), L.ptr(dev_bf16(v)), L.ptr(o), b, heads, t, t, d,
+                                      scale, None, L.ptr(ws), ws.numel()), "attention")
+    close(L.from_bf16_bits(o).cpu(), ref, 2 ** -6, 6e-3, "flash attention spike")
+
+
+@pytest.mark.parametrize("h,w,shift", [(8, 8, 0), (16, 24, 0), (16, 24, 4), (64, 64, 4)])
+def test_swin_window_attention(ctx, h, w, shift):
+    heads, hd, ws_ = 6, 30, 8
+    g = torch.Generator().manual_seed(h * w + shift)
+    B = 2
+    qkv = rb(torch.randn(B, h * w, 3, heads, hd, generator=g))
+    table = torch.randn(225, heads, generator=g) * 0.5
+    scale = hd ** -0.5
+    # reference: roll, partition, attention with relative-position bias + shift mask, reverse (swinir.py:44-73,125-156,227-283)
+    coords = torch.stack(torch.meshgrid(torch.arange(8), torch.arange(8), indexing="ij")).flatten(1)
+    rel = (coords[:, :, None] - coords[:, None, :]).permute(1, 2, 0) + 7
+    idx = rel[:, :, 0] * 15 + rel[:, :, 1]
+    bias = table[idx.view(-1)].view(64, 64, heads).permute(2, 0, 1)  # heads, q, k
+    x = qkv.view(B, h, w, 3 * heads * hd)
+    if shift:
+        x = torch.roll(x, (-shift, -shift), (1, 2))
+    xw = x.view(B, h // 8, 8, w // 8, 8, -1).permute(0, 1, 3, 2, 4, 5).reshape(-1, 64, 3, heads, hd)
+    qq, kk, vv = [xw[:, :, i].permute(0, 2, 1, 3) for i in range(3)]
+    attn = (qq * scale) @ kk.transpose(-2, -1) + bias[None]
+    if shift:
+        img = torch.zeros(1, h, w, 1)
+        cnt = 0
+        for hs in (slice(0, -8), slice(-8, -shift), slice(-shift, None)):
+            for wsl in (slice(0, -8), slice(-8, -shift), slice(-shift, None)):
+                img[:, hs, wsl, :] = cnt
+                cnt += 1
+        mw = img.view(1, h // 8, 8, w // 8, 8, 1).permute(0, 1, 3, 2, 4, 5).reshape(-1, 64)
+        am = mw[:, None, :] - mw[:, :, None]
+        am = am.masked_fill(am != 0, -100.0)
+        nW = am.shape[0]
+        attn = (attn.view(B, nW, heads, 64, 64) + am[None, :, None]).view(-1, heads, 64, 64)
+    o = (attn.softmax(-1) @ vv).transpose(1, 2).reshape(-1, 8, 8, heads * hd)
+    o = o.view(B, h // 8, w // 8, 8, 8, -1).permute(0, 1, 3, 2, 4, 5).reshape(B, h, w, -1)
+    if shift:
+        o = torch.roll(o, (shift, shift), (1, 2))
+    ref = o.reshape(B, h * w, heads, hd)
+    # device layout: [B][T][3][heads][32] zero padded
+    qp = torch.zeros(B, h * w, 3, heads, 32)
+    qp[..., :hd] = qkv
+    biasT = (bias.permute(0, 2, 1).contiguous() * math.log2(math.e)).contiguous()  # [heads][key][query]
+    out = torch.empty(B, h * w, heads, 32, dtype=torch.int16, device="cuda")
+    ctx.check(ctx.lib.ir_op_swin_attention(ctx.h, ctx.stream(), L.ptr(dev_bf16(qp)), L.ptr(out), L.ptr(biasT.cuda()), B, h, w, heads, shift, scale),
+              "swin attention")
+    got = L.from_bf16_bits(out).cpu()
+    assert got[..., hd:].abs().max() == 0
+    close(got[..., :hd], ref, 2 ** -6, 6e-3, "swin attention")
+
+
+def test_softmax_rows(ctx):
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(300, 4096, generator=g) * 4
+    y = torch.empty(300, 4096, dtype=torch.int16, device="cuda")
+    ctx.check(ctx.lib.ir_op_softmax_rows(ctx.h, ctx.stream(), L.ptr(x.cuda()), L.ptr(y), 300, 4096), "softmax")
+    close(L.from_bf16_bits(y).cpu(), x.softmax(-1), 2 ** -7, 1e-6, "softmax rows")
