@@ -16,8 +16,23 @@ def rb(t):  # round to bf16 and back (fp32, cpu)
     return t.to(torch.bfloat16).to(torch.float32)
 
 
+_KEEP = []
+
+
 def dev_bf16(t):
     return L.bf16_bits(t).cuda()
+
+
+def P(t):
+    """Pointer of a device tensor that stays referenced (a temporary freed before the launch could be re-used by the
+    next .cuda() in the same argument list)."""
+    if t is None:
+        return None
+    _KEEP.append(t)
+    if len(_KEEP) > 64:
+        torch.cuda.synchronize()
+        del _KEEP[:32]
+    return L.ptr(t)
 
 
 def close(got, ref, rtol, atol, what=""):
@@ -43,7 +58,7 @@ def test_linear(ctx, m, k, n):
     ref = x @ w.t() + b
     out = torch.empty(m, n, dtype=torch.float32, device="cuda")
     xd, wd, bd = dev_bf16(x), dev_bf16(w), b.cuda()
-    ctx.check(ctx.lib.ir_op_linear(ctx.h, ctx.stream(), L.ptr(xd), L.ptr(wd), L.ptr(bd), L.ptr(out), m, k, n, n, L.ACT_NONE,
+    ctx.check(ctx.lib.ir_op_linear(ctx.h, ctx.stream(), P(xd), P(wd), P(bd), P(out), m, k, n, n, L.ACT_NONE,
                                    None, None, 0, 1, 1.0), "linear")
     torch.cuda.synchronize()
     close(out.cpu(), ref, 1e-4, 2e-4 * math.sqrt(k), "linear f32")  # fp32 accumulate of exact bf16 products
@@ -60,23 +75,23 @@ def test_linear_epilogues(ctx):
     xd, wd = dev_bf16(x), dev_bf16(w)
     # gelu-tanh, bf16 out
     out = torch.empty(m, n, dtype=torch.int16, device="cuda")
-    ctx.check(ctx.lib.ir_op_linear(ctx.h, ctx.stream(), L.ptr(xd), L.ptr(wd), L.ptr(b.cuda()), L.ptr(out), m, k, n, n,
+    ctx.check(ctx.lib.ir_op_linear(ctx.h, ctx.stream(), P(xd), P(wd), P(b.cuda()), P(out), m, k, n, n,
                                    L.ACT_GELU_TANH, None, None, 0, 0, 1.0), "linear gelu")
     ref = F.gelu(x @ w.t() + b, approximate="tanh")
     close(L.from_bf16_bits(out).cpu(), ref, 2 ** -7, 1e-3, "gelu tanh bf16")
     # gelu-erf
-    ctx.check(ctx.lib.ir_op_linear(ctx.h, ctx.stream(), L.ptr(xd), L.ptr(wd), L.ptr(b.cuda()), L.ptr(out), m, k, n, n,
+    ctx.check(ctx.lib.ir_op_linear(ctx.h, ctx.stream(), P(xd), P(wd), P(b.cuda()), P(out), m, k, n, n,
                                    L.ACT_GELU_ERF, None, None, 0, 0, 1.0), "linear gelu erf")
     close(L.from_bf16_bits(out).cpu(), F.gelu(x @ w.t() + b), 2 ** -7, 1e-3, "gelu erf bf16")
     # gate * (acc+b) + fp32 residual, fp32 out, in place on the residual buffer
     resd = res.cuda().clone()
-    ctx.check(ctx.lib.ir_op_linear(ctx.h, ctx.stream(), L.ptr(xd), L.ptr(wd), L.ptr(b.cuda()), L.ptr(resd), m, k, n, n,
-                                   L.ACT_NONE, L.ptr(gate.cuda()), L.ptr(resd), 1, 1, 1.0), "linear gate res")
+    ctx.check(ctx.lib.ir_op_linear(ctx.h, ctx.stream(), P(xd), P(wd), P(b.cuda()), P(resd), m, k, n, n,
+                                   L.ACT_NONE, P(gate.cuda()), P(resd), 1, 1, 1.0), "linear gate res")
     close(resd.cpu(), res + gate * (x @ w.t() + b), 1e-4, 1e-3, "gate+residual")
     # bf16 residual, bf16 out, out_scale
     rbf = rb(res)
-    ctx.check(ctx.lib.ir_op_linear(ctx.h, ctx.stream(), L.ptr(xd), L.ptr(wd), None, L.ptr(out), m, k, n, n, L.ACT_NONE, None,
-                                   L.ptr(dev_bf16(rbf)), 0, 0, 0.5), "linear res bf16")
+    ctx.check(ctx.lib.ir_op_linear(ctx.h, ctx.stream(), P(xd), P(wd), None, P(out), m, k, n, n, L.ACT_NONE, None,
+                                   P(dev_bf16(rbf)), 0, 0, 0.5), "linear res bf16")
     close(L.from_bf16_bits(out).cpu(), rbf + 0.5 * (x @ w.t()), 2 ** -7, 1e-3, "bf16 residual + out_scale")
 
 
@@ -110,7 +125,7 @@ def test_conv3x3(ctx, case):
     ho, wo = ref.shape[-2:]
     out = torch.empty(n, ho, wo, cout, dtype=torch.float32, device="cuda")
     xd = dev_bf16(x.permute(0, 2, 3, 1).contiguous())
-    ctx.check(ctx.lib.ir_op_conv(ctx.h, ctx.stream(), L.ptr(xd), L.ptr(dev_bf16(wp)), L.ptr(bp.cuda()), L.ptr(out), n, h, w, cin, cout,
+    ctx.check(ctx.lib.ir_op_conv(ctx.h, ctx.stream(), P(xd), P(dev_bf16(wp)), P(bp.cuda()), P(out), n, h, w, cin, cout,
                                  cout_pad, 9, stride, pad, up, L.ACT_NONE, 0.0, None, 0, 1), "conv")
     torch.cuda.synchronize()
     close(out.cpu().permute(0, 3, 1, 2), ref, 1e-4, 1e-3, f"conv {case}")
@@ -126,9 +141,9 @@ def test_conv_lrelu_residual_bf16(ctx):
     y = F.conv2d(x, wt, b, padding=1)
     ref = F.leaky_relu(y, 0.2) + res
     out = torch.empty(n, h, w, cout, dtype=torch.int16, device="cuda")
-    ctx.check(ctx.lib.ir_op_conv(ctx.h, ctx.stream(), L.ptr(dev_bf16(x.permute(0, 2, 3, 1).contiguous())), L.ptr(dev_bf16(pack_conv(wt, cin, cout))),
-                                 L.ptr(b.cuda()), L.ptr(out), n, h, w, cin, cout, cout, 9, 1, 1, 0, L.ACT_LRELU, 0.2,
-                                 L.ptr(dev_bf16(res.permute(0, 2, 3, 1).contiguous())), 0, 0), "conv lrelu")
+    ctx.check(ctx.lib.ir_op_conv(ctx.h, ctx.stream(), P(dev_bf16(x.permute(0, 2, 3, 1).contiguous())), P(dev_bf16(pack_conv(wt, cin, cout))),
+                                 P(b.cuda()), P(out), n, h, w, cin, cout, cout, 9, 1, 1, 0, L.ACT_LRELU, 0.2,
+                                 P(dev_bf16(res.permute(0, 2, 3, 1).contiguous())), 0, 0), "conv lrelu")
     close(L.from_bf16_bits(out).cpu().permute(0, 3, 1, 2), ref, 2 ** -7, 2e-3, "conv lrelu + residual")
 
 
@@ -142,8 +157,8 @@ def test_groupnorm(ctx, n, hw, c, silu):
         ref = F.silu(ref)
     y = torch.empty(n, hw, c, dtype=torch.int16, device="cuda")
     ws = torch.empty(8 << 20, dtype=torch.uint8, device="cuda")
-    ctx.check(ctx.lib.ir_op_groupnorm(ctx.h, ctx.stream(), L.ptr(dev_bf16(x)), L.ptr(y), L.ptr(gamma.cuda()), L.ptr(beta.cuda()), n, hw, c,
-                                      32, 1e-6, silu, L.ptr(ws), ws.numel()), "groupnorm")
+    ctx.check(ctx.lib.ir_op_groupnorm(ctx.h, ctx.stream(), P(dev_bf16(x)), P(y), P(gamma.cuda()), P(beta.cuda()), n, hw, c,
+                                      32, 1e-6, silu, P(ws), ws.numel()), "groupnorm")
     close(L.from_bf16_bits(y).cpu(), ref, 2 ** -7, 4e-3, "groupnorm")
 
 
@@ -156,7 +171,7 @@ def test_layernorm(ctx, rows, c, ld):
     ref = torch.zeros(rows, ld)
     ref[:, :c] = F.layer_norm(x[:, :c], (c,), None, None, eps) * a + b
     y = torch.full((rows, ld), 0x7fff, dtype=torch.int16, device="cuda")
-    ctx.check(ctx.lib.ir_op_layernorm(ctx.h, ctx.stream(), L.ptr(x.cuda()), L.ptr(y), L.ptr(a.cuda()), L.ptr(b.cuda()), rows, c, ld, ld, eps),
+    ctx.check(ctx.lib.ir_op_layernorm(ctx.h, ctx.stream(), P(x.cuda()), P(y), P(a.cuda()), P(b.cuda()), rows, c, ld, ld, eps),
               "layernorm")
     close(L.from_bf16_bits(y).cpu(), ref, 2 ** -7, 2e-3, "layernorm")
 
@@ -175,8 +190,8 @@ def test_flash_attention(ctx, b, heads, tq, tk, d, bias):
     ref = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), attn_mask=mask, scale=scale).transpose(1, 2)
     o = torch.empty(b, tq, heads, d, dtype=torch.int16, device="cuda")
     ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
-    ctx.check(ctx.lib.ir_op_attention(ctx.h, ctx.stream(), L.ptr(dev_bf16(q)), L.ptr(dev_bf16(k)), L.ptr(dev_bf16(v)), L.ptr(o), b, heads, tq, tk,
-                                      d, scale, L.ptr(kb.cuda()) if bias else None, L.ptr(ws), ws.numel()), "attention")
+    ctx.check(ctx.lib.ir_op_attention(ctx.h, ctx.stream(), P(dev_bf16(q)), P(dev_bf16(k)), P(dev_bf16(v)), P(o), b, heads, tq, tk,
+                                      d, scale, P(kb.cuda()) if bias else None, P(ws), ws.numel()), "attention")
     # P is rounded to bf16 before PV and O is stored in bf16: tolerance a few bf16 ulps of |v|~1 averages
     close(L.from_bf16_bits(o).cpu(), ref, 2 ** -6, 6e-3, "flash attention")
 
@@ -194,8 +209,8 @@ def test_flash_attention_spike(ctx):
     ref = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), scale=scale).transpose(1, 2)
     o = torch.empty(b, t, heads, d, dtype=torch.int16, device="cuda")
     ws = torch.empty(8 << 20, dtype=torch.uint8, device="cuda")
-    ctx.check(ctx.lib.ir_op_attention(ctx.h, ctx.stream(), L.ptr(dev_bf16(q)), L.ptr(dev_bf16(k)), L.ptr(dev_bf16(v)), L.ptr(o), b, heads, t, t, d,
-                                      scale, None, L.ptr(ws), ws.numel()), "attention")
+    ctx.check(ctx.lib.ir_op_attention(ctx.h, ctx.stream(), P(dev_bf16(q)), P(dev_bf16(k)), P(dev_bf16(v)), P(o), b, heads, t, t, d,
+                                      scale, None, P(ws), ws.numel()), "attention")
     close(L.from_bf16_bits(o).cpu(), ref, 2 ** -6, 6e-3, "flash attention spike")
 
 
@@ -240,7 +255,7 @@ def test_swin_window_attention(ctx, h, w, shift):
     qp[..., :hd] = qkv
     biasT = (bias.permute(0, 2, 1).contiguous() * math.log2(math.e)).contiguous()  # [heads][key][query]
     out = torch.empty(B, h * w, heads, 32, dtype=torch.int16, device="cuda")
-    ctx.check(ctx.lib.ir_op_swin_attention(ctx.h, ctx.stream(), L.ptr(dev_bf16(qp)), L.ptr(out), L.ptr(biasT.cuda()), B, h, w, heads, shift, scale),
+    ctx.check(ctx.lib.ir_op_swin_attention(ctx.h, ctx.stream(), P(dev_bf16(qp)), P(out), P(biasT.cuda()), B, h, w, heads, shift, scale),
               "swin attention")
     got = L.from_bf16_bits(out).cpu()
     assert got[..., hd:].abs().max() == 0
@@ -251,5 +266,5 @@ def test_softmax_rows(ctx):
     g = torch.Generator().manual_seed(9)
     x = torch.randn(300, 4096, generator=g) * 4
     y = torch.empty(300, 4096, dtype=torch.int16, device="cuda")
-    ctx.check(ctx.lib.ir_op_softmax_rows(ctx.h, ctx.stream(), L.ptr(x.cuda()), L.ptr(y), 300, 4096), "softmax")
+    ctx.check(ctx.lib.ir_op_softmax_rows(ctx.h, ctx.stream(), P(x.cuda()), P(y), 300, 4096), "softmax")
     close(L.from_bf16_bits(y).cpu(), x.softmax(-1), 2 ** -7, 1e-6, "softmax rows")
