@@ -415,14 +415,15 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
         m = mn;
     }
     float wm = wave_max(m);
-    l *= __builtin_amdgcn_exp2f((m - wm) * L2E);
+    // threads (or whole waves) without elements hold m = -inf, l = 0: keep them at exactly 0 (avoid -inf - -inf)
+    l = (m == -INFINITY) ? 0.f : l * __builtin_amdgcn_exp2f((m - wm) * L2E);
     l = wave_sum(l);
     if (lane == 0) { red[wid] = wm; red[4 + wid] = l; }
     __syncthreads();
     float gm = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     float gl = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) gl += red[4 + i] * __builtin_amdgcn_exp2f((red[i] - gm) * L2E);
+    for (int i = 0; i < 4; ++i) gl += (red[i] == -INFINITY) ? 0.f : red[4 + i] * __builtin_amdgcn_exp2f((red[i] - gm) * L2E);
     const float inv = 1.0f / gl;
     bf16_t* yr = y + row * ldy;
     for (int c = tid * 4; c < cols; c += 1024) {

@@ -1,0 +1,435 @@
+"""Host-side mirrors of the objects test_scripts/inference.py builds in main() (:236-252) and calls in process()
+(:97,106-117): same constructor/loader names, argument meaning and error behaviour, but every forward is a call
+through the C ABI into HIP kernels. No torch.nn arithmetic happens here and there is no CPU fallback.
+
+  SwinIR            <- diffusion/model/swinir.py:629-905 (instantiate_from_config(configs/swinir.yaml) + load_state_dict)
+  AutoencoderKL     <- diffusers.AutoencoderKL  (inference.py:34,236-237: .encode(x).latent_dist.mode(), .decode(z).sample,
+                       .config.scaling_factor)
+  Transformer2DModel<- diffusers.Transformer2DModel (inference.py:238-242; generate.py:56,67-73,84: .config.sample_size,
+                       .config.out_channels, __call__(...).sample)
+  DDPMScheduler     <- diffusers.DDPMScheduler (inference.py:36; generate.py:45: .alphas_cumprod)
+"""
+import ctypes as C
+import json
+import os
+from types import SimpleNamespace
+
+import torch
+
+from . import _lib as L
+from . import weights as W
+
+_CONTEXTS = {}
+
+
+def get_context(device=None) -> L.Context:
+    """One ir_ctx per GPU, shared by all models on that device (so the fused pipeline sees all weights)."""
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device() if torch.cuda.is_available() else 0)
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise L.NativeLibraryError(f"instarevive_amd runs on MI355X GPUs only (asked for device '{device}'); there is no CPU path")
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _CONTEXTS:
+        _CONTEXTS[idx] = L.Context(idx)
+    return _CONTEXTS[idx]
+
+
+def _ints(v):
+    return (C.c_int * len(v))(*v)
+
+
+class _DeviceModule:
+    """Minimal nn.Module-like surface: state dict on the host, .to(device) uploads and binds."""
+
+    def __init__(self):
+        self._sd = None
+        self.ctx = None
+        self.device = torch.device("cpu")
+        self.training = False
+
+    def eval(self):
+        return self
+
+    def train(self, mode=True):
+        if mode:
+            raise RuntimeError("instarevive_amd models are inference-only")
+        return self
+
+    def requires_grad_(self, flag=False):
+        return self
+
+    def parameters(self):
+        return iter(self._sd.values()) if self._sd else iter(())
+
+    def state_dict(self):
+        return dict(self._sd) if self._sd is not None else {k: None for k in self._expected_keys()}
+
+    def to(self, *args, **kwargs):
+        device = kwargs.get("device")
+        for a in args:
+            if isinstance(a, (str, torch.device)) or isinstance(a, int):
+                device = a
+            # dtypes are accepted and ignored: storage precision is fixed by the kernels (bf16 weights, fp32 statistics)
+        if device is not None:
+            self.device = torch.device(device) if not isinstance(device, int) else torch.device("cuda", device)
+            self.ctx = get_context(self.device)
+            self.device = self.ctx.device
+            if self._sd is not None:
+                self._upload()
+        return self
+
+    def cuda(self, device=None):
+        return self.to(torch.device("cuda", device or 0))
+
+    def _check_keys(self, sd, strict, ignore=()):
+        exp = set(self._expected_keys())
+        got = set(sd.keys())
+        missing = sorted(k for k in exp - got if not any(s in k for s in ignore))
+        unexpected = sorted(k for k in got - exp if not any(s in k for s in ignore))
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict for {type(self).__name__}:\n\tMissing key(s): {missing[:8]}"
+                               f"{'...' if len(missing) > 8 else ''}\n\tUnexpected key(s): {unexpected[:8]}{'...' if len(unexpected) > 8 else ''}")
+        return SimpleNamespace(missing_keys=missing, unexpected_keys=unexpected)
+
+    def _ready(self):
+        if self.ctx is None or self._sd is None:
+            raise RuntimeError(f"{type(self).__name__}: load_state_dict(...) and .to('cuda') must both be called before forward")
+
+
+# ====================================================================================================== SwinIR
+class SwinIR(_DeviceModule):
+    def __init__(self, img_size=64, patch_size=1, in_chans=3, embed_dim=96, depths=(6, 6, 6, 6), num_heads=(6, 6, 6, 6), window_size=7,
+                 mlp_ratio=4.0, qkv_bias=True, qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.1, norm_layer=None,
+                 ape=False, patch_norm=True, use_checkpoint=False, sf=4, img_range=1.0, upsampler="", resi_connection="1conv",
+                 unshuffle=False, unshuffle_scale=None, hq_key="jpg", lq_key="hint", learning_rate=None, weight_decay=None):
+        super().__init__()
+        ok = (patch_size == 1 and in_chans == 3 and window_size == 8 and sf == 8 and upsampler == "nearest+conv" and
+              resi_connection == "1conv" and unshuffle and unshuffle_scale == 8 and qkv_bias and qk_scale is None and not ape and patch_norm and
+              len(set(num_heads)) == 1 and embed_dim % num_heads[0] == 0 and embed_dim // num_heads[0] <= 32)
+        if not ok:
+            raise NotImplementedError("the MI355X path implements the SwinIR variant of configs/swinir.yaml: window 8, sf 8, "
+                                      "'nearest+conv', PixelUnshuffle(8), '1conv', head_dim <= 32")
+        self.cfg = dict(embed_dim=embed_dim, depths=list(depths), num_heads=list(num_heads), window_size=8, mlp_ratio=mlp_ratio, sf=8,
+                        img_range=img_range, unshuffle_scale=8)
+        self.upscale, self.window_size = sf, window_size
+
+    def _expected_keys(self):
+        return W.swinir_expected_keys(self.cfg)
+
+    def load_state_dict(self, state_dict, strict=True):
+        res = self._check_keys(state_dict, strict)
+        self._sd = {k: v.detach().cpu() for k, v in state_dict.items()}
+        if self.ctx is not None:
+            self._upload()
+        return res
+
+    def _upload(self):
+        c = self.cfg
+        self.ctx.upload_all(W.pack_swinir(self._sd, c))
+        mean = (C.c_float * 3)(*W.SWIN_MEAN)
+        self.ctx.check(self.ctx.lib.ir_swinir_configure(self.ctx.h, c["embed_dim"], len(c["depths"]), _ints(c["depths"]), c["num_heads"][0],
+                                                         int(c["embed_dim"] * c["mlp_ratio"]), 64, float(c["img_range"]), mean),
+                       "ir_swinir_configure")
+
+    @torch.no_grad()
+    def __call__(self, x):
+        """x: [B,3,H,W] fp32 cuda in [0,1], H and W multiples of 64 (the CLI pads to 64: inference.py:287,291)."""
+        self._ready()
+        x = x.to(self.device, torch.float32).contiguous()
+        n, ch, h, w = x.shape
+        if ch != 3 or h % 64 or w % 64:
+            raise ValueError(f"SwinIR input must be [B,3,H,W] with H,W multiples of 64, got {tuple(x.shape)}")
+        out = torch.empty_like(x)
+        ws = self.ctx.workspace(self.ctx.ws_bytes(L.STAGE_SWINIR, n, h, w))
+        self.ctx.check(self.ctx.lib.ir_swinir_forward(self.ctx.h, self.ctx.stream(), L.ptr(x), L.ptr(out), n, h, w, L.ptr(ws), ws.numel()),
+                       "ir_swinir_forward")
+        return out
+
+    forward = __call__
+
+
+# ====================================================================================================== VAE
+def _load_weights_file(folder):
+    st = os.path.join(folder, "diffusion_pytorch_model.safetensors")
+    if os.path.exists(st):
+        from safetensors.torch import load_file
+        return load_file(st)
+    for name in ("diffusion_pytorch_model.bin", "diffusion_pytorch_model.pt"):
+        p = os.path.join(folder, name)
+        if os.path.exists(p):
+            return torch.load(p, map_location="cpu")
+    raise FileNotFoundError(f"no diffusion_pytorch_model.(safetensors|bin) under {folder}")
+
+
+def _resolve_pretrained(name_or_path, subfolder=None):
+    """A local folder, or a hub id resolved inside $HF_HOME-style caches / ./weights (no network access is attempted)."""
+    cands = [name_or_path, os.path.join("weights", name_or_path), os.path.join("weights", os.path.basename(name_or_path))]
+    for c in cands:
+        p = os.path.join(c, subfolder) if subfolder else c
+        if os.path.isdir(p):
+            return p
+    raise FileNotFoundError(f"'{name_or_path}'{' / ' + subfolder if subfolder else ''} not found locally (looked in {cands}); "
+                            "download the diffusers folder and pass its path")
+
+
+class _LatentDist:
+    def __init__(self, mean):
+        self.mean = mean
+
+    def mode(self):
+        return self.mean
+
+    def sample(self, generator=None):
+        raise NotImplementedError("the one-step path only uses latent_dist.mode() (test_scripts/inference.py:107)")
+
+
+class AutoencoderKL(_DeviceModule):
+    def __init__(self, in_channels=3, out_channels=3, block_out_channels=(128, 256, 512, 512), layers_per_block=2, latent_channels=4,
+                 norm_num_groups=32, scaling_factor=0.18215, **unused):
+        super().__init__()
+        ch = block_out_channels[0]
+        mult = [c // ch for c in block_out_channels]
+        if in_channels != 3 or out_channels != 3 or latent_channels != 4 or norm_num_groups != 32 or ch % 32 or any(c % ch for c in block_out_channels):
+            raise NotImplementedError("unsupported AutoencoderKL config for the MI355X path")
+        self.cfg = dict(ch=ch, ch_mult=mult, num_res_blocks=layers_per_block, z_channels=4)
+        self.config = SimpleNamespace(scaling_factor=scaling_factor, block_out_channels=list(block_out_channels), latent_channels=4,
+                                      layers_per_block=layers_per_block)
+
+    @classmethod
+    def from_pretrained(cls, name_or_path, subfolder=None, **kw):
+        folder = _resolve_pretrained(name_or_path, subfolder)
+        with open(os.path.join(folder, "config.json")) as f:
+            cfg = json.load(f)
+        m = cls(**{k: v for k, v in cfg.items() if not k.startswith("_")})
+        m.load_state_dict(_load_weights_file(folder))
+        return m
+
+    def _expected_keys(self):
+        keys = []
+        c = self.cfg
+        nl = len(c["ch_mult"])
+
+        def res(p, sc):
+            r = [p + f".{n}.{t}" for n in ("norm1", "conv1", "norm2", "conv2") for t in ("weight", "bias")]
+            return r + ([p + ".conv_shortcut.weight", p + ".conv_shortcut.bias"] if sc else [])
+
+        def attn(p):
+            return [p + f".{n}.{t}" for n in ("group_norm", "to_q", "to_k", "to_v", "to_out.0") for t in ("weight", "bias")]
+
+        for half in ("encoder", "decoder"):
+            keys += [f"{half}.{n}.{t}" for n in ("conv_in", "conv_norm_out", "conv_out") for t in ("weight", "bias")]
+            keys += res(f"{half}.mid_block.resnets.0", False) + res(f"{half}.mid_block.resnets.1", False) + attn(f"{half}.mid_block.attentions.0")
+        cin = c["ch"]
+        for l in range(nl):
+            cout = c["ch"] * c["ch_mult"][l]
+            for j in range(c["num_res_blocks"]):
+                keys += res(f"encoder.down_blocks.{l}.resnets.{j}", cin != cout)
+                cin = cout
+            if l != nl - 1:
+                keys += [f"encoder.down_blocks.{l}.downsamplers.0.conv.weight", f"encoder.down_blocks.{l}.downsamplers.0.conv.bias"]
+        for i in range(nl):
+            cout = c["ch"] * c["ch_mult"][nl - 1 - i]
+            for j in range(c["num_res_blocks"] + 1):
+                keys += res(f"decoder.up_blocks.{i}.resnets.{j}", cin != cout)
+                cin = cout
+            if i != nl - 1:
+                keys += [f"decoder.up_blocks.{i}.upsamplers.0.conv.weight", f"decoder.up_blocks.{i}.upsamplers.0.conv.bias"]
+        keys += ["quant_conv.weight", "quant_conv.bias", "post_quant_conv.weight", "post_quant_conv.bias"]
+        return keys
+
+    def load_state_dict(self, state_dict, strict=True):
+        sd = dict(state_dict)
+        # accept the pre-0.18 attention names (query/key/value/proj_attn) some sd-vae-ft-ema snapshots still carry
+        for k in list(sd):
+            for old, new in ((".query.", ".to_q."), (".key.", ".to_k."), (".value.", ".to_v."), (".proj_attn.", ".to_out.0.")):
+                if old in k and "attentions" in k:
+                    sd[k.replace(old, new)] = sd.pop(k)
+        res = self._check_keys(sd, strict)
+        self._sd = {k: v.detach().cpu() for k, v in sd.items()}
+        if self.ctx is not None:
+            self._upload()
+        return res
+
+    def _upload(self):
+        c = self.cfg
+        self.ctx.upload_all(W.pack_vae(self._sd, c))
+        self.ctx.check(self.ctx.lib.ir_vae_configure(self.ctx.h, c["ch"], len(c["ch_mult"]), _ints(c["ch_mult"]), c["num_res_blocks"], 1, 1),
+                       "ir_vae_configure")
+
+    @torch.no_grad()
+    def encode(self, x):
+        self._ready()
+        x = x.to(self.device, torch.float32).contiguous()
+        n, ch, h, w = x.shape
+        if ch != 3 or h % 64 or w % 64:
+            raise ValueError(f"VAE encode input must be [B,3,H,W] with H,W multiples of 64, got {tuple(x.shape)}")
+        lat = torch.empty(n, 4, h // 8, w // 8, dtype=torch.float32, device=self.device)
+        ws = self.ctx.workspace(self.ctx.ws_bytes(L.STAGE_VAE_ENCODE, n, h, w))
+        self.ctx.check(self.ctx.lib.ir_vae_encode(self.ctx.h, self.ctx.stream(), L.ptr(x), L.ptr(lat), n, h, w, L.ptr(ws), ws.numel()),
+                       "ir_vae_encode")
+        return SimpleNamespace(latent_dist=_LatentDist(lat))
+
+    @torch.no_grad()
+    def decode(self, z):
+        self._ready()
+        z = z.to(self.device, torch.float32).contiguous()
+        n, ch, h, w = z.shape
+        if ch != 4 or h % 8 or w % 8:
+            raise ValueError(f"VAE decode input must be [B,4,h,w] with h,w multiples of 8, got {tuple(z.shape)}")
+        out = torch.empty(n, 3, h * 8, w * 8, dtype=torch.float32, device=self.device)
+        ws = self.ctx.workspace(self.ctx.ws_bytes(L.STAGE_VAE_DECODE, n, h, w))
+        self.ctx.check(self.ctx.lib.ir_vae_decode(self.ctx.h, self.ctx.stream(), L.ptr(z), L.ptr(out), n, h, w, L.ptr(ws), ws.numel()),
+                       "ir_vae_decode")
+        return SimpleNamespace(sample=out)
+
+
+# ====================================================================================================== DiT
+class Transformer2DModel(_DeviceModule):
+    def __init__(self, num_attention_heads=16, attention_head_dim=72, in_channels=4, out_channels=8, num_layers=28, cross_attention_dim=1152,
+                 attention_bias=True, sample_size=64, patch_size=2, activation_fn="gelu-approximate", norm_type="ada_norm_single",
+                 norm_elementwise_affine=False, norm_eps=1e-6, caption_channels=4096, interpolation_scale=None, mlp_ratio=4, **unused):
+        super().__init__()
+        C_ = num_attention_heads * attention_head_dim
+        if (in_channels != 4 or out_channels != 8 or patch_size != 2 or norm_type != "ada_norm_single" or activation_fn != "gelu-approximate" or
+                norm_elementwise_affine or not attention_bias or attention_head_dim not in (32, 64, 72) or cross_attention_dim not in (None, C_)):
+            raise NotImplementedError("the MI355X path implements the PixArt-alpha Transformer2DModel configuration "
+                                      "(tools/convert_pixart_to_diffusers.py:163-180)")
+        if sample_size == 128:
+            raise NotImplementedError("micro-conditioning (sample_size 128) is not used by the InstaRevive checkpoint")
+        self.cfg = dict(num_layers=num_layers, num_attention_heads=num_attention_heads, attention_head_dim=attention_head_dim,
+                        sample_size=sample_size, caption_channels=caption_channels, mlp=mlp_ratio * C_,
+                        interpolation_scale=float(interpolation_scale) if interpolation_scale is not None else float(max(sample_size // 64, 1)))
+        self.config = SimpleNamespace(sample_size=sample_size, out_channels=out_channels, in_channels=in_channels, patch_size=patch_size,
+                                      num_layers=num_layers, num_attention_heads=num_attention_heads, attention_head_dim=attention_head_dim,
+                                      caption_channels=caption_channels)
+        self._prompt_key = None
+
+    @classmethod
+    def from_pretrained(cls, name_or_path, subfolder=None, **kw):
+        folder = _resolve_pretrained(name_or_path, subfolder)
+        with open(os.path.join(folder, "config.json")) as f:
+            cfg = json.load(f)
+        m = cls(**{k: v for k, v in cfg.items() if not k.startswith("_")})
+        try:
+            m.load_state_dict(_load_weights_file(folder))
+        except FileNotFoundError:
+            pass  # the CLI overwrites the hub weights with InstaRevive_v1.ckpt anyway (inference.py:239-242)
+        return m
+
+    def _expected_keys(self):
+        return W.dit_expected_keys(self.cfg)
+
+    def load_state_dict(self, state_dict, strict=True):
+        res = self._check_keys(state_dict, strict, ignore=("pos_embed.pos_embed",))
+        self._sd = {k: v.detach().cpu() for k, v in state_dict.items()}
+        if self.ctx is not None:
+            self._upload()
+        return res
+
+    def _upload(self):
+        c = self.cfg
+        self.ctx.upload_all(W.pack_dit(self._sd, c))
+        self.ctx.check(self.ctx.lib.ir_dit_configure(self.ctx.h, c["num_layers"], c["num_attention_heads"], c["attention_head_dim"], c["mlp"],
+                                                      c["caption_channels"], c["sample_size"] // 2), "ir_dit_configure")
+        self._prompt_key = None
+
+    def ensure_pos(self, gh, gw):
+        name = f"dit.pos.{gh}x{gw}"
+        if not self.ctx.has(name):
+            c = self.cfg
+            self.ctx.upload(name, W.sincos_pos_embed(c["num_attention_heads"] * c["attention_head_dim"], gh, gw, c["sample_size"] // 2,
+                                                     c["interpolation_scale"]))
+
+    def set_prompt(self, encoder_hidden_states, encoder_attention_mask=None):
+        """Project the caption and cache all layers' cross-attention K/V (constant across images and tiles)."""
+        self._ready()
+        y = encoder_hidden_states
+        key = (y.data_ptr(), tuple(y.shape), y._version, None if encoder_attention_mask is None else
+               (encoder_attention_mask.data_ptr(), tuple(encoder_attention_mask.shape), encoder_attention_mask._version))
+        if key == self._prompt_key:
+            return
+        y = y.detach().to("cpu", torch.float32)
+        y = y.reshape(-1, y.shape[-2], y.shape[-1])
+        if y.shape[0] != 1:
+            if not all(torch.equal(y[0], y[i]) for i in range(1, y.shape[0])):
+                raise NotImplementedError("one shared prompt per batch (the CLI uses a single fixed prompt file, inference.py:256-259)")
+        y = y[0].contiguous()
+        n_tok = y.shape[0]
+        if encoder_attention_mask is None:
+            bias = torch.zeros(n_tok)
+        else:
+            m = encoder_attention_mask.detach().to("cpu", torch.float32)
+            if m.ndim == 2:  # diffusers Transformer2DModel.forward: 2-D masks become (1 - m) * -10000
+                bias = (1 - m[0]) * -10000.0
+            else:            # ndim == 3 ([B,1,L], what the CLI passes): used as an additive bias as is
+                bias = m.reshape(-1, m.shape[-1])[0]
+        bias = bias.contiguous()
+        self.ctx.check(self.ctx.lib.ir_dit_set_prompt(self.ctx.h, self.ctx.stream(), C.c_void_p(y.data_ptr()), C.c_void_p(bias.data_ptr()), n_tok),
+                       "ir_dit_set_prompt")
+        self._prompt_key = key
+
+    @staticmethod
+    def _scalar_timestep(timestep):
+        t = torch.as_tensor(timestep).detach().reshape(-1).to("cpu", torch.float32)
+        if t.numel() > 1 and not bool((t == t[0]).all()):
+            raise NotImplementedError("one timestep per batch (generate.py:65 expands a single value)")
+        return float(t[0])
+
+    @torch.no_grad()
+    def __call__(self, hidden_states, timestep=None, encoder_hidden_states=None, encoder_attention_mask=None, added_cond_kwargs=None,
+                 return_dict=True, **unused):
+        self._ready()
+        self.set_prompt(encoder_hidden_states, encoder_attention_mask)
+        x = hidden_states.to(self.device, torch.float32).contiguous()
+        n, ch, h, w = x.shape
+        if ch != 4 or h % 2 or w % 2:
+            raise ValueError(f"latents must be [B,4,h,w] with even h,w, got {tuple(x.shape)}")
+        self.ensure_pos(h // 2, w // 2)
+        out = torch.empty(n, 8, h, w, dtype=torch.float32, device=self.device)
+        ws = self.ctx.workspace(self.ctx.ws_bytes(L.STAGE_DIT, n, h, w))
+        self.ctx.check(self.ctx.lib.ir_dit_forward(self.ctx.h, self.ctx.stream(), L.ptr(x), self._scalar_timestep(timestep), L.ptr(out), n, h, w,
+                                                    L.ptr(ws), ws.numel()), "ir_dit_forward")
+        return SimpleNamespace(sample=out) if return_dict else (out,)
+
+    forward = __call__
+
+    @torch.no_grad()
+    def step(self, latents, timestep, alpha_cumprod, encoder_hidden_states, encoder_attention_mask=None):
+        """Fused generate_sample_1step (generate.py:22-51): returns x0 without materialising the 8-channel output."""
+        self._ready()
+        self.set_prompt(encoder_hidden_states, encoder_attention_mask)
+        x = latents.to(self.device, torch.float32).contiguous()
+        n, ch, h, w = x.shape
+        self.ensure_pos(h // 2, w // 2)
+        out = torch.empty_like(x)
+        ws = self.ctx.workspace(self.ctx.ws_bytes(L.STAGE_DIT, n, h, w))
+        self.ctx.check(self.ctx.lib.ir_dit_step(self.ctx.h, self.ctx.stream(), L.ptr(x), L.ptr(out), n, h, w, self._scalar_timestep(timestep),
+                                                 float(alpha_cumprod), L.ptr(ws), ws.numel()), "ir_dit_step")
+        return out
+
+
+# ====================================================================================================== scheduler
+class DDPMScheduler:
+    """Only what the path consumes: alphas_cumprod (generate.py:45). Linear / scaled_linear betas like diffusers."""
+
+    def __init__(self, num_train_timesteps=1000, beta_start=1e-4, beta_end=2e-2, beta_schedule="linear", **unused):
+        if beta_schedule == "linear":
+            betas = torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=torch.float32)
+        elif beta_schedule == "scaled_linear":
+            betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        else:
+            raise NotImplementedError(beta_schedule)
+        self.betas = betas
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        self.config = SimpleNamespace(num_train_timesteps=num_train_timesteps, beta_start=beta_start, beta_end=beta_end, beta_schedule=beta_schedule)
+
+    @classmethod
+    def from_pretrained(cls, name_or_path, subfolder=None, **kw):
+        try:
+            folder = _resolve_pretrained(name_or_path, subfolder)
+            with open(os.path.join(folder, "scheduler_config.json")) as f:
+                cfg = json.load(f)
+            return cls(**{k: v for k, v in cfg.items() if not k.startswith("_")})
+        except FileNotFoundError:
+            return cls()  # PixArt-alpha's scheduler: linear betas 1e-4..2e-2, T=1000 (diffusion/model/gaussian_diffusion.py:107-116)

@@ -1,0 +1,266 @@
+"""Checkpoint surface -> device layouts.
+
+Takes state dicts with the REFERENCE's key names (SwinIR: diffusion/model/swinir.py module tree; VAE: diffusers
+AutoencoderKL; DiT: diffusers Transformer2DModel, i.e. tools/convert_pixart_to_diffusers.py:30-154 output) and produces
+the named, packed tensors the C ABI expects (ir_upload / ir_*_configure in include/instarevive_hip.h):
+
+  * conv weights   [Cout][Cin][3][3] fp32 -> bf16 [Cout_pad][9][Cin_pad]  (tap-major, channel-minor = K contiguous)
+  * linear weights [N][K] fp32           -> bf16 [N_pad][K_pad]
+  * biases / norm affine / tables        -> fp32
+Padding is zero-filled, so padded channels carry exact zeros through the network. This is load-time plumbing on the
+host (the reference does the equivalent in nn.Module.load_state_dict + .to(device)); no arithmetic of the hot path.
+"""
+import math
+
+import numpy as np
+import torch
+
+
+def _bf16(t):
+    return t.to(torch.float32).to(torch.bfloat16).contiguous().view(torch.int16)
+
+
+def pad_to(x, m):
+    return (x + m - 1) // m * m
+
+
+def pack_conv3x3(w, cin_pad, cout_pad, scale=1.0):
+    co, ci, kh, kw = w.shape
+    p = torch.zeros(cout_pad, kh * kw, cin_pad, dtype=torch.float32)
+    p[:co, :, :ci] = w.to(torch.float32).permute(0, 2, 3, 1).reshape(co, kh * kw, ci) * scale
+    return _bf16(p.reshape(cout_pad, kh * kw * cin_pad))
+
+
+def pack_linear(w, n_pad, k_pad, row_map=None, col_map=None):
+    """row_map / col_map: LongTensor giving, for each ORIGINAL row / column, its position in the padded layout."""
+    w = w.to(torch.float32).reshape(w.shape[0], -1)
+    n, k = w.shape
+    rows = torch.arange(n) if row_map is None else row_map
+    cols = torch.arange(k) if col_map is None else col_map
+    p = torch.zeros(n_pad, k_pad, dtype=torch.float32)
+    p[rows[:, None], cols[None, :]] = w
+    return _bf16(p)
+
+
+def pad_vec(b, n_pad, idx=None, scale=1.0, shift=None):
+    p = torch.zeros(n_pad, dtype=torch.float32)
+    v = b.to(torch.float32) * scale
+    if shift is not None:
+        v = v + shift
+    if idx is None:
+        p[: v.numel()] = v
+    else:
+        p[idx] = v
+    return p
+
+
+# ------------------------------------------------------------------------------------------------ SwinIR
+SWIN_MEAN = (0.4488, 0.4371, 0.4040)  # diffusion/model/swinir.py:693
+
+
+def swin_relative_position_index(ws=8):
+    coords = torch.stack(torch.meshgrid(torch.arange(ws), torch.arange(ws), indexing="ij")).flatten(1)
+    rel = (coords[:, :, None] - coords[:, None, :]).permute(1, 2, 0).contiguous()
+    rel[:, :, 0] += ws - 1
+    rel[:, :, 1] += ws - 1
+    rel[:, :, 0] *= 2 * ws - 1
+    return rel.sum(-1)
+
+
+def swinir_expected_keys(cfg):
+    """Names of the reference SwinIR state dict (parameters + the two kinds of buffers a strict load carries)."""
+    C, ws = cfg["embed_dim"], cfg["window_size"]
+    keys = ["conv_first.1.weight", "conv_first.1.bias", "patch_embed.norm.weight", "patch_embed.norm.bias"]
+    for i, depth in enumerate(cfg["depths"]):
+        for j in range(depth):
+            p = f"layers.{i}.residual_group.blocks.{j}."
+            keys += [p + k for k in ("norm1.weight", "norm1.bias", "attn.relative_position_bias_table", "attn.relative_position_index",
+                                     "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias", "norm2.weight", "norm2.bias",
+                                     "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias")]
+            if j % 2 == 1:
+                keys.append(p + "attn_mask")
+        keys += [f"layers.{i}.conv.weight", f"layers.{i}.conv.bias"]
+    keys += ["norm.weight", "norm.bias", "conv_after_body.weight", "conv_after_body.bias", "conv_before_upsample.0.weight",
+             "conv_before_upsample.0.bias"]
+    for n in ("conv_up1", "conv_up2", "conv_up3", "conv_hr", "conv_last"):
+        keys += [n + ".weight", n + ".bias"]
+    return keys
+
+
+def pack_swinir(sd, cfg):
+    C, heads = cfg["embed_dim"], cfg["num_heads"][0]
+    hd, Cp = C // heads, heads * 32
+    hid = int(C * cfg["mlp_ratio"])
+    hid_p = pad_to(hid, 32)
+    nf = 64
+    r = float(cfg["img_range"])
+    out = {}
+    # channel maps: qkv rows which*C + h*hd + d -> which*Cp + h*32 + d ; attention output columns h*hd + d -> h*32 + d
+    hmap = (torch.arange(C) // hd) * 32 + torch.arange(C) % hd
+    qmap = torch.cat([hmap + i * Cp for i in range(3)])
+    rpi = swin_relative_position_index(cfg["window_size"])
+    out["swin.conv_first.w"] = pack_conv3x3(sd["conv_first.1.weight"], 192, Cp)
+    out["swin.conv_first.b"] = pad_vec(sd["conv_first.1.bias"], Cp)
+    out["swin.pe_norm.g"], out["swin.pe_norm.b"] = sd["patch_embed.norm.weight"].float(), sd["patch_embed.norm.bias"].float()
+    out["swin.norm.g"], out["swin.norm.b"] = sd["norm.weight"].float(), sd["norm.bias"].float()
+    for i, depth in enumerate(cfg["depths"]):
+        for j in range(depth):
+            s, d = f"layers.{i}.residual_group.blocks.{j}.", f"swin.l{i}.b{j}."
+            out[d + "n1.g"], out[d + "n1.b"] = sd[s + "norm1.weight"].float(), sd[s + "norm1.bias"].float()
+            out[d + "n2.g"], out[d + "n2.b"] = sd[s + "norm2.weight"].float(), sd[s + "norm2.bias"].float()
+            out[d + "qkv.w"] = pack_linear(sd[s + "attn.qkv.weight"], 3 * Cp, Cp, row_map=qmap)
+            out[d + "qkv.b"] = pad_vec(sd[s + "attn.qkv.bias"], 3 * Cp, idx=qmap)
+            out[d + "proj.w"] = pack_linear(sd[s + "attn.proj.weight"], Cp, Cp, col_map=hmap)
+            out[d + "proj.b"] = pad_vec(sd[s + "attn.proj.bias"], Cp)
+            out[d + "fc1.w"] = pack_linear(sd[s + "mlp.fc1.weight"], hid_p, Cp)
+            out[d + "fc1.b"] = pad_vec(sd[s + "mlp.fc1.bias"], hid_p)
+            out[d + "fc2.w"] = pack_linear(sd[s + "mlp.fc2.weight"], Cp, hid_p)
+            out[d + "fc2.b"] = pad_vec(sd[s + "mlp.fc2.bias"], Cp)
+            table = sd[s + "attn.relative_position_bias_table"].float()
+            bias = table[rpi.view(-1)].view(64, 64, heads)                       # [query][key][head]  (swinir.py:138-140)
+            out[d + "biasT"] = (bias.permute(2, 1, 0) * math.log2(math.e)).contiguous()  # [head][key][query], log2 domain
+        out[f"swin.l{i}.conv.w"] = pack_conv3x3(sd[f"layers.{i}.conv.weight"], Cp, Cp)
+        out[f"swin.l{i}.conv.b"] = pad_vec(sd[f"layers.{i}.conv.bias"], Cp)
+    out["swin.after_body.w"] = pack_conv3x3(sd["conv_after_body.weight"], Cp, Cp)
+    out["swin.after_body.b"] = pad_vec(sd["conv_after_body.bias"], Cp)
+    out["swin.before_up.w"] = pack_conv3x3(sd["conv_before_upsample.0.weight"], Cp, nf)
+    out["swin.before_up.b"] = pad_vec(sd["conv_before_upsample.0.bias"], nf)
+    for src, dst in (("conv_up1", "up1"), ("conv_up2", "up2"), ("conv_up3", "up3"), ("conv_hr", "hr")):
+        out[f"swin.{dst}.w"] = pack_conv3x3(sd[src + ".weight"], nf, nf)
+        out[f"swin.{dst}.b"] = pad_vec(sd[src + ".bias"], nf)
+    # conv_last with `x / img_range + mean` (swinir.py:903) folded in
+    out["swin.last.w"] = pack_conv3x3(sd["conv_last.weight"], nf, 32, scale=1.0 / r)
+    out["swin.last.b"] = pad_vec(sd["conv_last.bias"], 32, scale=1.0 / r, shift=torch.tensor(SWIN_MEAN))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ VAE (diffusers keys)
+def _attn_key(sd, p, new, old, leaf):
+    k = f"{p}.{new}.{leaf}"
+    return sd[k] if k in sd else sd[f"{p}.{old}.{leaf}"]
+
+
+def pack_vae(sd, cfg, encoder=True, decoder=True):
+    ch, mult, nrb = cfg["ch"], list(cfg["ch_mult"]), cfg["num_res_blocks"]
+    nl = len(mult)
+    out = {}
+
+    def conv(dst, src, cin_pad=None, cout_pad=None):
+        w = sd[src + ".weight"]
+        co, ci = w.shape[:2]
+        out[dst + ".w"] = pack_conv3x3(w, cin_pad or ci, cout_pad or co)
+        out[dst + ".b"] = pad_vec(sd[src + ".bias"], cout_pad or co)
+
+    def norm(dst, src):
+        out[dst + ".g"], out[dst + ".b"] = sd[src + ".weight"].float().contiguous(), sd[src + ".bias"].float().contiguous()
+
+    def res(dst, src):
+        norm(dst + ".n1", src + ".norm1"); conv(dst + ".c1", src + ".conv1")
+        norm(dst + ".n2", src + ".norm2"); conv(dst + ".c2", src + ".conv2")
+        if src + ".conv_shortcut.weight" in sd:
+            w = sd[src + ".conv_shortcut.weight"]
+            out[dst + ".sc.w"] = pack_linear(w, w.shape[0], w.shape[1])
+            out[dst + ".sc.b"] = sd[src + ".conv_shortcut.bias"].float().contiguous()
+
+    def attn(dst, src):
+        norm(dst + ".n", src + ".group_norm")
+        for a, new, old in (("q", "to_q", "query"), ("k", "to_k", "key"), ("v", "to_v", "value"), ("o", "to_out.0", "proj_attn")):
+            w = _attn_key(sd, src, new, old, "weight")
+            out[f"{dst}.{a}.w"] = pack_linear(w, w.shape[0], w.shape[0])
+            out[f"{dst}.{a}.b"] = _attn_key(sd, src, new, old, "bias").float().contiguous()
+
+    if encoder:
+        conv("vae.enc.conv_in", "encoder.conv_in", cin_pad=32)
+        for l in range(nl):
+            for j in range(nrb):
+                res(f"vae.enc.down{l}.res{j}", f"encoder.down_blocks.{l}.resnets.{j}")
+            if l != nl - 1:
+                conv(f"vae.enc.down{l}.ds", f"encoder.down_blocks.{l}.downsamplers.0.conv")
+        res("vae.enc.mid.res0", "encoder.mid_block.resnets.0")
+        attn("vae.enc.mid.attn", "encoder.mid_block.attentions.0")
+        res("vae.enc.mid.res1", "encoder.mid_block.resnets.1")
+        norm("vae.enc.norm_out", "encoder.conv_norm_out")
+        conv("vae.enc.conv_out", "encoder.conv_out", cout_pad=32)
+        out["vae.quant.w"] = sd["quant_conv.weight"].float().reshape(8, 8).contiguous()
+        out["vae.quant.b"] = sd["quant_conv.bias"].float().contiguous()
+    if decoder:
+        conv("vae.dec.conv_in", "decoder.conv_in", cin_pad=32)
+        res("vae.dec.mid.res0", "decoder.mid_block.resnets.0")
+        attn("vae.dec.mid.attn", "decoder.mid_block.attentions.0")
+        res("vae.dec.mid.res1", "decoder.mid_block.resnets.1")
+        for i in range(nl):  # diffusers up_blocks.i  <->  ldm up[nl-1-i]
+            l = nl - 1 - i
+            for j in range(nrb + 1):
+                res(f"vae.dec.up{l}.res{j}", f"decoder.up_blocks.{i}.resnets.{j}")
+            if l != 0:
+                conv(f"vae.dec.up{l}.us", f"decoder.up_blocks.{i}.upsamplers.0.conv")
+        norm("vae.dec.norm_out", "decoder.conv_norm_out")
+        conv("vae.dec.conv_out", "decoder.conv_out", cout_pad=32)
+        out["vae.post_quant.w"] = sd["post_quant_conv.weight"].float().reshape(4, 4).contiguous()
+        out["vae.post_quant.b"] = sd["post_quant_conv.bias"].float().contiguous()
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ DiT (diffusers keys)
+def dit_expected_keys(cfg):
+    keys = []
+    for base in ("pos_embed.proj", "caption_projection.linear_1", "caption_projection.linear_2", "adaln_single.emb.timestep_embedder.linear_1",
+                 "adaln_single.emb.timestep_embedder.linear_2", "adaln_single.linear", "proj_out"):
+        keys += [base + ".weight", base + ".bias"]
+    keys.append("scale_shift_table")
+    for d in range(cfg["num_layers"]):
+        p = f"transformer_blocks.{d}."
+        keys.append(p + "scale_shift_table")
+        for a in ("attn1", "attn2"):
+            for n in ("to_q", "to_k", "to_v", "to_out.0"):
+                keys += [p + f"{a}.{n}.weight", p + f"{a}.{n}.bias"]
+        keys += [p + "ff.net.0.proj.weight", p + "ff.net.0.proj.bias", p + "ff.net.2.weight", p + "ff.net.2.bias"]
+    return keys
+
+
+def pack_dit(sd, cfg):
+    C = cfg["num_attention_heads"] * cfg["attention_head_dim"]
+    out = {}
+
+    def lin(dst, w, b, k_pad=None, n_pad=None):
+        w = w.reshape(w.shape[0], -1)
+        out[dst + ".w"] = pack_linear(w, n_pad or w.shape[0], k_pad or w.shape[1])
+        out[dst + ".b"] = pad_vec(b, n_pad or w.shape[0])
+
+    lin("dit.patch", sd["pos_embed.proj.weight"], sd["pos_embed.proj.bias"], k_pad=32)  # k = c*4 + p*2 + q
+    lin("dit.cap1", sd["caption_projection.linear_1.weight"], sd["caption_projection.linear_1.bias"])
+    lin("dit.cap2", sd["caption_projection.linear_2.weight"], sd["caption_projection.linear_2.bias"])
+    lin("dit.final", sd["proj_out.weight"], sd["proj_out.bias"], n_pad=32)
+    for dst, src in (("dit.temb1", "adaln_single.emb.timestep_embedder.linear_1"), ("dit.temb2", "adaln_single.emb.timestep_embedder.linear_2"),
+                     ("dit.tblock", "adaln_single.linear")):
+        out[dst + ".w"], out[dst + ".b"] = sd[src + ".weight"].float().contiguous(), sd[src + ".bias"].float().contiguous()
+    out["dit.final_sst"] = sd["scale_shift_table"].float().contiguous()
+    for d in range(cfg["num_layers"]):
+        s, p = f"transformer_blocks.{d}.", f"dit.l{d}."
+        out[p + "sst"] = sd[s + "scale_shift_table"].float().contiguous()
+        lin(p + "qkv", torch.cat([sd[s + f"attn1.{n}.weight"] for n in ("to_q", "to_k", "to_v")], 0),
+            torch.cat([sd[s + f"attn1.{n}.bias"] for n in ("to_q", "to_k", "to_v")], 0))
+        lin(p + "ao", sd[s + "attn1.to_out.0.weight"], sd[s + "attn1.to_out.0.bias"])
+        lin(p + "cq", sd[s + "attn2.to_q.weight"], sd[s + "attn2.to_q.bias"])
+        lin(p + "ckv", torch.cat([sd[s + "attn2.to_k.weight"], sd[s + "attn2.to_v.weight"]], 0),
+            torch.cat([sd[s + "attn2.to_k.bias"], sd[s + "attn2.to_v.bias"]], 0))
+        lin(p + "co", sd[s + "attn2.to_out.0.weight"], sd[s + "attn2.to_out.0.bias"])
+        lin(p + "fc1", sd[s + "ff.net.0.proj.weight"], sd[s + "ff.net.0.proj.bias"])
+        lin(p + "fc2", sd[s + "ff.net.2.weight"], sd[s + "ff.net.2.bias"])
+    return out
+
+
+def sincos_pos_embed(embed_dim, gh, gw, base_size, interpolation_scale=1.0):
+    """2-D sin-cos table regenerated per latent size, as the reference does on the host with numpy
+    (PixArtMS.py:177-182 / PixArt.py:258-307; diffusers PatchEmbed cropped/regenerated table). fp32 [gh*gw, D]."""
+    grid_h = np.arange(gh, dtype=np.float32) / (gh / base_size) / interpolation_scale
+    grid_w = np.arange(gw, dtype=np.float32) / (gw / base_size) / interpolation_scale
+    grid = np.stack(np.meshgrid(grid_w, grid_h), axis=0).reshape([2, 1, gw, gh])
+
+    def one(d, pos):
+        omega = 1.0 / 10000 ** (np.arange(d // 2, dtype=np.float64) / (d / 2.0))
+        o = np.einsum("m,d->md", pos.reshape(-1), omega)
+        return np.concatenate([np.sin(o), np.cos(o)], axis=1)
+
+    emb = np.concatenate([one(embed_dim // 2, grid[0]), one(embed_dim // 2, grid[1])], axis=1)
+    return torch.from_numpy(emb).to(torch.float32).contiguous()

@@ -262,9 +262,10 @@ def test_swin_window_attention(ctx, h, w, shift):
     close(got[..., :hd], ref, 2 ** -6, 6e-3, "swin attention")
 
 
-def test_softmax_rows(ctx):
+@pytest.mark.parametrize("rows,cols", [(300, 4096), (64, 64), (5, 260), (3, 1028)])
+def test_softmax_rows(ctx, rows, cols):
     g = torch.Generator().manual_seed(9)
-    x = torch.randn(300, 4096, generator=g) * 4
-    y = torch.empty(300, 4096, dtype=torch.int16, device="cuda")
-    ctx.check(ctx.lib.ir_op_softmax_rows(ctx.h, ctx.stream(), P(x.cuda()), P(y), 300, 4096), "softmax")
+    x = torch.randn(rows, cols, generator=g) * 4
+    y = torch.empty(rows, cols, dtype=torch.int16, device="cuda")
+    ctx.check(ctx.lib.ir_op_softmax_rows(ctx.h, ctx.stream(), P(x.cuda()), P(y), rows, cols), "softmax")
     close(L.from_bf16_bits(y).cpu(), x.softmax(-1), 2 ** -7, 1e-6, "softmax rows")
