@@ -1,0 +1,271 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 512 -> 2048 one-step super-resolution images/sec on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A step is ONE pass of the hot path — process() of test_scripts/inference.py:55-166: SwinIR -> VAE encode -> one
+PixArt-DiT step at t=400 (x0 from eps) -> VAE decode -> uint8 — over one batch of synthetic LQ images per rank, through
+the fused C-ABI entry ir_pipeline with input and output resident in HBM. Workload = BASELINE.json configs[1]:
+512x512 LQ, sr_scale 4 => 2048x2048 network input, untiled, batch 1 per GPU, full-size architectures (SwinIR 15.8 M,
+VAE 83.7 M, DiT 611 M parameters) with seeded random weights (no checkpoints exist offline; throughput is weight-
+independent). Images are independent, so ranks shard the batch with no data-path collective (weak scaling).
+
+Also printed on the same JSON line:
+  roofline     : the dominant kernel class (by GPU time) measured with HIP events on the launch stream during the timed
+                 steps (ir_profile_begin/end), algorithmic FLOPs / time vs the dense bf16 MFMA peak (2.5 PFLOP/s);
+  cpu_baseline : the oracle (CPU fp32 restatement of the reference, kind "port") timed on this box's host cores on a
+                 bounded sample (one 512x512 network pass), extrapolated to the 2048x2048 workload by algorithmic FLOPs.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA peak (/opt/skills/guides/MI355X_MICROARCH.md, chip-level table)
+PEAK_HBM_GBS = 8000.0
+
+
+# ---------------------------------------------------------------- algorithmic FLOP model (BASELINE.md section 2, 2*MAC, matmul/conv only)
+def flops_model(h, w, n_tok=300):
+    px = h * w
+    swin = 0.1815e12 / (512 * 512) * px                       # linear in pixels
+    t_vae = px // 64
+    enc = (1.1167e12 - 4 * 4096 ** 2 * 512) / (512 * 512) * px + 4.0 * t_vae ** 2 * 512
+    dec = (2.5145e12 - 4 * 4096 ** 2 * 512) / (512 * 512) * px + 4.0 * t_vae ** 2 * 512
+    t = px // 256
+    C, L = 1152, 28
+    dit = (14 * C * C * 2 * L + 4 * n_tok * C * L) * t + (n_tok * 2 * C * C * 2 * L + n_tok * (4096 * C + C * C) * 2) + 4.0 * t * t * C * L \
+        + t * (16 * C + 32 * C) * 2
+    return dict(swinir=swin, vae_encode=enc, dit=dit, vae_decode=dec, total=swin + enc + dit + dec)
+
+
+def conv_flops_model(h, w):
+    """Algorithmic FLOPs of the 3x3-convolution class alone (what the `conv3x3` kernel class executes, without padding)."""
+    px = h * w
+    # SwinIR: conv_first 192->180, 8 RSTB convs + conv_after_body 180->180 (at 1/64 res), before_up 180->64, up1..3, hr, last
+    g = px / 64
+    swin = 2 * 9 * (g * (192 * 180 + 9 * 180 * 180 + 180 * 64) + 64 * 64 * (4 * g + 16 * g + 64 * g + 64 * g) + 64 * 3 * 64 * g)
+    # VAE convs (incl. conv_in / conv_out); resnet shortcuts and attention projections are 1x1 -> `linear` class
+    def res(cin, cout, p):
+        return 2 * 9 * p * (cin * cout + cout * cout)
+    enc = 2 * 9 * px * 3 * 128 + res(128, 128, px) * 2 + 2 * 9 * (px / 4) * 128 * 128 + res(128, 256, px / 4) + res(256, 256, px / 4) + \
+        2 * 9 * (px / 16) * 256 * 256 + res(256, 512, px / 16) + res(512, 512, px / 16) + 2 * 9 * (px / 64) * 512 * 512 + \
+        res(512, 512, px / 64) * 4 + 2 * 9 * (px / 64) * 512 * 8
+    dec = 2 * 9 * (px / 64) * 4 * 512 + res(512, 512, px / 64) * 5 + 2 * 9 * (px / 16) * 512 * 512 + res(512, 512, px / 16) * 3 + \
+        2 * 9 * (px / 4) * 512 * 512 + res(512, 256, px / 4) + res(256, 256, px / 4) * 2 + 2 * 9 * px * 256 * 256 + res(256, 128, px) + \
+        res(128, 128, px) * 2 + 2 * 9 * px * 128 * 3
+    return swin + enc + dec
+
+
+# ---------------------------------------------------------------- synthetic weights in the reference checkpoints' key layout
+def random_state_dict(shapes, seed):
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for name, shape in shapes.items():
+        shape = tuple(shape)
+        leaf = name.rsplit(".", 1)[-1]
+        if "table" in name:
+            t = (torch.rand(shape, generator=g) - 0.5) * 0.4
+        elif leaf == "bias":
+            t = (torch.rand(shape, generator=g) - 0.5) * 0.1
+        elif len(shape) == 1:
+            t = 1.0 + (torch.rand(shape, generator=g) - 0.5) * 0.2
+        else:
+            fan_in = int(np.prod(shape[1:]))
+            t = (torch.rand(shape, generator=g) - 0.5) * 2 * (3.0 / fan_in) ** 0.5
+        sd[name] = t
+    return sd
+
+
+def build_models(device, log):
+    from instarevive_amd.models import AutoencoderKL, DDPMScheduler, SwinIR, Transformer2DModel
+    from instarevive_amd import weights as W
+    t0 = time.time()
+    swin_cfg = dict(embed_dim=180, depths=[6] * 8, num_heads=[6] * 8, window_size=8, mlp_ratio=2)
+    sds = dict(swin=random_state_dict(W.swinir_shapes(swin_cfg), 1),
+               vae=random_state_dict(W.vae_shapes(dict(ch=128, ch_mult=(1, 2, 4, 4), num_res_blocks=2)), 2),
+               dit=random_state_dict(W.dit_shapes(dict(num_layers=28, num_attention_heads=16, attention_head_dim=72, caption_channels=4096)), 3))
+    swin = SwinIR(img_size=64, patch_size=1, in_chans=3, embed_dim=180, depths=[6] * 8, num_heads=[6] * 8, window_size=8, mlp_ratio=2, sf=8,
+                  img_range=1.0, upsampler="nearest+conv", resi_connection="1conv", unshuffle=True, unshuffle_scale=8)
+    swin.load_state_dict(sds["swin"], strict=False)
+    vae = AutoencoderKL()
+    vae.load_state_dict(sds["vae"])
+    dit = Transformer2DModel()
+    dit.load_state_dict(sds["dit"])
+    for m in (swin, vae, dit):
+        m.to(device)
+    log(f"models built and uploaded in {time.time() - t0:.1f}s")
+    return swin, vae, dit, DDPMScheduler(), sds
+
+
+def synthetic_prompt(seed=1234, n_tok=300, valid=25):
+    g = torch.Generator().manual_seed(seed)
+    y = torch.randn(1, n_tok, 4096, generator=g) * 0.1
+    mask = torch.zeros(1, 1, n_tok)
+    mask[..., :valid] = 1
+    return y, mask
+
+
+def synthetic_lq(n, h, w, seed):
+    """uint8 HWC images: uniform noise low-passed by a 3x3 box (image-like spectrum), as SURVEY.md section 8(d) prescribes."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(n, 3, h, w, generator=g)
+    x = torch.nn.functional.avg_pool2d(torch.nn.functional.pad(x, (1, 1, 1, 1), mode="replicate"), 3, stride=1)
+    return (x.permute(0, 2, 3, 1) * 255).to(torch.uint8).contiguous()
+
+
+def upscale_bicubic(imgs_u8, scale):
+    from PIL import Image
+    out = []
+    for im in imgs_u8.numpy():
+        pil = Image.fromarray(im)
+        out.append(np.array(pil.resize((int(np.ceil(pil.size[0] * scale)), int(np.ceil(pil.size[1] * scale))), Image.BICUBIC)))
+    return torch.from_numpy(np.stack(out))
+
+
+def cpu_baseline(sds, y, mask, h_full, w_full, log):
+    """Oracle (kind 'port') on the host cores: one 512x512 network pass, extrapolated by algorithmic FLOPs."""
+    from oracle import dit as odit, glue as oglue, swinir as oswin, vae as ovae
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    hs = ws = 512
+    img = synthetic_lq(1, hs, ws, 77).numpy()
+    t0 = time.time()
+    oglue.process([img[0]], lambda x: oswin.swinir_forward(sds["swin"], x), lambda x: ovae.vae_encode_mean(sds["vae"], x),
+                  lambda lat, t, yy, mm: odit.dit_forward(sds["dit"], lat, t, yy, mm), lambda z: ovae.vae_decode(sds["vae"], z),
+                  oglue.alphas_cumprod_diffusers(), y, mask)
+    dt = time.time() - t0
+    f_s, f_full = flops_model(hs, ws)["total"], flops_model(h_full, w_full)["total"]
+    log(f"cpu baseline: 512x512 pass {dt:.1f}s on {cores} threads ({f_s / dt / 1e12:.3f} TFLOP/s)")
+    return dict(value=1.0 / (dt * f_full / f_s), unit="images/sec", cores=cores, kind="port",
+                sample=f"one 512x512 network pass of the fp32 oracle ({f_s / 1e12:.2f} of {f_full / 1e12:.2f} TFLOP), {dt:.2f} s, "
+                       f"extrapolated to {h_full}x{w_full} by algorithmic FLOPs")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--lq", type=int, default=512, help="LQ edge (pixels)")
+    ap.add_argument("--sr_scale", type=float, default=4.0)
+    ap.add_argument("--batch", type=int, default=1, help="images per GPU per step")
+    ap.add_argument("--tiled", action="store_true")
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X GPU; the product path has no CPU fallback")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    def log(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    from instarevive_amd import _lib as L
+    swin, vae, dit, sched, sds = build_models(device, log)
+    ctx = dit.ctx
+    y, mask = synthetic_prompt()
+    dit.set_prompt(y.to(device), mask.to(device))
+
+    lq = synthetic_lq(args.batch, args.lq, args.lq, 1000 + rank)
+    net_in = upscale_bicubic(lq, args.sr_scale) if args.sr_scale != 1 else lq        # inference.py:265-269 (host, outside the timed region)
+    n, h, w = net_in.shape[:3]
+    assert h % 64 == 0 and w % 64 == 0
+    flags = (L.FLAG_TILED | L.FLAG_FIX_WAVELET) if args.tiled else 0
+    tile_size, tile_stride = 512, 448
+    if args.tiled:
+        dit.ensure_pos(tile_size // 16, tile_size // 16)
+    else:
+        dit.ensure_pos(h // 16, w // 16)
+    din = net_in.to(device)
+    dout = torch.empty_like(din)
+    ws = ctx.workspace(ctx.ws_bytes(L.STAGE_PIPELINE, n, h, w, flags, tile_size, tile_stride))
+    log(f"workload {n}x{h}x{w} per GPU, workspace {ws.numel() / 2**30:.1f} GiB, flags {flags}")
+    acp, sf = float(sched.alphas_cumprod[400]), float(vae.config.scaling_factor)
+
+    def step():
+        ctx.check(ctx.lib.ir_pipeline(ctx.h, ctx.stream(), L.ptr(din), L.ptr(dout), None, n, h, w, flags, tile_size, tile_stride, 400.0, acp, sf,
+                                      L.ptr(ws), ws.numel()), "ir_pipeline")
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    ctx.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = ctx.profile_end()
+    if dist is not None:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+    ms_per_step = dt / args.steps * 1e3
+    value = world * n * args.steps / dt
+
+    if rank == 0:
+        fm = flops_model(h, w)
+        total_ms = sum(v["ms"] for v in prof.values())
+        dom = max(prof, key=lambda k: prof[k]["ms"])
+        for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
+            if v["launches"]:
+                log(f"  {k:13s} {v['ms'] / args.steps:9.2f} ms/step  {v['launches'] // args.steps:5d} launches/step  "
+                    f"{v['flops'] / max(v['ms'], 1e-9) / 1e9:8.1f} TFLOP/s(exec)  {v['bytes'] / max(v['ms'], 1e-9) / 1e6:8.1f} GB/s")
+        log(f"  kernels {total_ms / args.steps:.1f} ms/step of {ms_per_step:.1f} ms/step wall; whole path {fm['total'] * n / (ms_per_step / 1e3) / 1e12:.1f} TFLOP/s algorithmic")
+        d = prof[dom]
+        if dom == "conv3x3" and not args.tiled:
+            alg = conv_flops_model(h, w) * n * args.steps   # algorithmic (unpadded) FLOPs of the class
+        else:
+            alg = d["flops"]
+        if d["flops"] > 0:
+            ach = alg / (d["ms"] / 1e3) / 1e12
+            roof = dict(bound="mfma", kernel=dom, achieved=round(ach, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_BF16_TFLOPS, 4),
+                        traffic=None, launches_per_step=d["launches"] // args.steps, avg_launch_ms=round(d["ms"] / max(d["launches"], 1), 4),
+                        share_of_gpu_time=round(d["ms"] / total_ms, 3))
+        else:
+            ach = d["bytes"] / (d["ms"] / 1e3) / 1e9
+            roof = dict(bound="hbm", kernel=dom, achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(ach / PEAK_HBM_GBS, 4), traffic=None,
+                        launches_per_step=d["launches"] // args.steps, avg_launch_ms=round(d["ms"] / max(d["launches"], 1), 4),
+                        share_of_gpu_time=round(d["ms"] / total_ms, 3))
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(sds, y, mask, h, w, log)
+        print(json.dumps({
+            "metric": "512->2048 one-step SR images/sec", "value": round(value, 4), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.lq}x{args.lq} LQ, sr_scale {args.sr_scale:g} -> {h}x{w} network input, "
+                                   f"{'tiled 512/448 + wavelet' if args.tiled else 'untiled'}, batch {n} per GPU, full SwinIR->VAE-enc->DiT(t=400)->VAE-dec path",
+                       "parallelism": f"dp{world}", "weights": "seeded random, full-size architectures"},
+            "algorithmic_tflop_per_image": round(fm["total"] / 1e12, 2),
+            "path_tflops": round(fm["total"] * n * world / (ms_per_step / 1e3) / 1e12, 1),
+            "roofline": roof, "cpu_baseline": cpu}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -69,6 +69,12 @@ int ir_color_fix(ir_ctx* ctx, void* stream, int kind /*IR_FLAG_FIX_**/, const fl
 int ir_pipeline(ir_ctx* ctx, void* stream, const uint8_t* in, uint8_t* out, uint8_t* stage1, int n, int h, int w, int flags,
                 int tile_size, int tile_stride, float timestep, float alpha_cumprod, float scaling_factor, void* ws, size_t ws_bytes);
 
+/* Per-launch timing with HIP events recorded on the launch stream (measurement aid for bench.py; no reference
+ * counterpart). Classes: 0 conv3x3, 1 linear, 2 flash attention, 3 window attention, 4 groupnorm, 5 layernorm,
+ * 6 row softmax, 7 transpose, 8 other. ir_profile_end synchronises the stream and sums per class. */
+int ir_profile_begin(ir_ctx* ctx);
+int ir_profile_end(ir_ctx* ctx, void* stream, int n_classes, double* ms, double* flops, double* bytes, long long* launches);
+
 /* image <-> tensor helpers of process() (inference.py:92-93,159-161) */
 int ir_u8_to_nchw(ir_ctx* ctx, void* stream, const uint8_t* in, float* out, int n, int h, int w);
 int ir_nchw_to_u8(ir_ctx* ctx, void* stream, const float* in, uint8_t* out, int n, int h, int w);

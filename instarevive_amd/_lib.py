@@ -16,7 +16,7 @@ SYMBOLS = [
     "ir_abi_version", "ir_init", "ir_destroy", "ir_last_error", "ir_upload", "ir_has_tensor",
     "ir_swinir_configure", "ir_vae_configure", "ir_dit_configure", "ir_dit_set_prompt", "ir_workspace_bytes",
     "ir_swinir_forward", "ir_vae_encode", "ir_dit_forward", "ir_dit_step", "ir_vae_decode", "ir_color_fix",
-    "ir_pipeline", "ir_u8_to_nchw", "ir_nchw_to_u8",
+    "ir_pipeline", "ir_u8_to_nchw", "ir_nchw_to_u8", "ir_profile_begin", "ir_profile_end",
     "ir_op_conv", "ir_op_linear", "ir_op_groupnorm", "ir_op_layernorm", "ir_op_attention", "ir_op_swin_attention",
     "ir_op_softmax_rows",
 ]
@@ -64,6 +64,8 @@ def load_library():
     lib.ir_vae_decode.argtypes = [vp, vp, vp, vp, i, i, i, vp, sz]
     lib.ir_color_fix.argtypes = [vp, vp, i, vp, vp, vp, i, i, i, vp, sz]
     lib.ir_pipeline.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, f, f, f, vp, sz]
+    lib.ir_profile_begin.argtypes = [vp]
+    lib.ir_profile_end.argtypes = [vp, vp, i, vp, vp, vp, vp]
     lib.ir_u8_to_nchw.argtypes = [vp, vp, vp, vp, i, i, i]
     lib.ir_nchw_to_u8.argtypes = [vp, vp, vp, vp, i, i, i]
     lib.ir_op_conv.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, i, i, i, f, vp, i, i]
@@ -151,6 +153,18 @@ class Context:
             self._ws = None
             self._ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
         return self._ws
+
+    PROFILE_CLASSES = ["conv3x3", "linear", "flash_attn", "swin_attn", "groupnorm", "layernorm", "softmax_rows", "transpose", "other"]
+
+    def profile_begin(self):
+        self.check(self.lib.ir_profile_begin(self.h), "ir_profile_begin")
+
+    def profile_end(self):
+        """-> {class: dict(ms, flops, bytes, launches)} summed over every launch since profile_begin()."""
+        n = len(self.PROFILE_CLASSES)
+        ms, fl, by, la = (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)(), (C.c_longlong * n)()
+        self.check(self.lib.ir_profile_end(self.h, self.stream(), n, ms, fl, by, la), "ir_profile_end")
+        return {k: dict(ms=ms[i], flops=fl[i], bytes=by[i], launches=int(la[i])) for i, k in enumerate(self.PROFILE_CLASSES)}
 
     def ws_bytes(self, stage, n, h, w, flags=0, tile_size=0, tile_stride=0):
         return int(self.lib.ir_workspace_bytes(self.h, stage, n, h, w, flags, tile_size, tile_stride))

@@ -264,3 +264,93 @@ def sincos_pos_embed(embed_dim, gh, gw, base_size, interpolation_scale=1.0):
 
     emb = np.concatenate([one(embed_dim // 2, grid[0]), one(embed_dim // 2, grid[1])], axis=1)
     return torch.from_numpy(emb).to(torch.float32).contiguous()
+
+
+# ------------------------------------------------------------------------------------------------ checkpoint shape tables
+def swinir_shapes(cfg):
+    """name -> shape of the reference SwinIR parameters (buffers relative_position_index / attn_mask are derived, not stored)."""
+    C, ws, hid = cfg["embed_dim"], cfg["window_size"], int(cfg["embed_dim"] * cfg["mlp_ratio"])
+    s = {"conv_first.1.weight": (C, 192, 3, 3), "conv_first.1.bias": (C,), "patch_embed.norm.weight": (C,), "patch_embed.norm.bias": (C,)}
+    for i, depth in enumerate(cfg["depths"]):
+        nh = cfg["num_heads"][i]
+        for j in range(depth):
+            p = f"layers.{i}.residual_group.blocks.{j}."
+            s.update({p + "norm1.weight": (C,), p + "norm1.bias": (C,), p + "attn.relative_position_bias_table": ((2 * ws - 1) ** 2, nh),
+                      p + "attn.qkv.weight": (3 * C, C), p + "attn.qkv.bias": (3 * C,), p + "attn.proj.weight": (C, C), p + "attn.proj.bias": (C,),
+                      p + "norm2.weight": (C,), p + "norm2.bias": (C,), p + "mlp.fc1.weight": (hid, C), p + "mlp.fc1.bias": (hid,),
+                      p + "mlp.fc2.weight": (C, hid), p + "mlp.fc2.bias": (C,)})
+        s.update({f"layers.{i}.conv.weight": (C, C, 3, 3), f"layers.{i}.conv.bias": (C,)})
+    s.update({"norm.weight": (C,), "norm.bias": (C,), "conv_after_body.weight": (C, C, 3, 3), "conv_after_body.bias": (C,),
+              "conv_before_upsample.0.weight": (64, C, 3, 3), "conv_before_upsample.0.bias": (64,)})
+    for n in ("conv_up1", "conv_up2", "conv_up3", "conv_hr"):
+        s.update({n + ".weight": (64, 64, 3, 3), n + ".bias": (64,)})
+    s.update({"conv_last.weight": (3, 64, 3, 3), "conv_last.bias": (3,)})
+    return s
+
+
+def vae_shapes(cfg):
+    ch, mult, nrb, z = cfg["ch"], list(cfg["ch_mult"]), cfg["num_res_blocks"], cfg.get("z_channels", 4)
+    nl = len(mult)
+    s = {}
+
+    def res(p, cin, cout):
+        s.update({p + ".norm1.weight": (cin,), p + ".norm1.bias": (cin,), p + ".conv1.weight": (cout, cin, 3, 3), p + ".conv1.bias": (cout,),
+                  p + ".norm2.weight": (cout,), p + ".norm2.bias": (cout,), p + ".conv2.weight": (cout, cout, 3, 3), p + ".conv2.bias": (cout,)})
+        if cin != cout:
+            s.update({p + ".conv_shortcut.weight": (cout, cin, 1, 1), p + ".conv_shortcut.bias": (cout,)})
+
+    def attn(p, c):
+        s.update({p + ".group_norm.weight": (c,), p + ".group_norm.bias": (c,)})
+        for n in ("to_q", "to_k", "to_v", "to_out.0"):
+            s.update({f"{p}.{n}.weight": (c, c), f"{p}.{n}.bias": (c,)})
+
+    s.update({"encoder.conv_in.weight": (ch, 3, 3, 3), "encoder.conv_in.bias": (ch,)})
+    cin = ch
+    for l in range(nl):
+        cout = ch * mult[l]
+        for j in range(nrb):
+            res(f"encoder.down_blocks.{l}.resnets.{j}", cin, cout)
+            cin = cout
+        if l != nl - 1:
+            s.update({f"encoder.down_blocks.{l}.downsamplers.0.conv.weight": (cin, cin, 3, 3), f"encoder.down_blocks.{l}.downsamplers.0.conv.bias": (cin,)})
+    res("encoder.mid_block.resnets.0", cin, cin)
+    attn("encoder.mid_block.attentions.0", cin)
+    res("encoder.mid_block.resnets.1", cin, cin)
+    s.update({"encoder.conv_norm_out.weight": (cin,), "encoder.conv_norm_out.bias": (cin,), "encoder.conv_out.weight": (2 * z, cin, 3, 3),
+              "encoder.conv_out.bias": (2 * z,), "quant_conv.weight": (2 * z, 2 * z, 1, 1), "quant_conv.bias": (2 * z,)})
+    cin = ch * mult[-1]
+    s.update({"post_quant_conv.weight": (z, z, 1, 1), "post_quant_conv.bias": (z,), "decoder.conv_in.weight": (cin, z, 3, 3), "decoder.conv_in.bias": (cin,)})
+    res("decoder.mid_block.resnets.0", cin, cin)
+    attn("decoder.mid_block.attentions.0", cin)
+    res("decoder.mid_block.resnets.1", cin, cin)
+    for i in range(nl):
+        cout = ch * mult[nl - 1 - i]
+        for j in range(nrb + 1):
+            res(f"decoder.up_blocks.{i}.resnets.{j}", cin, cout)
+            cin = cout
+        if i != nl - 1:
+            s.update({f"decoder.up_blocks.{i}.upsamplers.0.conv.weight": (cin, cin, 3, 3), f"decoder.up_blocks.{i}.upsamplers.0.conv.bias": (cin,)})
+    s.update({"decoder.conv_norm_out.weight": (cin,), "decoder.conv_norm_out.bias": (cin,), "decoder.conv_out.weight": (3, cin, 3, 3),
+              "decoder.conv_out.bias": (3,)})
+    return s
+
+
+def dit_shapes(cfg):
+    C = cfg["num_attention_heads"] * cfg["attention_head_dim"]
+    cap, mlp = cfg["caption_channels"], cfg.get("mlp", 4 * C)
+    s = {"pos_embed.proj.weight": (C, 4, 2, 2), "pos_embed.proj.bias": (C,),
+         "caption_projection.linear_1.weight": (C, cap), "caption_projection.linear_1.bias": (C,),
+         "caption_projection.linear_2.weight": (C, C), "caption_projection.linear_2.bias": (C,),
+         "adaln_single.emb.timestep_embedder.linear_1.weight": (C, 256), "adaln_single.emb.timestep_embedder.linear_1.bias": (C,),
+         "adaln_single.emb.timestep_embedder.linear_2.weight": (C, C), "adaln_single.emb.timestep_embedder.linear_2.bias": (C,),
+         "adaln_single.linear.weight": (6 * C, C), "adaln_single.linear.bias": (6 * C,),
+         "proj_out.weight": (32, C), "proj_out.bias": (32,), "scale_shift_table": (2, C)}
+    for d in range(cfg["num_layers"]):
+        p = f"transformer_blocks.{d}."
+        s[p + "scale_shift_table"] = (6, C)
+        for a in ("attn1", "attn2"):
+            for n in ("to_q", "to_k", "to_v", "to_out.0"):
+                s[p + f"{a}.{n}.weight"], s[p + f"{a}.{n}.bias"] = (C, C), (C,)
+        s[p + "ff.net.0.proj.weight"], s[p + "ff.net.0.proj.bias"] = (mlp, C), (mlp,)
+        s[p + "ff.net.2.weight"], s[p + "ff.net.2.bias"] = (C, mlp), (C,)
+    return s
