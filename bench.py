@@ -133,7 +133,8 @@ def upscale_bicubic(imgs_u8, scale):
 def cpu_baseline(sds, y, mask, h_full, w_full, log):
     """Oracle (kind 'port') on the host cores: one 512x512 network pass, extrapolated by algorithmic FLOPs."""
     from oracle import dit as odit, glue as oglue, swinir as oswin, vae as ovae
-    cores = os.cpu_count() or 1
+    # a GPU box gives this job a CPU share (16 cores per GPU); os.cpu_count() reports the whole host
+    cores = int(os.environ.get("IR_CPU_THREADS", min(len(os.sched_getaffinity(0)), 16)))
     torch.set_num_threads(cores)
     hs = ws = 512
     img = synthetic_lq(1, hs, ws, 77).numpy()

@@ -28,6 +28,7 @@ struct Conv {  // packed conv / linear weight: w [cout_pad][taps*cin] bf16, b [c
     const bf16_t* w = nullptr;
     const float* b = nullptr;
     int cin = 0, cout = 0, cout_pad = 0, taps = 1;
+    long w_rs = 0;  // weight row stride in elements (0: taps*cin, densely packed)
 };
 struct Norm {
     const float *g = nullptr, *b = nullptr;
@@ -224,7 +225,7 @@ void conv(Run& r, const Conv& cw, const bf16_t* in, int N, int H, int W, int in_
         p.Ho = p.Wo = 1;
         p.M = N * H * W;
     }
-    p.wgt = cw.w; p.Cout = cw.cout; p.Cout_pad = cw.cout_pad; p.bias = cw.b;
+    p.wgt = cw.w; p.wgt_rs = cw.w_rs ? cw.w_rs : (long)cw.taps * cw.cin; p.Cout = cw.cout; p.Cout_pad = cw.cout_pad; p.bias = cw.b;
     p.act = act; p.slope = slope; p.out_scale = out_scale;
     p.gate = gate; p.gate_stride = 0; p.rows_per_batch = 1 << 30;
     p.res = res; p.res_f32 = res_f32; p.res_cs = res_cs; p.res_mod = res_mod;
@@ -374,9 +375,11 @@ int attnblock(Run& r, const AttnW& w, bf16_t* B[3], int ci, float* gws, int N, i
     bf16_t* k = r.a.alloc<bf16_t>(N * T * C);
     bf16_t* v = r.a.alloc<bf16_t>(N * T * C);
     bf16_t* o = r.a.alloc<bf16_t>(N * T * C);
-    bf16_t* vt = r.a.alloc<bf16_t>(T * C);
-    float* S = r.a.alloc<float>(T * T);
-    bf16_t* P = r.a.alloc<bf16_t>(T * T);
+    const long ld = T + 64;  // padded leading dimension of S, P and V^T: a power-of-two row stride would put every row of a
+                             // tile on the same memory channel
+    bf16_t* vt = r.a.alloc<bf16_t>(ld * C);
+    float* S = r.a.alloc<float>(T * ld);
+    bf16_t* P = r.a.alloc<bf16_t>(T * ld);
     groupnorm(r, w.n, B[ci], B[t1], gws, N, T, 0);
     linear(r, w.q, B[t1], (int)(N * T), C, q, C, 0, ACT_NONE, nullptr, 0, 0);
     linear(r, w.k, B[t1], (int)(N * T), C, k, C, 0, ACT_NONE, nullptr, 0, 0);
@@ -385,12 +388,12 @@ int attnblock(Run& r, const AttnW& w, bf16_t* B[3], int ci, float* gws, int N, i
     for (int b = 0; b < N; ++b) {
         Conv kw;  // S = q k^T * C^-0.5 : the keys play the role of the weight matrix [T][C]
         kw.w = k + b * T * C; kw.b = nullptr; kw.cin = C; kw.cout = (int)T; kw.cout_pad = (int)T; kw.taps = 1;
-        linear(r, kw, q + b * T * C, (int)T, C, S, (int)T, 1, ACT_NONE, nullptr, 0, 0, nullptr, 0, nullptr, 0, 1.0f / sqrtf((float)C));
-        LAUNCH(r, PC_SOFTMAX, 0.0, 0.0, ir_launch_softmax_rows(S, P, T, (int)T, T, T, r.s), "softmax_rows");
-        LAUNCH(r, PC_TRANSPOSE, 0.0, 0.0, ir_launch_transpose_v(v + b * T * C, vt, 0, C, dsub, 1, C / dsub, (int)T, (int)T, dsub, dsub, r.s), "transpose_v");
-        Conv vw;  // O = P V : V^T [C][T] is the weight matrix
-        vw.w = vt; vw.b = nullptr; vw.cin = (int)T; vw.cout = C; vw.cout_pad = C; vw.taps = 1;
-        linear(r, vw, P, (int)T, (int)T, o + b * T * C, C, 0, ACT_NONE, nullptr, 0, 0);
+        linear(r, kw, q + b * T * C, (int)T, C, S, (int)ld, 1, ACT_NONE, nullptr, 0, 0, nullptr, 0, nullptr, 0, 1.0f / sqrtf((float)C));
+        LAUNCH(r, PC_SOFTMAX, 0.0, 6.0 * (double)T * T, ir_launch_softmax_rows(S, P, T, (int)T, ld, ld, r.s), "softmax_rows");
+        LAUNCH(r, PC_TRANSPOSE, 0.0, 0.0, ir_launch_transpose_v(v + b * T * C, vt, 0, C, dsub, 1, C / dsub, (int)T, (int)ld, dsub, dsub, r.s), "transpose_v");
+        Conv vw;  // O = P V : V^T [C][ld] is the weight matrix
+        vw.w = vt; vw.b = nullptr; vw.cin = (int)T; vw.cout = C; vw.cout_pad = C; vw.taps = 1; vw.w_rs = ld;
+        linear(r, vw, P, (int)T, (int)ld, o + b * T * C, C, 0, ACT_NONE, nullptr, 0, 0);
     }
     linear(r, w.o, o, (int)(N * T), C, B[t2], C, 0, ACT_NONE, B[ci], 0, C);
     r.a.release(mk);
@@ -504,7 +507,7 @@ float* dit_tokens_run(Run& r, const float* lat, int n, int h, int w, float times
     DitModel& m = r.c->dit;
     const int gh = h / 2, gw = w / 2, C = m.C, Hh = m.heads, hd = m.hd;
     const long T = (long)gh * gw, BT = n * T;
-    const int Tpad = (int)((T + 63) & ~63L), DV = ir_attn_dv(hd);
+    const int Tpad = (int)((T + 63) & ~63L) + 64, DV = ir_attn_dv(hd);  // +64: no power-of-two row stride (channel conflicts)
     dit_update_timestep(r, timestep);
     float* tok = r.a.alloc<float>(BT * 32);
     const size_t mk = r.a.mark();
@@ -913,7 +916,7 @@ int ir_dit_set_prompt(ir_ctx* c, void* stream, const float* embeds_host, const f
     HIPOK(c, hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
     const int C = m.C, DV = ir_attn_dv(m.hd);
-    const int tok_pad = (n_tok + 63) & ~63;
+    const int tok_pad = ((n_tok + 63) & ~63) + 64;
     float* e32 = nullptr;
     bf16_t *e16 = nullptr, *y1 = nullptr, *y2 = nullptr;
     HIPOK(c, hipMalloc((void**)&e32, (size_t)n_tok * m.cap * 4));
@@ -1114,7 +1117,7 @@ int ir_op_layernorm(ir_ctx* c, void* stream, const float* x, uint16_t* y, const 
 int ir_op_attention(ir_ctx* c, void* stream, const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* o, int b, int heads,
                     int tq, int tk, int d, float scale, const float* key_bias, void* ws, size_t ws_bytes) {
     // q/o: [b][tq][heads*d], k/v: [b][tk][heads*d]
-    const int DV = ir_attn_dv(d), tkp = (tk + 63) & ~63;
+    const int DV = ir_attn_dv(d), tkp = ((tk + 63) & ~63) + 64;
     const size_t need = (size_t)b * heads * DV * tkp * 2;
     if (ws_bytes < need) return fail(c, -20, "attention workspace too small: need %zu", need);
     hipStream_t s = (hipStream_t)stream;

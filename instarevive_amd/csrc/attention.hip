@@ -19,21 +19,26 @@
 
 IR_DEVINL int swap23(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }
 
-template <int DQK, int DV>
-__global__ __launch_bounds__(256) void flash_attn_kernel(AttnParams p) {
-    constexpr int QS = DQK + 8;   // LDS row stride of Q/K tiles (bf16 elements); odd number of 16-B chunks
-    constexpr int VS = 64 + 8;    // LDS row stride of V^T tiles
-    constexpr int KCH = DQK / 8;  // 16-B chunks per Q/K row
+template <int D>
+__global__ __launch_bounds__(256, 2) void flash_attn_kernel(AttnParams p) {
+    constexpr int DQK = (D + 15) & ~15;  // head dim padded for the QK^T k-steps (16 per MFMA)
+    constexpr int DV = (D + 31) & ~31;   // head dim padded for the 32-row O^T tiles
+    constexpr int QS = DQK + 8;          // LDS row stride of Q/K tiles (bf16 elements); odd number of 16-B chunks
+    constexpr int VS = 64 + 8;           // LDS row stride of V^T tiles
+    constexpr int KCH = DQK / 8;         // 16-B chunks per LDS Q/K row
+    constexpr int RCH = D / 8;           // real 16-B chunks per row in HBM
     constexpr int NKS = DQK / 16;
     constexpr int NDT = DV / 32;
-    constexpr int OS = DV + 8;    // O staging row stride
-    constexpr int K_ITEMS = (64 * KCH + 255) / 256;
+    constexpr int OS = DV + 8;           // O staging row stride
+    constexpr int K_ITEMS = (64 * RCH + 255) / 256;
     constexpr int V_ITEMS = (DV * 8 + 255) / 256;
-    constexpr int Q_ITEMS = (128 * KCH + 255) / 256;
+    constexpr int Q_ITEMS = (128 * RCH + 255) / 256;
     constexpr int KV_ELEMS = 2 * 64 * QS + 2 * DV * VS;
     constexpr int O_ELEMS = 128 * OS;
     constexpr int TAIL = KV_ELEMS > O_ELEMS ? KV_ELEMS : O_ELEMS;
+    constexpr float RESCALE_THR = 8.0f;  // log2 units: skip the O/l rescale while the running max grows by less than 2^8
     __shared__ __attribute__((aligned(16))) bf16_t smem[128 * QS + TAIL];
+    __shared__ float kbs[2][64];         // per-tile additive key bias (log2 domain; -inf beyond Tk)
     bf16_t* Qs = smem;
     bf16_t* Ks = smem + 128 * QS;
     bf16_t* Vs = Ks + 2 * 64 * QS;
@@ -42,63 +47,69 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(AttnParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int q0 = blockIdx.x * 128, head = blockIdx.y, b = blockIdx.z;
-    const int dch = p.D >> 3;  // real 16-B chunks per row
 
     const bf16_t* qp = p.q + (long)b * p.q_bs + (long)head * p.q_hs;
     const bf16_t* kp = p.k + (long)b * p.k_bs + (long)head * p.k_hs;
     const bf16_t* vtp = p.vt + (long)b * p.vt_bs + (long)head * DV * p.Tk_pad;
     const float* kb = p.key_bias ? p.key_bias + (long)b * p.kb_bs : nullptr;
+    const bool general = kb || (p.Tk & 63);  // additive key bias and/or ragged last tile -> bias path through LDS
 
-    // ---- stage Q
-#pragma unroll
-    for (int i = 0; i < Q_ITEMS; ++i) {
-        int c = tid + i * 256;
-        if (c < 128 * KCH) {
-            int row = c / KCH, ch = c - row * KCH;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (q0 + row < p.Tq && ch < dch) v = *reinterpret_cast<const uint4*>(qp + (long)(q0 + row) * p.q_rs + ch * 8);
-            *reinterpret_cast<uint4*>(&Qs[row * QS + ch * 8]) = v;
+    // Every global load below is UNCONDITIONAL on a clamped, always-valid address and never feeds a select: hipcc turns
+    // "load, then zero if out of range" into a branch around the load plus a vmcnt(0) per element, which serialises
+    // the whole prefetch. Out-of-range keys are handled by the -inf key bias, out-of-range queries are never stored,
+    // and the zero padding of the head dim lives in LDS columns that are written once here.
+    if (KCH > RCH) {
+        for (int c = tid; c < 256 * (KCH - RCH); c += 256) {
+            const int row = c / (KCH - RCH), ch = RCH + c % (KCH - RCH);
+            *reinterpret_cast<uint4*>(&smem[row * QS + ch * 8]) = make_uint4(0, 0, 0, 0);  // Qs rows 0..127, Ks rows 0..127
         }
     }
-    uint4 kreg[K_ITEMS], vreg[V_ITEMS];
+#pragma unroll
+    for (int i = 0; i < Q_ITEMS; ++i) {
+        const int c = tid + i * 256;
+        const int row = min(c / RCH, 127), ch = c % RCH;
+        const uint4 v = *reinterpret_cast<const uint4*>(qp + (long)min(q0 + row, p.Tq - 1) * p.q_rs + ch * 8);
+        if (c < 128 * RCH) *reinterpret_cast<uint4*>(&Qs[row * QS + ch * 8]) = v;
+    }
+    uint4 kreg[K_ITEMS], vreg[V_ITEMS];  // initialised: an uninitialised array written under a condition stays in scratch
+#pragma unroll
+    for (int i = 0; i < K_ITEMS; ++i) kreg[i] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < V_ITEMS; ++i) vreg[i] = make_uint4(0, 0, 0, 0);
+    float kbreg = 0.f;
     auto load_kv = [&](int t) {
         const int key0 = t * 64;
 #pragma unroll
         for (int i = 0; i < K_ITEMS; ++i) {
-            int c = tid + i * 256;
-            if (c < 64 * KCH) {
-                int row = c / KCH, ch = c - row * KCH;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (key0 + row < p.Tk && ch < dch) v = *reinterpret_cast<const uint4*>(kp + (long)(key0 + row) * p.k_rs + ch * 8);
-                kreg[i] = v;
-            }
+            const int c = tid + i * 256;
+            const int row = min(c / RCH, 63), ch = c % RCH;
+            kreg[i] = *reinterpret_cast<const uint4*>(kp + (long)min(key0 + row, p.Tk - 1) * p.k_rs + ch * 8);
         }
 #pragma unroll
         for (int i = 0; i < V_ITEMS; ++i) {
-            int c = tid + i * 256;
-            if (c < DV * 8) {
-                int row = c >> 3, ch = c & 7;
-                vreg[i] = *reinterpret_cast<const uint4*>(vtp + (long)row * p.Tk_pad + key0 + ch * 8);
-            }
+            const int c = tid + i * 256;
+            const int row = min(c >> 3, DV - 1), ch = c & 7;
+            vreg[i] = *reinterpret_cast<const uint4*>(vtp + (long)row * p.Tk_pad + key0 + ch * 8);
+        }
+        if (general) {
+            const int key = key0 + (tid & 63);
+            float v = kb ? kb[min(key, p.Tk - 1)] * 1.44269504088896340736f : 0.f;
+            kbreg = key < p.Tk ? v : -INFINITY;
         }
     };
     auto store_kv = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < K_ITEMS; ++i) {
-            int c = tid + i * 256;
-            if (c < 64 * KCH) {
-                int row = c / KCH, ch = c - row * KCH;
-                *reinterpret_cast<uint4*>(&Ks[(buf * 64 + row) * QS + ch * 8]) = kreg[i];
-            }
+            const int c = tid + i * 256;
+            const int row = c / RCH, ch = c % RCH;
+            if (c < 64 * RCH) *reinterpret_cast<uint4*>(&Ks[(buf * 64 + row) * QS + ch * 8]) = kreg[i];
         }
 #pragma unroll
         for (int i = 0; i < V_ITEMS; ++i) {
-            int c = tid + i * 256;
-            if (c < DV * 8) {
-                int row = c >> 3, ch = c & 7;
-                *reinterpret_cast<uint4*>(&Vs[(buf * DV + row) * VS + ch * 8]) = vreg[i];
-            }
+            const int c = tid + i * 256;
+            if (c < DV * 8) *reinterpret_cast<uint4*>(&Vs[(buf * DV + (c >> 3)) * VS + (c & 7) * 8]) = vreg[i];
         }
+        if (general && tid < 64) kbs[buf][tid] = kbreg;
     };
     load_kv(0);
     store_kv(0);
@@ -120,7 +131,7 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(AttnParams p) {
     for (int t = 0; t < NT; ++t) {
         const bool more = t + 1 < NT;
         if (more) load_kv(t + 1);
-        // ---- S^T = K Q^T (two 32-key tiles)
+        // ---- S^T = K Q^T (two 32-key tiles); this lane's keys for (kt, g): t*64 + kt*32 + 16*(g>>3) + 8*h + (g&7)
         f32x16 s[2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
@@ -132,63 +143,59 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(AttnParams p) {
                 s[kt] = mfma32(a, qf[ks], s[kt]);
             }
         }
-        // ---- softmax update; this lane's keys for (kt, g): t*64 + kt*32 + 16*(g>>3) + 8*h + (g&7)
-        float mx = -INFINITY, m_new, alpha, rs = 0.f;
-        if (kb || (t == NT - 1 && (p.Tk & 63))) {  // wave-uniform: additive key bias and/or ragged last tile
-            const int kbase = t * 64 + 8 * h;
+        // ---- online softmax in the exp2 domain
+        float mx = -INFINITY;
+        if (general) {
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int g = 0; g < 16; ++g) {
-                    const int key = kbase + kt * 32 + 16 * (g >> 3) + (g & 7);
-                    float v = s[kt][g] * p.scale_log2;
-                    if (kb) v += kb[key < p.Tk ? key : 0] * 1.44269504088896340736f;
-                    v = key < p.Tk ? v : -INFINITY;
-                    s[kt][g] = v;
-                    mx = fmaxf(mx, v);
-                }
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            m_new = fmaxf(m_i, mx);
+                for (int g8 = 0; g8 < 2; ++g8) {
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(&kbs[cur][kt * 32 + 16 * g8 + 8 * h]);
+                    const f32x4 b1 = *reinterpret_cast<const f32x4*>(&kbs[cur][kt * 32 + 16 * g8 + 8 * h + 4]);
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int g = 0; g < 16; ++g) {
-                    const float pv = __builtin_amdgcn_exp2f(s[kt][g] - m_new);
-                    s[kt][g] = pv;
-                    rs += pv;
+                    for (int e = 0; e < 8; ++e) {
+                        const float v = __builtin_fmaf(s[kt][g8 * 8 + e], p.scale_log2, e < 4 ? b0[e & 3] : b1[e & 3]);
+                        s[kt][g8 * 8 + e] = v;
+                        mx = fmaxf(mx, v);
+                    }
                 }
-        } else {  // hot path: scale folded into the exponent's fma, max taken on raw scores (scale > 0)
+        } else {
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int g = 0; g < 16; ++g) mx = fmaxf(mx, s[kt][g]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            m_new = fmaxf(m_i, mx * p.scale_log2);
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int g = 0; g < 16; ++g) {
-                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][g], p.scale_log2, -m_new));
-                    s[kt][g] = pv;
-                    rs += pv;
-                }
+            mx *= p.scale_log2;  // scale > 0
         }
-        alpha = __builtin_amdgcn_exp2f(m_i - m_new);
-        rs += __shfl_xor(rs, 32);
-        l_i = l_i * alpha + rs;
-        m_i = m_new;
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        // deferred rescale: O and l are rescaled only when some query's max grew by more than RESCALE_THR; until then
+        // probabilities are taken against the (slightly stale) running max and stay <= 2^THR (exact in fp32 / bf16 range).
+        // The decision precedes this tile's exponentials, so everything at the old max (O, l) is scaled exactly once.
+        if (__any(mx > m_i + RESCALE_THR)) {
+            const float m_new = fmaxf(m_i, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_i - m_new);
+            l_i *= alpha;
+            m_i = m_new;
 #pragma unroll
-        for (int dt = 0; dt < NDT; ++dt)
+            for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
-            for (int g = 0; g < 16; ++g) o[dt][g] *= alpha;
-        // ---- P^T fragments (B operand): registers 8*s2 .. 8*s2+7 of tile kt
+                for (int g = 0; g < 16; ++g) o[dt][g] *= alpha;
+        }
+        // exponentials, row sum, and bf16 P^T fragments (B operand: registers 8*s2 .. 8*s2+7 of tile kt)
+        float rs = 0.f;
         bf16x8 pb[2][2];
+        const float sc = general ? 1.0f : p.scale_log2;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) pb[kt][s2][e] = (__bf16)s[kt][s2 * 8 + e];
+                for (int e = 0; e < 8; ++e) {
+                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][s2 * 8 + e], sc, -m_i));
+                    rs += pv;
+                    pb[kt][s2][e] = (__bf16)pv;
+                }
+        rs += __shfl_xor(rs, 32);
+        l_i += rs;
         // ---- O^T += V^T P^T
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt)
@@ -216,8 +223,8 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(AttnParams p) {
         }
     __syncthreads();
     bf16_t* op = p.o + (long)b * p.o_bs + (long)head * p.o_hs;
-    for (int c = lane; c < 32 * dch; c += 64) {
-        int row = c / dch, ch = c - row * dch;
+    for (int c = lane; c < 32 * RCH; c += 64) {
+        int row = c / RCH, ch = c - row * RCH;
         int q = q0 + wid * 32 + row;
         if (q < p.Tq) *reinterpret_cast<uint4*>(op + (long)q * p.o_rs + ch * 8) = *reinterpret_cast<const uint4*>(&ow[row * OS + ch * 8]);
     }
@@ -226,16 +233,17 @@ __global__ __launch_bounds__(256) void flash_attn_kernel(AttnParams p) {
 int ir_launch_flash_attn(const AttnParams& p, hipStream_t s) {
     if (p.Tq <= 0 || p.Tk <= 0 || p.B <= 0 || p.Hh <= 0) return -2;
     if ((p.D & 7) || (p.q_rs & 7) || (p.k_rs & 7) || (p.o_rs & 7) || (p.q_hs & 7) || (p.k_hs & 7) || (p.o_hs & 7) ||
-        (p.q_bs & 7) || (p.k_bs & 7) || (p.o_bs & 7))
+        (p.q_bs & 7) || (p.k_bs & 7) || (p.o_bs & 7) || (p.vt_bs & 7))
         return -3;
     if ((p.Tk_pad & 63) || p.Tk_pad < ((p.Tk + 63) & ~63)) return -4;
+    if (p.scale_log2 <= 0.f) return -6;
     dim3 grid((p.Tq + 127) / 128, p.Hh, p.B);
     if (p.D == 72)
-        hipLaunchKernelGGL((flash_attn_kernel<80, 96>), grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((flash_attn_kernel<72>), grid, dim3(256), 0, s, p);
     else if (p.D == 32)
-        hipLaunchKernelGGL((flash_attn_kernel<32, 32>), grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((flash_attn_kernel<32>), grid, dim3(256), 0, s, p);
     else if (p.D == 64)
-        hipLaunchKernelGGL((flash_attn_kernel<64, 64>), grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((flash_attn_kernel<64>), grid, dim3(256), 0, s, p);
     else
         return -5;
     return hipGetLastError() == hipSuccess ? 0 : -1;

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
 
     const int cchunks = p.Cin >> 5;
     const int KT = TAPS * cchunks;
-    const long Kw = (long)TAPS * p.Cin;
+    const long Kw = p.wgt_rs;
 
     // ---- per-thread A rows
     const int seg = tid & 3;
@@ -69,7 +69,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
     }
     const int Hc = p.up ? 2 * p.H : p.H, Wc = p.up ? 2 * p.W : p.W;
 
-    uint4 a_reg[A_CH], b_reg[B_CH];
+    uint4 a_reg[A_CH], b_reg[B_CH];  // initialised: an uninitialised array written under a condition stays in scratch
+#pragma unroll
+    for (int i = 0; i < A_CH; ++i) a_reg[i] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < B_CH; ++i) b_reg[i] = make_uint4(0, 0, 0, 0);
     auto load_tile = [&](int kt) {
         int tap = 0, cc = kt;
         if (TAPS > 1) { tap = kt / cchunks; cc = kt - tap * cchunks; }
@@ -263,6 +267,7 @@ int ir_launch_igemm(const IGemmParams& pin, hipStream_t s) {
     if (p.taps != 1 && p.taps != 9) return -2;
     if (p.Cin <= 0 || (p.Cin & 31) || (p.in_cs & 7) || p.in_cs < p.Cin) return -3;
     if (p.Cout <= 0 || p.Cout > p.Cout_pad || (p.Cout_pad & 31)) return -4;
+    if (p.wgt_rs < (long)p.taps * p.Cin || (p.wgt_rs & 7)) return -10;
     p.vec = !((p.out_cs & 3) || (p.res && (p.res_cs & 3)) || (p.out2 && (p.out2_cs & 3)) ||
               (reinterpret_cast<uintptr_t>(p.res) & 15) || (reinterpret_cast<uintptr_t>(p.out2) & 7) ||
               (p.gate && (p.gate_stride & 3)));

@@ -18,7 +18,8 @@ struct IGemmParams {
     int pad;        // 1: symmetric "same" pad; 0: pad only bottom/right (the VAE's (0,1,0,1) stride-2 downsample)
     int up;         // 1: conv runs on the nearest-2x upsampled input (2H x 2W), folded into addressing
     // B operand
-    const bf16_t* wgt;  // [Cout_pad][taps*Cin] bf16, K contiguous
+    const bf16_t* wgt;  // [Cout_pad][taps*Cin] bf16, K contiguous; rows wgt_rs elements apart
+    long wgt_rs;
     int Cout, Cout_pad, M;
     // epilogue: v = act(acc + bias) * out_scale; v *= gate; v += res; store
     const float* bias;  // [Cout_pad] or null

@@ -29,16 +29,24 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restric
     for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
     if (pl < ppi) {
         const bf16_t* base = x + (long)n * HW * C + cv * 8;
-        for (long pix = p0 + pl; pix < p1; pix += ppi) {
-            uint4 v = *reinterpret_cast<const uint4*>(base + pix * C);
-            uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        auto acc8 = [&](const uint4& v) {
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float a = bflo(w[e]), b = bfhi(w[e]);
                 s[2 * e] += a; q[2 * e] += a * a;
                 s[2 * e + 1] += b; q[2 * e + 1] += b * b;
             }
+        };
+        long pix = p0 + pl;
+        for (; pix + 3L * ppi < p1; pix += 4L * ppi) {  // 4 independent 16-byte loads in flight per lane
+            uint4 v0 = *reinterpret_cast<const uint4*>(base + pix * C);
+            uint4 v1 = *reinterpret_cast<const uint4*>(base + (pix + ppi) * C);
+            uint4 v2 = *reinterpret_cast<const uint4*>(base + (pix + 2L * ppi) * C);
+            uint4 v3 = *reinterpret_cast<const uint4*>(base + (pix + 3L * ppi) * C);
+            acc8(v0); acc8(v1); acc8(v2); acc8(v3);
         }
+        for (; pix < p1; pix += ppi) acc8(*reinterpret_cast<const uint4*>(base + pix * C));
     }
     // reduce over the ppi pixel lanes that share a channel vector
     for (int i = tid; i < 2 * 512; i += 256) (&s_sum[0][0])[i] = 0.f;
@@ -64,18 +72,27 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
                                                           float* __restrict__ shift, int HW, int C, int G, int chunks,
                                                           float eps) {
     __shared__ double s_mean[64], s_rstd[64];
+    __shared__ double s_part[2][256];
     const int n = blockIdx.x, tid = threadIdx.x;
     const int cpg = C / G;
-    // one wave-quarter (8 lanes) per group would be enough; keep it simple: thread g handles group g.
-    if (tid < G) {
-        double s = 0.0, q = 0.0;
-        for (int ch = 0; ch < chunks; ++ch) {
+    const int spg = 256 / G;                 // slices (threads) per group: 8 for G = 32
+    const int g = tid / spg, sl = tid % spg;
+    double s = 0.0, q = 0.0;
+    if (g < G) {
+        for (int ch = sl; ch < chunks; ch += spg) {
             const float* pp = part + ((long)n * chunks + ch) * 2 * C;
-            for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
+            for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
                 s += (double)pp[c];
                 q += (double)pp[C + c];
             }
         }
+    }
+    s_part[0][tid] = s;
+    s_part[1][tid] = q;
+    __syncthreads();
+    if (tid < G) {
+        s = 0.0; q = 0.0;
+        for (int i = 0; i < spg; ++i) { s += s_part[0][tid * spg + i]; q += s_part[1][tid * spg + i]; }
         const double cnt = (double)HW * cpg;
         const double mean = s / cnt;
         double var = q / cnt - mean * mean;
@@ -97,14 +114,13 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                                        long HW, int C, long nvec, int do_silu) {
     const int vpp = C >> 3;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+    auto one = [&](long i, const uint4& v) {
         const long pix = i / vpp;
         const int cv = (int)(i - pix * vpp);
         const int n = (int)(pix / HW);
-        uint4 v = *reinterpret_cast<const uint4*>(x + i * 8);
         const float* sc = scale + (long)n * C + cv * 8;
         const float* sh = shift + (long)n * C + cv * 8;
-        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
         uint32_t o[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -114,12 +130,22 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
             o[e] = pack2bf(a, b);
         }
         *reinterpret_cast<uint4*>(y + i * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+    };
+    const long stride = (long)gridDim.x * 256;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < nvec; i += 4 * stride) {  // 4 independent 16-byte loads in flight per lane
+        uint4 v0 = *reinterpret_cast<const uint4*>(x + i * 8);
+        uint4 v1 = *reinterpret_cast<const uint4*>(x + (i + stride) * 8);
+        uint4 v2 = *reinterpret_cast<const uint4*>(x + (i + 2 * stride) * 8);
+        uint4 v3 = *reinterpret_cast<const uint4*>(x + (i + 3 * stride) * 8);
+        one(i, v0); one(i + stride, v1); one(i + 2 * stride, v2); one(i + 3 * stride, v3);
     }
+    for (; i < nvec; i += stride) one(i, *reinterpret_cast<const uint4*>(x + i * 8));
 }
 
 int ir_launch_groupnorm(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, float* ws, int N, long HW, int C,
                         int G, float eps, int do_silu, hipStream_t s) {
-    if (C % 8 || C > 512 || G > 64 || C % G || 256 % (C / 8)) return -2;
+    if (C % 8 || C > 512 || G > 64 || C % G || 256 % (C / 8) || 256 % G) return -2;
     if (HW >= (1L << 31)) return -3;
     int chunks = ir_gn_chunks(HW);
     float* part = ws;                                  // [N][chunks][2][C]
