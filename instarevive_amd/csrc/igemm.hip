@@ -17,23 +17,35 @@
 #include "common.h"
 #include "kernels.h"
 
-#define LDS_STRIDE 40  // bf16 elements per LDS row (32 data + 8 pad)
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-template <int BM, int BN, int WM, int WN, int TAPS>
-__global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
+// 16-byte LDS-DMA: LDS[wave-uniform base + lane*16] <- *per-lane global address (asynchronous, counted by vmcnt).
+IR_DEVINL void glds16(const void* g, lds_ptr_t l) { __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0); }
+
+// 64 KB of zeros: zero-padding taps of a convolution read from here, so the LDS-DMA never needs a mask or a branch.
+__device__ uint4 g_zero_page[4096];
+
+template <int BM, int BN, int WM, int WN, int TAPS, int BK>
+__global__ __launch_bounds__(256, 2) void igemm_kernel(IGemmParams p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int A_CH = BM * 4 / 256;  // 16-byte chunks per thread per A tile
-    constexpr int B_CH = (BN * 4 + 255) / 256;
+    constexpr int SP = BK / 8;            // 16-byte slots per tile row
+    constexpr int ROWB = BK * 2;          // bytes per tile row in LDS (unpadded: LDS-DMA writes base + lane*16)
+    constexpr int RB = 256 / ROWB;        // tile rows per 256-byte LDS bank row
+    constexpr int RPI = 64 / SP;          // tile rows written by one wave-wide LDS-DMA instruction
+    constexpr int A_Q = BM / RPI, B_Q = BN / RPI;           // DMA instructions per A / B tile
+    constexpr int A_I = (A_Q + 3) / 4, B_I = (B_Q + 3) / 4;  // per wave (instruction q = wave + 4*i)
     constexpr int COLS = TN * 32;
-    constexpr int LDS_AB = 2 * (BM + BN) * LDS_STRIDE * 2;
+    constexpr int LDS_AB = 2 * (BM + BN) * ROWB;
     constexpr int LDS_EP = 4 * 32 * COLS * 4;
     constexpr int LDS_BYTES = LDS_AB > LDS_EP ? LDS_AB : LDS_EP;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
-    bf16_t(*As)[BM][LDS_STRIDE] = reinterpret_cast<bf16_t(*)[BM][LDS_STRIDE]>(smem);
-    bf16_t(*Bs)[BN][LDS_STRIDE] =
-        reinterpret_cast<bf16_t(*)[BN][LDS_STRIDE]>(smem + 2 * BM * LDS_STRIDE * 2);
+    __shared__ __attribute__((aligned(256))) unsigned char smem[LDS_BYTES];  // the ONLY LDS object of the kernel
+    // layout: A[0] | A[1] | B[0] | B[1]; element (row, 16-byte chunk c) of a tile lives at row*ROWB + ((c ^ swz(row)) * 16),
+    // swz(row) = (row / RB) % SP: 16 consecutive rows then cover all 16 slots of a 256-byte bank row => the ds_read_b128
+    // fragment reads are conflict-free although rows are unpadded. The swizzle is applied to the per-lane SOURCE address of
+    // the DMA and again on the read side (never to the LDS destination, which is lane-linear by construction).
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wu = __builtin_amdgcn_readfirstlane(wid);
     const int wm = wid / WN, wn = wid % WN;
     const int r = lane & 31, h = lane >> 5;
 
@@ -47,67 +59,63 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
     if (mt >= MT) return;
     const int m0 = mt * BM, n0 = nt * BN;
 
-    const int cchunks = p.Cin >> 5;
+    const int cchunks = p.Cin / BK;
     const int KT = TAPS * cchunks;
-    const long Kw = p.wgt_rs;
 
-    // ---- per-thread A rows
-    const int seg = tid & 3;
-    int a_n[A_CH], a_oy[A_CH], a_ox[A_CH];
-    bool a_ok[A_CH];
+    // ---- per-lane DMA sources. Every lane always issues its loads on a valid address: rows beyond M re-read row M-1 (never
+    // stored) and zero-padding taps read the zero page.
+    const int lrow = lane / SP, lslot = lane % SP;
+    const bf16_t* a_ptr[A_I];
+    int a_n[A_I], a_oy[A_I], a_ox[A_I], a_sw[A_I];
 #pragma unroll
-    for (int i = 0; i < A_CH; ++i) {
-        int m = m0 + (tid >> 2) + i * 64;
-        a_ok[i] = m < p.M;
+    for (int i = 0; i < A_I; ++i) {
+        const int row = min((wid + 4 * i) * RPI + lrow, BM - 1);
+        const int m = min(m0 + row, p.M - 1);
+        a_sw[i] = (lslot ^ ((row / RB) % SP)) * 8;
         if (TAPS == 1) {
-            a_n[i] = m; a_oy[i] = 0; a_ox[i] = 0;
+            a_n[i] = a_oy[i] = a_ox[i] = 0;
+            a_ptr[i] = p.in + (long)m * p.in_cs + a_sw[i];
         } else {
-            int hw = p.Ho * p.Wo;
-            int n = m / hw, rem = m - n * hw;
+            const int hw = p.Ho * p.Wo;
+            const int n = m / hw, rem = m - n * hw;
             a_n[i] = n; a_oy[i] = rem / p.Wo; a_ox[i] = rem - a_oy[i] * p.Wo;
+            a_ptr[i] = p.in;
         }
     }
     const int Hc = p.up ? 2 * p.H : p.H, Wc = p.up ? 2 * p.W : p.W;
-
-    uint4 a_reg[A_CH], b_reg[B_CH];  // initialised: an uninitialised array written under a condition stays in scratch
+    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page);
+    auto set_tap = [&](int tap) {  // TAPS == 9 only: source pixel (or the zero page) of every owned row for this tap
+        const int ky = tap / 3, kx = tap - ky * 3;
 #pragma unroll
-    for (int i = 0; i < A_CH; ++i) a_reg[i] = make_uint4(0, 0, 0, 0);
-#pragma unroll
-    for (int i = 0; i < B_CH; ++i) b_reg[i] = make_uint4(0, 0, 0, 0);
-    auto load_tile = [&](int kt) {
-        int tap = 0, cc = kt;
-        if (TAPS > 1) { tap = kt / cchunks; cc = kt - tap * cchunks; }
-        const int c0 = cc * 32 + seg * 8;
-#pragma unroll
-        for (int i = 0; i < A_CH; ++i) {
-            const bf16_t* src = nullptr;
-            if (TAPS == 1) {
-                if (a_ok[i]) src = p.in + (long)a_n[i] * p.in_cs + c0;
-            } else {
-                int ky = tap / 3, kx = tap - ky * 3;
-                int cy = a_oy[i] * p.stride + ky - p.pad, cx = a_ox[i] * p.stride + kx - p.pad;
-                if (a_ok[i] && cy >= 0 && cy < Hc && cx >= 0 && cx < Wc) {
-                    int iy = cy >> p.up, ix = cx >> p.up;
-                    src = p.in + (((long)a_n[i] * p.H + iy) * p.W + ix) * p.in_cs + c0;
-                }
-            }
-            a_reg[i] = src ? *reinterpret_cast<const uint4*>(src) : make_uint4(0, 0, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < B_CH; ++i) {
-            int row = (tid >> 2) + i * 64;
-            if (BN >= 64 || row < BN)
-                b_reg[i] = *reinterpret_cast<const uint4*>(p.wgt + (long)(n0 + row) * Kw + (long)kt * 32 + seg * 8);
+        for (int i = 0; i < A_I; ++i) {
+            const int cy = a_oy[i] * p.stride + ky - p.pad, cx = a_ox[i] * p.stride + kx - p.pad;
+            const bool ok = cy >= 0 && cy < Hc && cx >= 0 && cx < Wc;
+            const int iy = min(max(cy, 0), Hc - 1) >> p.up, ix = min(max(cx, 0), Wc - 1) >> p.up;
+            const bf16_t* src = p.in + (((long)a_n[i] * p.H + iy) * p.W + ix) * p.in_cs;
+            a_ptr[i] = (ok ? src : zero) + a_sw[i];
         }
     };
-    auto store_tile = [&](int buf) {
+    const bf16_t* b_ptr[B_I];
 #pragma unroll
-        for (int i = 0; i < A_CH; ++i)
-            *reinterpret_cast<uint4*>(&As[buf][(tid >> 2) + i * 64][seg * 8]) = a_reg[i];
+    for (int i = 0; i < B_I; ++i) {
+        const int row = min((wid + 4 * i) * RPI + lrow, BN - 1);
+        b_ptr[i] = p.wgt + (long)(n0 + row) * p.wgt_rs + (lslot ^ ((row / RB) % SP)) * 8;
+    }
+    int cc = 0, tap = 0;
+    auto stage = [&](int buf) {  // asynchronous global -> LDS copy of the k-tile the pointers address; then advance them
 #pragma unroll
-        for (int i = 0; i < B_CH; ++i) {
-            int row = (tid >> 2) + i * 64;
-            if (BN >= 64 || row < BN) *reinterpret_cast<uint4*>(&Bs[buf][row][seg * 8]) = b_reg[i];
+        for (int i = 0; i < A_I; ++i) {
+            const int q = wu + 4 * i;
+            if (A_Q % 4 == 0 || q < A_Q)
+                glds16(a_ptr[i], (lds_ptr_t)(smem + buf * BM * ROWB + q * RPI * ROWB));
+            a_ptr[i] += BK;
+        }
+#pragma unroll
+        for (int i = 0; i < B_I; ++i) {
+            const int q = wu + 4 * i;
+            if (B_Q % 4 == 0 || q < B_Q)
+                glds16(b_ptr[i], (lds_ptr_t)(smem + 2 * BM * ROWB + buf * BN * ROWB + q * RPI * ROWB));
+            b_ptr[i] += BK;
         }
     };
 
@@ -119,28 +127,44 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][jn][e] = 0.f;
 
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
+    // fragment read addresses (bytes): row base and the row's swizzle
+    int fa_base[TM], fa_sw[TM], fb_base[TN], fb_sw[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int R = wm * (BM / WM) + i * 32 + r;
+        fa_base[i] = R * ROWB; fa_sw[i] = (R / RB) % SP;
+    }
+#pragma unroll
+    for (int jn = 0; jn < TN; ++jn) {
+        const int R = wn * (BN / WN) + jn * 32 + r;
+        fb_base[jn] = 2 * BM * ROWB + R * ROWB; fb_sw[jn] = (R / RB) % SP;
+    }
+
+    if (TAPS > 1) set_tap(0);
+    stage(0);
+    __syncthreads();  // drains the DMA (vmcnt(0)) and publishes the tile to all waves
     int cur = 0;
     for (int kt = 0; kt < KT; ++kt) {
-        const bool more = kt + 1 < KT;
-        if (more) load_tile(kt + 1);
+        if (kt + 1 < KT) {
+            if (TAPS > 1 && ++cc == cchunks) { cc = 0; set_tap(++tap); }
+            stage(cur ^ 1);  // in flight while this k-tile is computed; its buffer was last read before the previous barrier
+        }
+        const unsigned char* Ab = smem + cur * BM * ROWB;
+        const unsigned char* Bb = smem + cur * BN * ROWB;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < BK / 16; ++ks) {
             bf16x8 af[TM], bfr[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                af[i] = *reinterpret_cast<const bf16x8*>(&As[cur][wm * (BM / WM) + i * 32 + r][ks * 16 + h * 8]);
+                af[i] = *reinterpret_cast<const bf16x8*>(Ab + fa_base[i] + (((2 * ks + h) ^ fa_sw[i]) << 4));
 #pragma unroll
             for (int jn = 0; jn < TN; ++jn)
-                bfr[jn] = *reinterpret_cast<const bf16x8*>(&Bs[cur][wn * (BN / WN) + jn * 32 + r][ks * 16 + h * 8]);
+                bfr[jn] = *reinterpret_cast<const bf16x8*>(Bb + fb_base[jn] + (((2 * ks + h) ^ fb_sw[jn]) << 4));
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int jn = 0; jn < TN; ++jn) acc[i][jn] = mfma32(af[i], bfr[jn], acc[i][jn]);
         }
-        if (more) store_tile(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
@@ -148,7 +172,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
     // ---- epilogue: per wave, 32 x COLS fp32 slab through LDS, then row-contiguous vector I/O
     float* slab = reinterpret_cast<float*>(smem) + wid * 32 * COLS;
     constexpr int LPR = COLS / 4;       // lanes per row
-    constexpr int RPI = 64 / LPR;       // rows per iteration
+    constexpr int ERPI = 64 / LPR;      // rows per iteration
     const int ecol = (lane % LPR) * 4;  // column (within the wave tile) of this lane's 4-vector
     const int nbase = n0 + wn * (BN / WN) + ecol;
     float bias4[4] = {0.f, 0.f, 0.f, 0.f};
@@ -166,8 +190,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
             for (int g = 0; g < 16; ++g) slab[mfma_row(g, lane) * COLS + jn * 32 + r] = acc[i][jn][g];
         __syncthreads();
 #pragma unroll
-        for (int it = 0; it < 32 / RPI; ++it) {
-            const int row = it * RPI + lane / LPR;
+        for (int it = 0; it < 32 / ERPI; ++it) {
+            const int row = it * ERPI + lane / LPR;
             const int m = m0 + wm * (BM / WM) + i * 32 + row;
             if (m >= p.M || nbase >= p.Cout) continue;
             f32x4 v = *reinterpret_cast<const f32x4*>(&slab[row * COLS + ecol]);
@@ -253,10 +277,14 @@ template <int BM, int BN, int WM, int WN>
 static int launch_cfg(const IGemmParams& p, hipStream_t s) {
     const int MT = (p.M + BM - 1) / BM, NT = p.Cout_pad / BN;
     const int grid = ((MT + 7) / 8) * 8 * NT;
-    if (p.taps == 9)
-        hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, 9>), dim3(grid), dim3(256), 0, s, p);
-    else
-        hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, 1>), dim3(grid), dim3(256), 0, s, p);
+    const bool k64 = (p.Cin & 63) == 0;
+    if (p.taps == 9) {
+        if (k64) hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, 9, 64>), dim3(grid), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, 9, 32>), dim3(grid), dim3(256), 0, s, p);
+    } else {
+        if (k64) hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, 1, 64>), dim3(grid), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, 1, 32>), dim3(grid), dim3(256), 0, s, p);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -268,6 +296,7 @@ int ir_launch_igemm(const IGemmParams& pin, hipStream_t s) {
     if (p.Cin <= 0 || (p.Cin & 31) || (p.in_cs & 7) || p.in_cs < p.Cin) return -3;
     if (p.Cout <= 0 || p.Cout > p.Cout_pad || (p.Cout_pad & 31)) return -4;
     if (p.wgt_rs < (long)p.taps * p.Cin || (p.wgt_rs & 7)) return -10;
+    if (p.taps == 9 && (long)p.Cin * 2 + 64 > (long)sizeof(uint4) * 4096) return -11;  // zero page must cover one tap's channels
     p.vec = !((p.out_cs & 3) || (p.res && (p.res_cs & 3)) || (p.out2 && (p.out2_cs & 3)) ||
               (reinterpret_cast<uintptr_t>(p.res) & 15) || (reinterpret_cast<uintptr_t>(p.out2) & 7) ||
               (p.gate && (p.gate_stride & 3)));
@@ -279,6 +308,7 @@ int ir_launch_igemm(const IGemmParams& pin, hipStream_t s) {
     if (p.taps == 9) {
         if (p.stride != 1 && p.stride != 2) return -8;
         if ((long)p.NB * p.Ho * p.Wo != p.M) return -9;
+        if (p.H <= 0 || p.W <= 0) return -9;
     }
     if (p.Cout_pad % 128 == 0) return launch_cfg<128, 128, 2, 2>(p, s);
     if (p.Cout_pad % 64 == 0) return launch_cfg<128, 64, 2, 2>(p, s);

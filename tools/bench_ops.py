@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Per-shape timing of the igemm / attention kernels through the C ABI (development aid; not part of bench.py)."""
+import sys, os, math
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from instarevive_amd import _lib as L, Context
+
+ctx = Context(0)
+
+
+def timeit(fn, iters=5, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def conv(n, h, w, cin, cout, up=0, stride=1):
+    x = torch.randn(n, h, w, cin, device="cuda").to(torch.bfloat16).view(torch.int16)
+    wt = (torch.randn(cout, 9 * cin, device="cuda") / math.sqrt(9 * cin)).to(torch.bfloat16).view(torch.int16)
+    b = torch.zeros(cout, device="cuda")
+    ho, wo = (h // 2, w // 2) if stride == 2 else ((2 * h, 2 * w) if up else (h, w))
+    out = torch.empty(n, ho, wo, cout, dtype=torch.int16, device="cuda")
+    fn = lambda: ctx.check(ctx.lib.ir_op_conv(ctx.h, ctx.stream(), L.ptr(x), L.ptr(wt), L.ptr(b), L.ptr(out), n, h, w, cin, cout, cout, 9, stride,
+                                              0 if stride == 2 else 1, up, 0, 0.0, None, 0, 0), "conv")
+    ms = timeit(fn)
+    fl = 2.0 * n * ho * wo * cout * 9 * cin
+    print(f"conv {n}x{h}x{w} {cin}->{cout} up={up} s={stride}: {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s")
+
+
+def linear(m, k, n, out_f32=0):
+    x = torch.randn(m, k, device="cuda").to(torch.bfloat16).view(torch.int16)
+    wt = (torch.randn(n, k, device="cuda") / math.sqrt(k)).to(torch.bfloat16).view(torch.int16)
+    b = torch.zeros(n, device="cuda")
+    out = torch.empty(m, n, dtype=torch.float32 if out_f32 else torch.int16, device="cuda")
+    fn = lambda: ctx.check(ctx.lib.ir_op_linear(ctx.h, ctx.stream(), L.ptr(x), L.ptr(wt), L.ptr(b), L.ptr(out), m, k, n, n, 0, None, None, 0, out_f32, 1.0), "linear")
+    ms = timeit(fn)
+    print(f"linear {m}x{k}->{n} f32={out_f32}: {ms:8.3f} ms  {2.0 * m * k * n / ms / 1e9:8.1f} TFLOP/s")
+
+
+def attn(b, heads, t, d):
+    q = torch.randn(b, t, heads, d, device="cuda").to(torch.bfloat16).view(torch.int16)
+    k = torch.randn(b, t, heads, d, device="cuda").to(torch.bfloat16).view(torch.int16)
+    v = torch.randn(b, t, heads, d, device="cuda").to(torch.bfloat16).view(torch.int16)
+    o = torch.empty_like(q)
+    ws = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+    fn = lambda: ctx.check(ctx.lib.ir_op_attention(ctx.h, ctx.stream(), L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(o), b, heads, t, t, d, d ** -0.5, None,
+                                                   L.ptr(ws), ws.numel()), "attn")
+    ms = timeit(fn)
+    print(f"attn b{b} h{heads} T{t} d{d}: {ms:8.3f} ms  {4.0 * b * heads * t * t * d / ms / 1e9:8.1f} TFLOP/s (incl. V transpose)")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["conv", "linear", "attn"]
+    if "conv" in which:
+        conv(1, 2048, 2048, 128, 128)
+        conv(1, 2048, 2048, 256, 256)
+        conv(1, 2048, 2048, 256, 128)
+        conv(1, 1024, 1024, 256, 256)
+        conv(1, 1024, 1024, 512, 512)
+        conv(1, 1024, 1024, 256, 256, up=1)
+        conv(1, 512, 512, 512, 512)
+        conv(1, 256, 256, 512, 512)
+        conv(1, 2048, 2048, 64, 64)
+        conv(1, 256, 256, 192, 192)
+    if "linear" in which:
+        linear(16384, 1152, 3456)
+        linear(16384, 1152, 1152)
+        linear(16384, 1152, 4608)
+        linear(16384, 4608, 1152)
+        linear(65536, 512, 65536, out_f32=1)
+        linear(65536, 65536, 512)
+        linear(65536, 192, 576)
+        linear(4194304, 128, 128)
+    if "attn" in which:
+        attn(1, 16, 16384, 72)
+        attn(1, 16, 1024, 72)
