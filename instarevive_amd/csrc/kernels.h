@@ -34,6 +34,7 @@ struct IGemmParams {
     int out_f32, out_cs;
     bf16_t* out2;       // optional extra bf16 copy of the result
     int out2_cs;
+    int force_generic;  // 1: never take the halo-tile conv path (A/B testing)
     int vec;            // set by the launcher: all strides/pointers allow 4-element vector I/O
 };
 int ir_launch_igemm(const IGemmParams& p, hipStream_t s);
