@@ -31,19 +31,63 @@ __device__ uint4 g_zero_page[4096];
 template <int TM, int TN, class MapRow>
 IR_DEVINL void igemm_epilogue(const IGemmParams& p, f32x16 (&acc)[TM][TN], unsigned char* smem, int wid, int lane, int n_wave, MapRow map_row) {
     constexpr int COLS = TN * 32;
-    // ---- epilogue: per wave, 32 x COLS fp32 slab through LDS, then row-contiguous vector I/O
-    float* slab = reinterpret_cast<float*>(smem) + wid * 32 * COLS;
-    const int r = lane & 31;
     constexpr int LPR = COLS / 4;       // lanes per row
     constexpr int ERPI = 64 / LPR;      // rows per iteration
+    constexpr int IT = 32 / ERPI;       // iterations per 32-row tile
+    float* slab = reinterpret_cast<float*>(smem) + wid * 32 * COLS;
+    const int r = lane & 31;
     const int ecol = (lane % LPR) * 4;  // column (within the wave tile) of this lane's 4-vector
     const int nbase = n_wave + ecol;
-    float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool vec_ok = p.vec && (nbase + 3 < p.Cout);
+    float bias4[4] = {0.f, 0.f, 0.f, 0.f}, gate4[4] = {1.f, 1.f, 1.f, 1.f};
     if (p.bias) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) bias4[e] = p.bias[nbase + e];
     }
-    const bool vec_ok = p.vec && (nbase + 3 < p.Cout);
+    const bool gate_const = p.gate && p.gate_stride == 0;  // one gate row for every output row (single timestep)
+    if (gate_const && nbase < p.Cout) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gate4[e] = (nbase + e < p.Cout) ? p.gate[nbase + e] : 1.f;
+    }
+    int mrow[TM][IT];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int it = 0; it < IT; ++it) mrow[i][it] = map_row(i, it * ERPI + lane / LPR);
+    // residual prefetch: all loads of the tile are issued back to back on clamped (always valid) rows BEFORE the LDS
+    // transposes, so their latency overlaps the transposes instead of being paid once per row group
+    f32x4 rres[TM][IT];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int it = 0; it < IT; ++it) rres[i][it] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (p.res && vec_ok) {
+        if (p.res_f32) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int it = 0; it < IT; ++it) {
+                    const int m = max(mrow[i][it], 0);
+                    const long rm = p.res_mod > 0 ? (long)(m % p.res_mod) : (long)m;
+                    rres[i][it] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.res) + rm * p.res_cs + nbase);
+                }
+        } else {
+            uint2 rb[TM][IT];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int it = 0; it < IT; ++it) {
+                    const int m = max(mrow[i][it], 0);
+                    const long rm = p.res_mod > 0 ? (long)(m % p.res_mod) : (long)m;
+                    rb[i][it] = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(p.res) + rm * p.res_cs + nbase);
+                }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int it = 0; it < IT; ++it)
+                    rres[i][it] = f32x4{bflo(rb[i][it].x), bfhi(rb[i][it].x), bflo(rb[i][it].y), bfhi(rb[i][it].y)};
+        }
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         __syncthreads();
@@ -53,9 +97,9 @@ IR_DEVINL void igemm_epilogue(const IGemmParams& p, f32x16 (&acc)[TM][TN], unsig
             for (int g = 0; g < 16; ++g) slab[mfma_row(g, lane) * COLS + jn * 32 + r] = acc[i][jn][g];
         __syncthreads();
 #pragma unroll
-        for (int it = 0; it < 32 / ERPI; ++it) {
+        for (int it = 0; it < IT; ++it) {
             const int row = it * ERPI + lane / LPR;
-            const int m = map_row(i, row);
+            const int m = mrow[i][it];
             if (m < 0 || nbase >= p.Cout) continue;
             f32x4 v = *reinterpret_cast<const f32x4*>(&slab[row * COLS + ecol]);
             float o[4];
@@ -69,37 +113,25 @@ IR_DEVINL void igemm_epilogue(const IGemmParams& p, f32x16 (&acc)[TM][TN], unsig
                     case IR_ACT_SILU: x = silu(x); break;
                     default: break;
                 }
-                o[e] = x * p.out_scale;
+                o[e] = x * p.out_scale * gate4[e];
             }
-            if (p.gate) {
+            if (p.gate && !gate_const) {
                 const float* g = p.gate + (long)(m / p.rows_per_batch) * p.gate_stride + nbase;
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
                     if (nbase + e < p.Cout) o[e] *= g[e];
             }
             if (p.res) {
-                const long rm = p.res_mod > 0 ? (long)(m % p.res_mod) : (long)m;
-                if (p.res_f32) {
-                    const float* rp = reinterpret_cast<const float*>(p.res) + rm * p.res_cs + nbase;
-                    if (vec_ok) {
-                        f32x4 rv = *reinterpret_cast<const f32x4*>(rp);
+                if (vec_ok) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] += rv[e];
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (nbase + e < p.Cout) o[e] += rp[e];
-                    }
+                    for (int e = 0; e < 4; ++e) o[e] += rres[i][it][e];
                 } else {
-                    const bf16_t* rp = reinterpret_cast<const bf16_t*>(p.res) + rm * p.res_cs + nbase;
-                    if (vec_ok) {
-                        uint2 rv = *reinterpret_cast<const uint2*>(rp);
-                        o[0] += bflo(rv.x); o[1] += bfhi(rv.x); o[2] += bflo(rv.y); o[3] += bfhi(rv.y);
-                    } else {
+                    const long rm = p.res_mod > 0 ? (long)(m % p.res_mod) : (long)m;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (nbase + e < p.Cout) o[e] += bf2f(rp[e]);
-                    }
+                    for (int e = 0; e < 4; ++e)
+                        if (nbase + e < p.Cout)
+                            o[e] += p.res_f32 ? reinterpret_cast<const float*>(p.res)[rm * p.res_cs + nbase + e]
+                                              : bf2f(reinterpret_cast<const bf16_t*>(p.res)[rm * p.res_cs + nbase + e]);
                 }
             }
             if (p.out_f32) {
