@@ -378,19 +378,28 @@ int attnblock(Run& r, const AttnW& w, bf16_t* B[3], int ci, float* gws, int N, i
     const long ld = T + 64;  // padded leading dimension of S, P and V^T: a power-of-two row stride would put every row of a
                              // tile on the same memory channel
     bf16_t* vt = r.a.alloc<bf16_t>(ld * C);
-    float* S = r.a.alloc<float>(T * ld);
-    bf16_t* P = r.a.alloc<bf16_t>(T * ld);
+    const bool flash = (C == 512 && (T & 63) == 0);
+    float* S = flash ? nullptr : r.a.alloc<float>(T * ld);
+    bf16_t* P = flash ? nullptr : r.a.alloc<bf16_t>(T * ld);
     groupnorm(r, w.n, B[ci], B[t1], gws, N, T, 0);
     linear(r, w.q, B[t1], (int)(N * T), C, q, C, 0, ACT_NONE, nullptr, 0, 0);
     linear(r, w.k, B[t1], (int)(N * T), C, k, C, 0, ACT_NONE, nullptr, 0, 0);
     linear(r, w.v, B[t1], (int)(N * T), C, v, C, 0, ACT_NONE, nullptr, 0, 0);
     const int dsub = (C % 128 == 0) ? 128 : (C % 64 == 0 ? 64 : 32);
     for (int b = 0; b < N; ++b) {
+        LAUNCH(r, PC_TRANSPOSE, 0.0, 4.0 * (double)T * C, ir_launch_transpose_v(v + b * T * C, vt, 0, C, dsub, 1, C / dsub, (int)T, (int)ld, dsub, dsub, r.s),
+               "transpose_v");
+        if (C == 512 && (T & 63) == 0) {  // flash path: scores never leave the chip
+            LAUNCH(r, PC_FLASH_ATTN, 4.0 * (double)T * T * C, 0.0,
+                   ir_launch_flash_attn_d512(q + b * T * C, k + b * T * C, vt, o + b * T * C, (int)T, C, C, ld, 1.0f / sqrtf((float)C), r.s),
+                   "vae_flash_attn");
+            continue;
+        }
+        // generic width (reduced test configurations): scores materialised per image in HBM (fp32 S, bf16 P)
         Conv kw;  // S = q k^T * C^-0.5 : the keys play the role of the weight matrix [T][C]
         kw.w = k + b * T * C; kw.b = nullptr; kw.cin = C; kw.cout = (int)T; kw.cout_pad = (int)T; kw.taps = 1;
         linear(r, kw, q + b * T * C, (int)T, C, S, (int)ld, 1, ACT_NONE, nullptr, 0, 0, nullptr, 0, nullptr, 0, 1.0f / sqrtf((float)C));
         LAUNCH(r, PC_SOFTMAX, 0.0, 6.0 * (double)T * T, ir_launch_softmax_rows(S, P, T, (int)T, ld, ld, r.s), "softmax_rows");
-        LAUNCH(r, PC_TRANSPOSE, 0.0, 0.0, ir_launch_transpose_v(v + b * T * C, vt, 0, C, dsub, 1, C / dsub, (int)T, (int)ld, dsub, dsub, r.s), "transpose_v");
         Conv vw;  // O = P V : V^T [C][ld] is the weight matrix
         vw.w = vt; vw.b = nullptr; vw.cin = (int)T; vw.cout = C; vw.cout_pad = C; vw.taps = 1; vw.w_rs = ld;
         linear(r, vw, P, (int)T, (int)ld, o + b * T * C, C, 0, ACT_NONE, nullptr, 0, 0);
@@ -1118,6 +1127,17 @@ int ir_op_attention(ir_ctx* c, void* stream, const uint16_t* q, const uint16_t* 
                     int tq, int tk, int d, float scale, const float* key_bias, void* ws, size_t ws_bytes) {
     // q/o: [b][tq][heads*d], k/v: [b][tk][heads*d]
     const int DV = ir_attn_dv(d), tkp = ((tk + 63) & ~63) + 64;
+    if (heads == 1 && d == 512 && tq == tk && key_bias == nullptr) {  // VAE mid-block form
+        const size_t need512 = (size_t)512 * tkp * 2;
+        if (ws_bytes < need512) return fail(c, -20, "attention workspace too small: need %zu", need512);
+        for (int i = 0; i < b; ++i) {
+            int rc = ir_launch_transpose_v(v + (long)i * tk * 512, (bf16_t*)ws, 0, 512, 128, 1, 4, tk, tkp, 128, 128, (hipStream_t)stream);
+            if (!rc) rc = ir_launch_flash_attn_d512(q + (long)i * tq * 512, k + (long)i * tk * 512, (const bf16_t*)ws, o + (long)i * tq * 512, tq, 512, 512,
+                                                    tkp, scale, (hipStream_t)stream);
+            if (rc) return fail(c, rc, "flash_attn_d512 failed (%d)", rc);
+        }
+        return 0;
+    }
     const size_t need = (size_t)b * heads * DV * tkp * 2;
     if (ws_bytes < need) return fail(c, -20, "attention workspace too small: need %zu", need);
     hipStream_t s = (hipStream_t)stream;

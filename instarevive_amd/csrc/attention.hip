@@ -249,6 +249,169 @@ int ir_launch_flash_attn(const AttnParams& p, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Single-head attention with head dim 512 (the VAE mid-block, reference ldm/modules/diffusionmodules/model.py:181-205),
+// flash style. One wave per SIMD with the whole 512-register budget: each wave owns 32 queries, keeps O^T (512 x 32 fp32)
+// in 256 accumulator registers and its Q^T fragments (32 k-steps) in 128 VGPRs. K (64 keys x 512, 64 KB) and V^T (512 x 64
+// keys, 64 KB) tiles are single-buffered in LDS and filled by LDS-DMA: K(t+1) lands while softmax + PV of tile t run, V(t+1)
+// lands while QK^T of tile t+1 runs, so every transfer has a 64-MFMA phase to hide behind and two plain barriers per tile
+// suffice. Same transposed-score formulation as flash_attn_kernel (S^T = K Q^T, O^T = V^T P^T, keys swap23-permuted).
+// q, k: [T][512] bf16 rows (row stride rs); vt: [512][vt_rs] bf16; o: [T][512]. T % 64 == 0.
+// Register budget: O^T for all 512 output dims (256 accumulators) plus the Q fragments (128) plus S/P exceeds what hipcc
+// allocates without spilling, so the output dims are split over blockIdx.y (DSPLIT = 2): each block recomputes S^T and owns
+// 256 output dims (128 accumulators). That costs 1.5x the MFMA work of an ideal kernel but keeps everything in registers.
+typedef __attribute__((address_space(3))) void* attn_lds_ptr_t;
+IR_DEVINL void attn_glds16(const void* g, attn_lds_ptr_t l) { __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0); }
+
+__global__ __launch_bounds__(256, 1) void flash_attn_d512_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                                  const bf16_t* __restrict__ vt, bf16_t* __restrict__ o, int T, int rs,
+                                                                  int o_rs, long vt_rs, float scale_log2) {
+    constexpr int D = 512, NKS = D / 16, DSPLIT = 2, DVB = D / DSPLIT, NDT = DVB / 32;
+    constexpr int KROW = 1024 + 16;  // K rows are one DMA instruction each, so they can be padded: (key*65 + c) % 16 is conflict-free
+    constexpr int KBYTES = 64 * KROW;
+    constexpr float RESCALE_THR = 8.0f;
+    __shared__ __attribute__((aligned(256))) unsigned char smem[KBYTES + DVB * 128];  // K tile | V^T tile (reused for O at the end)
+    unsigned char* Kb = smem;
+    unsigned char* Vb = smem + KBYTES;
+    const int dv0 = blockIdx.y * DVB;  // first output dim owned by this block
+    vt += (long)dv0 * vt_rs;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wu = __builtin_amdgcn_readfirstlane(wid);
+    const int r = lane & 31, h = lane >> 5;
+    const int q0 = blockIdx.x * 128;
+
+    const bf16_t* k_lane = k + lane * 8;                                                       // + key * rs
+    const bf16_t* v_lane = vt + (long)(wu * 8 + (lane >> 3)) * vt_rs + (((lane & 7) ^ ((lane >> 4) & 3) ^ (((wu * 8) >> 1) & 4)) << 3);
+    // V^T rows are 128 B (8 rows per DMA instruction, unpaddable): chunk c of row d sits at slot c ^ ((d >> 1) & 7). For the
+    // rows d = 8*qi + (lane>>3) of instruction qi = wu + 4i: (d >> 1) & 7 = ((lane >> 4) & 3) | ((qi & 1) << 2), and qi & 1 = wu & 1.
+    auto stage_k = [&](int key0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int kk = wu + 4 * i;
+            attn_glds16(k_lane + (long)(key0 + kk) * rs, (attn_lds_ptr_t)(Kb + kk * KROW));
+        }
+    };
+    auto stage_v = [&](int key0) {
+#pragma unroll
+        for (int i = 0; i < DVB / 32; ++i)
+            attn_glds16(v_lane + (long)(32 * i) * vt_rs + key0, (attn_lds_ptr_t)(Vb + (wu + 4 * i) * 1024));
+    };
+    stage_k(0);
+    stage_v(0);
+    // Q^T fragments straight from HBM in the MFMA B-operand layout (lane = query, 8 consecutive d per k-step half)
+    bf16x8 qf[NKS];
+    {
+        const bf16_t* qrow = q + (long)min(q0 + wid * 32 + r, T - 1) * rs + h * 8;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qrow + ks * 16);
+    }
+    f32x16 acc[NDT];
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) acc[dt][g] = 0.f;
+    float m_i = -1e30f, l_i = 0.f;
+    // LDS fragment addresses: ONE base per operand plus compile-time immediates (a lane-dependent XOR inside the unrolled
+    // loops would make hipcc hoist every address into its own register)
+    const unsigned char* k_base = Kb + swap23(r) * KROW + h * 16;                     // + kt*32*KROW + ks*32
+    const int vsw = (r >> 1) & 7;                                                    // swizzle of rows d = dt*32 + r
+    const unsigned char* v_base[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v_base[j] = Vb + r * 128 + ((((2 * j) | h) ^ vsw) << 4);  // + dt*4096 ; j = kt*2 + s2
+    const int NT = T >> 6;
+    __syncthreads();  // K(0), V(0) landed
+    for (int t = 0; t < NT; ++t) {
+        // ---- S^T = K Q^T
+        f32x16 s[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int g = 0; g < 16; ++g) s[kt][g] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                bf16x8 a = *reinterpret_cast<const bf16x8*>(k_base + kt * 32 * KROW + ks * 32);
+                s[kt] = mfma32(a, qf[ks], s[kt]);
+            }
+        }
+        __syncthreads();                       // every wave is done with the K tile (and V(t) has landed: vmcnt(0))
+        if (t + 1 < NT) stage_k((t + 1) * 64);  // lands during softmax + PV
+        // ---- online softmax (exp2 domain, deferred rescale)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) mx = fmaxf(mx, s[kt][g]);
+        mx *= scale_log2;
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        if (__any(mx > m_i + RESCALE_THR)) {
+            const float m_new = fmaxf(m_i, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_i - m_new);
+            l_i *= alpha;
+            m_i = m_new;
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) acc[dt][g] *= alpha;
+        }
+        float rsum = 0.f;
+        bf16x8 pb[4];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][s2 * 8 + e], scale_log2, -m_i));
+                    rsum += pv;
+                    pb[kt * 2 + s2][e] = (__bf16)pv;
+                }
+        rsum += __shfl_xor(rsum, 32);
+        l_i += rsum;
+        // ---- O^T += V^T P^T
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bf16x8 a = *reinterpret_cast<const bf16x8*>(v_base[j] + dt * 4096);
+                acc[dt] = mfma32(a, pb[j], acc[dt]);
+            }
+        __syncthreads();                       // every wave is done with the V^T tile (and K(t+1) has landed)
+        if (t + 1 < NT) stage_v((t + 1) * 64);  // lands during the next QK^T
+    }
+    // ---- finalise: O^T / l -> LDS [q][DVB] bf16 (16 KB per wave) -> 16-byte row stores
+    const float inv = 1.0f / l_i;
+    constexpr int OROW = DVB * 2;  // bytes per staged row
+    unsigned char* ow = smem + wid * 32 * OROW;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) {
+            uint2 w = make_uint2(pack2bf(acc[dt][4 * gg] * inv, acc[dt][4 * gg + 1] * inv),
+                                 pack2bf(acc[dt][4 * gg + 2] * inv, acc[dt][4 * gg + 3] * inv));
+            // row r (query), 8-byte chunk index (dt*32 + 8gg + 4h)/4; XOR with the row spreads the 32 rows over banks
+            const int c8 = (dt * 8 + 2 * gg + h) ^ (r & 31);
+            *reinterpret_cast<uint2*>(ow + r * OROW + c8 * 8) = w;
+        }
+    __syncthreads();
+    constexpr int OCH = DVB / 8;  // 16-byte chunks per staged row
+    for (int c = lane; c < 32 * OCH; c += 64) {
+        const int row = c / OCH, ch = c % OCH;
+        const int qq = q0 + wid * 32 + row;
+        // undo the 8-byte XOR swizzle: 16-byte chunk ch = 8-byte chunks 2ch, 2ch+1 -> stored at (2ch)^row, (2ch+1)^row
+        const uint2 lo = *reinterpret_cast<const uint2*>(ow + row * OROW + (((2 * ch) ^ (row & 31)) * 8));
+        const uint2 hi = *reinterpret_cast<const uint2*>(ow + row * OROW + (((2 * ch + 1) ^ (row & 31)) * 8));
+        if (qq < T) *reinterpret_cast<uint4*>(o + (long)qq * o_rs + dv0 + ch * 8) = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    }
+}
+
+int ir_launch_flash_attn_d512(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* o, int T, int rs, int o_rs, long vt_rs,
+                              float scale, hipStream_t s) {
+    if (T <= 0 || (T & 63) || (rs & 7) || (o_rs & 7) || (vt_rs & 7) || vt_rs < T) return -2;
+    hipLaunchKernelGGL(flash_attn_d512_kernel, dim3((T + 127) / 128, 2), dim3(256), 0, s, q, k, vt, o, T, rs, o_rs, vt_rs,
+                       scale * 1.44269504088896340736f);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 // V[b][t][head*D + d] (row stride v_rs) -> Vt[b][head][DV][Tpad]; rows d >= D and columns t >= T are zero.
 // grid = (Tpad/64, Hh, B), block 256. LDS tile [64 tokens][DV].
 __global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t* __restrict__ v, bf16_t* __restrict__ vt, long v_bs, int v_rs,

@@ -69,6 +69,8 @@ struct AttnParams {
     long kb_bs;
 };
 int ir_launch_flash_attn(const AttnParams& p, hipStream_t s);
+int ir_launch_flash_attn_d512(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* o, int T, int rs, int o_rs, long vt_rs,
+                              float scale, hipStream_t s);
 int ir_launch_transpose_v(const bf16_t* v, bf16_t* vt, long v_bs, int v_rs, int v_hs, int B, int Hh, int T, int Tpad, int D,
                           int DV, hipStream_t s);
 int ir_launch_swin_attn(const bf16_t* qkv, bf16_t* out, const float* biasT, int B, int H, int W, int heads, int ld, int ldo,

@@ -178,7 +178,8 @@ def test_layernorm(ctx, rows, c, ld):
 
 @pytest.mark.parametrize("b,heads,tq,tk,d,bias", [
     (1, 2, 128, 128, 72, False), (2, 3, 200, 200, 72, False), (1, 16, 1024, 1024, 72, False),
-    (2, 2, 130, 300, 72, True), (1, 2, 64, 64, 32, False), (1, 1, 256, 192, 64, True)])
+    (2, 2, 130, 300, 72, True), (1, 2, 64, 64, 32, False), (1, 1, 256, 192, 64, True),
+    (1, 1, 256, 256, 512, False), (2, 1, 1024, 1024, 512, False)])
 def test_flash_attention(ctx, b, heads, tq, tk, d, bias):
     g = torch.Generator().manual_seed(tq + tk + d)
     q = rb(torch.randn(b, tq, heads, d, generator=g))
