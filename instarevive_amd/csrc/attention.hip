@@ -19,7 +19,7 @@
 
 IR_DEVINL int swap23(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }
 
-template <int D>
+template <int D, bool GENERAL>
 __global__ __launch_bounds__(256, 2) void flash_attn_kernel(AttnParams p) {
     constexpr int DQK = (D + 15) & ~15;  // head dim padded for the QK^T k-steps (16 per MFMA)
     constexpr int DV = (D + 31) & ~31;   // head dim padded for the 32-row O^T tiles
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(AttnParams p) {
     const bf16_t* kp = p.k + (long)b * p.k_bs + (long)head * p.k_hs;
     const bf16_t* vtp = p.vt + (long)b * p.vt_bs + (long)head * DV * p.Tk_pad;
     const float* kb = p.key_bias ? p.key_bias + (long)b * p.kb_bs : nullptr;
-    const bool general = kb || (p.Tk & 63);  // additive key bias and/or ragged last tile -> bias path through LDS
+    constexpr bool general = GENERAL;  // additive key bias and/or ragged last tile -> bias path through LDS (separate instantiation)
 
     // Every global load below is UNCONDITIONAL on a clamped, always-valid address and never feeds a select: hipcc turns
     // "load, then zero if out of range" into a branch around the load plus a vmcnt(0) per element, which serialises
@@ -133,14 +133,13 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(AttnParams p) {
         if (more) load_kv(t + 1);
         // ---- S^T = K Q^T (two 32-key tiles); this lane's keys for (kt, g): t*64 + kt*32 + 16*(g>>3) + 8*h + (g&7)
         f32x16 s[2];
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
-            for (int g = 0; g < 16; ++g) s[kt][g] = 0.f;
-#pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
                 bf16x8 a = *reinterpret_cast<const bf16x8*>(&Ks[(cur * 64 + kt * 32 + kr) * QS + ks * 16 + h * 8]);
-                s[kt] = mfma32(a, qf[ks], s[kt]);
+                s[kt] = mfma32(a, qf[ks], ks == 0 ? zero16 : s[kt]);  // first k-step takes the constant 0 as C (no register zeroing)
             }
         }
         // ---- online softmax in the exp2 domain
@@ -238,14 +237,17 @@ int ir_launch_flash_attn(const AttnParams& p, hipStream_t s) {
     if ((p.Tk_pad & 63) || p.Tk_pad < ((p.Tk + 63) & ~63)) return -4;
     if (p.scale_log2 <= 0.f) return -6;
     dim3 grid((p.Tq + 127) / 128, p.Hh, p.B);
-    if (p.D == 72)
-        hipLaunchKernelGGL((flash_attn_kernel<72>), grid, dim3(256), 0, s, p);
-    else if (p.D == 32)
-        hipLaunchKernelGGL((flash_attn_kernel<32>), grid, dim3(256), 0, s, p);
-    else if (p.D == 64)
-        hipLaunchKernelGGL((flash_attn_kernel<64>), grid, dim3(256), 0, s, p);
-    else
-        return -5;
+    const bool general = p.key_bias != nullptr || (p.Tk & 63);
+#define IR_FA(DD)                                                                                     \
+    do {                                                                                              \
+        if (general) hipLaunchKernelGGL((flash_attn_kernel<DD, true>), grid, dim3(256), 0, s, p);     \
+        else hipLaunchKernelGGL((flash_attn_kernel<DD, false>), grid, dim3(256), 0, s, p);            \
+    } while (0)
+    if (p.D == 72) IR_FA(72);
+    else if (p.D == 32) IR_FA(32);
+    else if (p.D == 64) IR_FA(64);
+    else return -5;
+#undef IR_FA
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

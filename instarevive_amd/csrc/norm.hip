@@ -16,7 +16,6 @@
 // part: [N][chunks][2][C] fp32.
 __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restrict__ x, float* __restrict__ part,
                                                          int HW, int C, int chunks) {
-    __shared__ float s_sum[2][512];
     const int n = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
     const int vpp = C >> 3;             // 16-byte vectors per pixel
     const int ppi = 256 / vpp;          // pixels per block iteration (C=128:16, 256:8, 512:4)
@@ -48,21 +47,23 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restric
         }
         for (; pix < p1; pix += ppi) acc8(*reinterpret_cast<const uint4*>(base + pix * C));
     }
-    // reduce over the ppi pixel lanes that share a channel vector
-    for (int i = tid; i < 2 * 512; i += 256) (&s_sum[0][0])[i] = 0.f;
-    __syncthreads();
+    // reduce over the ppi pixel lanes that share a channel vector, in a FIXED order (no atomics: results must be bit-identical
+    // run to run): every lane parks its 8+8 partials in LDS, then one thread per channel adds the ppi partials in sequence
+    __shared__ float s_red[2][2048];  // [sum|sumsq][pl * C + c], ppi * C == 2048
     if (pl < ppi) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            atomicAdd(&s_sum[0][cv * 8 + e], s[e]);
-            atomicAdd(&s_sum[1][cv * 8 + e], q[e]);
+            s_red[0][pl * C + cv * 8 + e] = s[e];
+            s_red[1][pl * C + cv * 8 + e] = q[e];
         }
     }
     __syncthreads();
     float* out = part + ((long)n * chunks + chunk) * 2 * C;
     for (int c = tid; c < C; c += 256) {
-        out[c] = s_sum[0][c];
-        out[C + c] = s_sum[1][c];
+        float a = 0.f, b = 0.f;
+        for (int i = 0; i < ppi; ++i) { a += s_red[0][i * C + c]; b += s_red[1][i * C + c]; }
+        out[c] = a;
+        out[C + c] = b;
     }
 }
 

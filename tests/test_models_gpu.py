@@ -173,3 +173,79 @@ def test_process_disable_preprocess():
     got, got1 = process(dit, imgs, 1, "wavelet", True, False, 512, 448, preprocess_model=None, vae=vae, y=y.cuda(), y_mask=mask3.cuda())
     assert np.array_equal(got1[0], imgs[0]) and np.array_equal(ref1[0], imgs[0])  # stage-1 == LQ input, bit exact
     assert _psnr_u8(got, ref) >= 35.0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Full-size architectures (SwinIR 15.8 M, VAE 83.7 M, DiT 611 M parameters, 300 x 4096 prompt), seeded random weights.
+@pytest.fixture(scope="module")
+def full_models():
+    import bench
+    from instarevive_amd.models import AutoencoderKL, SwinIR, Transformer2DModel
+    from instarevive_amd import weights as W
+    swin_cfg = dict(embed_dim=180, depths=[6] * 8, num_heads=[6] * 8, window_size=8, mlp_ratio=2)
+    sds = dict(swin=bench.random_state_dict(W.swinir_shapes(swin_cfg), 1),
+               vae=bench.random_state_dict(W.vae_shapes(dict(ch=128, ch_mult=(1, 2, 4, 4), num_res_blocks=2)), 2),
+               dit=bench.random_state_dict(W.dit_shapes(dict(num_layers=28, num_attention_heads=16, attention_head_dim=72, caption_channels=4096)), 3))
+    swin = SwinIR(img_size=64, patch_size=1, in_chans=3, embed_dim=180, depths=[6] * 8, num_heads=[6] * 8, window_size=8, mlp_ratio=2, sf=8,
+                  img_range=1.0, upsampler="nearest+conv", resi_connection="1conv", unshuffle=True, unshuffle_scale=8)
+    swin.load_state_dict(sds["swin"], strict=False)
+    vae = AutoencoderKL()
+    vae.load_state_dict(sds["vae"])
+    dit = Transformer2DModel()
+    dit.load_state_dict(sds["dit"])
+    for m in (swin, vae, dit):
+        m.to("cuda")
+    y, mask = bench.synthetic_prompt()
+    return swin, vae, dit, sds, y, mask
+
+
+def test_full_arch_process_256_vs_oracle(full_models):
+    """Whole path at full depth (8x6 Swin blocks, 28 DiT layers, full VAE) on a 256x256 image against the fp32 oracle."""
+    import bench
+    from instarevive_amd.pipeline import process
+    swin, vae, dit, sds, y, mask = full_models
+    imgs = [bench.synthetic_lq(1, 256, 256, 5)[0].numpy()]
+    ref, ref1, inter = oglue.process(imgs, lambda x: oswin.swinir_forward(sds["swin"], x), lambda x: ovae.vae_encode_mean(sds["vae"], x),
+                                     lambda lat, t, yy, mm: odit.dit_forward(sds["dit"], lat, t, yy, mm), lambda z: ovae.vae_decode(sds["vae"], z),
+                                     oglue.alphas_cumprod_diffusers(), y, mask, return_intermediates=True)
+    got, got1 = process(dit, imgs, 1, "wavelet", False, False, 512, 448, preprocess_model=swin, vae=vae, y=y.cuda(), y_mask=mask.cuda())
+    p, p1 = _psnr_u8(got, ref), _psnr_u8(got1, ref1)
+    print(f"full-arch 256x256: PSNR vs fp32 oracle {p:.2f} dB (stage-1 {p1:.2f} dB)")
+    assert p >= 35.0 and p1 >= 40.0
+    # stage-level: x0 latent of the fused DiT step against the oracle's
+    lat = inter["init_noise"].cuda()
+    x0 = dit.step(lat, 400.0, float(oglue.alphas_cumprod_diffusers()[400]), y.cuda(), mask.cuda())
+    check(x0, inter["x0"], "full-arch DiT x0 (28 layers)", l2=0.03, worst=0.08)
+
+
+def test_full_arch_size_independent_properties(full_models):
+    """At a size the oracle cannot finish quickly (1024x1024): determinism, batch independence, single-tile == untiled."""
+    import bench
+    from instarevive_amd.pipeline import process
+    swin, vae, dit, sds, y, mask = full_models
+    a, b = [bench.synthetic_lq(1, 1024, 1024, s)[0].numpy() for s in (11, 12)]
+    kw = dict(preprocess_model=swin, vae=vae, y=y.cuda(), y_mask=mask.cuda())
+    pa, sa = process(dit, [a], 1, "none", False, False, 512, 448, **kw)
+    pa2, _ = process(dit, [a], 1, "none", False, False, 512, 448, **kw)
+    assert np.array_equal(pa[0], pa2[0]), "the path must be deterministic run to run"
+    pab, _ = process(dit, [a, b], 1, "none", False, False, 512, 448, **kw)
+    assert np.array_equal(pab[0], pa[0]), "an image's result must not depend on its batch neighbours"
+    # one 1024-px tile with stride 1024 covers the image exactly once: the tiled code path must reproduce the untiled result
+    pt, _ = process(dit, [a], 1, "none", False, True, 1024, 1024, **kw)
+    d = np.abs(pt[0].astype(int) - pa[0].astype(int))
+    assert d.max() <= 1, f"single-tile tiled vs untiled differ by {d.max()} grey levels"
+    assert pa[0].std() > 1.0 and sa[0].std() > 1.0  # not a constant image
+
+
+def test_full_arch_tiled_2048(full_models):
+    """2048x2048 --tiled (25 tiles, wavelet fix): runs, is finite/non-trivial and agrees with the stage-by-stage form."""
+    import bench
+    from instarevive_amd.pipeline import process
+    swin, vae, dit, sds, y, mask = full_models
+    a = bench.synthetic_lq(1, 2048, 2048, 21)[0].numpy()
+    kw = dict(preprocess_model=swin, vae=vae, y=y.cuda(), y_mask=mask.cuda())
+    fused, _ = process(dit, [a], 1, "wavelet", False, True, 512, 448, fused=True, **kw)
+    staged, _ = process(dit, [a], 1, "wavelet", False, True, 512, 448, fused=False, **kw)
+    p = _psnr_u8(fused, staged)
+    print(f"2048 tiled fused vs staged: {p:.2f} dB")
+    assert p >= 45.0 and fused[0].std() > 1.0
