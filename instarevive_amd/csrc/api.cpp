@@ -637,44 +637,54 @@ void pipeline_run(Run& r, const uint8_t* in, uint8_t* out, uint8_t* stage1, int 
         const float* pos = dit_pos(c, tl / 2, tl / 2, r.a.dry);
         if (!pos) { r.chk(-30, "dit.pos table for the tile size not uploaded"); r.a.release(mk); return; }
         std::vector<int> ys = starts(lh, tl, sl), xs = starts(lw, tl, sl);
+        std::vector<std::pair<int, int>> tiles;
+        for (int y : ys)
+            for (int x : xs) tiles.push_back({y, x});
+        // Tiles are independent inside each of the reference's two loops, so they are run as BATCHES (up to TB tiles per
+        // launch set): same arithmetic per tile, but every GEMM / conv sees TB x more rows and fills the chip.
+        const int NTl = (int)tiles.size(), TB = std::min(NTl, 32);
+        const long lat_tile = (long)n * 4 * tl * tl, px_tile = (long)n * 3 * tp * tp;
         float* nb = r.a.alloc<float>((long)n * 4 * lh * lw);
-        float* tl_in = r.a.alloc<float>((long)n * 4 * tl * tl);
-        float* tl_x0 = r.a.alloc<float>((long)n * 4 * tl * tl);
+        float* tl_in = r.a.alloc<float>(lat_tile * TB);
+        float* tl_x0 = r.a.alloc<float>(lat_tile * TB);
         if (!r.a.dry) {
             if (hipMemsetAsync(nb, 0, sizeof(float) * n * 4 * lh * lw, r.s) != hipSuccess) r.chk(-100, "memset");
             if (hipMemsetAsync(img, 0, sizeof(float) * n * 3 * HW, r.s) != hipSuccess) r.chk(-100, "memset");
         }
-        for (int y : ys)
-            for (int x : xs) {  // loop A: DiT tiles, averaged in latent space (inference.py:128-136)
-                const size_t mk2 = r.a.mark();
-                LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_crop_nchw(init, tl_in, n, 4, lh, lw, y, x, tl, tl, 1.f, r.s), "crop");
-                float* tok = dit_tokens_run(r, tl_in, n, tl, tl, timestep, pos);
-                LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_eps_to_x0(tok, tl_in, tl_x0, n, tl / 2, tl / 2, s0, s1, 1.f, r.s), "eps_to_x0");
-                LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_tile_add(nb, tl_x0, n, 4, lh, lw, tl, tl, y, x, r.s), "tile_add");
-                r.a.release(mk2);
-                if (r.a.dry) break;
-            }
+        for (int c0 = 0; c0 < NTl; c0 += TB) {  // loop A: DiT tiles, averaged in latent space (inference.py:128-136)
+            const int cb = std::min(TB, NTl - c0);
+            const size_t mk2 = r.a.mark();
+            for (int j = 0; j < cb; ++j)
+                LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_crop_nchw(init, tl_in + j * lat_tile, n, 4, lh, lw, tiles[c0 + j].first, tiles[c0 + j].second, tl, tl, 1.f, r.s), "crop");
+            float* tok = dit_tokens_run(r, tl_in, cb * n, tl, tl, timestep, pos);
+            LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_eps_to_x0(tok, tl_in, tl_x0, cb * n, tl / 2, tl / 2, s0, s1, 1.f, r.s), "eps_to_x0");
+            for (int j = 0; j < cb; ++j)
+                LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_tile_add(nb, tl_x0 + j * lat_tile, n, 4, lh, lw, tl, tl, tiles[c0 + j].first, tiles[c0 + j].second, r.s), "tile_add");
+            r.a.release(mk2);
+        }
         LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_tile_div(nb, n, 4, lh, lw, tl, tl, sl, sl, r.s), "tile_div");
-        float* t_img = r.a.alloc<float>((long)n * 3 * tp * tp);
-        float* t_sty = r.a.alloc<float>((long)n * 3 * tp * tp);
-        float* t_fix = r.a.alloc<float>((long)n * 3 * tp * tp);
-        float* o4 = r.a.alloc<float>((long)n * tp * tp * 4);
-        for (int y : ys)
-            for (int x : xs) {  // loop B: decode blended latents, colour-fix against the stage-1 tile, average (inference.py:139-153)
-                const size_t mk2 = r.a.mark();
-                LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_crop_nchw(nb, tl_in, n, 4, lh, lw, y, x, tl, tl, 1.0f / sf, r.s), "crop");
-                vae_decode_run(r, tl_in, 1.f, o4, n, tl, tl);
-                LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_nhwc_to_nchw(o4, 4, t_img, n, 3, (long)tp * tp, 0.5f, 0.5f, 0, r.s), "dec_out");
-                const float* src = t_img;
-                if (flags & (IR_FLAG_FIX_WAVELET | IR_FLAG_FIX_ADAIN)) {
-                    LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_crop_nchw(control, t_sty, n, 3, h, w, y * 8, x * 8, tp, tp, 1.f, r.s), "crop");
-                    colorfix_run(r, (flags & IR_FLAG_FIX_WAVELET) ? IR_FLAG_FIX_WAVELET : IR_FLAG_FIX_ADAIN, t_img, t_sty, t_fix, n, tp, tp);
-                    src = t_fix;
-                }
-                LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_tile_add(img, src, n, 3, h, w, tp, tp, y * 8, x * 8, r.s), "tile_add");
-                r.a.release(mk2);
-                if (r.a.dry) break;
+        float* t_img = r.a.alloc<float>(px_tile * TB);
+        float* t_sty = r.a.alloc<float>(px_tile * TB);
+        float* t_fix = r.a.alloc<float>(px_tile * TB);
+        float* o4 = r.a.alloc<float>((long)n * TB * tp * tp * 4);
+        for (int c0 = 0; c0 < NTl; c0 += TB) {  // loop B: decode blended latents, colour-fix against the stage-1 tile, average (inference.py:139-153)
+            const int cb = std::min(TB, NTl - c0);
+            const size_t mk2 = r.a.mark();
+            for (int j = 0; j < cb; ++j)
+                LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_crop_nchw(nb, tl_in + j * lat_tile, n, 4, lh, lw, tiles[c0 + j].first, tiles[c0 + j].second, tl, tl, 1.0f / sf, r.s), "crop");
+            vae_decode_run(r, tl_in, 1.f, o4, cb * n, tl, tl);
+            LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_nhwc_to_nchw(o4, 4, t_img, cb * n, 3, (long)tp * tp, 0.5f, 0.5f, 0, r.s), "dec_out");
+            const float* src = t_img;
+            if (flags & (IR_FLAG_FIX_WAVELET | IR_FLAG_FIX_ADAIN)) {
+                for (int j = 0; j < cb; ++j)
+                    LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_crop_nchw(control, t_sty + j * px_tile, n, 3, h, w, tiles[c0 + j].first * 8, tiles[c0 + j].second * 8, tp, tp, 1.f, r.s), "crop");
+                colorfix_run(r, (flags & IR_FLAG_FIX_WAVELET) ? IR_FLAG_FIX_WAVELET : IR_FLAG_FIX_ADAIN, t_img, t_sty, t_fix, cb * n, tp, tp);
+                src = t_fix;
             }
+            for (int j = 0; j < cb; ++j)
+                LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_tile_add(img, src + j * px_tile, n, 3, h, w, tp, tp, tiles[c0 + j].first * 8, tiles[c0 + j].second * 8, r.s), "tile_add");
+            r.a.release(mk2);
+        }
         LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_tile_div(img, n, 3, h, w, tp, tp, sl * 8, sl * 8, r.s), "tile_div");
     }
     LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_nchw_to_u8(img, out, n, HW, r.s), "out_u8");
