@@ -159,6 +159,7 @@ def main():
     ap.add_argument("--sr_scale", type=float, default=4.0)
     ap.add_argument("--batch", type=int, default=1, help="images per GPU per step")
     ap.add_argument("--tiled", action="store_true")
+    ap.add_argument("--net_hw", type=str, default="", help="HxW network input (overrides --lq/--sr_scale), e.g. 2176x3840 for the padded 4K case")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     args = ap.parse_args()
 
@@ -185,8 +186,12 @@ def main():
     y, mask = synthetic_prompt()
     dit.set_prompt(y.to(device), mask.to(device))
 
-    lq = synthetic_lq(args.batch, args.lq, args.lq, 1000 + rank)
-    net_in = upscale_bicubic(lq, args.sr_scale) if args.sr_scale != 1 else lq        # inference.py:265-269 (host, outside the timed region)
+    if args.net_hw:
+        hh, ww = (int(v) for v in args.net_hw.lower().split("x"))
+        net_in = synthetic_lq(args.batch, hh, ww, 1000 + rank)
+    else:
+        lq = synthetic_lq(args.batch, args.lq, args.lq, 1000 + rank)
+        net_in = upscale_bicubic(lq, args.sr_scale) if args.sr_scale != 1 else lq    # inference.py:265-269 (host, outside the timed region)
     n, h, w = net_in.shape[:3]
     assert h % 64 == 0 and w % 64 == 0
     flags = (L.FLAG_TILED | L.FLAG_FIX_WAVELET) if args.tiled else 0

@@ -118,7 +118,9 @@ class SwinIR(_DeviceModule):
         return W.swinir_expected_keys(self.cfg)
 
     def load_state_dict(self, state_dict, strict=True):
-        res = self._check_keys(state_dict, strict)
+        # relative_position_index / attn_mask are buffers derived from the window geometry: the released checkpoint carries
+        # them (732 entries) and they are accepted, but they are regenerated on the device and may be absent
+        res = self._check_keys(state_dict, strict, ignore=("relative_position_index", "attn_mask"))
         self._sd = {k: v.detach().cpu() for k, v in state_dict.items()}
         if self.ctx is not None:
             self._upload()

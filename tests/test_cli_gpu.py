@@ -1,0 +1,89 @@
+"""Drop-in surface end to end: write checkpoints in the reference's own formats (SwinIR .ckpt wrapped in {"state_dict"} with
+`module.` prefixes + yaml config, diffusers VAE folder with config.json + safetensors, diffusers transformer folder +
+flat DiT .ckpt, scheduler_config.json, prompt-embedding .pth), run the command line on PNG files and compare the saved
+images with the oracle run on the same files."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from oracle import dit as odit
+from oracle import glue as oglue
+from oracle import swinir as oswin
+from oracle import vae as ovae
+from tests.golden._det import det_input, det_state_dict
+from tests.test_models_gpu import DIT_SMALL, SWIN_SMALL, VAE_SMALL, _psnr_u8
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _write_artifacts(d):
+    from safetensors.torch import save_file
+    sws = det_state_dict(oswin.state_dict_shapes(SWIN_SMALL), seed=101)
+    svae = det_state_dict(ovae.state_dict_shapes(VAE_SMALL), seed=202)
+    sdit = det_state_dict(odit.state_dict_shapes(DIT_SMALL), seed=404)
+    os.makedirs(d / "weights", exist_ok=True)
+    full = dict(sws)  # the released file also carries the derived buffers; mimic that for every other block
+    full["layers.0.residual_group.blocks.0.attn.relative_position_index"] = torch.zeros(64, 64, dtype=torch.long)
+    full["layers.0.residual_group.blocks.1.attn_mask"] = torch.zeros(64, 64, 64)
+    torch.save({"state_dict": {"module." + k: v for k, v in full.items()}}, d / "weights" / "swinir.ckpt")
+    (d / "swinir.yaml").write_text(
+        "target: diffusion.model.swinir.SwinIR\nparams:\n  img_size: 64\n  patch_size: 1\n  in_chans: 3\n  embed_dim: 60\n"
+        "  depths: [2, 2]\n  num_heads: [6, 6]\n  window_size: 8\n  mlp_ratio: 2\n  sf: 8\n  img_range: 1.0\n"
+        "  upsampler: \"nearest+conv\"\n  resi_connection: \"1conv\"\n  unshuffle: True\n  unshuffle_scale: 8\n")
+    os.makedirs(d / "vae", exist_ok=True)
+    (d / "vae" / "config.json").write_text(json.dumps({"_class_name": "AutoencoderKL", "in_channels": 3, "out_channels": 3, "latent_channels": 4,
+                                                       "block_out_channels": [32, 64, 128, 128], "layers_per_block": 2, "norm_num_groups": 32,
+                                                       "scaling_factor": 0.18215, "act_fn": "silu", "sample_size": 256}))
+    save_file({k: v.contiguous() for k, v in svae.items()}, str(d / "vae" / "diffusion_pytorch_model.safetensors"))
+    os.makedirs(d / "pixart" / "transformer", exist_ok=True)
+    os.makedirs(d / "pixart" / "scheduler", exist_ok=True)
+    (d / "pixart" / "transformer" / "config.json").write_text(json.dumps({
+        "_class_name": "Transformer2DModel", "num_attention_heads": 4, "attention_head_dim": 72, "in_channels": 4, "out_channels": 8, "num_layers": 2,
+        "cross_attention_dim": 288, "attention_bias": True, "sample_size": 16, "patch_size": 2, "activation_fn": "gelu-approximate",
+        "norm_type": "ada_norm_single", "norm_elementwise_affine": False, "norm_eps": 1e-6, "caption_channels": 64, "num_embeds_ada_norm": 1000}))
+    (d / "pixart" / "scheduler" / "scheduler_config.json").write_text(json.dumps({"_class_name": "DDPMScheduler", "num_train_timesteps": 1000,
+                                                                                 "beta_start": 0.0001, "beta_end": 0.02, "beta_schedule": "linear"}))
+    torch.save(sdit, d / "weights" / "dit.ckpt")
+    y = det_input(9, (1, 20, 64), -1, 1)
+    mask = torch.zeros(1, 20)
+    mask[:, :13] = 1
+    torch.save({"caption_embeds": y, "emb_mask": mask}, d / "prompt.pth")
+    return sws, svae, sdit, y, mask
+
+
+def test_cli_matches_oracle(tmp_path):
+    d = tmp_path
+    sws, svae, sdit, y, mask = _write_artifacts(d)
+    os.makedirs(d / "in" / "sub", exist_ok=True)
+    imgs = {"a.png": (det_input(70, (64, 64, 3)) * 255).numpy().astype(np.uint8), "sub/b.png": (det_input(71, (40, 56, 3)) * 255).numpy().astype(np.uint8)}
+    for k, v in imgs.items():
+        Image.fromarray(v).save(d / "in" / k)
+    cmd = [sys.executable, os.path.join(ROOT, "inference.py"), "--ckpt", str(d / "weights" / "dit.ckpt"), "--input", str(d / "in"), "--output",
+           str(d / "out"), "--swinir_ckpt", str(d / "weights" / "swinir.ckpt"), "--swinir_config", str(d / "swinir.yaml"), "--vae", str(d / "vae"),
+           "--dit_config", str(d / "pixart"), "--prompt_embeds", str(d / "prompt.pth")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "save to" in r.stdout
+    for k, v in imgs.items():
+        out = d / "out" / (os.path.splitext(k)[0] + "_0.png")
+        assert out.exists(), (k, r.stdout)
+        got = np.array(Image.open(out).convert("RGB"))
+        # oracle on the reference's host pre/post-processing (inference.py:263-291, 326-346) around process()
+        lq = Image.fromarray(v)
+        rs = oglue.auto_resize(lq, 512)
+        x = oglue.pad(np.array(rs), 64)
+        ref, _ = oglue.process([x], lambda t: oswin.swinir_forward(sws, t, SWIN_SMALL), lambda t: ovae.vae_encode_mean(svae, t, VAE_SMALL),
+                               lambda lat, tt, yy, mm: odit.dit_forward(sdit, lat, tt, yy, mm, DIT_SMALL), lambda z: ovae.vae_decode(svae, z, VAE_SMALL),
+                               oglue.alphas_cumprod_diffusers(), y.reshape(1, 20, 64), mask.reshape(1, 1, 20))
+        want = np.array(Image.fromarray(ref[0][:rs.height, :rs.width]).resize(lq.size, Image.LANCZOS))
+        assert got.shape == want.shape == v.shape
+        p = _psnr_u8([got], [want])
+        print(f"cli {k}: PSNR vs oracle {p:.2f} dB")
+        assert p >= 35.0
