@@ -33,13 +33,24 @@ IR_DEVINL f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
 // C/D fragment of the 32x32 MFMA: column = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
 IR_DEVINL int mfma_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
 
-IR_DEVINL float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-IR_DEVINL float gelu_tanh(float x) {
-    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-    float u = k0 * (x + k1 * x * x * x);
-    return 0.5f * x * (1.0f + tanhf(u));
+// Compact activations (the epilogue is unrolled 16x per lane: a libm erff/tanhf there costs more instruction-cache misses
+// than arithmetic). fast_rcp: v_rcp_f32 (1 ulp); __expf: v_exp_f32 on x*log2(e).
+IR_DEVINL float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+IR_DEVINL float fast_sigmoid(float x) { return fast_rcp(1.0f + __expf(-x)); }
+// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, below fp32 rounding of the surrounding arithmetic)
+IR_DEVINL float fast_erf(float z) {
+    const float az = fabsf(z);
+    const float t = fast_rcp(1.0f + 0.3275911f * az);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float e = 1.0f - poly * __expf(-az * az);
+    return copysignf(e, z);
 }
-IR_DEVINL float silu(float x) { return x / (1.0f + __expf(-x)); }
+IR_DEVINL float gelu_erf(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f)); }
+IR_DEVINL float gelu_tanh(float x) {  // 0.5*(1 + tanh(u)) == sigmoid(2u)
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    return x * fast_sigmoid(2.0f * k0 * (x + k1 * x * x * x));
+}
+IR_DEVINL float silu(float x) { return x * fast_sigmoid(x); }
 
 IR_DEVINL float wave_sum(float v) {
 #pragma unroll

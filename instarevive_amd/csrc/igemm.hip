@@ -14,6 +14,8 @@
 // rows of 80 B (64 B data + 16 B pad => conflict-free ds_read_b128 fragment reads), double-buffered,
 // one barrier per k-tile. The epilogue transposes each wave's accumulators through LDS so that all
 // global traffic (bias, residual, gate, stores) is row-contiguous 8/16-byte vectors.
+#include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 #include "kernels.h"
 
@@ -28,6 +30,15 @@ __device__ uint4 g_zero_page[4096];
 // Epilogue shared by the igemm and halo-conv kernels: each wave transposes its accumulators through a private 32 x COLS fp32
 // LDS slab so that bias / activation / gate / residual / stores are row-contiguous 8-16-byte vectors.
 // map_row(i, row) gives the global output row (pixel / token index) of row `row` of the wave's i-th 32-row tile, or -1.
+template <int ACT>
+IR_DEVINL float apply_act(float x, float slope) {
+    if (ACT == IR_ACT_GELU_ERF) return gelu_erf(x);
+    if (ACT == IR_ACT_GELU_TANH) return gelu_tanh(x);
+    if (ACT == IR_ACT_LRELU) return x > 0.f ? x : x * slope;
+    if (ACT == IR_ACT_SILU) return silu(x);
+    return x;
+}
+
 template <int TM, int TN, class MapRow>
 IR_DEVINL void igemm_epilogue(const IGemmParams& p, f32x16 (&acc)[TM][TN], unsigned char* smem, int wid, int lane, int n_wave, MapRow map_row) {
     constexpr int COLS = TN * 32;
@@ -38,17 +49,7 @@ IR_DEVINL void igemm_epilogue(const IGemmParams& p, f32x16 (&acc)[TM][TN], unsig
     const int r = lane & 31;
     const int ecol = (lane % LPR) * 4;  // column (within the wave tile) of this lane's 4-vector
     const int nbase = n_wave + ecol;
-    const bool vec_ok = p.vec && (nbase + 3 < p.Cout);
-    float bias4[4] = {0.f, 0.f, 0.f, 0.f}, gate4[4] = {1.f, 1.f, 1.f, 1.f};
-    if (p.bias) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bias4[e] = p.bias[nbase + e];
-    }
-    const bool gate_const = p.gate && p.gate_stride == 0;  // one gate row for every output row (single timestep)
-    if (gate_const && nbase < p.Cout) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) gate4[e] = (nbase + e < p.Cout) ? p.gate[nbase + e] : 1.f;
-    }
+    const bool vec_ok = p.vec && (nbase + 3 < p.Cout);  // the fast, fully vectorised path (every layer of the network but Cout = 3)
     int mrow[TM][IT];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -88,83 +89,71 @@ IR_DEVINL void igemm_epilogue(const IGemmParams& p, f32x16 (&acc)[TM][TN], unsig
                     rres[i][it] = f32x4{bflo(rb[i][it].x), bfhi(rb[i][it].x), bflo(rb[i][it].y), bfhi(rb[i][it].y)};
         }
     }
+    // Bias / activation / scale / gate are per-column operations, so they are applied in the accumulator layout while the
+    // tile is written to the slab (column = lane & 31: one bias and one multiplier per lane and jn); the activation is chosen
+    // by a uniform switch OUTSIDE the unrolled writes. The row loop after the transpose then only adds the residual and stores
+    // and exists once (with the switch inside it, the epilogue was 18 k instructions and instruction-fetch bound).
+    float cbias[TN], cmul[TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        __syncthreads();
+    for (int jn = 0; jn < TN; ++jn) {
+        const int n = n_wave + jn * 32 + r;
+        cbias[jn] = (p.bias && n < p.Cout_pad) ? p.bias[n] : 0.f;
+        cmul[jn] = p.out_scale * ((p.gate && n < p.Cout) ? p.gate[n] : 1.f);
+    }
+    auto write_slab = [&](auto act_tag, int i) {
+        constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
         for (int jn = 0; jn < TN; ++jn)
 #pragma unroll
-            for (int g = 0; g < 16; ++g) slab[mfma_row(g, lane) * COLS + jn * 32 + r] = acc[i][jn][g];
-        __syncthreads();
+            for (int g = 0; g < 16; ++g)
+                slab[mfma_row(g, lane) * COLS + jn * 32 + r] = apply_act<ACT>(acc[i][jn][g] + cbias[jn], p.slope) * cmul[jn];
+    };
+    auto rows_fast = [&](int i) {
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
             const int row = it * ERPI + lane / LPR;
             const int m = mrow[i][it];
-            if (m < 0 || nbase >= p.Cout) continue;
-            f32x4 v = *reinterpret_cast<const f32x4*>(&slab[row * COLS + ecol]);
-            float o[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float x = v[e] + bias4[e];
-                switch (p.act) {
-                    case IR_ACT_GELU_ERF: x = gelu_erf(x); break;
-                    case IR_ACT_GELU_TANH: x = gelu_tanh(x); break;
-                    case IR_ACT_LRELU: x = x > 0.f ? x : x * p.slope; break;
-                    case IR_ACT_SILU: x = silu(x); break;
-                    default: break;
-                }
-                o[e] = x * p.out_scale * gate4[e];
-            }
-            if (p.gate && !gate_const) {
-                const float* g = p.gate + (long)(m / p.rows_per_batch) * p.gate_stride + nbase;
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (nbase + e < p.Cout) o[e] *= g[e];
-            }
-            if (p.res) {
-                if (vec_ok) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] += rres[i][it][e];
-                } else {
-                    const long rm = p.res_mod > 0 ? (long)(m % p.res_mod) : (long)m;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (nbase + e < p.Cout)
-                            o[e] += p.res_f32 ? reinterpret_cast<const float*>(p.res)[rm * p.res_cs + nbase + e]
-                                              : bf2f(reinterpret_cast<const bf16_t*>(p.res)[rm * p.res_cs + nbase + e]);
-                }
-            }
+            if (m < 0) continue;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&slab[row * COLS + ecol]);
+            const f32x4 o = v + rres[i][it];
             if (p.out_f32) {
-                float* op = reinterpret_cast<float*>(p.out) + (long)m * p.out_cs + nbase;
-                if (vec_ok) {
-                    f32x4 ov = {o[0], o[1], o[2], o[3]};
-                    *reinterpret_cast<f32x4*>(op) = ov;
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (nbase + e < p.Cout) op[e] = o[e];
-                }
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (long)m * p.out_cs + nbase) = o;
             } else {
-                bf16_t* op = reinterpret_cast<bf16_t*>(p.out) + (long)m * p.out_cs + nbase;
-                if (vec_ok) {
-                    *reinterpret_cast<uint2*>(op) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (nbase + e < p.Cout) op[e] = f2bf(o[e]);
-                }
+                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (long)m * p.out_cs + nbase) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
             }
-            if (p.out2) {
-                bf16_t* op = p.out2 + (long)m * p.out2_cs + nbase;
-                if (vec_ok) {
-                    *reinterpret_cast<uint2*>(op) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (nbase + e < p.Cout) op[e] = f2bf(o[e]);
-                }
+            if (p.out2) *reinterpret_cast<uint2*>(p.out2 + (long)m * p.out2_cs + nbase) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+        }
+    };
+    auto rows_slow = [&](int i) {  // scalar fallback (Cout not a multiple of 4 or unaligned strides): rolled, rare, tiny tensors
+        for (int it = 0; it < IT; ++it) {
+            const int row = it * ERPI + lane / LPR;
+            const int m = map_row(i, row);
+            if (m < 0) continue;
+            const long rm = p.res_mod > 0 ? (long)(m % p.res_mod) : (long)m;
+            for (int e = 0; e < 4; ++e) {
+                const int n = nbase + e;
+                if (n >= p.Cout) break;
+                float x = slab[row * COLS + ecol + e];
+                if (p.res) x += p.res_f32 ? reinterpret_cast<const float*>(p.res)[rm * p.res_cs + n] : bf2f(reinterpret_cast<const bf16_t*>(p.res)[rm * p.res_cs + n]);
+                if (p.out_f32) reinterpret_cast<float*>(p.out)[(long)m * p.out_cs + n] = x;
+                else reinterpret_cast<bf16_t*>(p.out)[(long)m * p.out_cs + n] = f2bf(x);
+                if (p.out2) p.out2[(long)m * p.out2_cs + n] = f2bf(x);
             }
         }
+    };
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        __syncthreads();
+        switch (p.act) {
+            case IR_ACT_GELU_ERF: write_slab(std::integral_constant<int, IR_ACT_GELU_ERF>{}, i); break;
+            case IR_ACT_GELU_TANH: write_slab(std::integral_constant<int, IR_ACT_GELU_TANH>{}, i); break;
+            case IR_ACT_LRELU: write_slab(std::integral_constant<int, IR_ACT_LRELU>{}, i); break;
+            case IR_ACT_SILU: write_slab(std::integral_constant<int, IR_ACT_SILU>{}, i); break;
+            default: write_slab(std::integral_constant<int, IR_ACT_NONE>{}, i); break;
+        }
+        __syncthreads();
+        if (vec_ok) rows_fast(i);
+        else if (nbase < p.Cout) rows_slow(i);
     }
 }
 
@@ -469,7 +458,8 @@ template <int BM, int BN, int WM, int WN>
 static int launch_cfg(const IGemmParams& p, hipStream_t s) {
     const int MT = (p.M + BM - 1) / BM, NT = p.Cout_pad / BN;
     const int grid = ((MT + 7) / 8) * 8 * NT;
-    const bool k64 = (p.Cin & 63) == 0;
+    static const bool force32 = getenv("IR_IGEMM_BK32") != nullptr;  // experiment knob
+    const bool k64 = (p.Cin & 63) == 0 && !force32;
     if (p.taps == 9) {
         if (k64) hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, 9, 64>), dim3(grid), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, 9, 32>), dim3(grid), dim3(256), 0, s, p);
@@ -493,7 +483,7 @@ int ir_launch_igemm(const IGemmParams& pin, hipStream_t s) {
               (reinterpret_cast<uintptr_t>(p.res) & 15) || (reinterpret_cast<uintptr_t>(p.out2) & 7) ||
               (p.gate && (p.gate_stride & 3)));
     if (!p.out) return -5;
-    if (p.gate && p.rows_per_batch <= 0) return -6;
+    if (p.gate && p.gate_stride != 0) return -6;  // one gate row per launch (single timestep per batch)
     if ((reinterpret_cast<uintptr_t>(p.in) & 15) || (reinterpret_cast<uintptr_t>(p.wgt) & 15) ||
         (reinterpret_cast<uintptr_t>(p.out) & 15))
         return -7;
@@ -502,7 +492,8 @@ int ir_launch_igemm(const IGemmParams& pin, hipStream_t s) {
         if ((long)p.NB * p.Ho * p.Wo != p.M) return -9;
         if (p.H <= 0 || p.W <= 0) return -9;
     }
-    if (p.taps == 9 && p.stride == 1 && p.pad == 1 && (p.Cin & 63) == 0 && !p.force_generic) {
+    static const bool no_halo = getenv("IR_NO_HALO") != nullptr;  // experiment knob
+    if (p.taps == 9 && p.stride == 1 && p.pad == 1 && (p.Cin & 63) == 0 && !p.force_generic && !no_halo) {
         if (p.Cout_pad % 128 == 0) return launch_halo<128>(p, s);
         if (p.Cout_pad % 64 == 0) return launch_halo<64>(p, s);
     }
