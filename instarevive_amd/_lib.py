@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libinstarevive_hip.so")
+# INSTAREVIVE_HIP_LIB points the loader at another build of the same library (A/B timing of kernel changes)
+LIB_PATH = os.environ.get("INSTAREVIVE_HIP_LIB") or os.path.join(_HERE, "csrc", "libinstarevive_hip.so")
 
 # every symbol include/instarevive_hip.h declares (tests check that the library exports all of them)
 SYMBOLS = [

@@ -321,6 +321,7 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d512_kernel(const bf16_t* _
 #pragma unroll
     for (int j = 0; j < 4; ++j) v_base[j] = Vb + r * 128 + ((((2 * j) | h) ^ vsw) << 4);  // + dt*4096 ; j = kt*2 + s2
     const int NT = T >> 6;
+    wait_dma();
     __syncthreads();  // K(0), V(0) landed
     for (int t = 0; t < NT; ++t) {
         // ---- S^T = K Q^T
@@ -335,6 +336,7 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d512_kernel(const bf16_t* _
                 s[kt] = mfma32(a, qf[ks], s[kt]);
             }
         }
+        wait_dma();
         __syncthreads();                       // every wave is done with the K tile (and V(t) has landed: vmcnt(0))
         if (t + 1 < NT) stage_k((t + 1) * 64);  // lands during softmax + PV
         // ---- online softmax (exp2 domain, deferred rescale)
@@ -377,6 +379,7 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d512_kernel(const bf16_t* _
                 bf16x8 a = *reinterpret_cast<const bf16x8*>(v_base[j] + dt * 4096);
                 acc[dt] = mfma32(a, pb[j], acc[dt]);
             }
+        wait_dma();
         __syncthreads();                       // every wave is done with the V^T tile (and K(t+1) has landed)
         if (t + 1 < NT) stage_v((t + 1) * 64);  // lands during the next QK^T
     }

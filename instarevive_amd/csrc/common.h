@@ -52,6 +52,10 @@ IR_DEVINL float gelu_tanh(float x) {  // 0.5*(1 + tanh(u)) == sigmoid(2u)
 }
 IR_DEVINL float silu(float x) { return x * fast_sigmoid(x); }
 
+// LDS-DMA (global_load ... lds) completion counts on vmcnt. hipcc does NOT order a later ds_read behind a pending DMA on its own
+// (a workgroup-scope fence only waits lgkmcnt on gfx950), so every barrier that publishes DMA-written LDS is preceded by this.
+IR_DEVINL void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 IR_DEVINL float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

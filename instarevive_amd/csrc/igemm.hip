@@ -27,6 +27,19 @@ IR_DEVINL void glds16(const void* g, lds_ptr_t l) { __builtin_amdgcn_global_load
 // 64 KB of zeros: zero-padding taps of a convolution read from here, so the LDS-DMA never needs a mask or a branch.
 __device__ uint4 g_zero_page[4096];
 
+// Diagnostic build only (-DIR_STAMPS, tools/conv_stamp.hip): per-block phase time stamps; never compiled into the library.
+#ifdef IR_STAMPS
+__device__ unsigned long long g_stamps[65536 * 8];  // [0..3] s_memrealtime (100 MHz) per phase edge, [4..7] s_memtime (core clock)
+#define IR_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 65536) { g_stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+                                                                        g_stamps[blockIdx.x * 8 + 4 + (k)] = __builtin_amdgcn_s_memtime(); } } while (0)
+#ifndef IR_KO
+#define IR_KO 0  // knock-out experiments of tools/conv_stamp.hip (results are wrong by design): 1 no per-step barrier, 2 no weight
+#endif           // re-staging, 3 no LDS fragment reads, 4 no MFMAs
+#else
+#define IR_STAMP(k) do { } while (0)
+#define IR_KO 0
+#endif
+
 // Epilogue shared by the igemm and halo-conv kernels: each wave transposes its accumulators through a private 32 x COLS fp32
 // LDS slab so that bias / activation / gate / residual / stores are row-contiguous 8-16-byte vectors.
 // map_row(i, row) gives the global output row (pixel / token index) of row `row` of the wave's i-th 32-row tile, or -1.
@@ -45,7 +58,8 @@ IR_DEVINL void igemm_epilogue(const IGemmParams& p, f32x16 (&acc)[TM][TN], unsig
     constexpr int LPR = COLS / 4;       // lanes per row
     constexpr int ERPI = 64 / LPR;      // rows per iteration
     constexpr int IT = 32 / ERPI;       // iterations per 32-row tile
-    float* slab = reinterpret_cast<float*>(smem) + wid * 32 * COLS;
+    float* slab0 = reinterpret_cast<float*>(smem) + wid * 32 * COLS;  // tile i uses slab0 + i * SLAB_I (wave-private)
+    constexpr int SLAB_I = 4 * 32 * COLS;
     const int r = lane & 31;
     const int ecol = (lane % LPR) * 4;  // column (within the wave tile) of this lane's 4-vector
     const int nbase = n_wave + ecol;
@@ -100,29 +114,38 @@ IR_DEVINL void igemm_epilogue(const IGemmParams& p, f32x16 (&acc)[TM][TN], unsig
         cbias[jn] = (p.bias && n < p.Cout_pad) ? p.bias[n] : 0.f;
         cmul[jn] = p.out_scale * ((p.gate && n < p.Cout) ? p.gate[n] : 1.f);
     }
-    auto write_slab = [&](auto act_tag, int i) {
+    auto write_slab = [&](auto act_tag) {
         constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
-        for (int jn = 0; jn < TN; ++jn)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int g = 0; g < 16; ++g)
-                slab[mfma_row(g, lane) * COLS + jn * 32 + r] = apply_act<ACT>(acc[i][jn][g] + cbias[jn], p.slope) * cmul[jn];
+            for (int jn = 0; jn < TN; ++jn)
+#pragma unroll
+                for (int g = 0; g < 16; ++g)
+                    slab0[i * SLAB_I + mfma_row(g, lane) * COLS + jn * 32 + r] = apply_act<ACT>(acc[i][jn][g] + cbias[jn], p.slope) * cmul[jn];
     };
-    auto rows_fast = [&](int i) {
+    auto rows_fast = [&]() {
+        // all LDS reads of the wave's tiles are issued back to back (one latency instead of one per row group), then the stores
+        f32x4 v[TM][IT];
 #pragma unroll
-        for (int it = 0; it < IT; ++it) {
-            const int row = it * ERPI + lane / LPR;
-            const int m = mrow[i][it];
-            if (m < 0) continue;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(&slab[row * COLS + ecol]);
-            const f32x4 o = v + rres[i][it];
-            if (p.out_f32) {
-                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (long)m * p.out_cs + nbase) = o;
-            } else {
-                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (long)m * p.out_cs + nbase) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int it = 0; it < IT; ++it)
+                v[i][it] = *reinterpret_cast<const f32x4*>(&slab0[i * SLAB_I + (it * ERPI + lane / LPR) * COLS + ecol]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int m = mrow[i][it];
+                if (m < 0) continue;
+                const f32x4 o = v[i][it] + rres[i][it];
+                if (p.out_f32) {
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (long)m * p.out_cs + nbase) = o;
+                } else {
+                    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (long)m * p.out_cs + nbase) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+                }
+                if (p.out2) *reinterpret_cast<uint2*>(p.out2 + (long)m * p.out2_cs + nbase) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
             }
-            if (p.out2) *reinterpret_cast<uint2*>(p.out2 + (long)m * p.out2_cs + nbase) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
-        }
     };
     auto rows_slow = [&](int i) {  // scalar fallback (Cout not a multiple of 4 or unaligned strides): rolled, rare, tiny tensors
         for (int it = 0; it < IT; ++it) {
@@ -133,7 +156,7 @@ IR_DEVINL void igemm_epilogue(const IGemmParams& p, f32x16 (&acc)[TM][TN], unsig
             for (int e = 0; e < 4; ++e) {
                 const int n = nbase + e;
                 if (n >= p.Cout) break;
-                float x = slab[row * COLS + ecol + e];
+                float x = slab0[i * SLAB_I + row * COLS + ecol + e];
                 if (p.res) x += p.res_f32 ? reinterpret_cast<const float*>(p.res)[rm * p.res_cs + n] : bf2f(reinterpret_cast<const bf16_t*>(p.res)[rm * p.res_cs + n]);
                 if (p.out_f32) reinterpret_cast<float*>(p.out)[(long)m * p.out_cs + n] = x;
                 else reinterpret_cast<bf16_t*>(p.out)[(long)m * p.out_cs + n] = f2bf(x);
@@ -141,19 +164,23 @@ IR_DEVINL void igemm_epilogue(const IGemmParams& p, f32x16 (&acc)[TM][TN], unsig
             }
         }
     };
+    __syncthreads();  // every wave has finished reading the main-loop buffers the slabs overlay
+    switch (p.act) {
+        case IR_ACT_GELU_ERF: write_slab(std::integral_constant<int, IR_ACT_GELU_ERF>{}); break;
+        case IR_ACT_GELU_TANH: write_slab(std::integral_constant<int, IR_ACT_GELU_TANH>{}); break;
+        case IR_ACT_LRELU: write_slab(std::integral_constant<int, IR_ACT_LRELU>{}); break;
+        case IR_ACT_SILU: write_slab(std::integral_constant<int, IR_ACT_SILU>{}); break;
+        default: write_slab(std::integral_constant<int, IR_ACT_NONE>{}); break;
+    }
+    // The slabs are wave-private and a wave's LDS operations complete in issue order, so no workgroup barrier is needed between
+    // the transposing writes and the reads; the fences only keep the compiler from reordering them.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (vec_ok) rows_fast();
+    else if (nbase < p.Cout) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        __syncthreads();
-        switch (p.act) {
-            case IR_ACT_GELU_ERF: write_slab(std::integral_constant<int, IR_ACT_GELU_ERF>{}, i); break;
-            case IR_ACT_GELU_TANH: write_slab(std::integral_constant<int, IR_ACT_GELU_TANH>{}, i); break;
-            case IR_ACT_LRELU: write_slab(std::integral_constant<int, IR_ACT_LRELU>{}, i); break;
-            case IR_ACT_SILU: write_slab(std::integral_constant<int, IR_ACT_SILU>{}, i); break;
-            default: write_slab(std::integral_constant<int, IR_ACT_NONE>{}, i); break;
-        }
-        __syncthreads();
-        if (vec_ok) rows_fast(i);
-        else if (nbase < p.Cout) rows_slow(i);
+        for (int i = 0; i < TM; ++i) rows_slow(i);
     }
 }
 
@@ -168,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IGemmParams p) {
     constexpr int A_I = (A_Q + 3) / 4, B_I = (B_Q + 3) / 4;  // per wave (instruction q = wave + 4*i)
     constexpr int COLS = TN * 32;
     constexpr int LDS_AB = 2 * (BM + BN) * ROWB;
-    constexpr int LDS_EP = 4 * 32 * COLS * 4;
+    constexpr int LDS_EP = TM * 4 * 32 * COLS * 4;  // one wave-private fp32 slab per 32-row tile of every wave
     constexpr int LDS_BYTES = LDS_AB > LDS_EP ? LDS_AB : LDS_EP;
     __shared__ __attribute__((aligned(256))) unsigned char smem[LDS_BYTES];  // the ONLY LDS object of the kernel
     // layout: A[0] | A[1] | B[0] | B[1]; element (row, 16-byte chunk c) of a tile lives at row*ROWB + ((c ^ swz(row)) * 16),
@@ -272,34 +299,55 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IGemmParams p) {
         fb_base[jn] = 2 * BM * ROWB + R * ROWB; fb_sw[jn] = (R / RB) % SP;
     }
 
+    // Main loop. Two k-tiles are resident (double-buffered LDS) and the fragments are double-buffered in registers. Per k-step the
+    // order is pinned with sched_barriers (hipcc otherwise sinks every LDS read below the MFMAs and waits lgkmcnt(0) four times
+    // per k-tile with nothing in flight): first MFMA of the step, then the reads of the NEXT step, then the remaining MFMAs, so a
+    // read always has >= 3 MFMAs (96 cycles) of cover. The workgroup barrier sits inside the last k-step of a tile, after its first
+    // MFMA: behind it the DMA of tile kt+2 is issued into the buffer just released and the first fragments of tile kt+1 are read
+    // while the last MFMAs of tile kt still issue.
+    constexpr int NK = BK / 16;
+    auto advance = [&]() { if (TAPS > 1 && ++cc == cchunks) { cc = 0; set_tap(++tap); } };
     if (TAPS > 1) set_tap(0);
     stage(0);
-    __syncthreads();  // drains the DMA (vmcnt(0)) and publishes the tile to all waves
-    int cur = 0;
+    if (KT > 1) { advance(); stage(1); }
+    wait_dma();
+    __syncthreads();  // both tiles landed and published to all waves
+    bf16x8 af[2][TM], bfr[2][TN];
+    auto load_frags = [&](int buf, int ks, int set) {
+        const unsigned char* Ab = smem + buf * BM * ROWB;
+        const unsigned char* Bb = smem + buf * BN * ROWB;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+            af[set][i] = *reinterpret_cast<const bf16x8*>(Ab + fa_base[i] + (((2 * ks + h) ^ fa_sw[i]) << 4));
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn)
+            bfr[set][jn] = *reinterpret_cast<const bf16x8*>(Bb + fb_base[jn] + (((2 * ks + h) ^ fb_sw[jn]) << 4));
+    };
+    auto mfmas = [&](int set, int first, int last) {
+#pragma unroll
+        for (int e = first; e < last; ++e) acc[e / TN][e % TN] = mfma32(af[set][e / TN], bfr[set][e % TN], acc[e / TN][e % TN]);
+    };
+    load_frags(0, 0, 0);
     for (int kt = 0; kt < KT; ++kt) {
-        if (kt + 1 < KT) {
-            if (TAPS > 1 && ++cc == cchunks) { cc = 0; set_tap(++tap); }
-            stage(cur ^ 1);  // in flight while this k-tile is computed; its buffer was last read before the previous barrier
+        const int cur = kt & 1;
+#pragma unroll
+        for (int ks = 0; ks < NK; ++ks) {
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(ks & 1, 0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 1 < NK) {
+                load_frags(cur, ks + 1, (ks + 1) & 1);
+            } else {
+                wait_dma();
+                __syncthreads();  // tile kt+1 has landed (issued a whole tile ago); every wave has read the last fragment of tile kt
+                if (kt + 2 < KT) { advance(); stage(cur); }
+                if (kt + 1 < KT) load_frags(cur ^ 1, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(ks & 1, 1, TM * TN);
         }
-        const unsigned char* Ab = smem + cur * BM * ROWB;
-        const unsigned char* Bb = smem + cur * BN * ROWB;
-#pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            bf16x8 af[TM], bfr[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-                af[i] = *reinterpret_cast<const bf16x8*>(Ab + fa_base[i] + (((2 * ks + h) ^ fa_sw[i]) << 4));
-#pragma unroll
-            for (int jn = 0; jn < TN; ++jn)
-                bfr[jn] = *reinterpret_cast<const bf16x8*>(Bb + fb_base[jn] + (((2 * ks + h) ^ fb_sw[jn]) << 4));
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int jn = 0; jn < TN; ++jn) acc[i][jn] = mfma32(af[i], bfr[jn], acc[i][jn]);
-        }
-        __syncthreads();
-        cur ^= 1;
     }
+    __builtin_amdgcn_sched_barrier(0);
 
     igemm_epilogue<TM, TN>(p, acc, smem, wid, lane, n0 + wn * (BN / WN), [&](int i, int row) {
         const int m = m0 + wm * (BM / WM) + i * 32 + row;
@@ -324,7 +372,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(IGemmParams p, int ti
     constexpr int TM = 2, TN = BN / 64;
     constexpr int HALO_BYTES = HPAD * ROWB, BT_BYTES = BN * ROWB;
     constexpr int LDS_MAIN = 2 * HALO_BYTES + 2 * BT_BYTES;
-    constexpr int LDS_EP = 4 * 32 * TN * 32 * 4;
+    constexpr int LDS_EP = TM * 4 * 32 * TN * 32 * 4;
     constexpr int LDS_BYTES = LDS_MAIN > LDS_EP ? LDS_MAIN : LDS_EP;
     __shared__ __attribute__((aligned(256))) unsigned char smem[LDS_BYTES];  // halo[0] | halo[1] | B[0] | B[1]
 
@@ -358,7 +406,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(IGemmParams p, int ti
         const bool ok = hp < HP && cy >= 0 && cy < Hc && cx >= 0 && cx < Wc;
         const int iy = min(max(cy, 0), Hc - 1) >> UP, ix = min(max(cx, 0), Wc - 1) >> UP;
         const bf16_t* src = p.in + (((long)img * p.H + iy) * p.W + ix) * p.in_cs;
-        h_ptr[i] = (ok ? src : zero) + ((lslot ^ ((hp >> 1) & 7)) << 3);
+        h_ptr[i] = (ok ? src : zero) + ((lslot ^ ((hx >> 1) & 7)) << 3);  // swizzle key from the halo COLUMN: see the read side
     }
     const bf16_t* b_ptr[B_I];
 #pragma unroll
@@ -399,48 +447,74 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(IGemmParams p, int ti
         fb_base[jn] = R * ROWB; fb_sw[jn] = (R >> 1) & 7;
     }
 
+    // Main loop over steps s = (chunk c, tap t); same pinned schedule as igemm_kernel: per k-step first MFMA, reads of the next
+    // k-step, remaining MFMAs; the workgroup barrier sits inside the last k-step, and behind it the weight tile of step s+2 (and,
+    // at the first tap of a chunk, the whole halo of the next chunk) is issued and the first fragments of step s+1 are read.
     const int steps = chunks * 9;
+    IR_STAMP(0);
     stage_halo(0);
     stage_b(0, 0);
+    stage_b(1, p.Cin);  // step 1 = (chunk 0, tap 1); steps >= 9 always
+    wait_dma();
     __syncthreads();
-    int c = 0, t = 0;
-    for (int s = 0; s < steps; ++s) {
-        // next step's (chunk, tap)
-        int tn = t + 1, cn = c;
-        if (tn == 9) { tn = 0; cn = c + 1; }
-        if (s + 1 < steps) {
-            if (t == 0 && c + 1 < chunks) stage_halo((c + 1) & 1);  // whole next chunk's halo, one chunk ahead
-            stage_b((s + 1) & 1, tn * p.Cin + cn * BK);
-        }
-        const unsigned char* Hb = smem + (c & 1) * HALO_BYTES;
-        const unsigned char* Bb = smem + 2 * HALO_BYTES + (s & 1) * BT_BYTES;
-        const int ky = t / 3, kx = t - ky * 3;
+    IR_STAMP(1);
+    bf16x8 af[2][TM], bfr[2][TN];
+    auto load_frags = [&](int cbuf, int bbuf, int tap, int ks, int set) {
+        const unsigned char* Hb = smem + cbuf * HALO_BYTES;
+        const unsigned char* Bb = smem + 2 * HALO_BYTES + bbuf * BT_BYTES;
+        const int ky = tap / 3, kx = tap - ky * 3;
         const int toff = ky * HW + kx;
-        int fa_base[TM], fa_sw[TM];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+            // A ds_read_b128 is served in groups of 16 lanes that span two patch rows (8 pixels of row y, 8 of row y+1): keyed on
+            // the halo column alone, the 16 slots are distinct; keyed on the pixel index (18 per row) they collided 2-way
+            // (SQ_LDS_BANK_CONFLICT was 30 % of the LDS cycles).
             const int hid = hid0[i] + toff;
-            fa_base[i] = hid * ROWB; fa_sw[i] = (hid >> 1) & 7;
+            const int sw = (((r & 15) + kx) >> 1) & 7;
+            af[set][i] = *reinterpret_cast<const bf16x8*>(Hb + hid * ROWB + (((2 * ks + h) ^ sw) << 4));
         }
+#pragma unroll
+        for (int jn = 0; jn < TN; ++jn) bfr[set][jn] = *reinterpret_cast<const bf16x8*>(Bb + fb_base[jn] + (((2 * ks + h) ^ fb_sw[jn]) << 4));
+    };
+    auto mfmas = [&](int set, int first, int last) {
+#pragma unroll
+        for (int e = first; e < last; ++e) acc[e / TN][e % TN] = mfma32(af[set][e / TN], bfr[set][e % TN], acc[e / TN][e % TN]);
+    };
+    int c = 0, t = 0;      // (chunk, tap) of step s
+    int c2 = 0, t2 = 2;    // (chunk, tap) of step s + 2
+    load_frags(0, 0, 0, 0, 0);
+    for (int s = 0; s < steps; ++s) {
+        int tn = t + 1, cn = c;  // step s + 1
+        if (tn == 9) { tn = 0; cn = c + 1; }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 af[TM], bfr[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(Hb + fa_base[i] + (((2 * ks + h) ^ fa_sw[i]) << 4));
-#pragma unroll
-            for (int jn = 0; jn < TN; ++jn) bfr[jn] = *reinterpret_cast<const bf16x8*>(Bb + fb_base[jn] + (((2 * ks + h) ^ fb_sw[jn]) << 4));
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int jn = 0; jn < TN; ++jn) acc[i][jn] = mfma32(af[i], bfr[jn], acc[i][jn]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (IR_KO != 4) mfmas(ks & 1, 0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 1 < 4) {
+                if (IR_KO != 3) load_frags(c & 1, s & 1, t, ks + 1, (ks + 1) & 1);
+            } else {
+                if (IR_KO != 1) {
+                    wait_dma();
+                    __syncthreads();  // step s+1's weights have landed; every wave has read the last fragments of step s
+                }
+                if (s + 2 < steps && IR_KO != 2) stage_b(s & 1, t2 * p.Cin + c2 * BK);
+                if (t == 0 && c + 1 < chunks) stage_halo((c + 1) & 1);  // whole next chunk's halo, eight steps ahead of its use
+                if (s + 1 < steps && IR_KO != 3) load_frags(cn & 1, (s + 1) & 1, tn, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (IR_KO != 4) mfmas(ks & 1, 1, TM * TN);
         }
-        __syncthreads();
         t = tn; c = cn;
+        if (++t2 == 9) { t2 = 0; ++c2; }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    IR_STAMP(2);
     igemm_epilogue<TM, TN>(p, acc, smem, wid, lane, n0 + wn * (BN / 2), [&](int i, int row) {
         const int oy = oy0 + wm * 4 + i * 2 + (row >> 4), ox = ox0 + (row & 15);
         return (oy < p.Ho && ox < p.Wo) ? (img * p.Ho + oy) * p.Wo + ox : -1;
     });
+    IR_STAMP(3);
 }
 
 template <int BN>

@@ -34,14 +34,19 @@ def conv(n, h, w, cin, cout, up=0, stride=1):
     print(f"conv {n}x{h}x{w} {cin}->{cout} up={up} s={stride}: {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s")
 
 
-def linear(m, k, n, out_f32=0):
+def linear(m, k, n, out_f32=0, act=0, res=0):
+    """res: 0 none, 1 bf16 residual, 2 fp32 residual + gate (the DiT residual stream)"""
     x = torch.randn(m, k, device="cuda").to(torch.bfloat16).view(torch.int16)
     wt = (torch.randn(n, k, device="cuda") / math.sqrt(k)).to(torch.bfloat16).view(torch.int16)
     b = torch.zeros(n, device="cuda")
     out = torch.empty(m, n, dtype=torch.float32 if out_f32 else torch.int16, device="cuda")
-    fn = lambda: ctx.check(ctx.lib.ir_op_linear(ctx.h, ctx.stream(), L.ptr(x), L.ptr(wt), L.ptr(b), L.ptr(out), m, k, n, n, 0, None, None, 0, out_f32, 1.0), "linear")
+    gate = torch.ones(n, device="cuda") if res == 2 else None
+    r = None if res == 0 else (torch.randn(m, n, device="cuda") if res == 2 else torch.randn(m, n, device="cuda").to(torch.bfloat16).view(torch.int16))
+    fn = lambda: ctx.check(ctx.lib.ir_op_linear(ctx.h, ctx.stream(), L.ptr(x), L.ptr(wt), L.ptr(b), L.ptr(out), m, k, n, n, act,
+                                                L.ptr(gate) if gate is not None else None, L.ptr(r) if r is not None else None,
+                                                1 if res == 2 else 0, out_f32, 1.0), "linear")
     ms = timeit(fn)
-    print(f"linear {m}x{k}->{n} f32={out_f32}: {ms:8.3f} ms  {2.0 * m * k * n / ms / 1e9:8.1f} TFLOP/s")
+    print(f"linear {m}x{k}->{n} f32={out_f32} act={act} res={res}: {ms:8.3f} ms  {2.0 * m * k * n / ms / 1e9:8.1f} TFLOP/s")
 
 
 def attn(b, heads, t, d):
@@ -58,6 +63,10 @@ def attn(b, heads, t, d):
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["conv", "linear", "attn"]
+    if "one" in which:  # the three heaviest shapes of the 2048^2 path (profiling runs)
+        conv(1, 2048, 2048, 128, 128)
+        linear(16384, 1152, 4608)
+        attn(1, 16, 16384, 72)
     if "conv" in which:
         conv(1, 2048, 2048, 128, 128)
         conv(1, 2048, 2048, 256, 256)
@@ -74,6 +83,11 @@ if __name__ == "__main__":
         linear(16384, 1152, 1152)
         linear(16384, 1152, 4608)
         linear(16384, 4608, 1152)
+        linear(16384, 1152, 1152, out_f32=1, res=2)
+        linear(16384, 4608, 1152, out_f32=1, res=2)
+        linear(16384, 1152, 4608, act=2)
+        linear(65536, 192, 192, res=1)
+        linear(65536, 192, 384, act=1)
         linear(65536, 512, 65536, out_f32=1)
         linear(65536, 65536, 512)
         linear(65536, 192, 576)
