@@ -16,8 +16,31 @@
 //      (reference ldm/modules/diffusionmodules/model.py:181-205).
 #include "common.h"
 #include "kernels.h"
+#include <cstdlib>
+#include <type_traits>
+
+// LDS-DMA: 16 bytes per lane from a per-lane global address to LDS base + lane*16 (wrapped in a device function: used directly
+// inside a template kernel the builtin suppresses the host stub)
+typedef __attribute__((address_space(3))) void* attn_lds_ptr_t;
+IR_DEVINL void attn_glds16(const void* g, attn_lds_ptr_t l) { __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0); }
 
 IR_DEVINL int swap23(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }
+
+// Knock-out experiments of tools/attn_stamp.hip (diagnostic builds only; results are wrong by design): 1 no per-tile barrier,
+// 2 no K/V global loads + LDS stores, 3 no LDS fragment reads, 4 no MFMAs, 5 no softmax arithmetic.
+#ifndef IR_KO_ATTN
+#define IR_KO_ATTN 0
+#endif
+// Diagnostic build only (-DIR_STAMPS_ATTN, tools/attn_stamp.hip): per-wave cycle sums (s_memtime) of the segments of
+// flash_attn_pp_kernel: [0] vector segment, [1] wait at the barrier after it, [2] matrix segment, [3] wait at the barrier after it.
+#ifdef IR_STAMPS_ATTN
+__device__ unsigned long long g_attn_stamps[4096 * 8 * 4];
+#define IR_ATT_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define IR_ATT_ACC(k, a, b) st_acc[k] += (b) - (a)
+#else
+#define IR_ATT_T(v) do { } while (0)
+#define IR_ATT_ACC(k, a, b) do { } while (0)
+#endif
 
 template <int D, bool GENERAL>
 __global__ __launch_bounds__(256, 2) void flash_attn_kernel(AttnParams p) {
@@ -37,6 +60,10 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(AttnParams p) {
     constexpr int O_ELEMS = 128 * OS;
     constexpr int TAIL = KV_ELEMS > O_ELEMS ? KV_ELEMS : O_ELEMS;
     constexpr float RESCALE_THR = 8.0f;  // log2 units: skip the O/l rescale while the running max grows by less than 2^8
+    // When the head dim leaves padded rows in the O^T tiles (72 -> 96), transpose_v_kernel fills row D of V^T with ones, so the
+    // second product accumulates the softmax denominator in O^T row D for free (no per-element row-sum adds on the VALU).
+    constexpr bool ONES = DV > D;
+    constexpr int L_DT = D / 32, L_G = ((D % 32) & 3) + 4 * ((D % 32) >> 3), L_H = ((D % 32) >> 2) & 1;
     __shared__ __attribute__((aligned(16))) bf16_t smem[128 * QS + TAIL];
     __shared__ float kbs[2][64];         // per-tile additive key bias (log2 domain; -inf beyond Tk)
     bf16_t* Qs = smem;
@@ -68,7 +95,12 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(AttnParams p) {
     for (int i = 0; i < Q_ITEMS; ++i) {
         const int c = tid + i * 256;
         const int row = min(c / RCH, 127), ch = c % RCH;
-        const uint4 v = *reinterpret_cast<const uint4*>(qp + (long)min(q0 + row, p.Tq - 1) * p.q_rs + ch * 8);
+        uint4 v = *reinterpret_cast<const uint4*>(qp + (long)min(q0 + row, p.Tq - 1) * p.q_rs + ch * 8);
+        // Q is pre-multiplied by scale * log2(e): the QK^T accumulators then are exp2-domain scores and need no per-element fma
+        v.x = pack2bf(bflo(v.x) * p.scale_log2, bfhi(v.x) * p.scale_log2);
+        v.y = pack2bf(bflo(v.y) * p.scale_log2, bfhi(v.y) * p.scale_log2);
+        v.z = pack2bf(bflo(v.z) * p.scale_log2, bfhi(v.z) * p.scale_log2);
+        v.w = pack2bf(bflo(v.w) * p.scale_log2, bfhi(v.w) * p.scale_log2);
         if (c < 128 * RCH) *reinterpret_cast<uint4*>(&Qs[row * QS + ch * 8]) = v;
     }
     uint4 kreg[K_ITEMS], vreg[V_ITEMS];  // initialised: an uninitialised array written under a condition stays in scratch
@@ -124,27 +156,31 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(AttnParams p) {
     for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
         for (int g = 0; g < 16; ++g) o[dt][g] = 0.f;
-    float m_i = -1e30f, l_i = 0.f;
+    // Online softmax state. m_i is the running max (exp2 domain) the probabilities are taken against; -m_i is kept broadcast in
+    // 16 registers and fed to the first QK^T MFMA as its C operand, so the accumulators come out as (score - m_i) directly.
+    float m_i = 0.f, l_i = 0.f;
+    f32x16 negm;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) negm[g] = 0.f;
     const int NT = (p.Tk + 63) >> 6;
     const int kr = swap23(r);
     int cur = 0;
     for (int t = 0; t < NT; ++t) {
         const bool more = t + 1 < NT;
-        if (more) load_kv(t + 1);
-        // ---- S^T = K Q^T (two 32-key tiles); this lane's keys for (kt, g): t*64 + kt*32 + 16*(g>>3) + 8*h + (g&7)
+        if (more && IR_KO_ATTN != 2) load_kv(t + 1);
+        // ---- S^T = K Q^T - m_i (two 32-key tiles); this lane's keys for (kt, g): t*64 + kt*32 + 16*(g>>3) + 8*h + (g&7)
         f32x16 s[2];
-        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
-                bf16x8 a = *reinterpret_cast<const bf16x8*>(&Ks[(cur * 64 + kt * 32 + kr) * QS + ks * 16 + h * 8]);
-                s[kt] = mfma32(a, qf[ks], ks == 0 ? zero16 : s[kt]);  // first k-step takes the constant 0 as C (no register zeroing)
+                bf16x8 a = qf[ks];
+                if (IR_KO_ATTN != 3) a = *reinterpret_cast<const bf16x8*>(&Ks[(cur * 64 + kt * 32 + kr) * QS + ks * 16 + h * 8]);
+                if (IR_KO_ATTN != 4) s[kt] = mfma32(a, qf[ks], ks == 0 ? negm : s[kt]);
+                else if (ks == 0) s[kt] = negm;
             }
         }
-        // ---- online softmax in the exp2 domain
-        float mx = -INFINITY;
-        if (general) {
+        if (general) {  // additive key bias (log2 domain; -inf beyond Tk)
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -152,49 +188,53 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(AttnParams p) {
                     const f32x4 b0 = *reinterpret_cast<const f32x4*>(&kbs[cur][kt * 32 + 16 * g8 + 8 * h]);
                     const f32x4 b1 = *reinterpret_cast<const f32x4*>(&kbs[cur][kt * 32 + 16 * g8 + 8 * h + 4]);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        const float v = __builtin_fmaf(s[kt][g8 * 8 + e], p.scale_log2, e < 4 ? b0[e & 3] : b1[e & 3]);
-                        s[kt][g8 * 8 + e] = v;
-                        mx = fmaxf(mx, v);
-                    }
+                    for (int e = 0; e < 8; ++e) s[kt][g8 * 8 + e] += e < 4 ? b0[e & 3] : b1[e & 3];
                 }
-        } else {
+        }
+        float mx = -INFINITY;  // max of this tile RELATIVE to m_i
+        if (IR_KO_ATTN != 5) {
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int g = 0; g < 16; ++g) mx = fmaxf(mx, s[kt][g]);
-            mx *= p.scale_log2;  // scale > 0
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        // deferred rescale: O and l are rescaled only when some query's max grew by more than RESCALE_THR; until then
-        // probabilities are taken against the (slightly stale) running max and stay <= 2^THR (exact in fp32 / bf16 range).
-        // The decision precedes this tile's exponentials, so everything at the old max (O, l) is scaled exactly once.
-        if (__any(mx > m_i + RESCALE_THR)) {
-            const float m_new = fmaxf(m_i, mx);
-            const float alpha = __builtin_amdgcn_exp2f(m_i - m_new);
+        // deferred rescale: the running max moves only when some query's scores exceed it by more than RESCALE_THR (and on the
+        // first tile); until then probabilities are taken against the slightly stale max and stay <= 2^THR (exact in fp32 / bf16
+        // range). The decision precedes this tile's exponentials, so everything at the old max is scaled exactly once.
+        if (t == 0 || __any(mx > RESCALE_THR)) {
+            const float delta = t == 0 ? (mx > -INFINITY ? mx : 0.f) : fmaxf(mx, 0.f);
+            const float alpha = t == 0 ? 1.0f : __builtin_amdgcn_exp2f(-delta);  // O and l are still zero on the first tile
+            m_i += delta;
             l_i *= alpha;
-            m_i = m_new;
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
                 for (int g = 0; g < 16; ++g) o[dt][g] *= alpha;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) s[kt][g] -= delta;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) negm[g] = -m_i;
         }
-        // exponentials, row sum, and bf16 P^T fragments (B operand: registers 8*s2 .. 8*s2+7 of tile kt)
+        // exponentials and bf16 P^T fragments (B operand: registers 8*s2 .. 8*s2+7 of tile kt)
         float rs = 0.f;
         bf16x8 pb[2][2];
-        const float sc = general ? 1.0f : p.scale_log2;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][s2 * 8 + e], sc, -m_i));
-                    rs += pv;
+                    const float pv = IR_KO_ATTN == 5 ? s[kt][s2 * 8 + e] : __builtin_amdgcn_exp2f(s[kt][s2 * 8 + e]);
+                    if (!ONES) rs += pv;
                     pb[kt][s2][e] = (__bf16)pv;
                 }
-        rs += __shfl_xor(rs, 32);
-        l_i += rs;
+        if (!ONES) {
+            rs += __shfl_xor(rs, 32);
+            l_i += rs;
+        }
         // ---- O^T += V^T P^T
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt)
@@ -202,14 +242,17 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(AttnParams p) {
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
-                    bf16x8 a = *reinterpret_cast<const bf16x8*>(&Vs[(cur * DV + dt * 32 + r) * VS + kt * 32 + s2 * 16 + h * 8]);
-                    o[dt] = mfma32(a, pb[kt][s2], o[dt]);
+                    bf16x8 a = pb[kt][s2];
+                    if (IR_KO_ATTN != 3) a = *reinterpret_cast<const bf16x8*>(&Vs[(cur * DV + dt * 32 + r) * VS + kt * 32 + s2 * 16 + h * 8]);
+                    if (IR_KO_ATTN != 4) o[dt] = mfma32(a, pb[kt][s2], o[dt]);
+                    else o[dt][0] += __builtin_bit_cast(float, (uint32_t)__builtin_bit_cast(uint16_t, pb[kt][s2][0]) + (uint32_t)__builtin_bit_cast(uint16_t, a[1]));
                 }
-        if (more) store_kv(cur ^ 1);
-        __syncthreads();
+        if (more && IR_KO_ATTN != 2) store_kv(cur ^ 1);
+        if (IR_KO_ATTN != 1) __syncthreads();
         cur ^= 1;
     }
     // ---- finalise: O^T[d][q] / l -> LDS [q][d] -> 16-byte row stores
+    if (ONES) l_i = __shfl(o[L_DT][L_G], r + 32 * L_H);  // O^T row D of this lane's query
     const float inv = 1.0f / l_i;
     bf16_t* ow = Os + wid * 32 * OS;
 #pragma unroll
@@ -229,6 +272,287 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(AttnParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Ping-pong flash attention for the DiT self-attention (16 heads x 72, T % 64 == 0, no key bias): the same mathematics and
+// register layouts as flash_attn_kernel (S^T = K Q^T - m, O^T = V^T P^T, keys swap23-permuted, softmax denominator from the
+// ones row of V^T), restructured so that the matrix pipe never waits for the softmax.
+// Two independent 4-wave workgroups per CU run in lockstep (QK^T together, exponentials together): measured with knock-outs,
+// their MFMA time and their VALU + data-movement time simply ADD (1.54 ms = 0.72 + 0.82). Here ONE 512-thread workgroup puts two
+// waves on every SIMD, wave w and w+4, each owning 32 queries, and forces complementary phases with workgroup barriers:
+//     segment:   sigma-1      sigma          sigma+1       sigma+2
+//     waves 0-3  softmax(t)   PV(t)+QK(t+1)  softmax(t+1)  PV(t+1)+QK(t+2)
+//     waves 4-7  PV+QK(t-1)   softmax(t)     PV(t)+QK(t+1) softmax(t+1)
+// so on every SIMD one wave issues MFMAs (22 per segment, 704 cycles) while its partner does the VALU work. K/V tiles are shared
+// by all 256 queries (half the L2->LDS traffic per query) and arrive by LDS-DMA into a ring of three stages, stage u = {V(u),
+// K(u+1)} in slot u % 3. Every wave issues its 2-3 one-KB pieces per tile at the start of its vector segment, which has slack
+// (about 500 cycles of softmax against 700+ of MFMAs): waves 0-3 those of stage t+1, waves 4-7 (a segment later) those of stage
+// t+2, each into a slot whose previous stage both halves finished reading at an earlier barrier, and each wave waits for its
+// own pieces (vmcnt) at the end of its following matrix segment; the barrier there publishes them a full segment before the
+// first read of that stage.
+// K rows are stored UNPADDED (144 B = 9 chunks, odd -> conflict-free): the fifth k-step reads elements 72..79 from the next
+// row's first chunk, finite values that meet the zero padding of the Q fragment. V^T rows are 128 B with the XOR swizzle of
+// flash_attn_d512_kernel. Q fragments come straight from HBM in the B-operand layout, pre-multiplied by scale * log2(e).
+// The fragment reads of a matrix segment are inline-asm ds_read_b128 with hand-counted s_waitcnt lgkmcnt(N): left to hipcc, every
+// fifth MFMA waited for lgkmcnt(0), i.e. for a read issued one instruction earlier (73 instead of 32 cycles per MFMA).
+template <int OFF>
+IR_DEVINL bf16x8 lds_read16(uint32_t addr) {
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+template <int N>
+IR_DEVINL void wait_lds() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N)); }
+
+template <int D>
+__global__ __launch_bounds__(512, 1) void flash_attn_pp_kernel(AttnParams p) {
+    constexpr int DQK = (D + 15) & ~15, DV = (D + 31) & ~31;
+    static_assert(DV > D, "needs a spare V^T row (ones) for the softmax denominator");
+    constexpr int RCH = D / 8;           // 16-byte chunks per K row, in HBM and in LDS
+    static_assert(RCH % 2 == 1, "unpadded K rows are conflict-free only with an odd chunk count");
+    constexpr int KROW = RCH * 16;       // bytes per K row in LDS
+    constexpr int NKS = DQK / 16, NDT = DV / 32;
+    constexpr int K_BYTES = 64 * KROW, V_BYTES = DV * 128;
+    static_assert(K_BYTES % 1024 == 0 && V_BYTES % 1024 == 0, "tiles are whole LDS-DMA instructions");
+    // DMA instructions per tile. V^T rows beyond D (the ones row) are never transferred: their O^T rows are never stored, and a row
+    // of O^T depends on no other row of V^T, so whatever those LDS rows hold is harmless.
+    constexpr int K_Q = K_BYTES / 1024, V_Q = (D + 1 + 7) / 8;
+    constexpr int NSLOT = 3;
+    constexpr int V_OFF = NSLOT * K_BYTES;
+    constexpr int OS = DV + 8;           // O staging row stride (elements)
+    constexpr int LDS_MAIN = NSLOT * (K_BYTES + V_BYTES), LDS_O = 8 * 32 * OS * 2;
+    constexpr int LDS_BYTES = LDS_MAIN > LDS_O ? LDS_MAIN : LDS_O;
+    constexpr int L_DT = D / 32, L_G = ((D % 32) & 3) + 4 * ((D % 32) >> 3), L_H = ((D % 32) >> 2) & 1;
+    constexpr float RESCALE_THR = 8.0f;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES];  // K[0..2] | V^T[0..2]
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wu = __builtin_amdgcn_readfirstlane(wid);
+    const int grp = wu >> 2;  // grp 1 (waves 4-7) runs one segment behind grp 0
+    const int r = lane & 31, h = lane >> 5;
+    const int q0 = blockIdx.x * 256 + wid * 32, head = blockIdx.y, b = blockIdx.z;
+    const bf16_t* qp = p.q + (long)b * p.q_bs + (long)head * p.q_hs;
+    const bf16_t* kp = p.k + (long)b * p.k_bs + (long)head * p.k_hs;
+    const bf16_t* vtp = p.vt + (long)b * p.vt_bs + (long)head * DV * p.Tk_pad;
+    const int NT = p.Tk >> 6;
+
+    // LDS-DMA pieces (1 KB each): a tile pair is K_Q + V_Q pieces, piece idx = wave + 8*k belongs to this wave (at most NPC). Per
+    // piece the lane's tile-0 source address is computed once; issuing it for a tile is one 64-bit multiply-add plus the DMA.
+    constexpr int NPC = (K_Q + V_Q + 7) / 8;
+    const bf16_t* pc_src[NPC];
+    int pc_stride[NPC], pc_dst[NPC];
+#pragma unroll
+    for (int k = 0; k < NPC; ++k) {
+        const int idx = wu + 8 * k;
+        if (idx < K_Q) {
+            const int ci = 64 * idx + lane, row = ci / RCH, ch = ci - row * RCH;
+            pc_src[k] = kp + (long)row * p.k_rs + ch * 8;
+            pc_stride[k] = 64 * p.k_rs;
+            pc_dst[k] = idx * 1024;
+        } else {
+            const int j = min(idx - K_Q, V_Q - 1);
+            const int d = 8 * j + (lane >> 3), c = (lane & 7) ^ ((d >> 1) & 7);  // LDS slot (lane & 7) of row d holds chunk c
+            pc_src[k] = vtp + (long)d * p.Tk_pad + c * 8;
+            pc_stride[k] = 64;
+            pc_dst[k] = V_OFF + j * 1024;
+        }
+    }
+    auto issue_k = [&](int tile, int slot) {  // this wave's K pieces of `tile` into K slot `slot`
+#pragma unroll
+        for (int k = 0; k < NPC; ++k)
+            if (wu + 8 * k < K_Q) attn_glds16(pc_src[k] + (long)tile * pc_stride[k], (attn_lds_ptr_t)(smem + slot * K_BYTES + pc_dst[k]));
+    };
+    auto issue_v = [&](int tile, int slot) {
+#pragma unroll
+        for (int k = 0; k < NPC; ++k)
+            if (wu + 8 * k >= K_Q && wu + 8 * k < K_Q + V_Q)
+                attn_glds16(pc_src[k] + (long)tile * pc_stride[k], (attn_lds_ptr_t)(smem + slot * V_BYTES + pc_dst[k]));
+    };
+    auto issue_stage = [&](int u) {  // stage u = {V(u), K(u+1)} -> ring slot u % 3
+        const int slot = u % NSLOT;
+        if (u < NT) issue_v(u, slot);
+        if (u + 1 < NT) issue_k(u + 1, slot);
+    };
+    // prologue: K(0) -> K slot 2 (free until stage 2) and stage 0; in the loop, vector segment t of waves 0-3 issues their pieces
+    // of stage t+1 and that of waves 4-7 (one segment later) their pieces of stage t+2, so waves 4-7 add stage 1 here
+    issue_k(0, 2);
+    issue_stage(0);
+    if (grp == 1) issue_stage(1);
+
+    // Q^T fragments (B operand: lane = query, 8 consecutive d per k-step half), scaled; d >= D is zero
+    bf16x8 qf[NKS];
+    {
+        const bf16_t* qrow = qp + (long)min(q0 + r, p.Tq - 1) * p.q_rs;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int d0 = ks * 16 + h * 8;
+            const uint4 v = *reinterpret_cast<const uint4*>(qrow + (d0 < D ? d0 : 0));  // unconditional load on a valid address
+            const float sc = d0 < D ? p.scale_log2 : 0.f;
+            uint4 w;
+            w.x = pack2bf(bflo(v.x) * sc, bfhi(v.x) * sc);
+            w.y = pack2bf(bflo(v.y) * sc, bfhi(v.y) * sc);
+            w.z = pack2bf(bflo(v.z) * sc, bfhi(v.z) * sc);
+            w.w = pack2bf(bflo(v.w) * sc, bfhi(v.w) * sc);
+            qf[ks] = __builtin_bit_cast(bf16x8, w);
+        }
+    }
+    f32x16 o[NDT], sacc[2], negm;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) o[dt][g] = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) negm[g] = 0.f;
+    float m_i = 0.f;
+    bf16x8 pb[2][2];
+
+    // LDS fragment addresses (bytes): one base per operand plus compile-time immediates
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(attn_lds_ptr_t)smem;
+    const uint32_t k_addr = lds0 + swap23(r) * KROW + h * 16;                       // + slot*K_BYTES + kt*32*KROW + ks*32
+    const int vsw = (r >> 1) & 7;                                                    // swizzle of rows d = dt*32 + r
+    uint32_t v_addr[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v_addr[j] = lds0 + V_OFF + r * 128 + ((((2 * j) | h) ^ vsw) << 4);  // + slot*V_BYTES + dt*4096
+
+    // One matrix segment: PV(t) (NDT*4 MFMAs) and, if QK, S^T(t+1) (2*NKS MFMAs); fragment reads run LA MFMAs ahead of their use.
+    // The first LA reads are issued by matrix_prefetch() at the END of the preceding vector segment, above the barrier (their
+    // tiles were published at least a segment earlier), so the segment opens with an MFMA instead of an LDS round trip; the S^T
+    // accumulators are preset to -m_i there as well, so every MFMA here accumulates in place.
+    constexpr int NPV = NDT * 4;
+    constexpr int LA = 4;   // only ONE wave per SIMD is in its matrix segment: nobody else hides its LDS latency
+    constexpr int NB = LA + 3;  // fragment buffers (registers stay allocated two MFMAs beyond their use, see below)
+    bf16x8 fr[NB];
+    uint32_t ka = 0, va[4] = {0, 0, 0, 0};
+    auto frag_read = [&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        if (IR_KO_ATTN == 12) { fr[j % NB] = qf[j % NKS]; return; }
+        if constexpr (j < NPV) fr[j % NB] = lds_read16<(j >> 2) * 4096>(va[j & 3]);
+        else fr[j % NB] = lds_read16<((j - NPV) / NKS) * 32 * KROW + ((j - NPV) % NKS) * 32>(ka);
+    };
+    auto matrix_prefetch = [&](auto pv_tag, auto qk_tag, int vslot, int kslot) {
+        constexpr bool PV = decltype(pv_tag)::value, QK = decltype(qk_tag)::value;
+        constexpr int J0 = PV ? 0 : NPV, J1 = QK ? NPV + 2 * NKS : NPV;
+        ka = k_addr + kslot * K_BYTES;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) va[j] = v_addr[j] + vslot * V_BYTES;
+        __builtin_amdgcn_sched_barrier(0);
+        [&]<int... I>(std::integer_sequence<int, I...>) { (frag_read(std::integral_constant<int, J0 + I>{}), ...); }(std::make_integer_sequence<int, (J1 - J0 < LA ? J1 - J0 : LA)>{});
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto matrix_segment = [&](auto pv_tag, auto qk_tag) {
+        constexpr bool PV = decltype(pv_tag)::value, QK = decltype(qk_tag)::value;
+        constexpr int J0 = PV ? 0 : NPV, J1 = QK ? NPV + 2 * NKS : NPV;
+        auto step = [&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (j + LA < J1) frag_read(std::integral_constant<int, j + LA>{});
+            wait_lds<(J1 - 1 - j < LA ? J1 - 1 - j : LA)>();  // reads issued after the one MFMA j consumes
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (j < NPV) o[j >> 2] = mfma32(fr[j % NB], pb[(j & 3) >> 1][j & 1], o[j >> 2]);
+            else sacc[(j - NPV) / NKS] = mfma32(fr[j % NB], qf[(j - NPV) % NKS], sacc[(j - NPV) / NKS]);
+            // keep the fragment of MFMA j-2 allocated until here: the register allocator otherwise hands its registers to the very
+            // next read, which then waits (with everything behind it) until that MFMA has finished reading them
+            if constexpr (j - 2 >= J0) asm volatile("" ::"v"(fr[(j - 2) % NB]));
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        __builtin_amdgcn_sched_barrier(0);
+        [&]<int... I>(std::integer_sequence<int, I...>) { (step(std::integral_constant<int, J0 + I>{}), ...); }(std::make_integer_sequence<int, J1 - J0>{});
+    };
+    // softmax of the tile whose (score - m_i) sits in sacc: running max with deferred rescale, exponentials -> pb
+    auto softmax_segment = [&](int t) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) mx = fmaxf(mx, sacc[kt][g]);
+        mx = xhalf_max(mx);
+        if (t == 0 || __any(mx > RESCALE_THR)) {
+            const float delta = t == 0 ? mx : fmaxf(mx, 0.f);
+            const float alpha = t == 0 ? 1.0f : __builtin_amdgcn_exp2f(-delta);  // O is still zero on the first tile
+            m_i += delta;
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) o[dt][g] *= alpha;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) sacc[kt][g] -= delta;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) negm[g] = -m_i;
+        }
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pb[kt][s2][e] = (__bf16)__builtin_amdgcn_exp2f(sacc[kt][s2 * 8 + e]);
+        sacc[0] = negm;  // the next S^T accumulates onto -m_i in place
+        sacc[1] = negm;
+    };
+
+    wait_dma();
+    __syncthreads();                   // K(0) and the prologue stages landed
+    if (grp == 1) __syncthreads();     // waves 4-7 start one segment late
+    sacc[0] = negm;
+    sacc[1] = negm;
+    matrix_prefetch(std::false_type{}, std::true_type{}, 0, 2);
+    matrix_segment(std::false_type{}, std::true_type{});  // S^T(0) from K slot 2
+    __syncthreads();
+#ifdef IR_STAMPS_ATTN
+    unsigned long long st_acc[4] = {0, 0, 0, 0};
+#endif
+    int slot = 0;  // t % 3
+    for (int t = 0; t < NT; ++t) {
+        // ---- vector segment (the SIMD partner is in its matrix segment): DMA issue, softmax, first fragment reads
+        IR_ATT_T(ta);
+        if (IR_KO_ATTN != 11) issue_stage(t + 1 + grp);
+        if (IR_KO_ATTN != 13) softmax_segment(t);
+        if (t + 1 < NT) matrix_prefetch(std::true_type{}, std::true_type{}, slot, slot);
+        else matrix_prefetch(std::true_type{}, std::false_type{}, slot, slot);
+        IR_ATT_T(tb);
+        __syncthreads();
+        IR_ATT_T(tc);
+        // ---- matrix segment: O^T += V^T(t) P^T(t); S^T(t+1) = K(t+1) Q^T - m
+        if (t + 1 < NT) matrix_segment(std::true_type{}, std::true_type{});
+        else matrix_segment(std::true_type{}, std::false_type{});
+        IR_ATT_T(td);
+        wait_dma();  // this wave's pieces, issued at the start of its vector segment: the barrier publishes them before any wave's
+                     // matrix_prefetch (which runs ABOVE the next barrier) can touch their stage
+        __syncthreads();
+        IR_ATT_T(te);
+        IR_ATT_ACC(0, ta, tb); IR_ATT_ACC(1, tb, tc); IR_ATT_ACC(2, tc, td); IR_ATT_ACC(3, td, te);
+        slot = slot == NSLOT - 1 ? 0 : slot + 1;
+    }
+#ifdef IR_STAMPS_ATTN
+    {
+        const int bl = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        if (lane == 0 && bl < 4096)
+            for (int k = 0; k < 4; ++k) g_attn_stamps[(bl * 8 + wid) * 4 + k] = st_acc[k];
+    }
+#endif
+    if (grp == 0) __syncthreads();     // pairs the late start of waves 4-7; afterwards nobody reads the K/V ring any more
+    wait_dma();
+
+    // ---- finalise: O^T[d][q] / l -> LDS [q][d] -> 16-byte row stores
+    const float l_i = __shfl(o[L_DT][L_G], r + 32 * L_H);  // O^T row D (ones row of V^T) of this lane's query
+    const float inv = 1.0f / l_i;
+    bf16_t* ow = reinterpret_cast<bf16_t*>(smem) + wid * 32 * OS;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) {
+            uint2 w = make_uint2(pack2bf(o[dt][4 * gg] * inv, o[dt][4 * gg + 1] * inv),
+                                 pack2bf(o[dt][4 * gg + 2] * inv, o[dt][4 * gg + 3] * inv));
+            *reinterpret_cast<uint2*>(&ow[r * OS + dt * 32 + 8 * gg + 4 * h]) = w;
+        }
+    __syncthreads();
+    bf16_t* op = p.o + (long)b * p.o_bs + (long)head * p.o_hs;
+    for (int c = lane; c < 32 * RCH; c += 64) {
+        int row = c / RCH, ch = c - row * RCH;
+        int q = q0 + row;
+        if (q < p.Tq) *reinterpret_cast<uint4*>(op + (long)q * p.o_rs + ch * 8) = *reinterpret_cast<const uint4*>(&ow[row * OS + ch * 8]);
+    }
+}
+
 int ir_launch_flash_attn(const AttnParams& p, hipStream_t s) {
     if (p.Tq <= 0 || p.Tk <= 0 || p.B <= 0 || p.Hh <= 0) return -2;
     if ((p.D & 7) || (p.q_rs & 7) || (p.k_rs & 7) || (p.o_rs & 7) || (p.q_hs & 7) || (p.k_hs & 7) || (p.o_hs & 7) ||
@@ -238,6 +562,11 @@ int ir_launch_flash_attn(const AttnParams& p, hipStream_t s) {
     if (p.scale_log2 <= 0.f) return -6;
     dim3 grid((p.Tq + 127) / 128, p.Hh, p.B);
     const bool general = p.key_bias != nullptr || (p.Tk & 63);
+    static const bool no_pp = getenv("IR_NO_PINGPONG") != nullptr;  // experiment knob
+    if (p.D == 72 && !general && p.Tq >= 256 && !no_pp) {  // the DiT self-attention: ping-pong kernel, 256 queries per workgroup
+        hipLaunchKernelGGL((flash_attn_pp_kernel<72>), dim3((p.Tq + 255) / 256, p.Hh, p.B), dim3(512), 0, s, p);
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
 #define IR_FA(DD)                                                                                     \
     do {                                                                                              \
         if (general) hipLaunchKernelGGL((flash_attn_kernel<DD, true>), grid, dim3(256), 0, s, p);     \
@@ -262,8 +591,6 @@ int ir_launch_flash_attn(const AttnParams& p, hipStream_t s) {
 // Register budget: O^T for all 512 output dims (256 accumulators) plus the Q fragments (128) plus S/P exceeds what hipcc
 // allocates without spilling, so the output dims are split over blockIdx.y (DSPLIT = 2): each block recomputes S^T and owns
 // 256 output dims (128 accumulators). That costs 1.5x the MFMA work of an ideal kernel but keeps everything in registers.
-typedef __attribute__((address_space(3))) void* attn_lds_ptr_t;
-IR_DEVINL void attn_glds16(const void* g, attn_lds_ptr_t l) { __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0); }
 
 __global__ __launch_bounds__(256, 1) void flash_attn_d512_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                                   const bf16_t* __restrict__ vt, bf16_t* __restrict__ o, int T, int rs,
@@ -428,6 +755,7 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t* __restri
         int tok = i / DV, d = i - tok * DV;
         bf16_t x = 0;
         if (d < D && t0 + tok < T) x = src[(long)(t0 + tok) * v_rs + d];
+        if (d == D && t0 + tok < T) x = 0x3f80;  // row D (if DV > D): ones over the real keys -> flash_attn_kernel's softmax denominator
         tile[tok][d] = x;
     }
     __syncthreads();

@@ -56,6 +56,14 @@ IR_DEVINL float silu(float x) { return x * fast_sigmoid(x); }
 // (a workgroup-scope fence only waits lgkmcnt on gfx950), so every barrier that publishes DMA-written LDS is preceded by this.
 IR_DEVINL void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// max / sum of a value with its partner lane in the other half of the wave (lane ^ 32): one v_permlane32_swap instead of an LDS
+// round trip (ds_bpermute). The swap returns {v with the upper half replaced by the lower, v with the lower replaced by the upper}.
+IR_DEVINL float xhalf_max(float v) {
+    const uint32_t u = __builtin_bit_cast(uint32_t, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+}
+
 IR_DEVINL float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -178,6 +178,7 @@ def test_layernorm(ctx, rows, c, ld):
 
 @pytest.mark.parametrize("b,heads,tq,tk,d,bias", [
     (1, 2, 128, 128, 72, False), (2, 3, 200, 200, 72, False), (1, 16, 1024, 1024, 72, False),
+    (2, 2, 384, 320, 72, False), (1, 1, 256, 64, 72, False), (1, 2, 300, 128, 72, False),  # ping-pong kernel: ragged Tq, odd / single tile counts
     (2, 2, 130, 300, 72, True), (1, 2, 64, 64, 32, False), (1, 1, 256, 192, 64, True),
     (1, 1, 256, 256, 512, False), (2, 1, 1024, 1024, 512, False)])
 def test_flash_attention(ctx, b, heads, tq, tk, d, bias):

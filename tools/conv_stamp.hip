@@ -1,5 +1,5 @@
 // Diagnostic: phase time stamps of conv_halo_kernel (prologue / main loop / epilogue per block) and the in-kernel clock.
-// Build:  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=fast -DIR_STAMPS -Iinstarevive_amd/csrc tools/conv_stamp.hip -o tools/conv_stamp
+// Build:  hipcc --offload-arch=gfx950 -O3 -std=c++20 -ffp-contract=fast -DIR_STAMPS -Iinstarevive_amd/csrc tools/conv_stamp.hip -o tools/conv_stamp
 // Run:    tools/conv_stamp [H W Cin Cout]
 #include "../instarevive_amd/csrc/igemm.hip"
 #include <algorithm>
