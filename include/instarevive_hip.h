@@ -83,6 +83,13 @@ int ir_nchw_to_u8(ir_ctx* ctx, void* stream, const float* in, uint8_t* out, int 
 int ir_op_conv(ir_ctx* ctx, void* stream, const uint16_t* in, const uint16_t* wgt, const float* bias, void* out, int n, int h, int w,
                int cin, int cout, int cout_pad, int taps, int stride, int pad, int up, int act, float slope, const void* res,
                int res_f32, int out_f32);
+/* 3x3 conv (stride 1 / 2, optional nearest-2x upsample, optional bf16 residual) with the GroupNorm(32) statistics of its output
+ * produced by the conv epilogue, followed by GroupNorm (+SiLU): the fused form of ResnetBlock's conv -> norm
+ * (ldm/modules/diffusionmodules/model.py:131-151). *fused receives the number of pixel tiles per image that wrote statistics
+ * (0: the shape fell back to the separate statistics pass). */
+int ir_op_conv_groupnorm(ir_ctx* ctx, void* stream, const uint16_t* in, const uint16_t* wgt, const float* bias, uint16_t* conv_out,
+                         uint16_t* y, const float* gamma, const float* beta, int n, int h, int w, int cin, int cout, int stride, int up,
+                         const void* res, int silu, void* ws, size_t ws_bytes, int* fused);
 int ir_op_linear(ir_ctx* ctx, void* stream, const uint16_t* in, const uint16_t* wgt, const float* bias, void* out, int m, int k, int n,
                  int n_pad, int act, const float* gate, const void* res, int res_f32, int out_f32, float out_scale);
 int ir_op_groupnorm(ir_ctx* ctx, void* stream, const uint16_t* x, uint16_t* y, const float* gamma, const float* beta, int n, int hw,

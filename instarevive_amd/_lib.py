@@ -18,7 +18,7 @@ SYMBOLS = [
     "ir_swinir_configure", "ir_vae_configure", "ir_dit_configure", "ir_dit_set_prompt", "ir_workspace_bytes",
     "ir_swinir_forward", "ir_vae_encode", "ir_dit_forward", "ir_dit_step", "ir_vae_decode", "ir_color_fix",
     "ir_pipeline", "ir_u8_to_nchw", "ir_nchw_to_u8", "ir_profile_begin", "ir_profile_end",
-    "ir_op_conv", "ir_op_linear", "ir_op_groupnorm", "ir_op_layernorm", "ir_op_attention", "ir_op_swin_attention",
+    "ir_op_conv", "ir_op_conv_groupnorm", "ir_op_linear", "ir_op_groupnorm", "ir_op_layernorm", "ir_op_attention", "ir_op_swin_attention",
     "ir_op_softmax_rows",
 ]
 
@@ -70,6 +70,7 @@ def load_library():
     lib.ir_u8_to_nchw.argtypes = [vp, vp, vp, vp, i, i, i]
     lib.ir_nchw_to_u8.argtypes = [vp, vp, vp, vp, i, i, i]
     lib.ir_op_conv.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, i, i, i, f, vp, i, i]
+    lib.ir_op_conv_groupnorm.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, vp, i, vp, sz, C.POINTER(C.c_int)]
     lib.ir_op_linear.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, i, vp, vp, i, i, f]
     lib.ir_op_groupnorm.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, f, i, vp, sz]
     lib.ir_op_layernorm.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, f]

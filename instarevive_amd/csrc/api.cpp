@@ -179,6 +179,13 @@ struct Run {
     Arena a;
     int rc = 0;
     const char* where = "";
+    // Fused GroupNorm statistics: a caller that knows a GroupNorm consumes the next conv's output sets gn_buf (and gn_want);
+    // conv() then asks the epilogue for per-group partial sums and groupnorm() skips its own statistics pass when its input
+    // is the tensor the pending partials describe.
+    float* gn_buf = nullptr;
+    bool gn_want = false;
+    const void* gn_x = nullptr;
+    int gn_chunks = 0;
     bool live() const { return !a.dry && rc == 0 && !a.overflow; }
     void chk(int r, const char* w) {
         if (r != 0 && rc == 0) { rc = r; where = w; }
@@ -230,6 +237,17 @@ void conv(Run& r, const Conv& cw, const bf16_t* in, int N, int H, int W, int in_
     p.gate = gate; p.gate_stride = 0; p.rows_per_batch = 1 << 30;
     p.res = res; p.res_f32 = res_f32; p.res_cs = res_cs; p.res_mod = res_mod;
     p.out = out; p.out_f32 = out_f32; p.out_cs = out_cs; p.out2 = out2; p.out2_cs = out2_cs;
+    static const bool no_gn_fuse = getenv("IR_NO_GN_FUSE") != nullptr;  // experiment knob
+    if (r.gn_want && r.gn_buf && !out_f32 && cw.cout % 32 == 0 && !no_gn_fuse) {
+        p.gn_cpg = cw.cout / 32;
+        p.gn_chunks = ir_igemm_gn_chunks(p);
+        if (p.gn_chunks > 0) {
+            p.gn_part = r.gn_buf;
+            r.gn_x = out;
+            r.gn_chunks = p.gn_chunks;
+        }
+    }
+    r.gn_want = false;
     LAUNCH(r, cw.taps == 9 ? PC_CONV3X3 : PC_LINEAR, 2.0 * p.M * (double)cw.cout * cw.taps * cw.cin,
            2.0 * ((double)p.M * cw.cin + (double)p.M * cw.cout + (double)cw.cout_pad * cw.taps * cw.cin), ir_launch_igemm(p, r.s), "igemm");
 }
@@ -241,6 +259,14 @@ void linear(Run& r, const Conv& cw, const bf16_t* in, int M, int in_cs, void* ou
 }
 void groupnorm(Run& r, const Norm& n, const bf16_t* x, bf16_t* y, float* ws, int N, long HW, int silu) {
     if (!r.live()) return;
+    if (r.gn_x == x && r.gn_chunks > 0) {  // statistics already produced by the conv that wrote x
+        const int chunks = r.gn_chunks;
+        r.gn_x = nullptr;
+        LAUNCH(r, PC_GROUPNORM, 0.0, 4.0 * N * (double)HW * n.c,
+               ir_launch_groupnorm_fused(x, y, n.g, n.b, r.gn_buf, ws, N, HW, n.c, 32, chunks, 1e-6f, silu, r.s), "groupnorm_fused");
+        return;
+    }
+    r.gn_x = nullptr;
     LAUNCH(r, PC_GROUPNORM, 0.0, 6.0 * N * (double)HW * n.c, ir_launch_groupnorm(x, y, n.g, n.b, ws, N, HW, n.c, 32, 1e-6f, silu, r.s), "groupnorm");
 }
 void layernorm(Run& r, const float* x, bf16_t* y, float* yf, const float* a, const float* b, long rows, int C, int ldx, int ldy,
@@ -351,10 +377,12 @@ void swinir_run(Run& r, const float* in, float* out, int n, int h, int w) {
 
 // ================================================================ VAE  (ldm/modules/diffusionmodules/model.py)
 // ResnetBlock (model.py:131-151) on three rotating NHWC bf16 buffers; returns the index holding the result.
-int resblock(Run& r, const ResW& w, bf16_t* B[3], int ci, float* gws, int N, int H, int W) {
+// gn_after: the block's output feeds a GroupNorm next (another ResnetBlock, the AttnBlock or norm_out).
+int resblock(Run& r, const ResW& w, bf16_t* B[3], int ci, float* gws, int N, int H, int W, bool gn_after) {
     const int t1 = (ci + 1) % 3, t2 = (ci + 2) % 3;
     const int cin = w.c1.cin, cout = w.c1.cout;
     groupnorm(r, w.n1, B[ci], B[t1], gws, N, (long)H * W, 1);
+    r.gn_want = true;  // conv1's output is norm2's input
     conv(r, w.c1, B[t1], N, H, W, cin, B[t2], cout, 0, 1, 1, 0, ACT_NONE, 0.f, nullptr, 0, 0);
     const bf16_t* res = B[ci];
     if (w.has_sc) {
@@ -362,6 +390,7 @@ int resblock(Run& r, const ResW& w, bf16_t* B[3], int ci, float* gws, int N, int
         res = B[t1];
     }
     groupnorm(r, w.n2, B[t2], B[t2], gws, N, (long)H * W, 1);
+    r.gn_want = gn_after;
     conv(r, w.c2, B[t2], N, H, W, cout, B[t1], cout, 0, 1, 1, 0, ACT_NONE, 0.f, res, 0, cout);
     return t1;
 }
@@ -426,6 +455,12 @@ long vae_act_elems(const VaeHalf& m, int N, int H, int W, bool decoder) {
     return best;
 }
 
+// floats per image of the fused GroupNorm partial-sum buffer at resolution h x w: (pixel tiles of the finest kernel) x 2 x 32 groups
+long gn_fused_floats(int h, int w) {
+    const long halo = (long)((h + 7) / 8) * ((w + 15) / 16), gemm = ((long)h * w + 127) / 128;
+    return (halo > gemm ? halo : gemm) * 64;
+}
+
 // Encoder.forward (model.py:521-546) + quant_conv + mode() (autoencoder.py:82-86). in: fp32 NCHW, v*in_scale+in_shift first.
 void vae_encode_run(Run& r, const float* in, float* lat, int n, int h, int w, float in_scale, float in_shift, float lat_scale) {
     const VaeHalf& m = r.c->vae.enc;
@@ -436,23 +471,29 @@ void vae_encode_run(Run& r, const float* in, float* lat, int n, int h, int w, fl
     for (int i = 0; i < 3; ++i) B[i] = r.a.alloc<bf16_t>(maxe);
     bf16_t* in32 = r.a.alloc<bf16_t>((long)n * h * w * 32);
     float* gws = r.a.alloc<float>(ir_gn_ws_floats(n, (long)h * w, 512));
+    r.gn_buf = r.a.alloc<float>((long)n * gn_fused_floats(h, w));
+    r.gn_x = nullptr;
     LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_nchw_to_nhwc_bf16(in, in32, n, 3, (long)h * w, 32, in_scale, in_shift, r.s), "nchw_to_nhwc");
+    r.gn_want = true;
     conv(r, m.conv_in, in32, n, h, w, 32, B[0], m.conv_in.cout, 0, 1, 1, 0, ACT_NONE, 0.f, nullptr, 0, 0);
     int ci = 0, H = h, W = w;
     for (int l = 0; l < nl; ++l) {
-        for (const ResW& rw : m.levels[l].res) ci = resblock(r, rw, B, ci, gws, n, H, W);
+        const size_t nres = m.levels[l].res.size();
+        for (size_t i = 0; i < nres; ++i) ci = resblock(r, m.levels[l].res[i], B, ci, gws, n, H, W, i + 1 < nres || !m.levels[l].has_resample);
         if (m.levels[l].has_resample) {  // Downsample: pad (0,1,0,1) + stride-2 conv (model.py:82-86)
             const int t1 = (ci + 1) % 3;
+            r.gn_want = true;
             conv(r, m.levels[l].resample, B[ci], n, H, W, m.levels[l].resample.cin, B[t1], m.levels[l].resample.cout, 0, 2, 0, 0,
                  ACT_NONE, 0.f, nullptr, 0, 0);
             ci = t1; H /= 2; W /= 2;
         }
     }
-    ci = resblock(r, m.mid1, B, ci, gws, n, H, W);
+    ci = resblock(r, m.mid1, B, ci, gws, n, H, W, true);
     ci = attnblock(r, m.attn, B, ci, gws, n, H, W);
-    ci = resblock(r, m.mid2, B, ci, gws, n, H, W);
+    ci = resblock(r, m.mid2, B, ci, gws, n, H, W, true);
     const int t1 = (ci + 1) % 3;
     groupnorm(r, m.norm_out, B[ci], B[t1], gws, n, (long)H * W, 1);
+    r.gn_buf = nullptr;
     float* h8 = r.a.alloc<float>((long)n * H * W * 8);
     conv(r, m.conv_out, B[t1], n, H, W, m.conv_out.cin, h8, 8, 1, 1, 1, 0, ACT_NONE, 0.f, nullptr, 0, 0);
     LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_quant_mean(h8, 8, r.c->vae.qw, r.c->vae.qb, lat, n, (long)H * W, lat_scale, r.s), "quant_mean");
@@ -470,16 +511,21 @@ void vae_decode_run(Run& r, const float* lat, float in_scale, float* out_nhwc4, 
     for (int i = 0; i < 3; ++i) B[i] = r.a.alloc<bf16_t>(maxe);
     bf16_t* z32 = r.a.alloc<bf16_t>((long)n * h * w * 32);
     float* gws = r.a.alloc<float>(ir_gn_ws_floats(n, (long)Hf * Wf, 512));
+    r.gn_buf = r.a.alloc<float>((long)n * gn_fused_floats(Hf, Wf));
+    r.gn_x = nullptr;
     LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_latent_prep(lat, r.c->vae.pqw, r.c->vae.pqb, z32, n, (long)h * w, 32, in_scale, r.s), "latent_prep");
+    r.gn_want = true;
     conv(r, m.conv_in, z32, n, h, w, 32, B[0], m.conv_in.cout, 0, 1, 1, 0, ACT_NONE, 0.f, nullptr, 0, 0);
     int ci = 0, H = h, W = w;
-    ci = resblock(r, m.mid1, B, ci, gws, n, H, W);
+    ci = resblock(r, m.mid1, B, ci, gws, n, H, W, true);
     ci = attnblock(r, m.attn, B, ci, gws, n, H, W);
-    ci = resblock(r, m.mid2, B, ci, gws, n, H, W);
+    ci = resblock(r, m.mid2, B, ci, gws, n, H, W, true);
     for (int l = nl - 1; l >= 0; --l) {
-        for (const ResW& rw : m.levels[l].res) ci = resblock(r, rw, B, ci, gws, n, H, W);
+        const size_t nres = m.levels[l].res.size();
+        for (size_t i = 0; i < nres; ++i) ci = resblock(r, m.levels[l].res[i], B, ci, gws, n, H, W, i + 1 < nres || !m.levels[l].has_resample);
         if (m.levels[l].has_resample) {  // Upsample: nearest x2 folded into the conv's addressing (model.py:63-67)
             const int t1 = (ci + 1) % 3;
+            r.gn_want = true;
             conv(r, m.levels[l].resample, B[ci], n, H, W, m.levels[l].resample.cin, B[t1], m.levels[l].resample.cout, 0, 1, 1, 1,
                  ACT_NONE, 0.f, nullptr, 0, 0);
             ci = t1; H *= 2; W *= 2;
@@ -487,6 +533,7 @@ void vae_decode_run(Run& r, const float* lat, float in_scale, float* out_nhwc4, 
     }
     const int t1 = (ci + 1) % 3;
     groupnorm(r, m.norm_out, B[ci], B[t1], gws, n, (long)H * W, 1);
+    r.gn_buf = nullptr;
     conv(r, m.conv_out, B[t1], n, H, W, m.conv_out.cin, out_nhwc4, 4, 1, 1, 1, 0, ACT_NONE, 0.f, nullptr, 0, 0);
     r.a.release(mk);
 }
@@ -1112,6 +1159,25 @@ int ir_op_conv(ir_ctx* c, void* stream, const uint16_t* in, const uint16_t* wgt,
     Conv cw;
     cw.w = wgt; cw.b = bias; cw.cin = cin; cw.cout = cout; cw.cout_pad = cout_pad; cw.taps = taps;
     conv(r, cw, in, n, h, w, cin, out, cout, out_f32, stride, pad, up, act, slope, res, res_f32, cout);
+    return finish(r, c, 0);
+}
+int ir_op_conv_groupnorm(ir_ctx* c, void* stream, const uint16_t* in, const uint16_t* wgt, const float* bias, uint16_t* conv_out, uint16_t* y,
+                         const float* gamma, const float* beta, int n, int h, int w, int cin, int cout, int stride, int up, const void* res,
+                         int silu, void* ws, size_t ws_bytes, int* fused) {
+    // 3x3 conv (+ optional bf16 residual) whose epilogue produces the GroupNorm(32) statistics, then finalise + apply
+    Run r = make_run(c, stream, nullptr, 0, false);
+    Conv cw;
+    cw.w = wgt; cw.b = bias; cw.cin = cin; cw.cout = cout; cw.cout_pad = cout; cw.taps = 9;
+    const int ho = stride == 2 ? h / 2 : (up ? 2 * h : h), wo = stride == 2 ? w / 2 : (up ? 2 * w : w);
+    const size_t part_floats = (size_t)n * gn_fused_floats(ho, wo), need = part_floats + (size_t)ir_gn_ws_floats(n, (long)ho * wo, cout);
+    if (ws_bytes < need * 4) return fail(c, -20, "conv_groupnorm workspace too small");
+    r.gn_buf = (float*)ws;
+    r.gn_want = true;
+    conv(r, cw, in, n, h, w, cin, conv_out, cout, 0, stride, stride == 2 ? 0 : 1, up, ACT_NONE, 0.f, res, 0, cout);
+    if (fused) *fused = (r.gn_x == (const void*)conv_out && r.gn_chunks > 0) ? r.gn_chunks : 0;
+    Norm nm;
+    nm.c = cout; nm.g = gamma; nm.b = beta;
+    groupnorm(r, nm, conv_out, y, (float*)ws + part_floats, n, (long)ho * wo, silu);
     return finish(r, c, 0);
 }
 int ir_op_linear(ir_ctx* c, void* stream, const uint16_t* in, const uint16_t* wgt, const float* bias, void* out, int m, int k, int n,

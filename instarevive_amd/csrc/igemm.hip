@@ -52,8 +52,9 @@ IR_DEVINL float apply_act(float x, float slope) {
     return x;
 }
 
-template <int TM, int TN, class MapRow>
-IR_DEVINL void igemm_epilogue(const IGemmParams& p, f32x16 (&acc)[TM][TN], unsigned char* smem, int wid, int lane, int n_wave, MapRow map_row) {
+template <int TM, int TN, int WN, class MapRow>
+IR_DEVINL void igemm_epilogue(const IGemmParams& p, f32x16 (&acc)[TM][TN], unsigned char* smem, int wid, int lane, int n_wave, int n0, int gn_img,
+                               int gn_chunk, MapRow map_row) {
     constexpr int COLS = TN * 32;
     constexpr int LPR = COLS / 4;       // lanes per row
     constexpr int ERPI = 64 / LPR;      // rows per iteration
@@ -124,7 +125,9 @@ IR_DEVINL void igemm_epilogue(const IGemmParams& p, f32x16 (&acc)[TM][TN], unsig
                 for (int g = 0; g < 16; ++g)
                     slab0[i * SLAB_I + mfma_row(g, lane) * COLS + jn * 32 + r] = apply_act<ACT>(acc[i][jn][g] + cbias[jn], p.slope) * cmul[jn];
     };
-    auto rows_fast = [&]() {
+    float gsum = 0.f, gsq = 0.f;  // fused GroupNorm statistics of this lane's 4 channels (one group) over its rows
+    auto rows_fast = [&](auto gn_tag) {
+        constexpr bool GN = decltype(gn_tag)::value;
         // all LDS reads of the wave's tiles are issued back to back (one latency instead of one per row group), then the stores
         f32x4 v[TM][IT];
 #pragma unroll
@@ -139,12 +142,15 @@ IR_DEVINL void igemm_epilogue(const IGemmParams& p, f32x16 (&acc)[TM][TN], unsig
                 const int m = mrow[i][it];
                 if (m < 0) continue;
                 const f32x4 o = v[i][it] + rres[i][it];
-                if (p.out_f32) {
-                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (long)m * p.out_cs + nbase) = o;
-                } else {
-                    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (long)m * p.out_cs + nbase) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+                const uint2 pk = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+                if (p.out_f32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (long)m * p.out_cs + nbase) = o;
+                else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (long)m * p.out_cs + nbase) = pk;
+                if (p.out2) *reinterpret_cast<uint2*>(p.out2 + (long)m * p.out2_cs + nbase) = pk;
+                if (GN) {  // statistics of the values as stored (bf16-rounded), like the stand-alone gn_partial pass reads them
+                    const float a = bflo(pk.x), b = bfhi(pk.x), c = bflo(pk.y), d = bfhi(pk.y);
+                    gsum += (a + b) + (c + d);
+                    gsq += (a * a + b * b) + (c * c + d * d);
                 }
-                if (p.out2) *reinterpret_cast<uint2*>(p.out2 + (long)m * p.out2_cs + nbase) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
             }
     };
     auto rows_slow = [&](int i) {  // scalar fallback (Cout not a multiple of 4 or unaligned strides): rolled, rare, tiny tensors
@@ -177,10 +183,45 @@ IR_DEVINL void igemm_epilogue(const IGemmParams& p, f32x16 (&acc)[TM][TN], unsig
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (vec_ok) rows_fast();
-    else if (nbase < p.Cout) {
+    if (vec_ok) {
+        if (p.gn_part) rows_fast(std::true_type{});
+        else rows_fast(std::false_type{});
+    } else if (nbase < p.Cout) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) rows_slow(i);
+    }
+    if (p.gn_part) {
+        // Fixed-order block reduction (bit-identical run to run, no atomics): every lane parks its two partials at the head of its
+        // wave's slab (its own slab reads completed above), then thread gl adds, in a fixed order, the lanes of every wave that
+        // hold group gl: the WM waves of the column half, the ERPI row lanes and the gn_cpg/4 adjacent column lanes.
+        constexpr int WM = 4 / WN;
+        float* red = reinterpret_cast<float*>(smem);  // [wave][lane][2] at the head of each wave's slab 0
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        slab0[lane * 2] = vec_ok ? gsum : 0.f;
+        slab0[lane * 2 + 1] = vec_ok ? gsq : 0.f;
+        __syncthreads();
+        const int tid = wid * 64 + lane;
+        const int groups = (WN * COLS) / p.gn_cpg;     // groups covered by this workgroup's BN channels
+        if (tid < groups) {
+            const int col0 = tid * p.gn_cpg;           // first channel of the group, relative to n0
+            const int wn = col0 / COLS, cl0 = (col0 - wn * COLS) / 4;
+            float a = 0.f, b = 0.f;
+            for (int wmi = 0; wmi < WM; ++wmi) {
+                const float* rw = red + (wmi * WN + wn) * 32 * COLS;
+                for (int rl = 0; rl < ERPI; ++rl)
+                    for (int cl = 0; cl < p.gn_cpg / 4; ++cl) {
+                        a += rw[(rl * LPR + cl0 + cl) * 2];
+                        b += rw[(rl * LPR + cl0 + cl) * 2 + 1];
+                    }
+            }
+            const int G = p.Cout / p.gn_cpg, g = n0 / p.gn_cpg + tid;
+            if (g < G) {
+                float* dst = p.gn_part + ((long)gn_img * p.gn_chunks + gn_chunk) * 2 * G;
+                dst[g] = a;
+                dst[G + g] = b;
+            }
+        }
     }
 }
 
@@ -349,7 +390,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IGemmParams p) {
     }
     __builtin_amdgcn_sched_barrier(0);
 
-    igemm_epilogue<TM, TN>(p, acc, smem, wid, lane, n0 + wn * (BN / WN), [&](int i, int row) {
+    const int gn_hw = !p.gn_part ? 1 : (p.taps == 9 ? p.Ho * p.Wo : p.M / p.NB);  // rows per image (fused GroupNorm statistics only)
+    igemm_epilogue<TM, TN, WN>(p, acc, smem, wid, lane, n0 + wn * (BN / WN), n0, m0 / gn_hw, (m0 % gn_hw) / BM, [&](int i, int row) {
         const int m = m0 + wm * (BM / WM) + i * 32 + row;
         return m < p.M ? m : -1;
     });
@@ -510,7 +552,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(IGemmParams p, int ti
     }
     __builtin_amdgcn_sched_barrier(0);
     IR_STAMP(2);
-    igemm_epilogue<TM, TN>(p, acc, smem, wid, lane, n0 + wn * (BN / 2), [&](int i, int row) {
+    igemm_epilogue<TM, TN, 2>(p, acc, smem, wid, lane, n0 + wn * (BN / 2), n0, img, trem, [&](int i, int row) {
         const int oy = oy0 + wm * 4 + i * 2 + (row >> 4), ox = ox0 + (row & 15);
         return (oy < p.Ho && ox < p.Wo) ? (img * p.Ho + oy) * p.Wo + ox : -1;
     });
@@ -544,6 +586,21 @@ static int launch_cfg(const IGemmParams& p, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// Fused GroupNorm statistics: which kernel would run and how many pixel tiles per image it has (0: cannot fuse).
+static bool takes_halo(const IGemmParams& p) {
+    static const bool no_halo = getenv("IR_NO_HALO") != nullptr;  // experiment knob
+    return p.taps == 9 && p.stride == 1 && p.pad == 1 && (p.Cin & 63) == 0 && !p.force_generic && !no_halo && p.Cout_pad % 64 == 0;
+}
+int ir_igemm_gn_chunks(const IGemmParams& p) {
+    if (p.gn_cpg < 4 || (p.gn_cpg & 3) || p.Cout % p.gn_cpg || p.Cout_pad % 64 || (p.Cout & 3) || p.NB <= 0) return 0;
+    if ((p.Cout_pad % 128 == 0 ? 128 : 64) % p.gn_cpg) return 0;
+    if (takes_halo(p)) return ((p.Ho + 7) / 8) * ((p.Wo + 15) / 16);
+    if (p.M % p.NB) return 0;
+    const long hw = p.taps == 9 ? (long)p.Ho * p.Wo : p.M / p.NB;
+    if (hw % 128) return 0;  // a 128-row tile must not straddle two images
+    return (int)(hw / 128);
+}
+
 // Host launcher. Returns 0 or a negative error code; validates every shape assumption the kernel makes.
 int ir_launch_igemm(const IGemmParams& pin, hipStream_t s) {
     IGemmParams p = pin;
@@ -566,10 +623,10 @@ int ir_launch_igemm(const IGemmParams& pin, hipStream_t s) {
         if ((long)p.NB * p.Ho * p.Wo != p.M) return -9;
         if (p.H <= 0 || p.W <= 0) return -9;
     }
-    static const bool no_halo = getenv("IR_NO_HALO") != nullptr;  // experiment knob
-    if (p.taps == 9 && p.stride == 1 && p.pad == 1 && (p.Cin & 63) == 0 && !p.force_generic && !no_halo) {
+    if (p.gn_part && (!p.vec || p.gn_chunks <= 0 || p.gn_chunks != ir_igemm_gn_chunks(p))) return -13;
+    if (takes_halo(p)) {
         if (p.Cout_pad % 128 == 0) return launch_halo<128>(p, s);
-        if (p.Cout_pad % 64 == 0) return launch_halo<64>(p, s);
+        return launch_halo<64>(p, s);
     }
     if (p.Cout_pad % 128 == 0) return launch_cfg<128, 128, 2, 2>(p, s);
     if (p.Cout_pad % 64 == 0) return launch_cfg<128, 64, 2, 2>(p, s);

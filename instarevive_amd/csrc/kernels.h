@@ -36,8 +36,15 @@ struct IGemmParams {
     int out2_cs;
     int force_generic;  // 1: never take the halo-tile conv path (A/B testing)
     int vec;            // set by the launcher: all strides/pointers allow 4-element vector I/O
+    // Optional fused GroupNorm statistics of the OUTPUT (the tensor a following GroupNorm normalises): every workgroup writes
+    // the per-group sum and sum of squares of its (bf16-rounded) outputs to gn_part[((image*gn_chunks + chunk)*2 + {0,1})*G + g],
+    // G = Cout / gn_cpg, chunk = the workgroup's pixel tile within the image. Set gn_chunks from ir_igemm_gn_chunks().
+    float* gn_part;
+    int gn_cpg, gn_chunks;
 };
 int ir_launch_igemm(const IGemmParams& p, hipStream_t s);
+// Pixel tiles per image the kernel ir_launch_igemm would pick for p writes statistics for, or 0 if this launch cannot fuse them.
+int ir_igemm_gn_chunks(const IGemmParams& p);
 
 // ---- norms (norm.hip)
 static inline int ir_gn_chunks(long HW) {
@@ -47,9 +54,16 @@ static inline int ir_gn_chunks(long HW) {
     return (int)c;
 }
 // workspace floats needed by ir_launch_groupnorm
-static inline long ir_gn_ws_floats(int N, long HW, int C) { return (long)N * ir_gn_chunks(HW) * 2 * C + 2L * N * C; }
+static inline long ir_gn_ws_floats(int N, long HW, int C) {
+    const long part = (long)N * ir_gn_chunks(HW) * 2 * C, part2 = (long)N * 256 * 64;  // stand-alone partials | fused second stage
+    return (part > part2 ? part : part2) + 2L * N * C;
+}
 int ir_launch_groupnorm(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, float* ws, int N, long HW, int C,
                         int G, float eps, int do_silu, hipStream_t s);
+// Same, with the statistics already reduced to per-group partials by the producing conv (IGemmParams::gn_part, `chunks` tiles per
+// image): only the finalise and apply launches run. ws needs 2*N*C + N*256*64 floats (scale, shift, second-stage partials).
+int ir_launch_groupnorm_fused(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, const float* part, float* ws, int N,
+                              long HW, int C, int G, int chunks, float eps, int do_silu, hipStream_t s);
 // y (bf16, may be null) and yf (fp32, may be null) both receive xn*a + b; columns C..ldy-1 are written as zero.
 int ir_launch_layernorm(const float* x, bf16_t* y, float* yf, const float* a, const float* b, long rows, int C, int ldx, int ldy,
                         float eps, long rows_per_batch, int ab_stride, hipStream_t s);

@@ -110,6 +110,48 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
     }
 }
 
+// Finalise from per-GROUP partials written by the producing conv's epilogue (igemm.hip): part [N][chunks][2][G]. Same fixed-order
+// fp64 reduction as above (thread (g, slice) sums every spg-th chunk, then the slices are added in order). grid = N, block = 256.
+__global__ __launch_bounds__(256) void gn_finalize_groups_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, float* __restrict__ scale,
+                                                                 float* __restrict__ shift, int HW, int C, int G, int chunks,
+                                                                 float eps) {
+    __shared__ double s_mean[64], s_rstd[64];
+    __shared__ double s_part[2][256];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int cpg = C / G;
+    const int spg = 256 / G;
+    const int g = tid / spg, sl = tid % spg;
+    double s = 0.0, q = 0.0;
+    if (g < G) {
+        for (int ch = sl; ch < chunks; ch += spg) {
+            const float* pp = part + ((long)n * chunks + ch) * 2 * G;
+            s += (double)pp[g];
+            q += (double)pp[G + g];
+        }
+    }
+    s_part[0][tid] = s;
+    s_part[1][tid] = q;
+    __syncthreads();
+    if (tid < G) {
+        s = 0.0; q = 0.0;
+        for (int i = 0; i < spg; ++i) { s += s_part[0][tid * spg + i]; q += s_part[1][tid * spg + i]; }
+        const double cnt = (double)HW * cpg;
+        const double mean = s / cnt;
+        double var = q / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        s_mean[tid] = mean;
+        s_rstd[tid] = 1.0 / sqrt(var + (double)eps);
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        const int gg = c / cpg;
+        const double a = s_rstd[gg] * (double)gamma[c];
+        scale[(long)n * C + c] = (float)a;
+        shift[(long)n * C + c] = (float)((double)beta[c] - s_mean[gg] * a);
+    }
+}
+
 // y = act(x*scale + shift); x,y: [N][HW][C] bf16; grid-stride over 16-byte vectors.
 __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
@@ -154,6 +196,45 @@ int ir_launch_groupnorm(const bf16_t* x, bf16_t* y, const float* gamma, const fl
     float* shift = scale + (long)N * C;                // [N][C]
     hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, N), dim3(256), 0, s, x, part, (int)HW, C, chunks);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), 0, s, part, gamma, beta, scale, shift, (int)HW, C, G, chunks, eps);
+    const long nvec = (long)N * HW * C / 8;
+    long blocks = (nvec + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, y, scale, shift, HW, C, nvec, do_silu);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// First reduction stage for many tiles: block (r, n) adds the per-group partials of a contiguous range of chunks in a fixed order
+// (4 interleaved slices per value, then the slices in order) -> part2 [N][R][2][G]. grid = (R, N), block = 256, 2*G <= 64.
+__global__ __launch_bounds__(256) void gn_reduce_groups_kernel(const float* __restrict__ part, float* __restrict__ part2, int G, int chunks,
+                                                               int R) {
+    __shared__ float s_red[4][64];
+    const int r = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+    const int idx = tid & 63, sl = tid >> 6;
+    const int per = (chunks + R - 1) / R;
+    const int c0 = r * per, c1 = min(c0 + per, chunks);
+    float a = 0.f;
+    if (idx < 2 * G)
+        for (int ch = c0 + sl; ch < c1; ch += 4) a += part[((long)n * chunks + ch) * 2 * G + idx];
+    s_red[sl][idx] = a;
+    __syncthreads();
+    if (tid < 2 * G) part2[((long)n * R + r) * 2 * G + tid] = ((s_red[0][tid] + s_red[1][tid]) + s_red[2][tid]) + s_red[3][tid];
+}
+
+int ir_launch_groupnorm_fused(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, const float* part, float* ws, int N,
+                              long HW, int C, int G, int chunks, float eps, int do_silu, hipStream_t s) {
+    if (C % 8 || C > 512 || G > 64 || C % G || 256 % (C / 8) || 256 % G || chunks <= 0) return -2;
+    if (HW >= (1L << 31)) return -3;
+    float* scale = ws;                 // [N][C]
+    float* shift = ws + (long)N * C;   // [N][C]
+    if (chunks > 512) {                // two-stage: a single finalise block per image would crawl through megabytes of partials
+        if (2 * G > 64) return -2;
+        const int R = 256;
+        float* part2 = shift + (long)N * C;  // [N][R][2][G]: fits the stand-alone path's partial area of ws (R*2*G <= chunks*2*C)
+        hipLaunchKernelGGL(gn_reduce_groups_kernel, dim3(R, N), dim3(256), 0, s, part, part2, G, chunks, R);
+        part = part2;
+        chunks = R;
+    }
+    hipLaunchKernelGGL(gn_finalize_groups_kernel, dim3(N), dim3(256), 0, s, part, gamma, beta, scale, shift, (int)HW, C, G, chunks, eps);
     const long nvec = (long)N * HW * C / 8;
     long blocks = (nvec + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;

@@ -162,6 +162,60 @@ def test_groupnorm(ctx, n, hw, c, silu):
     close(L.from_bf16_bits(y).cpu(), ref, 2 ** -7, 4e-3, "groupnorm")
 
 
+@pytest.mark.parametrize("n,h,w,cin,cout,stride,up,res,expect_fused", [
+    (1, 64, 64, 128, 128, 1, 0, True, True),      # halo kernel, whole tiles
+    (2, 40, 24, 128, 256, 1, 0, False, True),     # halo kernel, partial tiles at the image border, two images
+    (1, 16, 16, 256, 512, 1, 1, False, True),     # upsample conv -> 32 x 32
+    (1, 32, 32, 128, 128, 2, 0, False, True),     # stride-2 downsample (generic implicit GEMM): 256 rows per image = 2 tiles
+    (1, 24, 24, 128, 128, 2, 0, False, False),    # 144 rows per image: a tile would straddle images -> separate statistics pass
+    (1, 16, 16, 64, 64, 1, 0, False, False),      # 2 channels per group: below the 4-channel vector of the epilogue -> not fused
+])
+def test_conv_groupnorm_fused(ctx, n, h, w, cin, cout, stride, up, res, expect_fused):
+    """ResnetBlock's conv -> GroupNorm(32)+SiLU with the statistics produced by the conv epilogue (ldm model.py:131-151)."""
+    import ctypes
+    g = torch.Generator().manual_seed(h * w + cout + stride)
+    x = rb(torch.randn(n, cin, h, w, generator=g))
+    wt = rb(torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5))
+    b = torch.randn(cout, generator=g) * 0.1
+    gamma, beta = torch.randn(cout, generator=g), torch.randn(cout, generator=g)
+    xi = F.interpolate(x, scale_factor=2, mode="nearest") if up else x
+    if stride == 2:
+        co = F.conv2d(F.pad(xi, (0, 1, 0, 1)), wt, b, stride=2)
+    else:
+        co = F.conv2d(xi, wt, b, padding=1)
+    ho, wo = co.shape[-2:]
+    r = rb(torch.randn(n, cout, ho, wo, generator=g)) if res else None
+    if res:
+        co = co + r
+    co = rb(co)  # the conv output is stored in bf16 and GroupNorm normalises what is stored
+    ref = F.silu(F.group_norm(co, 32, gamma, beta, eps=1e-6))
+    xin = dev_bf16(x.permute(0, 2, 3, 1).contiguous())
+    wp = dev_bf16(wt.permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous())
+    rd = dev_bf16(r.permute(0, 2, 3, 1).contiguous()) if res else None
+    conv_out = torch.empty(n, ho, wo, cout, dtype=torch.int16, device="cuda")
+    y = torch.empty_like(conv_out)
+    ws = torch.empty(16 << 20, dtype=torch.uint8, device="cuda")
+    fused = ctypes.c_int(-1)
+    bd, gd, btd = b.cuda(), gamma.cuda(), beta.cuda()
+    ctx.check(ctx.lib.ir_op_conv_groupnorm(ctx.h, ctx.stream(), P(xin), P(wp), P(bd), P(conv_out), P(y), P(gd), P(btd), n, h, w, cin, cout,
+                                           stride, up, P(rd) if res else None, 1, P(ws), ws.numel(), ctypes.byref(fused)), "conv_groupnorm")
+    torch.cuda.synchronize()
+    assert (fused.value > 0) == expect_fused, fused.value
+    got_conv = L.from_bf16_bits(conv_out).cpu().permute(0, 3, 1, 2)
+    close(got_conv, co, 2 ** -7, 4e-3, "conv (fused-GN launch)")
+    # GroupNorm normalises the tensor as stored: reference statistics from the kernel's own conv output (an ulp flip of the conv
+    # against the CPU reference must not count against the normalisation), plus a looser end-to-end check against the CPU chain
+    ref_own = F.silu(F.group_norm(got_conv, 32, gamma, beta, eps=1e-6))
+    close(L.from_bf16_bits(y).cpu().permute(0, 3, 1, 2), ref_own, 2 ** -7, 4e-3, "groupnorm from fused statistics")
+    close(L.from_bf16_bits(y).cpu().permute(0, 3, 1, 2), ref, 2 ** -5, 3e-2, "conv -> groupnorm fused")
+    # run-to-run determinism of the fixed-order reductions
+    y2 = torch.empty_like(y)
+    ctx.check(ctx.lib.ir_op_conv_groupnorm(ctx.h, ctx.stream(), P(xin), P(wp), P(bd), P(conv_out), P(y2), P(gd), P(btd), n, h, w, cin, cout,
+                                           stride, up, P(rd) if res else None, 1, P(ws), ws.numel(), ctypes.byref(fused)), "conv_groupnorm")
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2)
+
+
 @pytest.mark.parametrize("rows,c,ld", [(1000, 180, 192), (513, 1152, 1152), (64, 60, 192)])
 def test_layernorm(ctx, rows, c, ld):
     g = torch.Generator().manual_seed(rows)
