@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libinstarevive_hip.so")
 SOURCES = ["igemm.hip", "norm.hip", "attention.hip", "elementwise.hip", "api.cpp"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-ffp-contract=fast"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-ffp-contract=fast"] + os.environ.get("IR_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def _newer(src, dst):

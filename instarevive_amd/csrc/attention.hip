@@ -302,6 +302,45 @@ IR_DEVINL bf16x8 lds_read16(uint32_t addr) {
 }
 template <int N>
 IR_DEVINL void wait_lds() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N)); }
+// MFMAs with the register file of each operand chosen by hand (flash_attn_d512_kernel): hipcc keeps the 128 registers of Q^T
+// fragments and the 128 of O^T in arch VGPRs "spilled" to AGPRs and moves ~400 of them per tile (v_accvgpr_read/write); the matrix
+// instruction can read B and accumulate C/D in AGPRs directly. Being asm, these are invisible to hipcc's hazard recogniser: the
+// caller separates them from VALU writes of their inputs and from VALU reads of their results with mfma_fence().
+IR_DEVINL void mfma32_b_agpr(f32x16& c, bf16x8 a, bf16x8 b) {  // c (VGPR) += a (VGPR) x b (AGPR)
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "a"(b));
+}
+IR_DEVINL void mfma32_v(f32x16& c, bf16x8 a, bf16x8 b) {  // c (VGPR) += a (VGPR) x b (VGPR)
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+IR_DEVINL void mfma32_c_agpr(f32x16& c, bf16x8 a, bf16x8 b) {  // c (AGPR) += a (VGPR) x b (VGPR)
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+// >= 18 wait states (16-pass MFMA result -> VALU read) and the few a VALU result needs before an MFMA reads it. The registers
+// concerned are in/out operands: without that data dependence hipcc is free to schedule the VALU instructions that consume (or
+// produce) them on the wrong side of the nops.
+// LONG = MFMA results about to be read by the VALU (18 wait states for a 16-pass MFMA; 24 given); short = VALU results about to
+// be read by an MFMA (4 given).
+template <bool LONG>
+IR_DEVINL void mfma_fence_v(f32x16& a, f32x16& b) {
+    if (LONG) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(a), "+v"(b));
+    else asm volatile("s_nop 3" : "+v"(a), "+v"(b));
+}
+template <bool LONG, int N>
+IR_DEVINL void mfma_fence_acc(f32x16 (&acc)[N], bf16x8 (&pb)[4]) {
+    static_assert(N % 8 == 0, "operand lists below are written out for 8 accumulator tiles at a time");
+#pragma unroll
+    for (int b = 0; b < N; b += 8) {
+        if (LONG && b == 0)
+            asm volatile("s_nop 15\n\ts_nop 7"
+                         : "+a"(acc[b]), "+a"(acc[b + 1]), "+a"(acc[b + 2]), "+a"(acc[b + 3]), "+a"(acc[b + 4]), "+a"(acc[b + 5]), "+a"(acc[b + 6]),
+                           "+a"(acc[b + 7]), "+v"(pb[0]), "+v"(pb[1]), "+v"(pb[2]), "+v"(pb[3]));
+        else
+            asm volatile("s_nop 3"
+                         : "+a"(acc[b]), "+a"(acc[b + 1]), "+a"(acc[b + 2]), "+a"(acc[b + 3]), "+a"(acc[b + 4]), "+a"(acc[b + 5]), "+a"(acc[b + 6]),
+                           "+a"(acc[b + 7]), "+v"(pb[0]), "+v"(pb[1]), "+v"(pb[2]), "+v"(pb[3]));
+    }
+}
+
 
 template <int D>
 __global__ __launch_bounds__(512, 1) void flash_attn_pp_kernel(AttnParams p) {
@@ -582,26 +621,35 @@ int ir_launch_flash_attn(const AttnParams& p, hipStream_t s) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Single-head attention with head dim 512 (the VAE mid-block, reference ldm/modules/diffusionmodules/model.py:181-205),
-// flash style. One wave per SIMD with the whole 512-register budget: each wave owns 32 queries, keeps O^T (512 x 32 fp32)
-// in 256 accumulator registers and its Q^T fragments (32 k-steps) in 128 VGPRs. K (64 keys x 512, 64 KB) and V^T (512 x 64
-// keys, 64 KB) tiles are single-buffered in LDS and filled by LDS-DMA: K(t+1) lands while softmax + PV of tile t run, V(t+1)
-// lands while QK^T of tile t+1 runs, so every transfer has a 64-MFMA phase to hide behind and two plain barriers per tile
-// suffice. Same transposed-score formulation as flash_attn_kernel (S^T = K Q^T, O^T = V^T P^T, keys swap23-permuted).
+// flash style. One wave per SIMD with the whole 512-register budget: each wave owns 32 queries and keeps its Q^T fragments (32
+// k-steps, pre-multiplied by scale * log2 e) in 128 VGPRs. K (64 keys x 512, 64 KB) and V^T (256 x 64 keys, 32 KB) tiles are
+// single-buffered in LDS and filled by LDS-DMA: K(t+1) lands while softmax + PV of tile t run, V(t+1) while QK^T of tile t+1
+// runs, two barriers per tile. Same transposed-score formulation as flash_attn_kernel (S^T = K Q^T - m via the accumulator
+// preset, O^T = V^T P^T, keys swap23-permuted).
 // q, k: [T][512] bf16 rows (row stride rs); vt: [512][vt_rs] bf16; o: [T][512]. T % 64 == 0.
 // Register budget: O^T for all 512 output dims (256 accumulators) plus the Q fragments (128) plus S/P exceeds what hipcc
 // allocates without spilling, so the output dims are split over blockIdx.y (DSPLIT = 2): each block recomputes S^T and owns
-// 256 output dims (128 accumulators). That costs 1.5x the MFMA work of an ideal kernel but keeps everything in registers.
-
+// 256 output dims (128 accumulators). That costs 1.5x the MFMA work of an ideal kernel but keeps everything in registers
+// (DSPLIT = 1 with O^T in all 256 AGPRs and Q^T in VGPRs was tried again with the asm MFMAs below: hipcc still spills, 17 ms
+// against 11.5 ms at T = 65536).
+// The MFMAs are inline asm with the register file of every operand chosen by hand: Q^T fragments in AGPRs (read directly as the B
+// operand), O^T accumulators in AGPRs, everything the VALU touches in VGPRs. Left to hipcc, Q^T and O^T sat in VGPRs "spilled" to
+// AGPRs with about 400 v_accvgpr moves per tile.
+// With one wave per SIMD nothing else hides what the wave does between MFMAs, so the two matrix loops are written as pinned
+// instruction streams (like flash_attn_pp_kernel): fragment reads LA MFMAs ahead with counted lgkmcnt waits, and the 24 LDS-DMA
+// pieces a wave issues per tile (16 of K, 8 of V^T) are interleaved one by one behind MFMAs instead of in two bursts after the
+// barriers, where they cost the wave about 2000 of its 7000 cycles per tile with the matrix pipe idle.
+template <int DSPLIT>
 __global__ __launch_bounds__(256, 1) void flash_attn_d512_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                                   const bf16_t* __restrict__ vt, bf16_t* __restrict__ o, int T, int rs,
                                                                   int o_rs, long vt_rs, float scale_log2) {
-    constexpr int D = 512, NKS = D / 16, DSPLIT = 2, DVB = D / DSPLIT, NDT = DVB / 32;
+    constexpr int D = 512, NKS = D / 16, DVB = D / DSPLIT, NDT = DVB / 32;
+    constexpr bool QF_AGPR = DSPLIT > 1;  // DSPLIT 1: the 256 AGPRs are all O^T, the Q^T fragments stay in VGPRs
     constexpr int KROW = 1024 + 16;  // K rows are one DMA instruction each, so they can be padded: (key*65 + c) % 16 is conflict-free
     constexpr int KBYTES = 64 * KROW;
+    constexpr int NKP = 16, NVP = DVB / 32;  // DMA pieces per wave and tile: K rows wu + 4i, V^T row groups wu + 4i
     constexpr float RESCALE_THR = 8.0f;
     __shared__ __attribute__((aligned(256))) unsigned char smem[KBYTES + DVB * 128];  // K tile | V^T tile (reused for O at the end)
-    unsigned char* Kb = smem;
-    unsigned char* Vb = smem + KBYTES;
     const int dv0 = blockIdx.y * DVB;  // first output dim owned by this block
     vt += (long)dv0 * vt_rs;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -609,108 +657,169 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d512_kernel(const bf16_t* _
     const int r = lane & 31, h = lane >> 5;
     const int q0 = blockIdx.x * 128;
 
-    const bf16_t* k_lane = k + lane * 8;                                                       // + key * rs
+    // DMA sources. K piece i of tile t: row t*64 + wu + 4i, 16 bytes per lane. V^T rows are 128 B (8 rows per DMA instruction,
+    // unpaddable): chunk c of row d sits at slot c ^ ((d >> 1) & 7). For the rows d = 8*qi + (lane>>3) of instruction qi = wu + 4i:
+    // (d >> 1) & 7 = ((lane >> 4) & 3) | ((qi & 1) << 2), and qi & 1 = wu & 1.
+    const bf16_t* k_lane = k + (long)wu * rs + lane * 8;
     const bf16_t* v_lane = vt + (long)(wu * 8 + (lane >> 3)) * vt_rs + (((lane & 7) ^ ((lane >> 4) & 3) ^ (((wu * 8) >> 1) & 4)) << 3);
-    // V^T rows are 128 B (8 rows per DMA instruction, unpaddable): chunk c of row d sits at slot c ^ ((d >> 1) & 7). For the
-    // rows d = 8*qi + (lane>>3) of instruction qi = wu + 4i: (d >> 1) & 7 = ((lane >> 4) & 3) | ((qi & 1) << 2), and qi & 1 = wu & 1.
-    auto stage_k = [&](int key0) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int kk = wu + 4 * i;
-            attn_glds16(k_lane + (long)(key0 + kk) * rs, (attn_lds_ptr_t)(Kb + kk * KROW));
-        }
+    const long k_step = 4L * rs, v_step = 32L * vt_rs;  // element strides between a wave's consecutive pieces
+    auto k_piece = [&](int tile, int i) {
+        attn_glds16(k_lane + (long)tile * 64 * rs + i * k_step, (attn_lds_ptr_t)(smem + (wu + 4 * i) * KROW));
     };
-    auto stage_v = [&](int key0) {
-#pragma unroll
-        for (int i = 0; i < DVB / 32; ++i)
-            attn_glds16(v_lane + (long)(32 * i) * vt_rs + key0, (attn_lds_ptr_t)(Vb + (wu + 4 * i) * 1024));
+    auto v_piece = [&](int tile, int i) {
+        attn_glds16(v_lane + i * v_step + tile * 64, (attn_lds_ptr_t)(smem + KBYTES + (wu + 4 * i) * 1024));
     };
-    stage_k(0);
-    stage_v(0);
-    // Q^T fragments straight from HBM in the MFMA B-operand layout (lane = query, 8 consecutive d per k-step half)
+#pragma unroll
+    for (int i = 0; i < NKP; ++i) k_piece(0, i);
+#pragma unroll
+    for (int i = 0; i < NVP; ++i) v_piece(0, i);
+    // Q^T fragments straight from HBM in the MFMA B-operand layout (lane = query, 8 consecutive d per k-step half), scaled
     bf16x8 qf[NKS];
     {
         const bf16_t* qrow = q + (long)min(q0 + wid * 32 + r, T - 1) * rs + h * 8;
 #pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qrow + ks * 16);
+        for (int ks = 0; ks < NKS; ++ks) {
+            const uint4 v = *reinterpret_cast<const uint4*>(qrow + ks * 16);
+            uint4 w;
+            w.x = pack2bf(bflo(v.x) * scale_log2, bfhi(v.x) * scale_log2);
+            w.y = pack2bf(bflo(v.y) * scale_log2, bfhi(v.y) * scale_log2);
+            w.z = pack2bf(bflo(v.z) * scale_log2, bfhi(v.z) * scale_log2);
+            w.w = pack2bf(bflo(v.w) * scale_log2, bfhi(v.w) * scale_log2);
+            qf[ks] = __builtin_bit_cast(bf16x8, w);
+        }
     }
-    f32x16 acc[NDT];
+    f32x16 acc[NDT], sacc[2];
 #pragma unroll
     for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
         for (int g = 0; g < 16; ++g) acc[dt][g] = 0.f;
-    float m_i = -1e30f, l_i = 0.f;
-    // LDS fragment addresses: ONE base per operand plus compile-time immediates (a lane-dependent XOR inside the unrolled
-    // loops would make hipcc hoist every address into its own register)
-    const unsigned char* k_base = Kb + swap23(r) * KROW + h * 16;                     // + kt*32*KROW + ks*32
-    const int vsw = (r >> 1) & 7;                                                    // swizzle of rows d = dt*32 + r
-    const unsigned char* v_base[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v_base[j] = Vb + r * 128 + ((((2 * j) | h) ^ vsw) << 4);  // + dt*4096 ; j = kt*2 + s2
+    for (int g = 0; g < 16; ++g) sacc[0][g] = sacc[1][g] = 0.f;
+    float m_i = 0.f, l_i = 0.f;
+    bf16x8 pb[4];
+    // LDS fragment addresses (bytes): ONE base per operand plus compile-time immediates
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(attn_lds_ptr_t)smem;
+    const uint32_t k_addr = lds0 + swap23(r) * KROW + h * 16;                       // + kt*32*KROW + ks*32
+    const int vsw = (r >> 1) & 7;                                                    // swizzle of rows d = dt*32 + r
+    uint32_t v_addr[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v_addr[j] = lds0 + KBYTES + r * 128 + ((((2 * j) | h) ^ vsw) << 4);  // + dt*4096 ; j = kt*2 + s2
+
+    constexpr int LA = 4, NB = LA + 3;  // reads in flight ahead of their MFMA; fragment buffers (see flash_attn_pp_kernel)
+    bf16x8 fr[NB];
+    // S^T(t) = K Q^T - m: 64 MFMAs; the V^T pieces of tile vtile (if >= 0) ride behind MFMAs 1, 9, 17, ...
+    auto qk_loop = [&](int vtile) {
+        auto read = [&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            fr[j % NB] = lds_read16<(j / NKS) * 32 * KROW + (j % NKS) * 32>(k_addr);
+        };
+        auto step = [&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (j + LA < 2 * NKS) read(std::integral_constant<int, j + LA>{});
+            wait_lds<(2 * NKS - 1 - j < LA ? 2 * NKS - 1 - j : LA)>();
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (QF_AGPR) mfma32_b_agpr(sacc[j / NKS], fr[j % NB], qf[j % NKS]);
+            else mfma32_v(sacc[j / NKS], fr[j % NB], qf[j % NKS]);
+            if constexpr (j >= 2) asm volatile("" ::"v"(fr[(j - 2) % NB]));
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (j % 8 == 1 && j / 8 < NVP) {
+                if (vtile >= 0) v_piece(vtile, j / 8);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        __builtin_amdgcn_sched_barrier(0);
+        [&]<int... I>(std::integer_sequence<int, I...>) { (read(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, LA>{});
+        __builtin_amdgcn_sched_barrier(0);
+        [&]<int... I>(std::integer_sequence<int, I...>) { (step(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, 2 * NKS>{});
+    };
+    // O^T += V^T(t) P^T: 32 MFMAs; the K pieces of tile ktile (if >= 0) ride behind MFMAs 1, 3, 5, ...
+    auto pv_loop = [&](int ktile) {
+        auto read = [&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            fr[j % NB] = lds_read16<(j >> 2) * 4096>(v_addr[j & 3]);
+        };
+        auto step = [&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (j + LA < NDT * 4) read(std::integral_constant<int, j + LA>{});
+            wait_lds<(NDT * 4 - 1 - j < LA ? NDT * 4 - 1 - j : LA)>();
+            __builtin_amdgcn_sched_barrier(0);
+            mfma32_c_agpr(acc[j >> 2], fr[j % NB], pb[j & 3]);
+            if constexpr (j >= 2) asm volatile("" ::"v"(fr[(j - 2) % NB]));
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (j % 2 == 1 && j / 2 < NKP) {
+                if (ktile >= 0) k_piece(ktile, j / 2);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        __builtin_amdgcn_sched_barrier(0);
+        [&]<int... I>(std::integer_sequence<int, I...>) { (read(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, LA>{});
+        __builtin_amdgcn_sched_barrier(0);
+        [&]<int... I>(std::integer_sequence<int, I...>) { (step(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, NDT * 4>{});
+    };
+
     const int NT = T >> 6;
     wait_dma();
     __syncthreads();  // K(0), V(0) landed
     for (int t = 0; t < NT; ++t) {
-        // ---- S^T = K Q^T
-        f32x16 s[2];
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-            for (int g = 0; g < 16; ++g) s[kt][g] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
-                bf16x8 a = *reinterpret_cast<const bf16x8*>(k_base + kt * 32 * KROW + ks * 32);
-                s[kt] = mfma32(a, qf[ks], s[kt]);
-            }
-        }
+        // ---- S^T = K Q^T - m (accumulators preset to -m). The V^T tile is free since the barrier that ended PV(t-1), so the pieces
+        // of V^T(t) ride behind this loop's MFMAs (V^T(0) came with the prologue); they are needed only after the next barrier.
+        mfma_fence_v<false>(sacc[0], sacc[1]);  // the accumulator preset (VALU) precedes
+        qk_loop(t >= 1 ? t : -1);
+        mfma_fence_v<true>(sacc[0], sacc[1]);   // the softmax (VALU) follows
         wait_dma();
-        __syncthreads();                       // every wave is done with the K tile (and V(t) has landed: vmcnt(0))
-        if (t + 1 < NT) stage_k((t + 1) * 64);  // lands during softmax + PV
-        // ---- online softmax (exp2 domain, deferred rescale)
+        __syncthreads();                       // every wave is done with the K tile, and V^T(t) has landed
+        // ---- online softmax (exp2 domain, deferred rescale); the scores are relative to the running max already
         float mx = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int g = 0; g < 16; ++g) mx = fmaxf(mx, s[kt][g]);
-        mx *= scale_log2;
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        if (__any(mx > m_i + RESCALE_THR)) {
-            const float m_new = fmaxf(m_i, mx);
-            const float alpha = __builtin_amdgcn_exp2f(m_i - m_new);
+            for (int g = 0; g < 16; ++g) mx = fmaxf(mx, sacc[kt][g]);
+        mx = xhalf_max(mx);
+        if (t == 0 || __any(mx > RESCALE_THR)) {
+            const float delta = t == 0 ? mx : fmaxf(mx, 0.f);
+            const float alpha = t == 0 ? 1.0f : __builtin_amdgcn_exp2f(-delta);  // O and l are still zero on the first tile
+            m_i += delta;
             l_i *= alpha;
-            m_i = m_new;
+            // the O^T accumulators live in AGPRs; pinning them there at both ends of this rare path keeps hipcc from hoisting the
+            // 128 v_accvgpr_reads of the rescale above the branch, into every tile
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) asm volatile("" : "+a"(acc[dt]));
 #pragma unroll
             for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
                 for (int g = 0; g < 16; ++g) acc[dt][g] *= alpha;
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) asm volatile("" : "+a"(acc[dt]));
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) sacc[kt][g] -= delta;
         }
         float rsum = 0.f;
-        bf16x8 pb[4];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][s2 * 8 + e], scale_log2, -m_i));
+                    const float pv = __builtin_amdgcn_exp2f(sacc[kt][s2 * 8 + e]);
                     rsum += pv;
                     pb[kt * 2 + s2][e] = (__bf16)pv;
                 }
         rsum += __shfl_xor(rsum, 32);
         l_i += rsum;
-        // ---- O^T += V^T P^T
 #pragma unroll
-        for (int dt = 0; dt < NDT; ++dt)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                bf16x8 a = *reinterpret_cast<const bf16x8*>(v_base[j] + dt * 4096);
-                acc[dt] = mfma32(a, pb[j], acc[dt]);
-            }
+        for (int g = 0; g < 16; ++g) sacc[0][g] = sacc[1][g] = -m_i;  // the next S^T accumulates onto -m in place
+        // ---- O^T += V^T P^T, with the K(t+1) pieces behind its MFMAs (every wave passed the barrier above: the K tile is free)
+        mfma_fence_acc<false>(acc, pb);  // pb (VALU) precedes
+        pv_loop(t + 1 < NT ? t + 1 : -1);
+        // The O^T accumulators are next touched by the following tile's PV MFMAs (in place: no hazard) or, rarely, by its rescale,
+        // which comes after a whole QK^T loop; the epilogue below fences for itself.
         wait_dma();
-        __syncthreads();                       // every wave is done with the V^T tile (and K(t+1) has landed)
-        if (t + 1 < NT) stage_v((t + 1) * 64);  // lands during the next QK^T
+        __syncthreads();                       // every wave is done with the V^T tile, and K(t+1) has landed
     }
     // ---- finalise: O^T / l -> LDS [q][DVB] bf16 (16 KB per wave) -> 16-byte row stores
+    mfma_fence_acc<true>(acc, pb);
     const float inv = 1.0f / l_i;
     constexpr int OROW = DVB * 2;  // bytes per staged row
     unsigned char* ow = smem + wid * 32 * OROW;
@@ -739,7 +848,7 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d512_kernel(const bf16_t* _
 int ir_launch_flash_attn_d512(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* o, int T, int rs, int o_rs, long vt_rs,
                               float scale, hipStream_t s) {
     if (T <= 0 || (T & 63) || (rs & 7) || (o_rs & 7) || (vt_rs & 7) || vt_rs < T) return -2;
-    hipLaunchKernelGGL(flash_attn_d512_kernel, dim3((T + 127) / 128, 2), dim3(256), 0, s, q, k, vt, o, T, rs, o_rs, vt_rs,
+    hipLaunchKernelGGL(flash_attn_d512_kernel<2>, dim3((T + 127) / 128, 2), dim3(256), 0, s, q, k, vt, o, T, rs, o_rs, vt_rs,
                        scale * 1.44269504088896340736f);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""HBM traffic of the conv/GEMM kernels from two rocprofv3 PMC passes -> profiles/rNN_pmc_igemm.json.
+
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -o f -- python3 bench.py --steps 1 --warmup 0 --no_cpu_baseline
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -o w -- python3 bench.py --steps 1 --warmup 0 --no_cpu_baseline
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01_pmc_igemm.json
+
+FETCH_SIZE / WRITE_SIZE are in KB. On gfx950 FETCH_SIZE reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM
+section; re-checked here on gn_apply_kernel, whose traffic is known exactly), so reads are doubled; WRITE_SIZE is exact.
+passes = pipeline passes in the profiled command (steps + warmup).
+"""
+import csv, glob, json, os, sys
+from collections import defaultdict
+
+
+def load(root, counter):
+    tot, cnt = defaultdict(float), defaultdict(int)
+    for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row["Counter_Name"] != counter:
+                continue
+            name = row["Kernel_Name"].split("(")[0].replace("void ", "")
+            tot[name] += float(row["Counter_Value"])
+            cnt[name] += 1
+    return tot, cnt
+
+
+fetch, fc = load(sys.argv[1], "FETCH_SIZE")
+write, wc = load(sys.argv[2], "WRITE_SIZE")
+passes = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+fam = [k for k in fetch if k.startswith("igemm_kernel") or k.startswith("conv_halo_kernel")]
+f_kb = sum(fetch[k] for k in fam) / passes
+w_kb = sum(write[k] for k in fam) / passes
+launches = sum(fc[k] for k in fam) / passes
+hbm = (2.0 * f_kb + w_kb) * 1024.0
+calib = {k: {"fetch_kb": fetch[k] / fc[k], "write_kb": write[k] / wc[k], "launches": fc[k]} for k in fetch if k.startswith("gn_apply")}
+out = {
+    "workload": "1x2048x2048 untiled", "kernel": "igemm_kernel + conv_halo_kernel", "round": 1,
+    "fetch_size_kb_per_step": f_kb, "write_size_kb_per_step": w_kb, "launches_per_step": launches,
+    "hbm_bytes_per_step": hbm, "hbm_bytes_per_launch": hbm / max(launches, 1),
+    "per_kernel_kb": {k: {"fetch_kb_x2": 2 * fetch[k] / passes, "write_kb": write[k] / passes, "launches": fc[k] / passes} for k in sorted(fam)},
+    "calibration_gn_apply_per_launch": calib,
+    "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (bench.py --steps 1 --warmup 0); FETCH_SIZE doubled "
+            "(gfx950 reports half the bytes of wide coalesced reads; WRITE_SIZE exact)",
+}
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+print(json.dumps({k: out[k] for k in ("fetch_size_kb_per_step", "write_size_kb_per_step", "launches_per_step", "hbm_bytes_per_launch")}))
