@@ -294,14 +294,6 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(AttnParams p) {
 // flash_attn_d512_kernel. Q fragments come straight from HBM in the B-operand layout, pre-multiplied by scale * log2(e).
 // The fragment reads of a matrix segment are inline-asm ds_read_b128 with hand-counted s_waitcnt lgkmcnt(N): left to hipcc, every
 // fifth MFMA waited for lgkmcnt(0), i.e. for a read issued one instruction earlier (73 instead of 32 cycles per MFMA).
-template <int OFF>
-IR_DEVINL bf16x8 lds_read16(uint32_t addr) {
-    bf16x8 v;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
-    return v;
-}
-template <int N>
-IR_DEVINL void wait_lds() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N)); }
 // MFMAs with the register file of each operand chosen by hand (flash_attn_d512_kernel): hipcc keeps the 128 registers of Q^T
 // fragments and the 128 of O^T in arch VGPRs "spilled" to AGPRs and moves ~400 of them per tile (v_accvgpr_read/write); the matrix
 // instruction can read B and accumulate C/D in AGPRs directly. Being asm, these are invisible to hipcc's hazard recogniser: the

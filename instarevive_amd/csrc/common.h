@@ -56,6 +56,23 @@ IR_DEVINL float silu(float x) { return x * fast_sigmoid(x); }
 // (a workgroup-scope fence only waits lgkmcnt on gfx950), so every barrier that publishes DMA-written LDS is preceded by this.
 IR_DEVINL void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// Hand-scheduled LDS fragment reads: an inline-asm ds_read_b128 is invisible to hipcc's waitcnt insertion, so the caller counts
+// s_waitcnt lgkmcnt(N) itself (N = reads issued after the one about to be consumed). Left to hipcc, a read issued for a LATER MFMA
+// is often waited for together with the current one (lgkmcnt(0)), which exposes the full LDS latency when only one wave per SIMD is
+// in its matrix phase. Pin the order around these with __builtin_amdgcn_sched_barrier(0).
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+template <int OFF>
+IR_DEVINL bf16x8 lds_read16(uint32_t addr) {
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+template <int N>
+IR_DEVINL void wait_lds() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N)); }
+template <int N>
+IR_DEVINL void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }  // all but the N youngest VMEM / LDS-DMA ops
+IR_DEVINL uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(lds_ptr_t)p; }
+
 // max / sum of a value with its partner lane in the other half of the wave (lane ^ 32): one v_permlane32_swap instead of an LDS
 // round trip (ds_bpermute). The swap returns {v with the upper half replaced by the lower, v with the lower replaced by the upper}.
 IR_DEVINL float xhalf_max(float v) {

@@ -40,6 +40,20 @@ int main(int argc, char** argv) {
     CK(hipStreamSynchronize(st));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 10;
     printf("conv %dx%d %d->%d: %.3f ms  %.1f TFLOP/s\n", H, W, Cin, Cout, ms, 2.0 * H * W * Cout * 9 * Cin / ms / 1e9);
+    if (!getenv("IR_NO_CONV_PP") && Cout % 128 == 0) {  // ping-pong kernel: per-segment cycle sums of waves 0 and 4 of every workgroup
+        const long nb = std::min<long>(32768, (long)((H + 15) / 16) * ((W + 15) / 16) * (Cout / 128));
+        std::vector<unsigned long long> st(nb * 16);
+        CK(hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamps), nb * 16 * 8));
+        const double nsteps = 9.0 * (Cin / 64);
+        for (int g = 0; g < 2; ++g) {
+            double a[4] = {0, 0, 0, 0};
+            for (long b = 0; b < nb; ++b)
+                for (int k = 0; k < 4; ++k) a[k] += (double)st[(b * 2 + g) * 8 + k];
+            printf("  waves %d-%d per step (s_memtime ticks): matrix %.0f, wait+barrier %.0f, vector %.0f, barrier %.0f (sum %.0f)\n", g * 4, g * 4 + 3,
+                   a[0] / nb / nsteps, a[1] / nb / nsteps, a[2] / nb / nsteps, a[3] / nb / nsteps, (a[0] + a[1] + a[2] + a[3]) / nb / nsteps);
+        }
+        return 0;
+    }
     const long nblk = std::min<long>(65536, (long)((H + 7) / 8) * ((W + 15) / 16) * (Cout / (Cout % 128 == 0 ? 128 : 64)));
     std::vector<unsigned long long> st8(nblk * 8), st4(nblk * 4);
     CK(hipMemcpyFromSymbol(st8.data(), HIP_SYMBOL(g_stamps), nblk * 8 * 8));
