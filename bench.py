@@ -161,6 +161,7 @@ def main():
     ap.add_argument("--tiled", action="store_true")
     ap.add_argument("--net_hw", type=str, default="", help="HxW network input (overrides --lq/--sr_scale), e.g. 2176x3840 for the padded 4K case")
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_profile", action="store_true", help="experiment: time the loop without the per-launch HIP events (no roofline)")
     args = ap.parse_args()
 
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
@@ -218,12 +219,17 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    ctx.profile_begin()
+    if not args.no_profile:
+        ctx.profile_begin()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
+    if args.no_profile:
+        if rank == 0:
+            log(f"unprofiled: {dt / args.steps * 1e3:.2f} ms/step")
+        return
     prof = ctx.profile_end()
     if dist is not None:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
