@@ -152,17 +152,25 @@ __global__ __launch_bounds__(256) void gn_finalize_groups_kernel(const float* __
     }
 }
 
-// y = act(x*scale + shift); x,y: [N][HW][C] bf16; grid-stride over 16-byte vectors.
+// y = act(x*scale + shift); x,y: [N][HW][C] bf16. grid = (blocks, N): blockIdx.y is the image, the blocks of an image stride over
+// its 16-byte vectors. The stride (blocks * 256) is a multiple of the vectors per pixel, so a thread always meets the same 8
+// channels: its scale / shift live in registers and the loop has no index arithmetic beyond one add (the first version divided
+// two 64-bit indices per vector and re-read scale / shift for every vector: 3.6 TB/s).
 __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
-                                                       long HW, int C, long nvec, int do_silu) {
+                                                       long HW, int C, long nvec_img, int do_silu) {
     const int vpp = C >> 3;
+    const int n = blockIdx.y;
+    const int cv = threadIdx.x % vpp;  // blockDim.x * gridDim.x % vpp == 0 (launcher)
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        sc[e] = scale[(long)n * C + cv * 8 + e];
+        sh[e] = shift[(long)n * C + cv * 8 + e];
+    }
+    x += (long)n * nvec_img * 8;
+    y += (long)n * nvec_img * 8;
     auto one = [&](long i, const uint4& v) {
-        const long pix = i / vpp;
-        const int cv = (int)(i - pix * vpp);
-        const int n = (int)(pix / HW);
-        const float* sc = scale + (long)n * C + cv * 8;
-        const float* sh = shift + (long)n * C + cv * 8;
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
         uint32_t o[4];
 #pragma unroll
@@ -176,14 +184,23 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
     };
     const long stride = (long)gridDim.x * 256;
     long i = (long)blockIdx.x * 256 + threadIdx.x;
-    for (; i + 3 * stride < nvec; i += 4 * stride) {  // 4 independent 16-byte loads in flight per lane
+    for (; i + 3 * stride < nvec_img; i += 4 * stride) {  // 4 independent 16-byte loads in flight per lane
         uint4 v0 = *reinterpret_cast<const uint4*>(x + i * 8);
         uint4 v1 = *reinterpret_cast<const uint4*>(x + (i + stride) * 8);
         uint4 v2 = *reinterpret_cast<const uint4*>(x + (i + 2 * stride) * 8);
         uint4 v3 = *reinterpret_cast<const uint4*>(x + (i + 3 * stride) * 8);
         one(i, v0); one(i + stride, v1); one(i + 2 * stride, v2); one(i + 3 * stride, v3);
     }
-    for (; i < nvec; i += stride) one(i, *reinterpret_cast<const uint4*>(x + i * 8));
+    for (; i < nvec_img; i += stride) one(i, *reinterpret_cast<const uint4*>(x + i * 8));
+}
+
+static void launch_gn_apply(const bf16_t* x, bf16_t* y, const float* scale, const float* shift, int N, long HW, int C, int do_silu,
+                            hipStream_t s) {
+    const long nvec_img = HW * C / 8;
+    long blocks = (nvec_img + 255) / 256;
+    const long cap = (256L * 16 + N - 1) / N;  // about 16 blocks per CU over the whole launch
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)blocks, N), dim3(256), 0, s, x, y, scale, shift, HW, C, nvec_img, do_silu);
 }
 
 int ir_launch_groupnorm(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, float* ws, int N, long HW, int C,
@@ -196,10 +213,7 @@ int ir_launch_groupnorm(const bf16_t* x, bf16_t* y, const float* gamma, const fl
     float* shift = scale + (long)N * C;                // [N][C]
     hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, N), dim3(256), 0, s, x, part, (int)HW, C, chunks);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), 0, s, part, gamma, beta, scale, shift, (int)HW, C, G, chunks, eps);
-    const long nvec = (long)N * HW * C / 8;
-    long blocks = (nvec + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, y, scale, shift, HW, C, nvec, do_silu);
+    launch_gn_apply(x, y, scale, shift, N, HW, C, do_silu, s);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -235,10 +249,7 @@ int ir_launch_groupnorm_fused(const bf16_t* x, bf16_t* y, const float* gamma, co
         chunks = R;
     }
     hipLaunchKernelGGL(gn_finalize_groups_kernel, dim3(N), dim3(256), 0, s, part, gamma, beta, scale, shift, (int)HW, C, G, chunks, eps);
-    const long nvec = (long)N * HW * C / 8;
-    long blocks = (nvec + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, y, scale, shift, HW, C, nvec, do_silu);
+    launch_gn_apply(x, y, scale, shift, N, HW, C, do_silu, s);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -291,12 +302,72 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
+// Vectorised form (C, ldx, ldy multiples of 4, 16-byte aligned rows): a lane owns float4 columns j = i*64 + lane, so the row is read
+// with 16-byte loads, a / b with 16-byte loads, and written as 8-byte bf16 (16-byte fp32) vectors. VPL4 = float4 per lane.
+template <int VPL4>
+__global__ __launch_bounds__(256) void layernorm_v4_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, float* __restrict__ yf,
+                                                           const float* __restrict__ a, const float* __restrict__ b, long rows,
+                                                           int C, int ldx, int ldy, float eps, long rows_per_batch, int ab_stride) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * ldx;
+    const int C4 = C >> 2, L4 = ldy >> 2;
+    f32x4 v[VPL4];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL4; ++i) {
+        const int j = i * 64 + lane;
+        v[i] = *reinterpret_cast<const f32x4*>(xr + 4 * min(j, C4 - 1));  // unconditional load on a valid address
+        if (j >= C4) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    const float mean = wave_sum(sum) / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL4; ++i) {
+        const int j = i * 64 + lane;
+        if (j < C4) {
+            const f32x4 d = v[i] - mean;
+            sq += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)C + eps);
+    const long batch = row / rows_per_batch;
+    const float* ap = a ? a + batch * ab_stride : nullptr;
+    const float* bp = b ? b + batch * ab_stride : nullptr;
+#pragma unroll
+    for (int i = 0; i < VPL4; ++i) {
+        const int j = i * 64 + lane;
+        if (j < L4) {
+            f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (j < C4) {
+                o = (v[i] - mean) * rstd;
+                if (ap) o *= *reinterpret_cast<const f32x4*>(ap + 4 * j);
+                if (bp) o += *reinterpret_cast<const f32x4*>(bp + 4 * j);
+            }
+            if (y) *reinterpret_cast<uint2*>(y + row * ldy + 4 * j) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+            if (yf) *reinterpret_cast<f32x4*>(yf + row * ldy + 4 * j) = o;
+        }
+    }
+}
+
 int ir_launch_layernorm(const float* x, bf16_t* y, float* yf, const float* a, const float* b, long rows, int C, int ldx, int ldy,
                         float eps, long rows_per_batch, int ab_stride, hipStream_t s) {
     if (rows <= 0) return 0;
     if (C > ldx || C > ldy || ldy > 1152) return -2;
     if (rows_per_batch <= 0) return -3;
     const unsigned grid = (unsigned)((rows + 3) / 4);
+    const bool v4 = !((C | ldx | ldy | ab_stride) & 3) && !(reinterpret_cast<uintptr_t>(x) & 15) && !(reinterpret_cast<uintptr_t>(y) & 7) &&
+                    !(reinterpret_cast<uintptr_t>(yf) & 15) && !(reinterpret_cast<uintptr_t>(a) & 15) && !(reinterpret_cast<uintptr_t>(b) & 15);
+    if (v4 && ldy <= 256) {
+        hipLaunchKernelGGL((layernorm_v4_kernel<1>), dim3(grid), dim3(256), 0, s, x, y, yf, a, b, rows, C, ldx, ldy, eps, rows_per_batch, ab_stride);
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
+    if (v4 && ldy <= 1280) {
+        hipLaunchKernelGGL((layernorm_v4_kernel<5>), dim3(grid), dim3(256), 0, s, x, y, yf, a, b, rows, C, ldx, ldy, eps, rows_per_batch, ab_stride);
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
     if (ldy <= 192)
         hipLaunchKernelGGL((layernorm_kernel<3>), dim3(grid), dim3(256), 0, s, x, y, yf, a, b, rows, C, ldx, ldy, eps, rows_per_batch, ab_stride);
     else if (ldy <= 1152)
