@@ -49,7 +49,8 @@ def pack_conv(w, cin_pad, cout_pad):
     return p.reshape(cout_pad, kh * kw * cin_pad)
 
 
-@pytest.mark.parametrize("m,k,n", [(128, 32, 128), (300, 96, 192), (1000, 1152, 64), (77, 64, 32), (256, 4608, 1152)])
+@pytest.mark.parametrize("m,k,n", [(128, 32, 128), (300, 96, 192), (1000, 1152, 64), (77, 64, 32), (256, 4608, 1152),
+                                   (2304, 2304, 128), (2100, 4608, 256)])  # long K loops, whole and ragged M
 def test_linear(ctx, m, k, n):
     g = torch.Generator().manual_seed(m + k + n)
     x = rb(torch.randn(m, k, generator=g))
