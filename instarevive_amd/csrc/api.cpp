@@ -573,6 +573,7 @@ float* dit_tokens_run(Run& r, const float* lat, int n, int h, int w, float times
     bf16_t* xn = r.a.alloc<bf16_t>(BT * C);
     bf16_t* qkv = r.a.alloc<bf16_t>(BT * 3 * C);
     bf16_t* vt = r.a.alloc<bf16_t>((long)n * Hh * DV * Tpad);
+    int* attn_flag = r.a.alloc<int>(16);  // 4 bytes used: overflow flag of the ping-pong self-attention kernel
     bf16_t* att = r.a.alloc<bf16_t>(BT * C);
     bf16_t* cq = r.a.alloc<bf16_t>(BT * C);
     bf16_t* hid = r.a.alloc<bf16_t>(BT * m.mlp);
@@ -592,6 +593,7 @@ float* dit_tokens_run(Run& r, const float* lat, int n, int h, int w, float times
             p.q_bs = p.k_bs = T * 3 * C; p.o_bs = T * C; p.vt_bs = (long)Hh * DV * Tpad;
             p.q_rs = p.k_rs = 3 * C; p.o_rs = C; p.q_hs = p.k_hs = p.o_hs = hd;
             p.B = n; p.Hh = Hh; p.Tq = (int)T; p.Tk = (int)T; p.Tk_pad = Tpad; p.D = hd; p.scale_log2 = sl2;
+            p.ovf_flag = attn_flag;
             LAUNCH(r, PC_FLASH_ATTN, 4.0 * n * Hh * (double)T * T * hd, 0.0, ir_launch_flash_attn(p, r.s), "self_attn");
         }
         linear(r, Lw.ao, att, (int)BT, C, x, C, 1, ACT_NONE, x, 1, C, xb, C, mod + 2 * C);
@@ -1222,6 +1224,7 @@ int ir_op_attention(ir_ctx* c, void* stream, const uint16_t* q, const uint16_t* 
     AttnParams p;
     memset(&p, 0, sizeof p);
     p.q = q; p.k = k; p.vt = (const bf16_t*)ws; p.o = o;
+    if (ws_bytes >= need + 64) p.ovf_flag = (int*)((char*)ws + ((need + 15) & ~(size_t)15));
     p.q_bs = (long)tq * heads * d; p.k_bs = (long)tk * heads * d; p.o_bs = p.q_bs; p.vt_bs = (long)heads * DV * tkp;
     p.q_rs = p.k_rs = p.o_rs = heads * d; p.q_hs = p.k_hs = p.o_hs = d;
     p.B = b; p.Hh = heads; p.Tq = tq; p.Tk = tk; p.Tk_pad = tkp; p.D = d;

@@ -74,6 +74,8 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(AttnParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int q0 = blockIdx.x * 128, head = blockIdx.y, b = blockIdx.z;
+    // launched behind flash_attn_pp_kernel as its fallback: nothing to do unless that kernel flagged a query it could not handle
+    if (p.ovf_flag && *reinterpret_cast<volatile const int*>(p.ovf_flag) == 0) return;
 
     const bf16_t* qp = p.q + (long)b * p.q_bs + (long)head * p.q_hs;
     const bf16_t* kp = p.k + (long)b * p.k_bs + (long)head * p.k_hs;
@@ -478,6 +480,8 @@ __global__ __launch_bounds__(512, 1) void flash_attn_pp_kernel(AttnParams p) {
             wait_lds<(J1 - 1 - j < LA ? J1 - 1 - j : LA)>();  // reads issued after the one MFMA j consumes
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (j < NPV) o[j >> 2] = mfma32(fr[j % NB], pb[(j & 3) >> 1][j & 1], o[j >> 2]);
+            else if constexpr ((j - NPV) % NKS == 0)  // first k-step of a score tile: D = A x B + (-m), D and C in different registers
+                asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(sacc[(j - NPV) / NKS]) : "v"(fr[j % NB]), "v"(qf[0]), "v"(negm));
             else sacc[(j - NPV) / NKS] = mfma32(fr[j % NB], qf[(j - NPV) % NKS], sacc[(j - NPV) / NKS]);
             // keep the fragment of MFMA j-2 allocated until here: the register allocator otherwise hands its registers to the very
             // next read, which then waits (with everything behind it) until that MFMA has finished reading them
@@ -487,7 +491,15 @@ __global__ __launch_bounds__(512, 1) void flash_attn_pp_kernel(AttnParams p) {
         __builtin_amdgcn_sched_barrier(0);
         [&]<int... I>(std::integer_sequence<int, I...>) { (step(std::integral_constant<int, J0 + I>{}), ...); }(std::make_integer_sequence<int, J1 - J0>{});
     };
-    // softmax of the tile whose (score - m_i) sits in sacc: running max with deferred rescale, exponentials -> pb
+    // Softmax of the tile whose (score - m) sits in sacc. The reference m is FIXED after the first tile (its maximum): the
+    // probabilities of later tiles are exp2(score - m) whatever they are, up to 2^OVF_LIMIT - bf16 and fp32 have the exponent range,
+    // and relative precision does not depend on the reference. Without a rescale path the accumulators have one definition per tile
+    // (hipcc had kept the two paths' O^T in different registers: 24 64-bit moves per tile on the common path) and -m can stay
+    // broadcast in 16 registers that the first QK^T MFMA of a tile takes as its C operand (no per-tile preset of the S^T
+    // accumulators). A query whose scores outgrow 2^OVF_LIMIT raises a flag; the launcher runs the rescaling 4-wave kernel after
+    // this one, which returns at once unless the flag is set.
+    constexpr float OVF_LIMIT = 64.0f;
+    bool ovf = false;
     auto softmax_segment = [&](int t) {
         float mx = -INFINITY;
 #pragma unroll
@@ -495,20 +507,16 @@ __global__ __launch_bounds__(512, 1) void flash_attn_pp_kernel(AttnParams p) {
 #pragma unroll
             for (int g = 0; g < 16; ++g) mx = fmaxf(mx, sacc[kt][g]);
         mx = xhalf_max(mx);
-        if (t == 0 || __any(mx > RESCALE_THR)) {
-            const float delta = t == 0 ? mx : fmaxf(mx, 0.f);
-            const float alpha = t == 0 ? 1.0f : __builtin_amdgcn_exp2f(-delta);  // O is still zero on the first tile
-            m_i += delta;
-#pragma unroll
-            for (int dt = 0; dt < NDT; ++dt)
-#pragma unroll
-                for (int g = 0; g < 16; ++g) o[dt][g] *= alpha;
+        if (t == 0) {  // the accumulators of tile 0 were computed against m = 0
+            m_i = mx;
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int g = 0; g < 16; ++g) sacc[kt][g] -= delta;
+                for (int g = 0; g < 16; ++g) sacc[kt][g] -= mx;
 #pragma unroll
-            for (int g = 0; g < 16; ++g) negm[g] = -m_i;
+            for (int g = 0; g < 16; ++g) negm[g] = -mx;
+        } else {
+            ovf |= mx > OVF_LIMIT;
         }
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
@@ -516,15 +524,11 @@ __global__ __launch_bounds__(512, 1) void flash_attn_pp_kernel(AttnParams p) {
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) pb[kt][s2][e] = (__bf16)__builtin_amdgcn_exp2f(sacc[kt][s2 * 8 + e]);
-        sacc[0] = negm;  // the next S^T accumulates onto -m_i in place
-        sacc[1] = negm;
     };
 
     wait_dma();
     __syncthreads();                   // K(0) and the prologue stages landed
     if (grp == 1) __syncthreads();     // waves 4-7 start one segment late
-    sacc[0] = negm;
-    sacc[1] = negm;
     matrix_prefetch(std::false_type{}, std::true_type{}, 0, 2);
     matrix_segment(std::false_type{}, std::true_type{});  // S^T(0) from K slot 2
     __syncthreads();
@@ -563,6 +567,7 @@ __global__ __launch_bounds__(512, 1) void flash_attn_pp_kernel(AttnParams p) {
     if (grp == 0) __syncthreads();     // pairs the late start of waves 4-7; afterwards nobody reads the K/V ring any more
     wait_dma();
 
+    if (__any(ovf) && lane == 0) atomicOr(p.ovf_flag, 1);
     // ---- finalise: O^T[d][q] / l -> LDS [q][d] -> 16-byte row stores
     const float l_i = __shfl(o[L_DT][L_G], r + 32 * L_H);  // O^T row D (ones row of V^T) of this lane's query
     const float inv = 1.0f / l_i;
@@ -594,14 +599,18 @@ int ir_launch_flash_attn(const AttnParams& p, hipStream_t s) {
     dim3 grid((p.Tq + 127) / 128, p.Hh, p.B);
     const bool general = p.key_bias != nullptr || (p.Tk & 63);
     static const bool no_pp = getenv("IR_NO_PINGPONG") != nullptr;  // experiment knob
-    if (p.D == 72 && !general && p.Tq >= 256 && !no_pp) {  // the DiT self-attention: ping-pong kernel, 256 queries per workgroup
+    if (p.D == 72 && !general && p.Tq >= 256 && p.ovf_flag && !no_pp) {  // the DiT self-attention: ping-pong kernel, 256 queries per workgroup
+        if (hipMemsetAsync(p.ovf_flag, 0, sizeof(int), s) != hipSuccess) return -1;
         hipLaunchKernelGGL((flash_attn_pp_kernel<72>), dim3((p.Tq + 255) / 256, p.Hh, p.B), dim3(512), 0, s, p);
+        hipLaunchKernelGGL((flash_attn_kernel<72, false>), grid, dim3(256), 0, s, p);  // fallback: returns at once unless flagged
         return hipGetLastError() == hipSuccess ? 0 : -1;
     }
+    AttnParams q = p;
+    q.ovf_flag = nullptr;  // stand-alone use of the 4-wave kernel below
 #define IR_FA(DD)                                                                                     \
     do {                                                                                              \
-        if (general) hipLaunchKernelGGL((flash_attn_kernel<DD, true>), grid, dim3(256), 0, s, p);     \
-        else hipLaunchKernelGGL((flash_attn_kernel<DD, false>), grid, dim3(256), 0, s, p);            \
+        if (general) hipLaunchKernelGGL((flash_attn_kernel<DD, true>), grid, dim3(256), 0, s, q);     \
+        else hipLaunchKernelGGL((flash_attn_kernel<DD, false>), grid, dim3(256), 0, s, q);            \
     } while (0)
     if (p.D == 72) IR_FA(72);
     else if (p.D == 32) IR_FA(32);

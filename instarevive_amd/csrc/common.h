@@ -73,12 +73,15 @@ template <int N>
 IR_DEVINL void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }  // all but the N youngest VMEM / LDS-DMA ops
 IR_DEVINL uint32_t lds_addr(const void* p) { return (uint32_t)(uintptr_t)(lds_ptr_t)p; }
 
-// max / sum of a value with its partner lane in the other half of the wave (lane ^ 32): one v_permlane32_swap instead of an LDS
-// round trip (ds_bpermute). The swap returns {v with the upper half replaced by the lower, v with the lower replaced by the upper}.
+// max of a value with its partner lane in the other half of the wave (lane ^ 32): one v_permlane32_swap instead of an LDS round
+// trip (ds_bpermute). The instruction swaps the upper half of its first operand with the lower half of its second; with both
+// holding v, afterwards a = {v[0..31], v[0..31]} and b = {v[32..63], v[32..63]}, so max(a, b) is the cross-half max on every lane.
+// Inline asm on purpose: written with __builtin_amdgcn_permlane32_swap, hipcc (ROCm 7.2) folds max(r[0], r[1]) to r[0] - it never
+// emits the second extract - and the exchange silently disappears. The s_nop covers the VALU-write -> permlane read hazard.
 IR_DEVINL float xhalf_max(float v) {
-    const uint32_t u = __builtin_bit_cast(uint32_t, v);
-    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return fmaxf(a, b);
 }
 
 IR_DEVINL float wave_sum(float v) {

@@ -81,6 +81,7 @@ struct AttnParams {
     float scale_log2;          // softmax scale * log2(e)
     const float* key_bias;     // optional additive bias per key [B][kb_bs] (natural-log domain)
     long kb_bs;
+    int* ovf_flag;             // optional 4 bytes of device scratch: enables the fixed-reference ping-pong kernel (see attention.hip)
 };
 int ir_launch_flash_attn(const AttnParams& p, hipStream_t s);
 int ir_launch_flash_attn_d512(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* o, int T, int rs, int o_rs, long vt_rs,

@@ -253,22 +253,30 @@ def test_flash_attention(ctx, b, heads, tq, tk, d, bias):
     close(L.from_bf16_bits(o).cpu(), ref, 2 ** -6, 6e-3, "flash attention")
 
 
-def test_flash_attention_spike(ctx):
-    """Force the online-softmax rescale: a late key dominates one query (max jumps in the last tile)."""
+@pytest.mark.parametrize("t,gain", [(256, 4.0), (512, 8.0), (512, 12.0)])
+def test_flash_attention_spike(ctx, t, gain):
+    """A late key dominates one query (the maximum jumps in the last tile). gain 4: inside the fixed-reference range of the
+    ping-pong kernel (scores up to 2^64 above the first tile's maximum); gain 8 / 12: beyond it -> its overflow flag and the
+    rescaling fallback kernel."""
     g = torch.Generator().manual_seed(3)
-    b, heads, t, d = 1, 1, 256, 72
+    b, heads, d = 1, 1, 72
     q = rb(torch.randn(b, t, heads, d, generator=g))
     k = rb(torch.randn(b, t, heads, d, generator=g))
     v = rb(torch.randn(b, t, heads, d, generator=g))
-    k[0, 250, 0] = q[0, 7, 0] * 4.0
+    k[0, t - 6, 0] = q[0, 7, 0] * gain
     k = rb(k)
     scale = d ** -0.5
-    ref = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2), scale=scale).transpose(1, 2)
+    # explicit float64 softmax: torch's CPU SDPA returns NaN for logits this large
+    qd64, kd64, vd64 = (x_.transpose(1, 2).double() for x_ in (q, k, v))
+    ref = (torch.softmax(qd64 @ kd64.transpose(-1, -2) * scale, dim=-1) @ vd64).transpose(1, 2).float()
     o = torch.empty(b, t, heads, d, dtype=torch.int16, device="cuda")
     ws = torch.empty(8 << 20, dtype=torch.uint8, device="cuda")
     ctx.check(ctx.lib.ir_op_attention(ctx.h, ctx.stream(), P(dev_bf16(q)), P(dev_bf16(k)), P(dev_bf16(v)), P(o), b, heads, t, t, d,
                                       scale, None, P(ws), ws.numel()), "attention")
-    close(L.from_bf16_bits(o).cpu(), ref, 2 ** -6, 6e-3, "flash attention spike")
+    # logits of +-60..150 (log2 units) carry the bf16 rounding of q and k at full weight: 2^-9 relative is +-0.1..0.3 in the exponent
+    # for the few queries whose second-largest key is close to the spike; the extreme case is here for the overflow path, not for ulps
+    rtol, atol = (2 ** -6, 6e-3) if gain <= 8 else (2 ** -4, 4e-2)
+    close(L.from_bf16_bits(o).cpu(), ref, rtol, atol, "flash attention spike")
 
 
 @pytest.mark.parametrize("h,w,shift", [(8, 8, 0), (16, 24, 0), (16, 24, 4), (64, 64, 4)])
