@@ -1062,11 +1062,13 @@ static int launch_cfg(const IGemmParams& p, hipStream_t s) {
     static const bool force32 = getenv("IR_IGEMM_BK32") != nullptr;  // experiment knob
     const bool k64 = (p.Cin & 63) == 0 && !force32;
     if (p.taps == 9) {
-        if (k64) hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, 9, 64>), dim3(grid), dim3(256), 0, s, p);
+        static const bool m16t = getenv("IR_NO_MFMA16") == nullptr;
+        if (k64 && m16t) hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, 9, 64, true>), dim3(grid), dim3(256), 0, s, p);
+        else if (k64) hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, 9, 64>), dim3(grid), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, 9, 32>), dim3(grid), dim3(256), 0, s, p);
     } else {
         static const bool m16 = getenv("IR_NO_MFMA16") == nullptr;  // 16x16x32 MFMA form of the 128x128 GEMM (knob: A/B against 32x32x16)
-        if (k64 && m16 && BM == 128 && BN == 128) hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, 1, 64, true>), dim3(grid), dim3(256), 0, s, p);
+        if (k64 && m16) hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, 1, 64, true>), dim3(grid), dim3(256), 0, s, p);
         else if (k64) hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, 1, 64>), dim3(grid), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, 1, 32>), dim3(grid), dim3(256), 0, s, p);
     }
