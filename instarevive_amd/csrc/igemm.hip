@@ -1082,7 +1082,8 @@ static bool takes_halo(const IGemmParams& p) {
 }
 static bool takes_halo_pp(const IGemmParams& p) {  // the 8-wave ping-pong variant: 16 x 16 patches x 128 channels
     static const bool no_pp = getenv("IR_NO_CONV_PP") != nullptr;  // experiment knob
-    return takes_halo(p) && p.Cout_pad % 128 == 0 && p.Cin >= 256 && !no_pp;  // measured: +6 % at 512 channels, +1 % at 256, -2 % at 128
+    return takes_halo(p) && p.Cout_pad % 128 == 0 && p.Cin >= 128 && !no_pp;  // measured with the 16x16x32 MFMAs: +8 % at 512 channels,
+                                                                               // +7 % at 256, +2 % at 128 over the 4-wave kernel
 }
 int ir_igemm_gn_chunks(const IGemmParams& p) {
     if (p.gn_cpg < 4 || (p.gn_cpg & 3) || p.Cout % p.gn_cpg || p.Cout_pad % 64 || (p.Cout & 3) || p.NB <= 0) return 0;

@@ -28,7 +28,7 @@ def load(root, counter):
 fetch, fc = load(sys.argv[1], "FETCH_SIZE")
 write, wc = load(sys.argv[2], "WRITE_SIZE")
 passes = int(sys.argv[4]) if len(sys.argv) > 4 else 1
-fam = [k for k in fetch if k.startswith("igemm_kernel") or k.startswith("conv_halo_kernel")]
+fam = [k for k in fetch if k.startswith("igemm_kernel") or k.startswith("conv_halo")]
 f_kb = sum(fetch[k] for k in fam) / passes
 w_kb = sum(write[k] for k in fam) / passes
 launches = sum(fc[k] for k in fam) / passes
