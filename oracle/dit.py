@@ -64,9 +64,11 @@ def cross_attention_bias(mask):
 
 
 @torch.no_grad()
-def dit_forward(sd, latents, timestep, encoder_hidden_states, encoder_attention_mask=None, cfg=None):
+def dit_forward(sd, latents, timestep, encoder_hidden_states, encoder_attention_mask=None, cfg=None, c=None):
     """latents [B,4,h,w], timestep [B] (or scalar), encoder_hidden_states [B|1,L,cap], mask [B|1,1,L] or [B|1,L].
-    Returns the model output [B,8,h,w] (eps || sigma), i.e. Transformer2DModel(...).sample."""
+    Returns the model output [B,8,h,w] (eps || sigma), i.e. Transformer2DModel(...).sample.
+    c [B,4,h,w] (optional): the control latent of the ControlNet-Half variant; sd then also holds the
+    `controlnet.{i}.{copied_block.*, after_proj.*}` / `controlnet.0.before_proj.*` tensors and the base model's keys unprefixed."""
     cfg = dict(DEFAULT_CFG, **(cfg or {}))
     nh, hd, ps = cfg["num_attention_heads"], cfg["attention_head_dim"], cfg["patch_size"]
     C = nh * hd
@@ -85,8 +87,7 @@ def dit_forward(sd, latents, timestep, encoder_hidden_states, encoder_attention_
     bias = cross_attention_bias(encoder_attention_mask)
     if bias is not None:
         bias = bias.reshape(-1, 1, 1, bias.shape[-1]).expand(B, 1, 1, -1)
-    for l in range(cfg["num_layers"]):
-        p = f"transformer_blocks.{l}."
+    def block(p, x):  # one BasicTransformerBlock (ada_norm_single), weights under prefix p
         sh_msa, sc_msa, g_msa, sh_mlp, sc_mlp, g_mlp = (sd[p + "scale_shift_table"][None] + t6.reshape(B, 6, -1)).chunk(6, dim=1)
         h = F.layer_norm(x, (C,), eps=1e-6) * (1 + sc_msa) + sh_msa
         a = F.scaled_dot_product_attention(_heads(_lin(sd, p + "attn1.to_q", h), nh), _heads(_lin(sd, p + "attn1.to_k", h), nh),
@@ -96,12 +97,57 @@ def dit_forward(sd, latents, timestep, encoder_hidden_states, encoder_attention_
                                            _heads(_lin(sd, p + "attn2.to_v", y), nh), attn_mask=bias)
         x = x + _lin(sd, p + "attn2.to_out.0", a.transpose(1, 2).reshape(B, -1, C))
         h = F.layer_norm(x, (C,), eps=1e-6) * (1 + sc_mlp) + sh_mlp
-        x = x + g_mlp * _lin(sd, p + "ff.net.2", F.gelu(_lin(sd, p + "ff.net.0.proj", h), approximate="tanh"))
+        return x + g_mlp * _lin(sd, p + "ff.net.2", F.gelu(_lin(sd, p + "ff.net.0.proj", h), approximate="tanh"))
+
+    if c is None:
+        for l in range(cfg["num_layers"]):
+            x = block(f"transformer_blocks.{l}.", x)
+    else:
+        # ControlNet-Half (diffusion/model/nets/transformer_controlnet.py:98-173, pixart_controlnet.py:17-50): the first
+        # copy_blocks_num blocks have trainable copies that process the control tokens c = pos_embed(c_latent); copy i feeds
+        # base block i+1 through the zero-initialised after_proj; copy 0 starts from x + before_proj(c).
+        ncopy = cfg.get("copy_blocks_num", 13)
+        cs = F.conv2d(c, sd["pos_embed.proj.weight"], sd["pos_embed.proj.bias"], stride=ps).flatten(2).transpose(1, 2)
+        cs = cs + torch.from_numpy(pos).float().unsqueeze(0)
+        x = block("transformer_blocks.0.", x)
+        for i in range(1, ncopy + 1):
+            q = f"controlnet.{i - 1}."
+            if i == 1:
+                cs = x + _lin(sd, q + "before_proj", cs)
+            cs = block(q + "copied_block.", cs)
+            x = block(f"transformer_blocks.{i}.", x + _lin(sd, q + "after_proj", cs))
+        for l in range(ncopy + 1, cfg["num_layers"]):
+            x = block(f"transformer_blocks.{l}.", x)
     shift, scale = (sd["scale_shift_table"][None] + emb[:, None]).chunk(2, dim=1)
     x = _lin(sd, "proj_out", F.layer_norm(x, (C,), eps=1e-6) * (1 + scale) + shift)
     oc = cfg["out_channels"]
     x = x.reshape(B, gh, gw, ps, ps, oc)
     return torch.einsum("nhwpqc->nchpwq", x).reshape(B, oc, gh * ps, gw * ps)
+
+
+def _block_to_diffusers(sd, q, p, o):
+    """One block: in-tree keys under prefix q -> diffusers BasicTransformerBlock keys under prefix p (converter :62-154)."""
+    o[p + "scale_shift_table"] = sd[q + "scale_shift_table"]
+    for n, w, b in zip(("to_q", "to_k", "to_v"), sd[q + "attn.qkv.weight"].chunk(3, 0), sd[q + "attn.qkv.bias"].chunk(3, 0)):
+        o[p + f"attn1.{n}.weight"], o[p + f"attn1.{n}.bias"] = w, b
+    o[p + "attn1.to_out.0.weight"], o[p + "attn1.to_out.0.bias"] = sd[q + "attn.proj.weight"], sd[q + "attn.proj.bias"]
+    o[p + "attn2.to_q.weight"], o[p + "attn2.to_q.bias"] = sd[q + "cross_attn.q_linear.weight"], sd[q + "cross_attn.q_linear.bias"]
+    for n, w, b in zip(("to_k", "to_v"), sd[q + "cross_attn.kv_linear.weight"].chunk(2, 0), sd[q + "cross_attn.kv_linear.bias"].chunk(2, 0)):
+        o[p + f"attn2.{n}.weight"], o[p + f"attn2.{n}.bias"] = w, b
+    o[p + "attn2.to_out.0.weight"], o[p + "attn2.to_out.0.bias"] = sd[q + "cross_attn.proj.weight"], sd[q + "cross_attn.proj.bias"]
+    o[p + "ff.net.0.proj.weight"], o[p + "ff.net.0.proj.bias"] = sd[q + "mlp.fc1.weight"], sd[q + "mlp.fc1.bias"]
+    o[p + "ff.net.2.weight"], o[p + "ff.net.2.bias"] = sd[q + "mlp.fc2.weight"], sd[q + "mlp.fc2.bias"]
+
+
+def control_to_diffusers(sd, copy_blocks_num):
+    """ControlPixArtHalf state dict (pixart_controlnet.py:55-69: `controlnet.{i}.copied_block.<in-tree block keys>`, `.after_proj`,
+    `controlnet.0.before_proj`) -> the key names of the diffusers flavour ControlTransformerHalf (transformer_controlnet.py:62-76)."""
+    o = {}
+    for i in range(copy_blocks_num):
+        _block_to_diffusers(sd, f"controlnet.{i}.copied_block.", f"controlnet.{i}.copied_block.", o)
+        for n in ("after_proj",) + (("before_proj",) if i == 0 else ()):
+            o[f"controlnet.{i}.{n}.weight"], o[f"controlnet.{i}.{n}.bias"] = sd[f"controlnet.{i}.{n}.weight"], sd[f"controlnet.{i}.{n}.bias"]
+    return o
 
 
 def pixart_to_diffusers(sd, num_layers):
@@ -146,4 +192,18 @@ def state_dict_shapes(cfg=None, mlp_ratio=4):
                 s[p + f"{a}.{n}.weight"], s[p + f"{a}.{n}.bias"] = (C, C), (C,)
         s[p + "ff.net.0.proj.weight"], s[p + "ff.net.0.proj.bias"] = (mlp_ratio * C, C), (mlp_ratio * C,)
         s[p + "ff.net.2.weight"], s[p + "ff.net.2.bias"] = (C, mlp_ratio * C), (C,)
+    return s
+
+
+def control_state_dict_shapes(cfg=None, mlp_ratio=4, copy_blocks_num=13):
+    """Extra tensors of ControlTransformerHalf (transformer_controlnet.py:19-40,62-76), keyed as its state_dict names them."""
+    base = state_dict_shapes(cfg, mlp_ratio)
+    cfg = dict(DEFAULT_CFG, **(cfg or {}))
+    C = cfg["num_attention_heads"] * cfg["attention_head_dim"]
+    s = {"controlnet.0.before_proj.weight": (C, C), "controlnet.0.before_proj.bias": (C,)}
+    for i in range(copy_blocks_num):
+        s[f"controlnet.{i}.after_proj.weight"], s[f"controlnet.{i}.after_proj.bias"] = (C, C), (C,)
+        for k, v in base.items():
+            if k.startswith("transformer_blocks.0."):
+                s[f"controlnet.{i}.copied_block." + k[len("transformer_blocks.0."):]] = v
     return s

@@ -41,27 +41,60 @@ def test_vae_matches_reference():
         torch.testing.assert_close(ovae.vae_decode(sd, fx[k], cfg), fx[k + "_dec"], rtol=1e-4, atol=2e-5)
 
 
+def _pixart_block_shapes(p, C):
+    return {p + "scale_shift_table": (6, C), p + "attn.qkv.weight": (3 * C, C), p + "attn.qkv.bias": (3 * C,),
+            p + "attn.proj.weight": (C, C), p + "attn.proj.bias": (C,), p + "cross_attn.q_linear.weight": (C, C),
+            p + "cross_attn.q_linear.bias": (C,), p + "cross_attn.kv_linear.weight": (2 * C, C), p + "cross_attn.kv_linear.bias": (2 * C,),
+            p + "cross_attn.proj.weight": (C, C), p + "cross_attn.proj.bias": (C,), p + "mlp.fc1.weight": (4 * C, C),
+            p + "mlp.fc1.bias": (4 * C,), p + "mlp.fc2.weight": (C, 4 * C), p + "mlp.fc2.bias": (C,)}
+
+
+def _pixart_shapes(depth, C, cap, prefix=""):
+    """in-tree PixArtMS parameter names (what make_golden.py seeded)"""
+    shapes = {"x_embedder.proj.weight": (C, 4, 2, 2), "x_embedder.proj.bias": (C,),
+              "t_embedder.mlp.0.weight": (C, 256), "t_embedder.mlp.0.bias": (C,), "t_embedder.mlp.2.weight": (C, C), "t_embedder.mlp.2.bias": (C,),
+              "t_block.1.weight": (6 * C, C), "t_block.1.bias": (6 * C,),
+              "y_embedder.y_proj.fc1.weight": (C, cap), "y_embedder.y_proj.fc1.bias": (C,),
+              "y_embedder.y_proj.fc2.weight": (C, C), "y_embedder.y_proj.fc2.bias": (C,),
+              "final_layer.linear.weight": (32, C), "final_layer.linear.bias": (32,), "final_layer.scale_shift_table": (2, C)}
+    for d in range(depth):
+        shapes.update(_pixart_block_shapes(f"blocks.{d}.", C))
+    return {prefix + k: v for k, v in shapes.items()}
+
+
 def _dit_small():
     depth, heads, hidden, cap = 2, 2, 144, 64
-    shapes = {}
-    # in-tree PixArtMS parameter names (what make_golden.py seeded), converted with the restated key map
-    C = hidden
-    shapes.update({"x_embedder.proj.weight": (C, 4, 2, 2), "x_embedder.proj.bias": (C,),
-                   "t_embedder.mlp.0.weight": (C, 256), "t_embedder.mlp.0.bias": (C,), "t_embedder.mlp.2.weight": (C, C), "t_embedder.mlp.2.bias": (C,),
-                   "t_block.1.weight": (6 * C, C), "t_block.1.bias": (6 * C,),
-                   "y_embedder.y_proj.fc1.weight": (C, cap), "y_embedder.y_proj.fc1.bias": (C,),
-                   "y_embedder.y_proj.fc2.weight": (C, C), "y_embedder.y_proj.fc2.bias": (C,),
-                   "final_layer.linear.weight": (32, C), "final_layer.linear.bias": (32,), "final_layer.scale_shift_table": (2, C)})
-    for d in range(depth):
-        p = f"blocks.{d}."
-        shapes.update({p + "scale_shift_table": (6, C), p + "attn.qkv.weight": (3 * C, C), p + "attn.qkv.bias": (3 * C,),
-                       p + "attn.proj.weight": (C, C), p + "attn.proj.bias": (C,), p + "cross_attn.q_linear.weight": (C, C),
-                       p + "cross_attn.q_linear.bias": (C,), p + "cross_attn.kv_linear.weight": (2 * C, C), p + "cross_attn.kv_linear.bias": (2 * C,),
-                       p + "cross_attn.proj.weight": (C, C), p + "cross_attn.proj.bias": (C,), p + "mlp.fc1.weight": (4 * C, C),
-                       p + "mlp.fc1.bias": (4 * C,), p + "mlp.fc2.weight": (C, 4 * C), p + "mlp.fc2.bias": (C,)})
-    sd = det_state_dict(shapes, seed=303)
+    sd = det_state_dict(_pixart_shapes(depth, hidden, cap), seed=303)  # converted below with the restated key map
     cfg = dict(num_layers=depth, num_attention_heads=heads, attention_head_dim=hidden // heads, sample_size=16, caption_channels=cap)
     return sd, odit.pixart_to_diffusers(sd, depth), cfg
+
+
+def _dit_control_small():
+    depth, heads, hidden, cap, ncopy = 4, 2, 144, 64, 2
+    shapes = _pixart_shapes(depth, hidden, cap, "base_model.")
+    for i in range(ncopy):
+        shapes.update(_pixart_block_shapes(f"controlnet.{i}.copied_block.", hidden))
+        for n in ("after_proj",) + (("before_proj",) if i == 0 else ()):
+            shapes.update({f"controlnet.{i}.{n}.weight": (hidden, hidden), f"controlnet.{i}.{n}.bias": (hidden,)})
+    sd = det_state_dict(shapes, seed=404)
+    bsd = {k[len("base_model."):]: v for k, v in sd.items() if k.startswith("base_model.")}
+    dsd = dict(odit.pixart_to_diffusers(bsd, depth), **odit.control_to_diffusers(sd, ncopy))
+    cfg = dict(num_layers=depth, num_attention_heads=heads, attention_head_dim=hidden // heads, sample_size=16, caption_channels=cap,
+               copy_blocks_num=ncopy)
+    return sd, dsd, cfg
+
+
+def test_dit_control_matches_reference_wiring():
+    """ControlNet-Half branch (pixart_controlnet.py:40-128) against the fixture made from the reference."""
+    fx = load("dit_control_small.npz")
+    sd, dsd, cfg = _dit_control_small()
+    assert abs(checksum(sd) - float(fx["wsum"])) < 1e-6 * float(fx["wsum"])
+    assert abs(checksum(dsd) - float(fx["wsum_diffusers"])) < 1e-6 * float(fx["wsum_diffusers"])
+    out = odit.dit_forward(dsd, fx["lat"], 400.0, fx["y"], None, cfg, c=fx["c"])
+    torch.testing.assert_close(out, fx["out_c"], rtol=2e-4, atol=2e-5)
+    out0 = odit.dit_forward(dsd, fx["lat"], 400.0, fx["y"], None, cfg)
+    torch.testing.assert_close(out0, fx["out_0"], rtol=2e-4, atol=2e-5)
+    assert (fx["out_c"] - fx["out_0"]).abs().max() > 1e-2  # the control branch really contributes in the fixture
 
 
 def test_dit_matches_reference_wiring():
