@@ -411,6 +411,109 @@ class Transformer2DModel(_DeviceModule):
         return out
 
 
+class ControlTransformerHalf(_DeviceModule):
+    """ControlNet-Half over the DiT (diffusion/model/nets/transformer_controlnet.py:58-173): copies of the
+    first copy_blocks_num blocks run on the patch-embedded condition latent `c`, and block i (1..copy_blocks_num) of the base model
+    receives x + after_proj(copy i-1). Same constructor, state-dict layout (`base_model.*`, `controlnet.{i}.copied_block.*`,
+    `controlnet.{i}.after_proj`, `controlnet.0.before_proj`) and call signature as the reference class; attributes it does not
+    define fall through to the base model, as the reference's __getattr__ does (:78-84)."""
+
+    def __init__(self, base_model, copy_blocks_num=13):
+        super().__init__()
+        if not isinstance(base_model, Transformer2DModel):
+            raise TypeError("base_model must be an instarevive_amd Transformer2DModel")
+        if not 1 <= copy_blocks_num < base_model.cfg["num_layers"]:
+            raise ValueError(f"copy_blocks_num must be in 1..{base_model.cfg['num_layers'] - 1}")
+        self.base_model = base_model
+        self.copy_blocks_num = copy_blocks_num
+        self.total_blocks_num = base_model.cfg["num_layers"]
+        if base_model._sd is not None:  # the copies start as clones of the base blocks, the projections as zeros (:23-39)
+            C_ = base_model.cfg["num_attention_heads"] * base_model.cfg["attention_head_dim"]
+            sd = {}
+            for i in range(copy_blocks_num):
+                for k in W._dit_block_keys(""):
+                    sd[f"controlnet.{i}.copied_block.{k}"] = base_model._sd[f"transformer_blocks.{i}.{k}"].clone()
+                for n_ in (("before_proj",) if i == 0 else ()) + ("after_proj",):
+                    sd[f"controlnet.{i}.{n_}.weight"], sd[f"controlnet.{i}.{n_}.bias"] = torch.zeros(C_, C_), torch.zeros(C_)
+            self._sd = sd
+        if base_model.ctx is not None:
+            self.to(base_model.device)
+
+    def __getattr__(self, name):  # only reached for names not set on the wrapper
+        if name in ("base_model", "_sd", "ctx"):
+            raise AttributeError(name)
+        return getattr(self.base_model, name)
+
+    def _expected_keys(self):
+        return W.dit_control_expected_keys(self.copy_blocks_num)
+
+    def state_dict(self):
+        sd = {"base_model." + k: v for k, v in self.base_model.state_dict().items()}
+        sd.update(super().state_dict())
+        return sd
+
+    def load_state_dict(self, state_dict, strict=True):
+        if not all(k.startswith(("base_model", "controlnet")) for k in state_dict):  # a bare base checkpoint (:154-166 of the in-tree twin)
+            return self.base_model.load_state_dict(state_dict, strict)
+        base = {k[len("base_model."):]: v for k, v in state_dict.items() if k.startswith("base_model.")}
+        ctrl = {k: v for k, v in state_dict.items() if k.startswith("controlnet.")}
+        res = None
+        if base or strict:
+            res = self.base_model.load_state_dict(base, strict)
+        res2 = self._check_keys(ctrl, strict)
+        self._sd = {k: v.detach().cpu() for k, v in ctrl.items()}
+        if self.ctx is not None:
+            self._upload()
+        return res2 if res is None else res
+
+    def to(self, *args, **kwargs):
+        self.base_model.to(*args, **kwargs)
+        return super().to(*args, **kwargs)
+
+    def _upload(self):
+        if self.base_model.ctx is not self.ctx or self.base_model._sd is None:
+            raise RuntimeError("the base model must be loaded and on the same device before the control branch is uploaded")
+        self.ctx.upload_all(W.pack_dit_control(self._sd, self.copy_blocks_num))
+        self.ctx.check(self.ctx.lib.ir_dit_control_configure(self.ctx.h, self.copy_blocks_num), "ir_dit_control_configure")
+        self.base_model._prompt_key = None  # the control copies' prompt K/V caches are built by the next set_prompt
+
+    def _prep(self, hidden_states, c, encoder_hidden_states, encoder_attention_mask):
+        if c is None:
+            raise ValueError("ControlTransformerHalf needs the condition latent c (the reference dereferences it unconditionally, :44)")
+        self._ready()
+        self.base_model.set_prompt(encoder_hidden_states, encoder_attention_mask)
+        x = hidden_states.to(self.device, torch.float32).contiguous()
+        cc = c.to(self.device, torch.float32).contiguous()
+        n, ch, h, w = x.shape
+        if ch != 4 or h % 2 or w % 2 or cc.shape != x.shape:
+            raise ValueError(f"latents and c must both be [B,4,h,w] with even h,w, got {tuple(x.shape)} and {tuple(cc.shape)}")
+        self.base_model.ensure_pos(h // 2, w // 2)
+        return x, cc, self.ctx.workspace(self.ctx.ws_bytes(L.STAGE_DIT, n, h, w))
+
+    @torch.no_grad()
+    def __call__(self, hidden_states, encoder_hidden_states=None, timestep=None, added_cond_kwargs=None, class_labels=None,
+                 cross_attention_kwargs=None, attention_mask=None, encoder_attention_mask=None, c=None, return_dict=True):
+        x, cc, ws = self._prep(hidden_states, c, encoder_hidden_states, encoder_attention_mask)
+        n, _, h, w = x.shape
+        out = torch.empty(n, 8, h, w, dtype=torch.float32, device=self.device)
+        self.ctx.check(self.ctx.lib.ir_dit_forward_control(self.ctx.h, self.ctx.stream(), L.ptr(x), L.ptr(cc), self._scalar_timestep(timestep),
+                                                            L.ptr(out), n, h, w, L.ptr(ws), ws.numel()), "ir_dit_forward_control")
+        return out if return_dict else (out,)  # the reference returns the bare tensor here (:169-172), not a .sample holder
+
+    forward = __call__
+
+    @torch.no_grad()
+    def step(self, latents, timestep, alpha_cumprod, encoder_hidden_states, encoder_attention_mask=None, c=None):
+        """Fused generate_sample_1step(..., c=c) (generate.py:22-51): x0 from the eps half, inside the HIP path."""
+        x, cc, ws = self._prep(latents, c, encoder_hidden_states, encoder_attention_mask)
+        n, _, h, w = x.shape
+        out = torch.empty_like(x)
+        self.ctx.check(self.ctx.lib.ir_dit_step_control(self.ctx.h, self.ctx.stream(), L.ptr(x), L.ptr(cc), L.ptr(out), n, h, w,
+                                                         self._scalar_timestep(timestep), float(alpha_cumprod), L.ptr(ws), ws.numel()),
+                       "ir_dit_step_control")
+        return out
+
+
 # ====================================================================================================== scheduler
 class DDPMScheduler:
     """Only what the path consumes: alphas_cumprod (generate.py:45). Linear / scaled_linear betas like diffusers."""

@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from . import _lib as L
-from .models import AutoencoderKL, DDPMScheduler, SwinIR, Transformer2DModel
+from .models import AutoencoderKL, ControlTransformerHalf, DDPMScheduler, SwinIR, Transformer2DModel
 
 
 def _sliding_windows(h: int, w: int, tile_size: int, tile_stride: int):
@@ -34,12 +34,14 @@ def eps_to_mu(scheduler, model_output, sample, timesteps):
 
 
 def forward_model(model, latents, timestep, prompt_embeds, prompt_attention_masks=None, c=None):
-    if c is not None:
-        raise NotImplementedError("ControlNet-conditioned variants have no released weights (SURVEY.md section 8(f) N1)")
     added = {"resolution": None, "aspect_ratio": None}
     timestep = timestep.expand(latents.shape[0])
-    noise_pred = model(latents, timestep=timestep, encoder_hidden_states=prompt_embeds, encoder_attention_mask=prompt_attention_masks,
-                       added_cond_kwargs=added).sample
+    if c is None:
+        noise_pred = model(latents, timestep=timestep, encoder_hidden_states=prompt_embeds, encoder_attention_mask=prompt_attention_masks,
+                           added_cond_kwargs=added).sample
+    else:  # ControlTransformerHalf returns the tensor itself (generate.py:74-82)
+        noise_pred = model(latents, timestep=timestep, encoder_hidden_states=prompt_embeds, encoder_attention_mask=prompt_attention_masks,
+                           added_cond_kwargs=added, c=c)
     if model.config.out_channels // 2 == latents.shape[1]:
         noise_pred = noise_pred.chunk(2, dim=1)[0]
     return noise_pred
@@ -48,6 +50,8 @@ def forward_model(model, latents, timestep, prompt_embeds, prompt_attention_mask
 def generate_sample_1step(model, scheduler, latents, maxt, prompt_embeds, prompt_attention_masks=None, c=None):
     if isinstance(model, Transformer2DModel) and c is None:  # fused epilogue: eps half + eps_to_mu inside the HIP path
         return model.step(latents, float(maxt), float(scheduler.alphas_cumprod[int(maxt)]), prompt_embeds, prompt_attention_masks)
+    if isinstance(model, ControlTransformerHalf) and c is not None:
+        return model.step(latents, float(maxt), float(scheduler.alphas_cumprod[int(maxt)]), prompt_embeds, prompt_attention_masks, c=c)
     t = torch.full((1,), maxt, device=latents.device).long()
     noise_pred = forward_model(model, latents=latents, timestep=t, prompt_embeds=prompt_embeds, prompt_attention_masks=prompt_attention_masks, c=c)
     return eps_to_mu(scheduler, noise_pred, latents, t)

@@ -202,6 +202,14 @@ def pack_vae(sd, cfg, encoder=True, decoder=True):
 
 
 # ------------------------------------------------------------------------------------------------ DiT (diffusers keys)
+def _dit_block_keys(p):
+    keys = [p + "scale_shift_table"]
+    for a in ("attn1", "attn2"):
+        for n in ("to_q", "to_k", "to_v", "to_out.0"):
+            keys += [p + f"{a}.{n}.weight", p + f"{a}.{n}.bias"]
+    return keys + [p + "ff.net.0.proj.weight", p + "ff.net.0.proj.bias", p + "ff.net.2.weight", p + "ff.net.2.bias"]
+
+
 def dit_expected_keys(cfg):
     keys = []
     for base in ("pos_embed.proj", "caption_projection.linear_1", "caption_projection.linear_2", "adaln_single.emb.timestep_embedder.linear_1",
@@ -209,44 +217,62 @@ def dit_expected_keys(cfg):
         keys += [base + ".weight", base + ".bias"]
     keys.append("scale_shift_table")
     for d in range(cfg["num_layers"]):
-        p = f"transformer_blocks.{d}."
-        keys.append(p + "scale_shift_table")
-        for a in ("attn1", "attn2"):
-            for n in ("to_q", "to_k", "to_v", "to_out.0"):
-                keys += [p + f"{a}.{n}.weight", p + f"{a}.{n}.bias"]
-        keys += [p + "ff.net.0.proj.weight", p + "ff.net.0.proj.bias", p + "ff.net.2.weight", p + "ff.net.2.bias"]
+        keys += _dit_block_keys(f"transformer_blocks.{d}.")
     return keys
 
 
+def dit_control_expected_keys(copy_blocks_num):
+    """Parameters ControlTransformerHalf adds to its base model (transformer_controlnet.py:19-39,62-76)."""
+    keys = []
+    for i in range(copy_blocks_num):
+        keys += _dit_block_keys(f"controlnet.{i}.copied_block.")
+        for n in (("before_proj",) if i == 0 else ()) + ("after_proj",):
+            keys += [f"controlnet.{i}.{n}.weight", f"controlnet.{i}.{n}.bias"]
+    return keys
+
+
+def _pack_lin(out, dst, w, b, k_pad=None, n_pad=None):
+    w = w.reshape(w.shape[0], -1)
+    out[dst + ".w"] = pack_linear(w, n_pad or w.shape[0], k_pad or w.shape[1])
+    out[dst + ".b"] = pad_vec(b, n_pad or w.shape[0])
+
+
+def _pack_dit_block(out, sd, s, p):
+    """One BasicTransformerBlock: diffusers keys under prefix s -> device tensors under prefix p (q|k|v and k|v fused)."""
+    out[p + "sst"] = sd[s + "scale_shift_table"].float().contiguous()
+    _pack_lin(out, p + "qkv", torch.cat([sd[s + f"attn1.{n}.weight"] for n in ("to_q", "to_k", "to_v")], 0),
+              torch.cat([sd[s + f"attn1.{n}.bias"] for n in ("to_q", "to_k", "to_v")], 0))
+    _pack_lin(out, p + "ao", sd[s + "attn1.to_out.0.weight"], sd[s + "attn1.to_out.0.bias"])
+    _pack_lin(out, p + "cq", sd[s + "attn2.to_q.weight"], sd[s + "attn2.to_q.bias"])
+    _pack_lin(out, p + "ckv", torch.cat([sd[s + "attn2.to_k.weight"], sd[s + "attn2.to_v.weight"]], 0),
+              torch.cat([sd[s + "attn2.to_k.bias"], sd[s + "attn2.to_v.bias"]], 0))
+    _pack_lin(out, p + "co", sd[s + "attn2.to_out.0.weight"], sd[s + "attn2.to_out.0.bias"])
+    _pack_lin(out, p + "fc1", sd[s + "ff.net.0.proj.weight"], sd[s + "ff.net.0.proj.bias"])
+    _pack_lin(out, p + "fc2", sd[s + "ff.net.2.weight"], sd[s + "ff.net.2.bias"])
+
+
 def pack_dit(sd, cfg):
-    C = cfg["num_attention_heads"] * cfg["attention_head_dim"]
     out = {}
-
-    def lin(dst, w, b, k_pad=None, n_pad=None):
-        w = w.reshape(w.shape[0], -1)
-        out[dst + ".w"] = pack_linear(w, n_pad or w.shape[0], k_pad or w.shape[1])
-        out[dst + ".b"] = pad_vec(b, n_pad or w.shape[0])
-
-    lin("dit.patch", sd["pos_embed.proj.weight"], sd["pos_embed.proj.bias"], k_pad=32)  # k = c*4 + p*2 + q
-    lin("dit.cap1", sd["caption_projection.linear_1.weight"], sd["caption_projection.linear_1.bias"])
-    lin("dit.cap2", sd["caption_projection.linear_2.weight"], sd["caption_projection.linear_2.bias"])
-    lin("dit.final", sd["proj_out.weight"], sd["proj_out.bias"], n_pad=32)
+    _pack_lin(out, "dit.patch", sd["pos_embed.proj.weight"], sd["pos_embed.proj.bias"], k_pad=32)  # k = c*4 + p*2 + q
+    _pack_lin(out, "dit.cap1", sd["caption_projection.linear_1.weight"], sd["caption_projection.linear_1.bias"])
+    _pack_lin(out, "dit.cap2", sd["caption_projection.linear_2.weight"], sd["caption_projection.linear_2.bias"])
+    _pack_lin(out, "dit.final", sd["proj_out.weight"], sd["proj_out.bias"], n_pad=32)
     for dst, src in (("dit.temb1", "adaln_single.emb.timestep_embedder.linear_1"), ("dit.temb2", "adaln_single.emb.timestep_embedder.linear_2"),
                      ("dit.tblock", "adaln_single.linear")):
         out[dst + ".w"], out[dst + ".b"] = sd[src + ".weight"].float().contiguous(), sd[src + ".bias"].float().contiguous()
     out["dit.final_sst"] = sd["scale_shift_table"].float().contiguous()
     for d in range(cfg["num_layers"]):
-        s, p = f"transformer_blocks.{d}.", f"dit.l{d}."
-        out[p + "sst"] = sd[s + "scale_shift_table"].float().contiguous()
-        lin(p + "qkv", torch.cat([sd[s + f"attn1.{n}.weight"] for n in ("to_q", "to_k", "to_v")], 0),
-            torch.cat([sd[s + f"attn1.{n}.bias"] for n in ("to_q", "to_k", "to_v")], 0))
-        lin(p + "ao", sd[s + "attn1.to_out.0.weight"], sd[s + "attn1.to_out.0.bias"])
-        lin(p + "cq", sd[s + "attn2.to_q.weight"], sd[s + "attn2.to_q.bias"])
-        lin(p + "ckv", torch.cat([sd[s + "attn2.to_k.weight"], sd[s + "attn2.to_v.weight"]], 0),
-            torch.cat([sd[s + "attn2.to_k.bias"], sd[s + "attn2.to_v.bias"]], 0))
-        lin(p + "co", sd[s + "attn2.to_out.0.weight"], sd[s + "attn2.to_out.0.bias"])
-        lin(p + "fc1", sd[s + "ff.net.0.proj.weight"], sd[s + "ff.net.0.proj.bias"])
-        lin(p + "fc2", sd[s + "ff.net.2.weight"], sd[s + "ff.net.2.bias"])
+        _pack_dit_block(out, sd, f"transformer_blocks.{d}.", f"dit.l{d}.")
+    return out
+
+
+def pack_dit_control(sd, copy_blocks_num):
+    """controlnet.{i}.copied_block.* / .after_proj / controlnet.0.before_proj -> dit.ctrl{i}.* (ir_dit_control_configure)."""
+    out = {}
+    for i in range(copy_blocks_num):
+        _pack_dit_block(out, sd, f"controlnet.{i}.copied_block.", f"dit.ctrl{i}.")
+        _pack_lin(out, f"dit.ctrl{i}.after", sd[f"controlnet.{i}.after_proj.weight"], sd[f"controlnet.{i}.after_proj.bias"])
+    _pack_lin(out, "dit.ctrl0.before", sd["controlnet.0.before_proj.weight"], sd["controlnet.0.before_proj.bias"])
     return out
 
 

@@ -134,6 +134,83 @@ def test_dit_step_matches_eps_to_mu():
     torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
 
 
+def make_dit_control(cfg, ncopy, seed=505):
+    """Base DiT + ControlTransformerHalf, both loaded through the wrapper's state-dict layout (base_model.* / controlnet.*)."""
+    from instarevive_amd.models import ControlTransformerHalf
+    base, _ = make_dit(cfg)
+    sd = det_state_dict(dict({"base_model." + k: v for k, v in odit.state_dict_shapes(cfg).items()},
+                             **odit.control_state_dict_shapes(cfg, copy_blocks_num=ncopy)), seed=seed)
+    m = ControlTransformerHalf(base, copy_blocks_num=ncopy)
+    m.load_state_dict(sd, strict=True)
+    flat = {(k[len("base_model."):] if k.startswith("base_model.") else k): v for k, v in sd.items()}
+    return m, flat
+
+
+def test_dit_control_vs_reference_fixture():
+    """the HIP ControlNet-Half step against the output of the reference's ControlPixArtHalf."""
+    from instarevive_amd.models import ControlTransformerHalf, Transformer2DModel
+    from tests.test_oracle_golden import _dit_control_small
+    fx = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(G, "dit_control_small.npz")).items() if v.dtype.kind == "f"}
+    _, dsd, cfg = _dit_control_small()
+    base = Transformer2DModel(num_attention_heads=cfg["num_attention_heads"], attention_head_dim=cfg["attention_head_dim"],
+                              num_layers=cfg["num_layers"], sample_size=16, caption_channels=cfg["caption_channels"], cross_attention_dim=288)
+    m = ControlTransformerHalf(base, copy_blocks_num=cfg["copy_blocks_num"])
+    m.load_state_dict({("base_model." + k if not k.startswith("controlnet.") else k): v for k, v in dsd.items()}, strict=True)
+    m.to("cuda")
+    y = fx["y"][None]
+    kw = dict(timestep=torch.full((1,), 400), encoder_hidden_states=y.cuda(), added_cond_kwargs={"resolution": None, "aspect_ratio": None})
+    check(m(fx["lat"].cuda(), c=fx["c"].cuda(), **kw), fx["out_c"], "control dit vs reference fixture")
+    check(base(fx["lat"].cuda(), **kw).sample, fx["out_0"], "base dit of the control fixture, c=None")
+
+
+def test_dit_control_small_vs_oracle():
+    from instarevive_amd.models import DDPMScheduler
+    from instarevive_amd.pipeline import eps_to_mu, forward_model, generate_sample_1step
+    cfg = dict(DIT_SMALL, num_layers=4)
+    m, sd = make_dit_control(cfg, 2)
+    y, mask3 = _prompt(cfg)
+    for shape in ((1, 4, 16, 16), (2, 4, 16, 24)):
+        lat, c = det_input(sum(shape), shape, -2, 2), det_input(sum(shape) + 1, shape, -2, 2)
+        ref = odit.dit_forward(sd, lat, 400.0, y, mask3, dict(cfg, copy_blocks_num=2), c=c)
+        out = m(lat.cuda(), timestep=torch.full((lat.shape[0],), 400), encoder_hidden_states=y.cuda(), encoder_attention_mask=mask3.cuda(),
+                added_cond_kwargs={"resolution": None, "aspect_ratio": None}, c=c.cuda())
+        check(out, ref, f"control dit small {shape}")
+        assert rel_l2(out.cpu(), odit.dit_forward(sd, lat, 400.0, y, mask3, cfg)) > 0.05  # the branch is not a no-op here
+    # fused step == forward_model + eps_to_mu through the reference's hook (generate.py:22-51 with c)
+    sch, t = DDPMScheduler(), torch.full((1,), 400).long()
+    lat, c = det_input(41, (1, 4, 16, 16), -2, 2).cuda(), det_input(42, (1, 4, 16, 16), -2, 2).cuda()
+    want = eps_to_mu(sch, forward_model(m, lat, t, y.cuda(), mask3.cuda(), c=c), lat, t.cuda())
+    got = generate_sample_1step(m, sch, lat, 400, y.cuda(), mask3.cuda(), c=c)
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)
+    with pytest.raises(ValueError):
+        m(lat, timestep=t, encoder_hidden_states=y.cuda(), c=None)
+
+
+def test_dit_control_zero_init_is_the_base_model():
+    """A freshly wrapped model (zero before/after projections, transformer_controlnet.py:33-39) must reproduce its base model."""
+    from instarevive_amd.models import ControlTransformerHalf
+    cfg = dict(DIT_SMALL, num_layers=3)
+    base, _ = make_dit(cfg)
+    m = ControlTransformerHalf(base, copy_blocks_num=2)
+    assert set(m.state_dict()) == {"base_model." + k for k in odit.state_dict_shapes(cfg)} | set(odit.control_state_dict_shapes(cfg, copy_blocks_num=2))
+    y, mask3 = _prompt(cfg)
+    lat, c = det_input(51, (1, 4, 16, 16), -2, 2).cuda(), det_input(52, (1, 4, 16, 16), -2, 2).cuda()
+    kw = dict(timestep=torch.full((1,), 400), encoder_hidden_states=y.cuda(), encoder_attention_mask=mask3.cuda())
+    torch.testing.assert_close(m(lat, c=c, **kw), base(lat, **kw).sample, rtol=0, atol=0)
+    with pytest.raises(ValueError):
+        ControlTransformerHalf(base, copy_blocks_num=3)
+
+
+def test_dit_control_full_arch_256_tokens():
+    """28 blocks + 13 copies at the released width (1152, 16 heads of 72), 32x32 latent: the kernels the 512 px path runs."""
+    m, sd = make_dit_control(dict(caption_channels=64), 13, seed=606)
+    y, mask3 = _prompt(dict(caption_channels=64), ntok=40, valid=29)
+    lat, c = det_input(61, (1, 4, 32, 32), -2, 2), det_input(62, (1, 4, 32, 32), -2, 2)
+    ref = odit.dit_forward(sd, lat, 400.0, y, mask3, dict(caption_channels=64), c=c)
+    out = m(lat.cuda(), timestep=torch.full((1,), 400), encoder_hidden_states=y.cuda(), encoder_attention_mask=mask3.cuda(), c=c.cuda())
+    check(out, ref, "control dit full arch 32x32", l2=0.03)
+
+
 def _small_models():
     return make_swin(SWIN_SMALL), make_vae(VAE_SMALL), make_dit(DIT_SMALL)
 

@@ -70,7 +70,7 @@ def _dit_small():
 
 
 def _dit_control_small():
-    depth, heads, hidden, cap, ncopy = 4, 2, 144, 64, 2
+    depth, heads, hidden, cap, ncopy = 4, 4, 288, 64, 2
     shapes = _pixart_shapes(depth, hidden, cap, "base_model.")
     for i in range(ncopy):
         shapes.update(_pixart_block_shapes(f"controlnet.{i}.copied_block.", hidden))
