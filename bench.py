@@ -33,7 +33,7 @@ PEAK_HBM_GBS = 8000.0
 
 
 # ---------------------------------------------------------------- algorithmic FLOP model (BASELINE.md section 2, 2*MAC, matmul/conv only)
-def flops_model(h, w, n_tok=300):
+def flops_model(h, w, n_tok=300, copies=0):
     px = h * w
     swin = 0.1815e12 / (512 * 512) * px                       # linear in pixels
     t_vae = px // 64
@@ -43,6 +43,9 @@ def flops_model(h, w, n_tok=300):
     C, L = 1152, 28
     dit = (14 * C * C * 2 * L + 4 * n_tok * C * L) * t + (n_tok * 2 * C * C * 2 * L + n_tok * (4096 * C + C * C) * 2) + 4.0 * t * t * C * L \
         + t * (16 * C + 32 * C) * 2
+    if copies:  # ControlNet-Half: `copies` more blocks (with their prompt K/V), after_proj each, before_proj, patch embedding of c
+        dit += (14 * C * C * 2 + 4 * n_tok * C) * copies * t + n_tok * 2 * C * C * 2 * copies + 4.0 * t * t * C * copies \
+            + (copies + 1) * 2 * C * C * t + t * 16 * C * 2
     return dict(swinir=swin, vae_encode=enc, dit=dit, vae_decode=dec, total=swin + enc + dit + dec)
 
 
@@ -84,8 +87,8 @@ def random_state_dict(shapes, seed):
     return sd
 
 
-def build_models(device, log):
-    from instarevive_amd.models import AutoencoderKL, DDPMScheduler, SwinIR, Transformer2DModel
+def build_models(device, log, control=0):
+    from instarevive_amd.models import AutoencoderKL, ControlTransformerHalf, DDPMScheduler, SwinIR, Transformer2DModel
     from instarevive_amd import weights as W
     t0 = time.time()
     swin_cfg = dict(embed_dim=180, depths=[6] * 8, num_heads=[6] * 8, window_size=8, mlp_ratio=2)
@@ -101,6 +104,11 @@ def build_models(device, log):
     dit.load_state_dict(sds["dit"])
     for m in (swin, vae, dit):
         m.to(device)
+    if control:  # ControlNet-Half branch with seeded non-zero projections (zero-initialised ones would still run the same kernels)
+        ctl = ControlTransformerHalf(dit, copy_blocks_num=control)
+        g = torch.Generator().manual_seed(4)
+        ctl.load_state_dict(dict({"base_model." + k: v for k, v in sds["dit"].items()},
+                                 **{k: (v if "copied_block" in k else (torch.rand(v.shape, generator=g) - 0.5) * 0.05) for k, v in ctl._sd.items()}))
     log(f"models built and uploaded in {time.time() - t0:.1f}s")
     return swin, vae, dit, DDPMScheduler(), sds
 
@@ -161,6 +169,8 @@ def main():
     ap.add_argument("--tiled", action="store_true")
     ap.add_argument("--net_hw", type=str, default="", help="HxW network input (overrides --lq/--sr_scale), e.g. 2176x3840 for the padded 4K case")
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--control", type=int, default=0, metavar="COPIES", help="diagnostic: run the DiT step with the ControlNet-Half branch "
+                    "(COPIES copied blocks, 13 in the reference configs; c = the LQ latent). Not the headline workload: no such weights are released")
     ap.add_argument("--no_profile", action="store_true", help="experiment: time the loop without the per-launch HIP events (no roofline)")
     args = ap.parse_args()
 
@@ -182,7 +192,7 @@ def main():
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
     from instarevive_amd import _lib as L
-    swin, vae, dit, sched, sds = build_models(device, log)
+    swin, vae, dit, sched, sds = build_models(device, log, args.control)
     ctx = dit.ctx
     y, mask = synthetic_prompt()
     dit.set_prompt(y.to(device), mask.to(device))
@@ -195,7 +205,7 @@ def main():
         net_in = upscale_bicubic(lq, args.sr_scale) if args.sr_scale != 1 else lq    # inference.py:265-269 (host, outside the timed region)
     n, h, w = net_in.shape[:3]
     assert h % 64 == 0 and w % 64 == 0
-    flags = (L.FLAG_TILED | L.FLAG_FIX_WAVELET) if args.tiled else 0
+    flags = ((L.FLAG_TILED | L.FLAG_FIX_WAVELET) if args.tiled else 0) | (L.FLAG_CONTROL_LQ if args.control else 0)
     tile_size, tile_stride = 512, 448
     if args.tiled:
         dit.ensure_pos(tile_size // 16, tile_size // 16)
@@ -239,7 +249,7 @@ def main():
     value = world * n * args.steps / dt
 
     if rank == 0:
-        fm = flops_model(h, w)
+        fm = flops_model(h, w, copies=args.control)
         total_ms = sum(v["ms"] for v in prof.values())
         dom = max(prof, key=lambda k: prof[k]["ms"])
         for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
@@ -270,14 +280,15 @@ def main():
                         traffic=None, launches_per_step=d["launches"] // args.steps, avg_launch_ms=round(d["ms"] / max(d["launches"], 1), 4),
                         share_of_gpu_time=round(d["ms"] / total_ms, 3))
         cpu = None
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.control:  # the CPU baseline times the headline workload only
             cpu = cpu_baseline(sds, y, mask, h, w, log)
         print(json.dumps({
             "metric": "512->2048 one-step SR images/sec", "value": round(value, 4), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{args.lq}x{args.lq} LQ, sr_scale {args.sr_scale:g} -> {h}x{w} network input, "
-                                   f"{'tiled 512/448 + wavelet' if args.tiled else 'untiled'}, batch {n} per GPU, full SwinIR->VAE-enc->DiT(t=400)->VAE-dec path",
+                                   f"{'tiled 512/448 + wavelet' if args.tiled else 'untiled'}, batch {n} per GPU, full SwinIR->VAE-enc->DiT(t=400)->VAE-dec path"
+                                   + (f" + ControlNet-Half ({args.control} copied blocks, c = LQ latent)" if args.control else ""),
                        "parallelism": f"dp{world}", "weights": "seeded random, full-size architectures"},
             "algorithmic_tflop_per_image": round(fm["total"] / 1e12, 2),
             "path_tflops": round(fm["total"] * n * world / (ms_per_step / 1e3) / 1e12, 1),

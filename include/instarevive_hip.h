@@ -25,7 +25,11 @@ typedef struct ir_ctx ir_ctx;
 enum { IR_STAGE_SWINIR = 0, IR_STAGE_VAE_ENCODE = 1, IR_STAGE_DIT = 2, IR_STAGE_VAE_DECODE = 3, IR_STAGE_PIPELINE = 4,
        IR_STAGE_COLORFIX = 5 };
 /* ir_pipeline flags */
-enum { IR_FLAG_NO_PREPROCESS = 1, IR_FLAG_TILED = 2, IR_FLAG_FIX_WAVELET = 4, IR_FLAG_FIX_ADAIN = 8 };
+enum { IR_FLAG_NO_PREPROCESS = 1, IR_FLAG_TILED = 2, IR_FLAG_FIX_WAVELET = 4, IR_FLAG_FIX_ADAIN = 8,
+       /* ir_pipeline only, needs ir_dit_control_configure: run the DiT step with the ControlNet-Half branch, condition latent
+        * c = the scaled LQ latent the step starts from (per tile under IR_FLAG_TILED). The reference's process() never passes c
+        * (inference.py:114,131); this is the generate_sample_1step(..., c=) hook (generate.py:32-40) applied to that call. */
+       IR_FLAG_CONTROL_LQ = 16 };
 
 int ir_abi_version(void);
 int ir_init(int device, ir_ctx** out);

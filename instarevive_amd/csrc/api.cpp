@@ -719,7 +719,7 @@ void pipeline_run(Run& r, const uint8_t* in, uint8_t* out, uint8_t* stage1, int 
         const float* pos = dit_pos(c, lh / 2, lw / 2, r.a.dry);
         if (!pos) { r.chk(-30, "dit.pos table for this size not uploaded"); r.a.release(mk); return; }
         const size_t mk2 = r.a.mark();
-        float* tok = dit_tokens_run(r, init, n, lh, lw, timestep, pos);
+        float* tok = dit_tokens_run(r, init, n, lh, lw, timestep, pos, (flags & IR_FLAG_CONTROL_LQ) ? init : nullptr);
         float* x0 = r.a.alloc<float>((long)n * 4 * lh * lw);
         LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_eps_to_x0(tok, init, x0, n, lh / 2, lw / 2, s0, s1, 1.0f / sf, r.s), "eps_to_x0");
         float* o4 = r.a.alloc<float>(n * HW * 4);
@@ -751,7 +751,7 @@ void pipeline_run(Run& r, const uint8_t* in, uint8_t* out, uint8_t* stage1, int 
             const size_t mk2 = r.a.mark();
             for (int j = 0; j < cb; ++j)
                 LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_crop_nchw(init, tl_in + j * lat_tile, n, 4, lh, lw, tiles[c0 + j].first, tiles[c0 + j].second, tl, tl, 1.f, r.s), "crop");
-            float* tok = dit_tokens_run(r, tl_in, cb * n, tl, tl, timestep, pos);
+            float* tok = dit_tokens_run(r, tl_in, cb * n, tl, tl, timestep, pos, (flags & IR_FLAG_CONTROL_LQ) ? tl_in : nullptr);
             LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_eps_to_x0(tok, tl_in, tl_x0, cb * n, tl / 2, tl / 2, s0, s1, 1.f, r.s), "eps_to_x0");
             for (int j = 0; j < cb; ++j)
                 LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_tile_add(nb, tl_x0 + j * lat_tile, n, 4, lh, lw, tl, tl, tiles[c0 + j].first, tiles[c0 + j].second, r.s), "tile_add");
@@ -1217,6 +1217,7 @@ int ir_pipeline(ir_ctx* c, void* stream, const uint8_t* in, uint8_t* out, uint8_
     REQUIRE(c && c->vae.enc.ok && c->vae.dec.ok && c->dit.ok && c->dit.prompt_ok, "pipeline: VAE / DiT / prompt not configured");
     REQUIRE((flags & IR_FLAG_NO_PREPROCESS) || c->swin.ok, "pipeline: SwinIR not configured");
     REQUIRE(acp > 0.f && acp < 1.f && sf > 0.f, "pipeline: bad alpha_cumprod / scaling factor");
+    REQUIRE(!(flags & IR_FLAG_CONTROL_LQ) || c->dit.ncopy > 0, "pipeline: IR_FLAG_CONTROL_LQ without ir_dit_control_configure");
     if (int e = check_size(c, n, h, w, 64)) return e;
     Run r = make_run(c, stream, ws, ws_bytes, false);
     pipeline_run(r, in, out, stage1, n, h, w, flags, tile_size, tile_stride, timestep, acp, sf);

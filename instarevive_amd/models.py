@@ -454,7 +454,10 @@ class ControlTransformerHalf(_DeviceModule):
 
     def load_state_dict(self, state_dict, strict=True):
         if not all(k.startswith(("base_model", "controlnet")) for k in state_dict):  # a bare base checkpoint (:154-166 of the in-tree twin)
-            return self.base_model.load_state_dict(state_dict, strict)
+            res = self.base_model.load_state_dict(state_dict, strict)
+            if self.ctx is not None and self._sd is not None:
+                self._upload()  # re-binding the base model dropped the device-side control branch
+            return res
         base = {k[len("base_model."):]: v for k, v in state_dict.items() if k.startswith("base_model.")}
         ctrl = {k: v for k, v in state_dict.items() if k.startswith("controlnet.")}
         res = None

@@ -81,7 +81,7 @@ def _color_fix(kind, content, style):
 
 
 def _fused_ok(model, preprocess_model, vae, disable_preprocess_model):
-    if not (isinstance(model, Transformer2DModel) and isinstance(vae, AutoencoderKL)):
+    if not (isinstance(model, (Transformer2DModel, ControlTransformerHalf)) and isinstance(vae, AutoencoderKL)):
         return False
     if not disable_preprocess_model and not isinstance(preprocess_model, SwinIR):
         return False
@@ -96,7 +96,10 @@ def process(model, control_imgs: List[np.ndarray], strength: float, color_fix_ty
             tile_size: int, tile_stride: int, preprocess_model=None, vae=None, y=None, y_mask=None, noise_scheduler=None,
             fused: bool = True) -> Tuple[List[np.ndarray], List[np.ndarray]]:
     """test_scripts/inference.py:55-166. control_imgs: list of HWC uint8 RGB arrays of equal size (multiples of 64).
-    Returns (preds, stage1_preds) as lists of HWC uint8 arrays."""
+    Returns (preds, stage1_preds) as lists of HWC uint8 arrays.
+
+    Extension (no reference counterpart: the reference's process() never passes c): when `model` is a ControlTransformerHalf, the
+    one-step call becomes generate_sample_1step(..., c=<the scaled LQ latent the step starts from>), per tile under `tiled`."""
     noise_scheduler = noise_scheduler or DDPMScheduler()
     n = len(control_imgs)
     imgs = np.ascontiguousarray(np.stack(control_imgs))
@@ -108,6 +111,7 @@ def process(model, control_imgs: List[np.ndarray], strength: float, color_fix_ty
     sf = float(vae.config.scaling_factor)
     if fused and _fused_ok(model, preprocess_model, vae, disable_preprocess_model):
         ctx = model.ctx
+        with_c = isinstance(model, ControlTransformerHalf)
         model.set_prompt(y, y_mask)
         if tiled:
             model.ensure_pos(tile_size // 16, tile_size // 16)
@@ -115,6 +119,7 @@ def process(model, control_imgs: List[np.ndarray], strength: float, color_fix_ty
             model.ensure_pos(h // 16, w // 16)
         flags = (L.FLAG_NO_PREPROCESS if disable_preprocess_model else 0) | (L.FLAG_TILED if tiled else 0)
         flags |= {"wavelet": L.FLAG_FIX_WAVELET, "adain": L.FLAG_FIX_ADAIN}.get(color_fix_type, 0) if tiled else 0
+        flags |= L.FLAG_CONTROL_LQ if with_c else 0
         din = torch.from_numpy(imgs).to(device)
         dout = torch.empty_like(din)
         dst1 = torch.empty_like(din)
@@ -132,15 +137,17 @@ def process(model, control_imgs: List[np.ndarray], strength: float, color_fix_ty
     lh, lw = height // 8, width // 8
     c_latent = vae.encode(control * 2 - 1).latent_dist.mode().to(torch.float32)
     init_noise = c_latent * sf
+    with_c = isinstance(model, ControlTransformerHalf)
     if not tiled:
-        latents = generate_sample_1step(model, noise_scheduler, init_noise, 400, y, y_mask)
+        latents = generate_sample_1step(model, noise_scheduler, init_noise, 400, y, y_mask, c=init_noise if with_c else None)
         img_buffer = vae.decode(latents / sf).sample / 2 + 0.5
     else:
         wins = _sliding_windows(lh, lw, tile_size // 8, tile_stride // 8)
         count = torch.zeros((n, 4, lh, lw), device=device)
         noise_buffer = torch.zeros_like(init_noise)
         for hi, he, wi, we in wins:
-            noise_buffer[:, :, hi:he, wi:we] += generate_sample_1step(model, noise_scheduler, init_noise[:, :, hi:he, wi:we].contiguous(), 400, y, y_mask)
+            tile = init_noise[:, :, hi:he, wi:we].contiguous()
+            noise_buffer[:, :, hi:he, wi:we] += generate_sample_1step(model, noise_scheduler, tile, 400, y, y_mask, c=tile if with_c else None)
             count[:, :, hi:he, wi:we] += 1
         noise_buffer.div_(count)
         img_buffer = torch.zeros_like(control)

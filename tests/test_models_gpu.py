@@ -241,6 +241,32 @@ def test_process_small_vs_oracle(tiled, fix):
         assert p >= 35.0 and p1 >= 40.0
 
 
+@pytest.mark.parametrize("tiled", [False, True])
+def test_process_with_control_branch(tiled):
+    """process() with a ControlTransformerHalf (c = the scaled LQ latent, per tile when tiled): fused ir_pipeline with
+    IR_FLAG_CONTROL_LQ and the staged generate_sample_1step(..., c=) form against the oracle given the same c."""
+    from instarevive_amd.pipeline import process
+    cfg = dict(DIT_SMALL, num_layers=3)
+    (sw, sws), (vae, svae) = make_swin(SWIN_SMALL), make_vae(VAE_SMALL)
+    ctl, sd = make_dit_control(cfg, 2)
+    y, mask3 = _prompt(cfg)
+    h, w = (128, 192) if tiled else (64, 128)
+    imgs = [(det_input(70 + i, (h, w, 3)) * 255).numpy().astype(np.uint8) for i in range(2)]
+    kw = dict(color_fix_type="wavelet", tiled=tiled, tile_size=64, tile_stride=32)
+    ocfg = dict(cfg, copy_blocks_num=2)
+    ref, _ = oglue.process(imgs, lambda x: oswin.swinir_forward(sws, x, SWIN_SMALL), lambda x: ovae.vae_encode_mean(svae, x, VAE_SMALL),
+                           lambda lat, t, yy, mm: odit.dit_forward(sd, lat, t, yy, mm, ocfg, c=lat), lambda z: ovae.vae_decode(svae, z, VAE_SMALL),
+                           oglue.alphas_cumprod_diffusers(), y, mask3, **kw)
+    plain, _ = oglue.process(imgs, lambda x: oswin.swinir_forward(sws, x, SWIN_SMALL), lambda x: ovae.vae_encode_mean(svae, x, VAE_SMALL),
+                             lambda lat, t, yy, mm: odit.dit_forward(sd, lat, t, yy, mm, cfg), lambda z: ovae.vae_decode(svae, z, VAE_SMALL),
+                             oglue.alphas_cumprod_diffusers(), y, mask3, **kw)
+    for fused in (True, False):
+        got, _ = process(ctl, imgs, 1, "wavelet", False, tiled, 64, 32, preprocess_model=sw, vae=vae, y=y.cuda(), y_mask=mask3.cuda(), fused=fused)
+        p, q = _psnr_u8(got, ref), _psnr_u8(got, plain)
+        print(f"process+control tiled={tiled} fused={fused}: PSNR vs oracle with c {p:.2f} dB, vs oracle without c {q:.2f} dB")
+        assert p >= 35.0 and q < p - 3.0  # matches the conditioned oracle, and the branch visibly changes the image
+
+
 def test_process_disable_preprocess():
     from instarevive_amd.pipeline import process
     (sw, sws), (vae, svae), (dit, sdit) = _small_models()
