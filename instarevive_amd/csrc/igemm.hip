@@ -15,6 +15,7 @@
 // one barrier per k-tile. The epilogue transposes each wave's accumulators through LDS so that all
 // global traffic (bias, residual, gate, stores) is row-contiguous 8/16-byte vectors.
 #include <stdlib.h>
+#include <algorithm>
 #include <type_traits>
 #include <utility>
 #include "common.h"
@@ -1028,6 +1029,304 @@ __global__ __launch_bounds__(512, 1) void conv_halo_pp_kernel(IGemmParams p, int
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Ping-pong big-tile GEMM for the DiT linears (TAPS = 1, Cout % 288 == 0: 1152 = 4, 3456 = 12, 4608 = 16 column tiles, so a
+// 16384-token launch is exactly 1, 3 or 4 rounds of 256 workgroups): one 512-thread workgroup per CU computes a 256 x 288 tile, half
+// the staged bytes per MFMA of the 128 x 128 kernel. Structure (that of conv_halo_pp_kernel / flash_attn_pp_kernel): waves w and
+// w+4 share a SIMD; waves 0-3 own columns 0-143, waves 4-7 columns 144-287, each wave a 64 x 144 sub-tile (4 x 9 MFMA tiles of
+// 16 x 16, 144 accumulator registers). k-tiles are 32 wide (one v_mfma_f32_16x16x32_bf16 step, 36 MFMAs per wave), staged by LDS-DMA
+// into a ring of FIVE 16 KB A slots (256 rows x 64 B) and FOUR 18 KB B slots (288 x 64 B). Workgroup barriers keep the halves in
+// complementary segments:
+//     segment:    2k              2k+1                        2k+2
+//     waves 0-3   matrix(k)       B(k+3) DMA, frags(k+1)      matrix(k+1)
+//     waves 4-7   A(k+4) DMA,     matrix(k)                   A(k+5) DMA, frags(k+1)
+//                 frags(k)
+// matrix(k) = 36 MFMAs on the 13 fragments read in the wave's preceding vector segment (no LDS read inside a matrix segment; LDS-DMA
+// pieces issued between the MFMAs instead were measured slower: the issuing wave blocks ~64 cycles per piece). The slots tile k+4
+// (A) and k+3 (B) go to held tile k-1, whose last fragment reads (waves 4-7, segment 2k-2) were consumed by matrix(k-1) in segment
+// 2k-1. The loop is LATENCY bound before it is anything else (activations come from HBM: with a cache-resident A operand the same
+// loop ran 10-22 % faster), hence the deep A ring: waves 4-7 wait vmcnt(12) at the end of every vector segment - A(k+1) has landed,
+// three younger 4-piece batches may fly (3+ k-tiles of latency cover); waves 0-3 wait vmcnt(5) at the end of every matrix segment
+// - B(k+1) has landed, B(k+2) may fly (weights are L2 hits; every wave issues exactly 5 B pieces per batch: 18 pieces over 4 waves,
+// the two spare slots re-issue a piece, which is idempotent). Every wait is followed by a workgroup barrier before the first read.
+// LDS image: row r of a 16-row fragment tile is 64 B (4 chunks of 16 B); chunk c is stored at slot c ^ f(r >> 2), f = {0,2,3,1},
+// which makes the 16 lanes of every ds_read_b128 lane group cover all 64 banks (applied to the DMA source and to the read).
+struct GemmPP {
+    static constexpr int BM = 256, BN = 288, BK = 32, NSA = 5, NSB = 4;
+    static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2;   // 16384, 18432
+    static constexpr int B_BASE = NSA * A_BYTES;                          // 81920
+    static constexpr int RING = B_BASE + NSB * B_BYTES;                   // 155648
+    static constexpr int TM = 4, TN = 9;                                  // 16 x 16 tiles per wave
+    static constexpr int SLAB = 32 * 144 * 4;                             // epilogue: two 16-row tiles of a wave at a time (fp32)
+    static constexpr int LDS = RING > 8 * SLAB ? RING : 8 * SLAB;
+};
+
+__global__ __launch_bounds__(512, 1) void gemm_pp_kernel(IGemmParams p) {
+    typedef GemmPP G;
+    typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[G::LDS];  // the ONLY LDS object of the kernel
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wu = __builtin_amdgcn_readfirstlane(wid);
+    const int grp = wu >> 2, wq = wu & 3;   // half (column group) and row quarter of this wave
+    const int NT = p.Cout_pad / G::BN, MT = (p.M + G::BM - 1) / G::BM;
+    const int bid = blockIdx.x, xcd = bid & 7, jb = bid >> 3;
+    const int mt = (jb / NT) * 8 + xcd, nt = jb % NT;   // an XCD runs the column tiles of one row tile back to back (A re-read from its L2)
+    if (mt >= MT) return;
+    const int m0 = mt * G::BM, n0 = nt * G::BN;
+    const int KT = p.Cin / G::BK;
+
+    // ---- DMA sources: a piece = 16 tile rows x 64 B; lane l covers row l >> 2, LDS slot l & 3 <- global chunk (l & 3) ^ f(row >> 2)
+    const int prow = lane >> 2;
+    const int fsw = (0x1320 >> (4 * ((prow >> 2) & 3))) & 3;   // f = {0, 2, 3, 1}
+    const int pchunk = ((lane & 3) ^ fsw) * 8;                 // element offset of the source chunk within the k-tile
+    // waves 4-7: A pieces 4*wq .. 4*wq+3 (rows beyond M re-read row M-1 and are never stored); waves 0-3: B pieces wq + 4*i, i < 5
+    const bf16_t* src[5];
+    int dst[5];
+    if (grp == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = wq * 4 + i;
+            src[i] = p.in + (long)min(m0 + q * 16 + prow, p.M - 1) * p.in_cs + pchunk;
+            dst[i] = q * 1024;
+        }
+        src[4] = src[3]; dst[4] = dst[3];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int q = (wq + 4 * i) < 18 ? wq + 4 * i : wq + 12;   // spare slots repeat a piece (same bytes, same destination)
+            src[i] = p.wgt + (long)(n0 + q * 16 + prow) * p.wgt_rs + pchunk;
+            dst[i] = G::B_BASE + q * 1024;
+        }
+    }
+    // prologue: A tiles 0..3 and B tiles 0..2 by all 8 waves (A piece q = wu + 8*i, i < 2; B piece q = wu + 8*i, i < 3, q < 18)
+    auto issue_prologue = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int kt = 0; kt < G::NSA - 1; ++kt)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int q = wu + 8 * i;
+                glds16(p.in + (long)min(m0 + q * 16 + prow, p.M - 1) * p.in_cs + pchunk + kt * G::BK, (lds_ptr_t)(smem + kt * G::A_BYTES + q * 1024));
+            }
+#pragma unroll
+        for (int kt = 0; kt < G::NSB - 1; ++kt)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int q = wu + 8 * i;
+                if (q < 18)
+                    glds16(p.wgt + (long)(n0 + q * 16 + prow) * p.wgt_rs + pchunk + kt * G::BK, (lds_ptr_t)(smem + G::B_BASE + kt * G::B_BYTES + q * 1024));
+            }
+    };
+
+    // ---- fragments: lane (r16 = l & 15, kq = l >> 4) reads chunk kq of row r16 of a 16-row tile
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int frag_off = r16 * 64 + ((kq ^ ((0x1320 >> (4 * ((r16 >> 2) & 3))) & 3)) << 4);
+    const unsigned char* fbase = smem + frag_off + wq * 4 * 1024;                     // A tiles 4*wq + i
+    const unsigned char* gbase = smem + frag_off + G::B_BASE + grp * 9 * 1024;        // B tiles 9*grp + j
+    bf16x8 fa[G::TM], fb[G::TN];
+    auto read_frags = [&](int sa, int sb) __attribute__((always_inline)) {   // A slot sa, B slot sb
+#pragma unroll
+        for (int i = 0; i < G::TM; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(fbase + sa * G::A_BYTES + i * 1024);
+#pragma unroll
+        for (int j = 0; j < G::TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(gbase + sb * G::B_BYTES + j * 1024);
+    };
+    f32x4_t acc[G::TM][G::TN];
+#pragma unroll
+    for (int i = 0; i < G::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < G::TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    auto matrix = [&]() __attribute__((always_inline)) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 0; j < G::TN; ++j)
+#pragma unroll
+            for (int i = 0; i < G::TM; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    issue_prologue();
+    wait_dma();
+    __builtin_amdgcn_s_barrier();
+    if (grp == 0) {
+        read_frags(0, 0);
+        int sa1 = 1;   // A slot of tile kt+1
+        for (int kt = 0; kt < KT; ++kt) {
+            __builtin_amdgcn_sched_barrier(0);
+            matrix();
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 3 < KT) wait_vm<5>(); else wait_dma();       // B(kt+1) has landed (only B(kt+2) may be in flight)
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 3 < KT) {
+                unsigned char* base = smem + ((kt + 3) & 3) * G::B_BYTES;
+                const int ko = (kt + 3) * G::BK;
+#pragma unroll
+                for (int i = 0; i < 5; ++i) glds16(src[i] + ko, (lds_ptr_t)(base + dst[i]));
+            }
+            if (kt + 1 < KT) read_frags(sa1, (kt + 1) & 3);
+            sa1 = sa1 == G::NSA - 1 ? 0 : sa1 + 1;
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        }
+    } else {
+        int sa = 0, sa4 = G::NSA - 1;   // A slots of tiles kt and kt+4
+        for (int kt = 0; kt < KT; ++kt) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 4 < KT) {
+                unsigned char* base = smem + sa4 * G::A_BYTES;
+                const int ko = (kt + 4) * G::BK;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) glds16(src[i] + ko, (lds_ptr_t)(base + dst[i]));
+            }
+            read_frags(sa, kt & 3);
+            // A(kt+1) has landed; the batches of A(kt+2) .. A(kt+4) may be in flight (fewer at the end of the K loop)
+            const int rem = KT - 2 - kt;
+            if (rem >= 3) wait_vm<12>(); else if (rem == 2) wait_vm<8>(); else if (rem == 1) wait_vm<4>(); else wait_dma();
+            sa = sa == G::NSA - 1 ? 0 : sa + 1;
+            sa4 = sa4 == G::NSA - 1 ? 0 : sa4 + 1;
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            matrix();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- epilogue: v = act(acc + bias) * out_scale * gate + res, through a wave-private fp32 slab (two 16-row tiles = 32 x 144
+    // at a time) so that residual reads and stores are row-contiguous 16-byte vectors. All loop reads were consumed before the last
+    // barrier, so the slabs may overlay the ring.
+    float* slab = reinterpret_cast<float*>(smem) + wu * (G::SLAB / 4);
+    const int col = lane & 15, rq = lane >> 4;
+    const int nw = n0 + grp * 144;          // first column of this wave
+    float cb[G::TN], cm[G::TN];
+#pragma unroll
+    for (int j = 0; j < G::TN; ++j) {
+        const int n = nw + j * 16 + col;
+        cb[j] = p.bias ? p.bias[n] : 0.f;
+        cm[j] = p.out_scale * (p.gate ? p.gate[n] : 1.f);
+    }
+    auto half = [&](auto act_tag, int hh) __attribute__((always_inline)) {
+        constexpr int ACT = decltype(act_tag)::value;
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+            for (int j = 0; j < G::TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float a = hh == 0 ? acc[ii][j][q] : acc[2 + ii][j][q];
+                    slab[(ii * 16 + rq * 4 + q) * 144 + j * 16 + col] = apply_act<ACT>(a + cb[j], p.slope) * cm[j];
+                }
+    };
+    // Row phase of one half. The forms the DiT uses are specialised so that no uniform condition sits inside the unrolled loops
+    // (hipcc turns those into branches with a full vmcnt(0) per vector): KIND 0 = no residual, bf16 out; KIND 1 = fp32 residual, fp32
+    // out (+ optional bf16 copy), whose 18 residual vectors are all requested back to back (one exposed latency per half); KIND 2 = anything else.
+    auto write_half = [&](int hh) __attribute__((always_inline)) {
+        switch (p.act) {
+            case IR_ACT_GELU_TANH: half(std::integral_constant<int, IR_ACT_GELU_TANH>{}, hh); break;
+            case IR_ACT_GELU_ERF: half(std::integral_constant<int, IR_ACT_GELU_ERF>{}, hh); break;
+            case IR_ACT_SILU: half(std::integral_constant<int, IR_ACT_SILU>{}, hh); break;
+            case IR_ACT_LRELU: half(std::integral_constant<int, IR_ACT_LRELU>{}, hh); break;
+            default: half(std::integral_constant<int, IR_ACT_NONE>{}, hh); break;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    auto done_half = [&]() __attribute__((always_inline)) {  // the next half's slab writes must not pass this half's slab reads
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    const int kind = (!p.res && !p.out_f32 && !p.out2) ? 0 : (p.res && p.res_f32 && p.out_f32 && p.res_mod == 0) ? 1 : 2;
+    const int mw = m0 + wq * 64;
+    // fast forms address with 32-bit element offsets from the uniform base pointers (the launcher checks that they fit): one
+    // address register per vector instead of two
+    if (kind == 0) {
+        bf16_t* outb = reinterpret_cast<bf16_t*>(p.out);
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            write_half(hh);
+#pragma unroll
+            for (int it = 0; it < 18; ++it) {
+                const int v = it * 64 + lane, row = v / 36, c4 = (v - row * 36) * 4;
+                const int m = mw + hh * 32 + row;
+                const f32x4_t o = *reinterpret_cast<const f32x4_t*>(&slab[row * 144 + c4]);
+                if (m < p.M) *reinterpret_cast<uint2*>(outb + (unsigned)(m * p.out_cs + nw + c4)) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+            }
+            done_half();
+        }
+    } else if (kind == 1) {
+        const float* resf = reinterpret_cast<const float*>(p.res);
+        float* outf = reinterpret_cast<float*>(p.out);
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            write_half(hh);   // first: this half's 72 accumulator registers die here and make room for the residual vectors
+#pragma unroll
+            for (int bt = 0; bt < 3; ++bt) {   // three batches of 6 vectors: 6 residual requests back to back, then 6 add + stores
+                f32x4_t rr[6];
+#pragma unroll
+                for (int it = 0; it < 6; ++it) {
+                    const int v = (bt * 6 + it) * 64 + lane, row = v / 36, c4 = (v - row * 36) * 4;
+                    const int m = min(mw + hh * 32 + row, p.M - 1);
+                    rr[it] = *reinterpret_cast<const f32x4_t*>(resf + (unsigned)(m * p.res_cs + nw + c4));
+                }
+#pragma unroll
+                for (int it = 0; it < 6; ++it) {
+                    const int v = (bt * 6 + it) * 64 + lane, row = v / 36, c4 = (v - row * 36) * 4;
+                    const int m = mw + hh * 32 + row;
+                    const f32x4_t o = *reinterpret_cast<const f32x4_t*>(&slab[row * 144 + c4]) + rr[it];
+                    if (m < p.M) {
+                        *reinterpret_cast<f32x4_t*>(outf + (unsigned)(m * p.out_cs + nw + c4)) = o;
+                        if (p.out2) *reinterpret_cast<uint2*>(p.out2 + (unsigned)(m * p.out2_cs + nw + c4)) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+                    }
+                }
+            }
+            done_half();
+        }
+    } else {
+        for (int hh = 0; hh < 2; ++hh) {
+            write_half(hh);
+            for (int it = 0; it < 18; ++it) {
+                const int v = it * 64 + lane, row = v / 36, c4 = (v - row * 36) * 4;
+                const int m = mw + hh * 32 + row;
+                f32x4_t o = *reinterpret_cast<const f32x4_t*>(&slab[row * 144 + c4]);
+                if (m < p.M) {
+                    const int n = nw + c4;
+                    if (p.res) {
+                        const long rm = p.res_mod > 0 ? (long)(m % p.res_mod) : (long)m;
+                        if (p.res_f32) o += *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(p.res) + rm * p.res_cs + n);
+                        else {
+                            const uint2 rb = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(p.res) + rm * p.res_cs + n);
+                            o += f32x4_t{bflo(rb.x), bfhi(rb.x), bflo(rb.y), bfhi(rb.y)};
+                        }
+                    }
+                    const uint2 pk = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+                    if (p.out_f32) *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(p.out) + (long)m * p.out_cs + n) = o;
+                    else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (long)m * p.out_cs + n) = pk;
+                    if (p.out2) *reinterpret_cast<uint2*>(p.out2 + (long)m * p.out2_cs + n) = pk;
+                }
+            }
+            done_half();
+        }
+    }
+}
+
+static bool takes_gemm_pp(const IGemmParams& p) {
+    static const bool off = getenv("IR_NO_GEMM_PP") != nullptr;  // experiment knob
+    if (off || p.taps != 1 || p.force_generic || !p.vec || p.gn_part) return false;
+    if (p.Cout != p.Cout_pad || p.Cout % GemmPP::BN || p.Cin % GemmPP::BK || p.Cin < 8 * GemmPP::BK) return false;
+    const long span = (long)p.M * std::max(std::max(p.out_cs, p.res ? p.res_cs : 0), p.out2 ? p.out2_cs : 0);
+    if (span >= (1L << 31)) return false;  // the epilogue's 32-bit element offsets
+    const long blocks = (long)((p.M + GemmPP::BM - 1) / GemmPP::BM) * (p.Cout / GemmPP::BN);
+    return blocks >= 192;  // below that the 128 x 128 kernel fills the chip better
+}
+static int launch_gemm_pp(const IGemmParams& p, hipStream_t s) {
+    const int MT = (p.M + GemmPP::BM - 1) / GemmPP::BM, NT = p.Cout / GemmPP::BN;
+    hipLaunchKernelGGL(gemm_pp_kernel, dim3(((MT + 7) / 8) * 8 * NT), dim3(512), 0, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 static int launch_halo_pp(const IGemmParams& p, hipStream_t s) {
     const int tiles_y = (p.Ho + 15) / 16, tiles_x = (p.Wo + 15) / 16;
     const long MT = (long)p.NB * tiles_y * tiles_x, NT = p.Cout_pad / 128;
@@ -1120,6 +1419,7 @@ int ir_launch_igemm(const IGemmParams& pin, hipStream_t s) {
     }
     if (p.gn_part && (!p.vec || p.gn_chunks <= 0 || p.gn_chunks != ir_igemm_gn_chunks(p))) return -13;
     if (takes_halo_pp(p)) return launch_halo_pp(p, s);
+    if (takes_gemm_pp(p)) return launch_gemm_pp(p, s);
     if (takes_halo(p)) {
         if (p.Cout_pad % 128 == 0) return launch_halo<128>(p, s);
         return launch_halo<64>(p, s);

@@ -65,6 +65,33 @@ def test_linear(ctx, m, k, n):
     close(out.cpu(), ref, 1e-4, 2e-4 * math.sqrt(k), "linear f32")  # fp32 accumulate of exact bf16 products
 
 
+@pytest.mark.parametrize("m,k,n", [(16384, 1152, 1152), (12545, 1152, 3456), (16384, 4608, 1152), (6400, 128, 4608)])
+def test_linear_big_tile(ctx, m, k, n):
+    """Shapes the 256 x 288 ping-pong GEMM takes (Cout % 288 == 0, >= 192 workgroups): the DiT linears at 2048 px, whole and ragged M,
+    short and long K, with every epilogue form the DiT uses."""
+    g = torch.Generator().manual_seed(m + k + n)
+    x = rb(torch.randn(m, k, generator=g))
+    w = rb(torch.randn(n, k, generator=g) / math.sqrt(k))
+    b = torch.randn(n, generator=g)
+    gate = torch.randn(n, generator=g)
+    res = torch.randn(m, n, generator=g)
+    y = x @ w.t() + b
+    xd, wd, bd = dev_bf16(x), dev_bf16(w), b.cuda()
+    out = torch.empty(m, n, dtype=torch.float32, device="cuda")
+    ctx.check(ctx.lib.ir_op_linear(ctx.h, ctx.stream(), P(xd), P(wd), P(bd), P(out), m, k, n, n, L.ACT_NONE, None, None, 0, 1, 1.0), "linear")
+    close(out.cpu(), y, 1e-4, 2e-4 * math.sqrt(k), "big tile f32")
+    o16 = torch.empty(m, n, dtype=torch.int16, device="cuda")
+    ctx.check(ctx.lib.ir_op_linear(ctx.h, ctx.stream(), P(xd), P(wd), P(bd), P(o16), m, k, n, n, L.ACT_GELU_TANH, None, None, 0, 0, 1.0), "gelu")
+    close(L.from_bf16_bits(o16).cpu(), F.gelu(y, approximate="tanh"), 2 ** -7, 1e-3, "big tile gelu tanh bf16")
+    resd = res.cuda().clone()
+    ctx.check(ctx.lib.ir_op_linear(ctx.h, ctx.stream(), P(xd), P(wd), P(bd), P(resd), m, k, n, n, L.ACT_NONE, P(gate.cuda()), P(resd), 1, 1, 1.0),
+              "gate res")
+    close(resd.cpu(), res + gate * y, 1e-4, 1e-3, "big tile gate + fp32 residual in place")
+    rbf = rb(res)
+    ctx.check(ctx.lib.ir_op_linear(ctx.h, ctx.stream(), P(xd), P(wd), None, P(o16), m, k, n, n, L.ACT_NONE, None, P(dev_bf16(rbf)), 0, 0, 0.5), "res bf16")
+    close(L.from_bf16_bits(o16).cpu(), rbf + 0.5 * (y - b), 2 ** -7, 1e-3, "big tile bf16 residual + out_scale")
+
+
 def test_linear_epilogues(ctx):
     g = torch.Generator().manual_seed(5)
     m, k, n = 260, 128, 96
