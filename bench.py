@@ -171,6 +171,8 @@ def main():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--control", type=int, default=0, metavar="COPIES", help="diagnostic: run the DiT step with the ControlNet-Half branch "
                     "(COPIES copied blocks, 13 in the reference configs; c = the LQ latent). Not the headline workload: no such weights are released")
+    ap.add_argument("--graph", action="store_true", help="diagnostic: replay the step as one hipGraph (IR_FLAG_GRAPH); implies --no_profile, "
+                    "so the JSON line carries no roofline")
     ap.add_argument("--no_profile", action="store_true", help="experiment: time the loop without the per-launch HIP events (no roofline)")
     args = ap.parse_args()
 
@@ -206,6 +208,9 @@ def main():
     n, h, w = net_in.shape[:3]
     assert h % 64 == 0 and w % 64 == 0
     flags = ((L.FLAG_TILED | L.FLAG_FIX_WAVELET) if args.tiled else 0) | (L.FLAG_CONTROL_LQ if args.control else 0)
+    if args.graph:
+        flags |= L.FLAG_GRAPH
+        args.no_profile = True
     tile_size, tile_stride = 512, 448
     if args.tiled:
         dit.ensure_pos(tile_size // 16, tile_size // 16)

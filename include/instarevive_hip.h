@@ -29,7 +29,12 @@ enum { IR_FLAG_NO_PREPROCESS = 1, IR_FLAG_TILED = 2, IR_FLAG_FIX_WAVELET = 4, IR
        /* ir_pipeline only, needs ir_dit_control_configure: run the DiT step with the ControlNet-Half branch, condition latent
         * c = the scaled LQ latent the step starts from (per tile under IR_FLAG_TILED). The reference's process() never passes c
         * (inference.py:114,131); this is the generate_sample_1step(..., c=) hook (generate.py:32-40) applied to that call. */
-       IR_FLAG_CONTROL_LQ = 16 };
+       IR_FLAG_CONTROL_LQ = 16,
+       /* ir_pipeline only: record the launch sequence of this exact call (same pointers, sizes, flags, timestep) into a hipGraph on
+        * first use and replay it with one hipGraphLaunch afterwards (BASELINE.json configs[2]: "hipGraph-captured per-tile step").
+        * The caller keeps in/out/stage1/ws alive and at the same addresses; uploads, *_configure and ir_dit_set_prompt drop the
+        * recorded graphs. Ignored while ir_profile_begin is active (per-launch events need individual launches). */
+       IR_FLAG_GRAPH = 32 };
 
 int ir_abi_version(void);
 int ir_init(int device, ir_ctx** out);

@@ -23,7 +23,7 @@ SYMBOLS = [
 ]
 
 STAGE_SWINIR, STAGE_VAE_ENCODE, STAGE_DIT, STAGE_VAE_DECODE, STAGE_PIPELINE, STAGE_COLORFIX = range(6)
-FLAG_NO_PREPROCESS, FLAG_TILED, FLAG_FIX_WAVELET, FLAG_FIX_ADAIN, FLAG_CONTROL_LQ = 1, 2, 4, 8, 16
+FLAG_NO_PREPROCESS, FLAG_TILED, FLAG_FIX_WAVELET, FLAG_FIX_ADAIN, FLAG_CONTROL_LQ, FLAG_GRAPH = 1, 2, 4, 8, 16, 32
 ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_LRELU, ACT_SILU = range(5)
 
 _lib = None

@@ -140,6 +140,19 @@ struct ir_ctx {
     SwinModel swin;
     VaeModel vae;
     DitModel dit;
+    // hipGraph cache of ir_pipeline (IR_FLAG_GRAPH): one instantiated graph per exact call signature. `generation` changes whenever
+    // device allocations or bindings may have moved (upload with a new size, *_configure, set_prompt), which drops every graph.
+    struct GraphKey {
+        const void *in, *out, *stage1, *ws;
+        size_t ws_bytes;
+        int n, h, w, flags, tile_size, tile_stride;
+        float timestep, acp, sf;
+        bool operator==(const GraphKey& o) const { return memcmp(this, &o, sizeof *this) == 0; }
+    };
+    struct GraphEntry { GraphKey key; hipGraphExec_t exec; };
+    std::vector<GraphEntry> graphs;
+    unsigned long generation = 0, graphs_generation = 0;
+    hipStream_t cap_stream = nullptr;  // recording happens on a private stream (the caller's may be the legacy default stream, which cannot capture)
 };
 
 namespace {
@@ -742,10 +755,8 @@ void pipeline_run(Run& r, const uint8_t* in, uint8_t* out, uint8_t* stage1, int 
         float* nb = r.a.alloc<float>((long)n * 4 * lh * lw);
         float* tl_in = r.a.alloc<float>(lat_tile * TB);
         float* tl_x0 = r.a.alloc<float>(lat_tile * TB);
-        if (!r.a.dry) {
-            if (hipMemsetAsync(nb, 0, sizeof(float) * n * 4 * lh * lw, r.s) != hipSuccess) r.chk(-100, "memset");
-            if (hipMemsetAsync(img, 0, sizeof(float) * n * 3 * HW, r.s) != hipSuccess) r.chk(-100, "memset");
-        }
+        LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_zero_f32(nb, (long)n * 4 * lh * lw, r.s), "zero");
+        LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_zero_f32(img, (long)n * 3 * HW, r.s), "zero");
         for (int c0 = 0; c0 < NTl; c0 += TB) {  // loop A: DiT tiles, averaged in latent space (inference.py:128-136)
             const int cb = std::min(TB, NTl - c0);
             const size_t mk2 = r.a.mark();
@@ -827,6 +838,8 @@ void ir_destroy(ir_ctx* c) {
     for (auto& kv : c->t) (void)hipFree(kv.second.p);
     for (void* p : c->owned) (void)hipFree(p);
     for (hipEvent_t e : c->prof.pool) (void)hipEventDestroy(e);
+    for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.exec);
+    if (c->cap_stream) (void)hipStreamDestroy(c->cap_stream);
     delete c;
 }
 
@@ -841,6 +854,7 @@ int ir_upload(ir_ctx* c, const char* name, const void* host, size_t bytes) {
         t.p = nullptr;
         HIPOK(c, hipMalloc(&t.p, (bytes + 255) & ~(size_t)255));
         t.bytes = bytes;
+        ++c->generation;
     }
     HIPOK(c, hipMemcpy(t.p, host, bytes, hipMemcpyHostToDevice));
     return 0;
@@ -886,6 +900,7 @@ int ir_swinir_configure(ir_ctx* c, int embed_dim, int n_layers, const int* depth
     if (!b.ok) return fail(c, -2, "ir_swinir_configure: tensor %s", b.missing.c_str());
     m.ok = true;
     c->swin = m;
+    ++c->generation;
     return 0;
 }
 
@@ -970,6 +985,7 @@ int ir_vae_configure(ir_ctx* c, int ch, int n_levels, const int* ch_mult, int nu
     if (!with_encoder) m.enc = c->vae.enc, m.qw = c->vae.qw, m.qb = c->vae.qb;
     if (!with_decoder) m.dec = c->vae.dec, m.pqw = c->vae.pqw, m.pqb = c->vae.pqb;
     c->vae = m;
+    ++c->generation;
     return 0;
 }
 
@@ -1022,6 +1038,7 @@ int ir_dit_configure(ir_ctx* c, int n_layers, int heads, int head_dim, int mlp_h
     if (rc) return rc;
     m.ok = true;
     c->dit = m;
+    ++c->generation;
     return 0;
 }
 
@@ -1043,6 +1060,7 @@ int ir_dit_control_configure(ir_ctx* c, int copy_blocks_num) {
     float* tab = nullptr;
     if (dev_alloc(c, (void**)&tab, (size_t)copy_blocks_num * 6 * m.C * 4)) return -100;
     m.ctrl = ctrl; m.after = after; m.before = before; m.ctrl_modtab = tab; m.ncopy = copy_blocks_num;
+    ++c->generation;
     m.cached_t = -1e30f;   // the control blocks' modulation tables are built with the timestep tables
     m.prompt_ok = false;   // ... and their prompt K/V caches with the prompt: ir_dit_set_prompt must run (again)
     m.key_bias = nullptr;
@@ -1087,6 +1105,7 @@ int ir_dit_set_prompt(ir_ctx* c, void* stream, const float* embeds_host, const f
     (void)hipFree(e32); (void)hipFree(e16); (void)hipFree(y1); (void)hipFree(y2);
     if (r.rc) return fail(c, r.rc, "ir_dit_set_prompt: %s failed", r.where);
     m.n_tok = n_tok; m.tok_pad = tok_pad; m.prompt_ok = true;
+    ++c->generation;
     return 0;
 }
 
@@ -1219,9 +1238,58 @@ int ir_pipeline(ir_ctx* c, void* stream, const uint8_t* in, uint8_t* out, uint8_
     REQUIRE(acp > 0.f && acp < 1.f && sf > 0.f, "pipeline: bad alpha_cumprod / scaling factor");
     REQUIRE(!(flags & IR_FLAG_CONTROL_LQ) || c->dit.ncopy > 0, "pipeline: IR_FLAG_CONTROL_LQ without ir_dit_control_configure");
     if (int e = check_size(c, n, h, w, 64)) return e;
-    Run r = make_run(c, stream, ws, ws_bytes, false);
+    if (!(flags & IR_FLAG_GRAPH) || c->prof.on) {  // per-launch profiling needs the individual launches
+        Run r = make_run(c, stream, ws, ws_bytes, false);
+        pipeline_run(r, in, out, stage1, n, h, w, flags, tile_size, tile_stride, timestep, acp, sf);
+        return finish(r, c, ws_bytes);
+    }
+    // ---- hipGraph form: the first call with this exact signature records the whole launch sequence (about 1600 kernel and memset
+    // nodes at 2048 x 2048) on the caller's stream and instantiates it; later calls replay it with one hipGraphLaunch.
+    hipStream_t s = (hipStream_t)stream;
+    if (c->graphs_generation != c->generation) {
+        for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.exec);
+        c->graphs.clear();
+        c->graphs_generation = c->generation;
+    }
+    ir_ctx::GraphKey key;
+    memset(&key, 0, sizeof key);  // padding bytes too: keys are compared with memcmp
+    key.in = in; key.out = out; key.stage1 = stage1; key.ws = ws; key.ws_bytes = ws_bytes;
+    key.n = n; key.h = h; key.w = w; key.flags = flags; key.tile_size = tile_size; key.tile_stride = tile_stride;
+    key.timestep = timestep; key.acp = acp; key.sf = sf;
+    for (auto& g : c->graphs)
+        if (g.key == key) {
+            HIPOK(c, hipGraphLaunch(g.exec, s));
+            return 0;
+        }
+    {   // size the workspace before capturing anything
+        Run dry = make_run(c, nullptr, nullptr, 0, true);
+        pipeline_run(dry, in, out, stage1, n, h, w, flags, tile_size, tile_stride, timestep, acp, sf);
+        if (dry.a.peak > ws_bytes) return fail(c, -20, "workspace too small: need %zu bytes, got %zu", dry.a.peak, ws_bytes);
+    }
+    c->dit.cached_t = -1e30f;  // the graph must contain the timestep-table kernels: it may be replayed after another timestep was used
+    if (!c->cap_stream) HIPOK(c, hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
+    HIPOK(c, hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
+    Run r = make_run(c, c->cap_stream, ws, ws_bytes, false);
     pipeline_run(r, in, out, stage1, n, h, w, flags, tile_size, tile_stride, timestep, acp, sf);
-    return finish(r, c, ws_bytes);
+    hipGraph_t graph = nullptr;
+    const hipError_t ee = hipStreamEndCapture(c->cap_stream, &graph);
+    c->dit.cached_t = -1e30f;  // nothing ran yet: the tables on the device are not those of `timestep`
+    if (int rc = finish(r, c, ws_bytes)) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return rc;
+    }
+    if (ee != hipSuccess || !graph) return fail(c, -101, "hipStreamEndCapture: %s", hipGetErrorString(ee));
+    hipGraphExec_t exec = nullptr;
+    const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ei != hipSuccess) return fail(c, -101, "hipGraphInstantiate: %s", hipGetErrorString(ei));
+    if (c->graphs.size() >= 16) {  // bounded cache: drop the oldest
+        (void)hipGraphExecDestroy(c->graphs.front().exec);
+        c->graphs.erase(c->graphs.begin());
+    }
+    c->graphs.push_back({key, exec});
+    HIPOK(c, hipGraphLaunch(exec, s));
+    return 0;
 }
 
 int ir_profile_begin(ir_ctx* c) {

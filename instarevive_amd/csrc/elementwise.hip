@@ -273,6 +273,15 @@ __global__ void tile_add_kernel(float* dst, const float* src, int C, int H, int 
         dst[(nc * H + y0 + y) * W + x0 + x] += src[i];
     }
 }
+// Zero fill as a kernel: memset NODES of a recorded hipGraph did not re-run reliably on replay (tiled pipeline, ROCm 7.2), kernels do.
+__global__ void zero_f32_kernel(float* p, long n) {
+    FOR_GRID(i, n) p[i] = 0.f;
+}
+int ir_launch_zero_f32(float* p, long n, hipStream_t s) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(zero_f32_kernel, GRID1D(n), dim3(256), 0, s, p, n);
+    return LAUNCH_OK();
+}
 int ir_launch_tile_add(float* dst, const float* src, int N, int C, int H, int W, int th, int tw, int y0, int x0, hipStream_t s) {
     if (y0 < 0 || x0 < 0 || y0 + th > H || x0 + tw > W) return -2;
     long total = (long)N * C * th * tw;
@@ -345,7 +354,7 @@ __global__ void add2_kernel(const float* a, const float* b, float* o, long total
 int ir_launch_wavelet_fix(const float* content, const float* style, float* out, float* tmp, int N, int H, int W, hipStream_t s) {
     const long total = (long)N * 3 * H * W;
     float *ping = tmp, *pong = tmp + total, *high = tmp + 2 * total;
-    if (hipMemsetAsync(high, 0, total * sizeof(float), s) != hipSuccess) return -1;
+    if (ir_launch_zero_f32(high, total, s)) return -1;
     const float* cur = content;
     for (int lvl = 0; lvl < 5; ++lvl) {
         float* dst = (lvl & 1) ? pong : ping;

@@ -94,12 +94,14 @@ def _fused_ok(model, preprocess_model, vae, disable_preprocess_model):
 @torch.no_grad()
 def process(model, control_imgs: List[np.ndarray], strength: float, color_fix_type: str, disable_preprocess_model: bool, tiled: bool,
             tile_size: int, tile_stride: int, preprocess_model=None, vae=None, y=None, y_mask=None, noise_scheduler=None,
-            fused: bool = True) -> Tuple[List[np.ndarray], List[np.ndarray]]:
+            fused: bool = True, graph: bool = False) -> Tuple[List[np.ndarray], List[np.ndarray]]:
     """test_scripts/inference.py:55-166. control_imgs: list of HWC uint8 RGB arrays of equal size (multiples of 64).
     Returns (preds, stage1_preds) as lists of HWC uint8 arrays.
 
     Extension (no reference counterpart: the reference's process() never passes c): when `model` is a ControlTransformerHalf, the
-    one-step call becomes generate_sample_1step(..., c=<the scaled LQ latent the step starts from>), per tile under `tiled`."""
+    one-step call becomes generate_sample_1step(..., c=<the scaled LQ latent the step starts from>), per tile under `tiled`.
+    graph=True (fused form only): the launch sequence is recorded into a hipGraph per image size / flag set and replayed on later
+    calls (staging buffers are kept per size so that the recorded addresses stay valid)."""
     noise_scheduler = noise_scheduler or DDPMScheduler()
     n = len(control_imgs)
     imgs = np.ascontiguousarray(np.stack(control_imgs))
@@ -120,9 +122,18 @@ def process(model, control_imgs: List[np.ndarray], strength: float, color_fix_ty
         flags = (L.FLAG_NO_PREPROCESS if disable_preprocess_model else 0) | (L.FLAG_TILED if tiled else 0)
         flags |= {"wavelet": L.FLAG_FIX_WAVELET, "adain": L.FLAG_FIX_ADAIN}.get(color_fix_type, 0) if tiled else 0
         flags |= L.FLAG_CONTROL_LQ if with_c else 0
-        din = torch.from_numpy(imgs).to(device)
-        dout = torch.empty_like(din)
-        dst1 = torch.empty_like(din)
+        if graph:  # stable device addresses for the recorded graph: one set of staging buffers per call signature
+            flags |= L.FLAG_GRAPH
+            bufs = ctx.__dict__.setdefault("_graph_bufs", {})
+            key = (n, h, w, flags, tile_size, tile_stride)
+            if key not in bufs:
+                bufs[key] = tuple(torch.empty((n, h, w, 3), dtype=torch.uint8, device=device) for _ in range(3))
+            din, dout, dst1 = bufs[key]
+            din.copy_(torch.from_numpy(imgs))
+        else:
+            din = torch.from_numpy(imgs).to(device)
+            dout = torch.empty_like(din)
+            dst1 = torch.empty_like(din)
         ws = ctx.workspace(ctx.ws_bytes(L.STAGE_PIPELINE, n, h, w, flags, tile_size, tile_stride))
         ctx.check(ctx.lib.ir_pipeline(ctx.h, ctx.stream(), L.ptr(din), L.ptr(dout), L.ptr(dst1), n, h, w, flags, tile_size, tile_stride, 400.0, acp,
                                       sf, L.ptr(ws), ws.numel()), "ir_pipeline")

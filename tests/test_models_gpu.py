@@ -267,6 +267,25 @@ def test_process_with_control_branch(tiled):
         assert p >= 35.0 and q < p - 3.0  # matches the conditioned oracle, and the branch visibly changes the image
 
 
+@pytest.mark.parametrize("tiled", [False, True])
+def test_process_hipgraph_replay_is_identical(tiled):
+    """IR_FLAG_GRAPH (BASELINE configs[2], "hipGraph-captured per-tile step"): recording, replaying on new pixels through the same
+    buffers, and re-recording after the prompt changed must all be bit-identical to the plain launch sequence."""
+    from instarevive_amd.pipeline import process
+    (sw, _), (vae, _), (dit, _) = _small_models()
+    y, mask3 = _prompt(DIT_SMALL)
+    h, w = (128, 192) if tiled else (64, 128)
+    kw = dict(preprocess_model=sw, vae=vae, y_mask=mask3.cuda())
+    args = (1, "wavelet", False, tiled, 64, 32)
+    for rnd, yy in enumerate((y.cuda(), (y * 0.5).cuda())):   # the second prompt invalidates the recorded graphs (ir_dit_set_prompt)
+        for i in range(3):                    # i = 0 records (first round) / re-records (second round), i > 0 replays
+            imgs = [(det_input(90 + 10 * rnd + i, (h, w, 3)) * 255).numpy().astype(np.uint8)]
+            want, want1 = process(dit, imgs, *args, y=yy, **kw)
+            got, got1 = process(dit, imgs, *args, y=yy, graph=True, **kw)
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got1[0], want1[0]), (rnd, i)
+    assert len({a.tobytes() for a in (want[0],)}) == 1 and want[0].std() > 1  # a real image, not zeros
+
+
 def test_process_disable_preprocess():
     from instarevive_amd.pipeline import process
     (sw, sws), (vae, svae), (dit, sdit) = _small_models()
