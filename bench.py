@@ -262,7 +262,8 @@ def main():
                 log(f"  {k:13s} {v['ms'] / args.steps:9.2f} ms/step  {v['launches'] // args.steps:5d} launches/step  "
                     f"{v['flops'] / max(v['ms'], 1e-9) / 1e9:8.1f} TFLOP/s(exec)  {v['bytes'] / max(v['ms'], 1e-9) / 1e6:8.1f} GB/s")
         log(f"  kernels {total_ms / args.steps:.1f} ms/step of {ms_per_step:.1f} ms/step wall; whole path {fm['total'] * n / (ms_per_step / 1e3) / 1e12:.1f} TFLOP/s algorithmic")
-        # conv3x3 and linear launches are the same kernel (igemm_kernel<...>); quote them together when they dominate
+        # conv3x3 and linear launches are one kernel family (the LDS-DMA MFMA contractions of igemm.hip: conv_halo_pp_kernel,
+        # conv_halo_kernel, igemm_kernel, gemm_pp_kernel), bounded by the same roofline; quote them together when they dominate
         ig_ms = prof["conv3x3"]["ms"] + prof["linear"]["ms"]
         if ig_ms >= prof[dom]["ms"]:
             # algorithmic FLOPs of everything igemm executes = whole path minus the two attention-core classes
@@ -274,7 +275,7 @@ def main():
             pmc = os.path.join(ROOT, "profiles", "r01_pmc_igemm.json")
             if os.path.exists(pmc) and not args.tiled and (h, w, n) == (2048, 2048, 1):
                 traffic = json.load(open(pmc))["hbm_bytes_per_launch"]  # measured with rocprofv3 --pmc on this exact workload
-            roof = dict(bound="mfma", kernel="igemm_kernel (3x3-conv + linear launches)", achieved=round(ach, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
+            roof = dict(bound="mfma", kernel="igemm.hip family: conv_halo_pp_kernel + conv_halo_kernel + igemm_kernel + gemm_pp_kernel (3x3-conv + linear launches)", achieved=round(ach, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
                         frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=traffic, launches_per_step=launches // args.steps,
                         avg_launch_ms=round(ig_ms / max(launches, 1), 4), share_of_gpu_time=round(ig_ms / total_ms, 3),
                         algorithmic_tflop_per_step=round(alg / args.steps / 1e12, 2))
