@@ -334,6 +334,12 @@ def test_full_arch_process_256_vs_oracle(full_models):
     p, p1 = _psnr_u8(got, ref), _psnr_u8(got1, ref1)
     print(f"full-arch 256x256: PSNR vs fp32 oracle {p:.2f} dB (stage-1 {p1:.2f} dB)")
     assert p >= 35.0 and p1 >= 40.0
+    # north_star's acceptance form: PSNR against a ground truth must be within 0.1 dB of the reference path's PSNR against it.
+    # Any third image serves as "ground truth" for that comparison; here the LQ input itself.
+    gt = [np.asarray(i) for i in imgs]
+    d = abs(_psnr_u8(got, gt) - _psnr_u8(ref, gt))
+    print(f"full-arch 256x256: |PSNR(ours, GT) - PSNR(oracle, GT)| = {d:.4f} dB")
+    assert d <= 0.1
     # stage-level: x0 latent of the fused DiT step against the oracle's
     lat = inter["init_noise"].cuda()
     x0 = dit.step(lat, 400.0, float(oglue.alphas_cumprod_diffusers()[400]), y.cuda(), mask.cuda())
