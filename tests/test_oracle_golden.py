@@ -123,6 +123,31 @@ def test_dit_3d_mask_is_additive_not_dropping():
     assert not torch.allclose(a, b, atol=1e-5) and not torch.allclose(a, c, atol=1e-5)
 
 
+T5_SMALL = dict(d_model=128, d_kv=32, num_heads=4, d_ff=256, num_layers=2, vocab_size=100)
+
+
+def _t5_small():
+    from oracle import t5 as ot5
+    sd = det_state_dict(ot5.state_dict_shapes(T5_SMALL), seed=707)
+    sd["shared.weight"] = sd["shared.weight"] * 8.0
+    return sd
+
+
+def test_t5_encoder_matches_transformers():
+    """the prompt producer's T5 v1.1 encoder (diffusion/model/t5.py:82-101 -> transformers.T5EncoderModel)
+    against outputs of the installed transformers package on a reduced configuration."""
+    from oracle import t5 as ot5
+    fx = load("t5_small.npz")
+    sd = _t5_small()
+    assert abs(checksum(sd) - float(fx["wsum"])) < 1e-6 * float(fx["wsum"])
+    ids, mask = torch.from_numpy(fx["ids"]).long(), torch.from_numpy(fx["mask"]).long()
+    torch.testing.assert_close(ot5.t5_encode(sd, ids, mask, T5_SMALL), fx["out"], rtol=2e-4, atol=2e-5)
+    torch.testing.assert_close(ot5.t5_encode(sd, ids, None, T5_SMALL), fx["out_nomask"], rtol=2e-4, atol=2e-5)
+    # bucket function spot checks (bidirectional, 32 buckets, max distance 128): exact up to +-7, log-spaced beyond, saturating
+    b = ot5.relative_position_bucket(torch.tensor([0, 1, -1, 7, -7, 8, 127, 128, 1000, -1000]))
+    assert b.tolist() == [0, 17, 1, 23, 7, 24, 31, 31, 31, 15]
+
+
 def test_glue_matches_reference():
     fx = load("glue.npz")
     acp = oglue.alphas_cumprod()
