@@ -23,7 +23,7 @@ typedef struct ir_ctx ir_ctx;
 
 /* stages for ir_workspace_bytes */
 enum { IR_STAGE_SWINIR = 0, IR_STAGE_VAE_ENCODE = 1, IR_STAGE_DIT = 2, IR_STAGE_VAE_DECODE = 3, IR_STAGE_PIPELINE = 4,
-       IR_STAGE_COLORFIX = 5 };
+       IR_STAGE_COLORFIX = 5, IR_STAGE_T5 = 6 /* ir_workspace_bytes(ctx, IR_STAGE_T5, batch, tokens, 0, ...) */ };
 /* ir_pipeline flags */
 enum { IR_FLAG_NO_PREPROCESS = 1, IR_FLAG_TILED = 2, IR_FLAG_FIX_WAVELET = 4, IR_FLAG_FIX_ADAIN = 8,
        /* ir_pipeline only, needs ir_dit_control_configure: run the DiT step with the ControlNet-Half branch, condition latent
@@ -60,6 +60,15 @@ int ir_dit_control_configure(ir_ctx* ctx, int copy_blocks_num);
 /* encoder_hidden_states / encoder_attention_mask of the fixed prompt (inference.py:256-259,273-277): host fp32
  * [n_tok][caption_dim] and [n_tok]; projects the caption and caches K/V of all layers on the device. */
 int ir_dit_set_prompt(ir_ctx* ctx, void* stream, const float* embeds_host, const float* mask_host, int n_tok);
+
+/* The prompt producer's text encoder: T5EncoderModel.from_pretrained(...) — diffusion/model/t5.py:80 (T5 v1.1: gated-GELU, relative
+ * position bias, no biases). Tensors `t5.embed`, `t5.final_ln`, `t5.l{i}.{ln1,ln2,qkv,o,wi,wo}`; the additive position bias of a
+ * sequence length is the tensor `t5.bias.{tokens}` [heads][tokens][tokens] fp32 (uploaded by the host mirror on first use). */
+int ir_t5_configure(ir_ctx* ctx, int n_layers, int d_model, int heads, int d_kv, int d_ff, int vocab);
+/* self.model(input_ids=, attention_mask=)['last_hidden_state'] — t5.py:95-100. ids: device int32 [b][tokens]; key_mask: device fp32
+ * [b][tokens], 1 = token, 0 = padding (NULL: none); out: device fp32 [b][tokens][d_model]. tokens <= 512. Synchronises the stream
+ * (the producer runs once per prompt) and fails on an id outside the vocabulary. */
+int ir_t5_encode(ir_ctx* ctx, void* stream, const int32_t* ids, const float* key_mask, float* out, int b, int tokens, void* ws, size_t ws_bytes);
 
 size_t ir_workspace_bytes(ir_ctx* ctx, int stage, int n, int h, int w, int flags, int tile_size, int tile_stride);
 

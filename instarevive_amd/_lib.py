@@ -15,14 +15,14 @@ LIB_PATH = os.environ.get("INSTAREVIVE_HIP_LIB") or os.path.join(_HERE, "csrc", 
 # every symbol include/instarevive_hip.h declares (tests check that the library exports all of them)
 SYMBOLS = [
     "ir_abi_version", "ir_init", "ir_destroy", "ir_last_error", "ir_upload", "ir_has_tensor",
-    "ir_swinir_configure", "ir_vae_configure", "ir_dit_configure", "ir_dit_control_configure", "ir_dit_set_prompt", "ir_workspace_bytes",
+    "ir_swinir_configure", "ir_vae_configure", "ir_dit_configure", "ir_dit_control_configure", "ir_dit_set_prompt", "ir_t5_configure", "ir_t5_encode", "ir_workspace_bytes",
     "ir_swinir_forward", "ir_vae_encode", "ir_dit_forward", "ir_dit_step", "ir_dit_forward_control", "ir_dit_step_control", "ir_vae_decode", "ir_color_fix",
     "ir_pipeline", "ir_u8_to_nchw", "ir_nchw_to_u8", "ir_profile_begin", "ir_profile_end",
     "ir_op_conv", "ir_op_conv_groupnorm", "ir_op_linear", "ir_op_groupnorm", "ir_op_layernorm", "ir_op_attention", "ir_op_swin_attention",
     "ir_op_softmax_rows",
 ]
 
-STAGE_SWINIR, STAGE_VAE_ENCODE, STAGE_DIT, STAGE_VAE_DECODE, STAGE_PIPELINE, STAGE_COLORFIX = range(6)
+STAGE_SWINIR, STAGE_VAE_ENCODE, STAGE_DIT, STAGE_VAE_DECODE, STAGE_PIPELINE, STAGE_COLORFIX, STAGE_T5 = range(7)
 FLAG_NO_PREPROCESS, FLAG_TILED, FLAG_FIX_WAVELET, FLAG_FIX_ADAIN, FLAG_CONTROL_LQ, FLAG_GRAPH = 1, 2, 4, 8, 16, 32
 ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_LRELU, ACT_SILU = range(5)
 
@@ -57,6 +57,8 @@ def load_library():
     lib.ir_dit_configure.argtypes = [vp, i, i, i, i, i, i]
     lib.ir_dit_control_configure.argtypes = [vp, i]
     lib.ir_dit_set_prompt.argtypes = [vp, vp, vp, vp, i]
+    lib.ir_t5_configure.argtypes = [vp, i, i, i, i, i, i]
+    lib.ir_t5_encode.argtypes = [vp, vp, vp, vp, vp, i, i, vp, sz]
     lib.ir_workspace_bytes.argtypes = [vp, i, i, i, i, i, i, i]
     lib.ir_workspace_bytes.restype = sz
     lib.ir_swinir_forward.argtypes = [vp, vp, vp, vp, i, i, i, vp, sz]

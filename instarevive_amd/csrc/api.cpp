@@ -107,6 +107,20 @@ struct DitModel {
     float* ctrl_modtab = nullptr;
 };
 
+// T5 v1.1 encoder (prompt producer, diffusion/model/t5.py:82-101)
+struct T5Layer {
+    const float *ln1 = nullptr, *ln2 = nullptr;
+    Conv qkv, o, wi, wo;   // q|k|v fused [3*H*dk][D]; wi_0|wi_1 fused [2F][D]
+};
+struct T5Model {
+    bool ok = false;
+    int L = 0, D = 0, H = 0, dk = 0, F = 0, vocab = 0;
+    const bf16_t* embed = nullptr;
+    const float* final_ln = nullptr;
+    std::vector<T5Layer> layers;
+    int* bad = nullptr;   // device flag: an input id was outside the vocabulary
+};
+
 }  // namespace
 
 // optional per-launch timing with HIP events on the launch stream (bench.py's roofline numbers come from here)
@@ -140,6 +154,7 @@ struct ir_ctx {
     SwinModel swin;
     VaeModel vae;
     DitModel dit;
+    T5Model t5;
     // hipGraph cache of ir_pipeline (IR_FLAG_GRAPH): one instantiated graph per exact call signature. `generation` changes whenever
     // device allocations or bindings may have moved (upload with a new size, *_configure, set_prompt), which drops every graph.
     struct GraphKey {
@@ -1123,6 +1138,7 @@ int ir_dit_set_prompt(ir_ctx* c, void* stream, const float* embeds_host, const f
 #define REQUIRE(cond, msg) \
     if (!(cond)) return fail(c, -11, msg)
 
+static void t5_run(Run& r, const int* ids, const float* key_mask, const float* bias, float* out, int B, int T);
 static int stage_dispatch(ir_ctx* c, Run& r, int stage, int n, int h, int w, int flags, int tile_size, int tile_stride) {
     // dry-run bodies used by ir_workspace_bytes; pointers are fake and never dereferenced
     const float* fin = reinterpret_cast<const float*>((uintptr_t)0x1000);
@@ -1145,6 +1161,7 @@ static int stage_dispatch(ir_ctx* c, Run& r, int stage, int n, int h, int w, int
             pipeline_run(r, (const uint8_t*)fin, (uint8_t*)fout, nullptr, n, h, w, flags, tile_size, tile_stride, 0.f, 0.5f, 1.f);
             break;
         case IR_STAGE_COLORFIX: colorfix_run(r, IR_FLAG_FIX_WAVELET, fin, fin, fout, n, h, w); break;
+        case IR_STAGE_T5: t5_run(r, (const int*)fin, nullptr, fin, fout, n, h); break;  // n = batch, h = tokens
         default: return fail(c, -1, "unknown stage %d", stage);
     }
     return 0;
@@ -1300,6 +1317,82 @@ int ir_pipeline(ir_ctx* c, void* stream, const uint8_t* in, uint8_t* out, uint8_
     }
     c->graphs.push_back({key, exec});
     HIPOK(c, hipGraphLaunch(exec, s));
+    return 0;
+}
+
+// ================================================================ T5 encoder (transformers T5Stack as the reference calls it, t5.py:95-100)
+static void t5_run(Run& r, const int* ids, const float* key_mask, const float* bias, float* out, int B, int T) {
+    T5Model& m = r.c->t5;
+    const long BT = (long)B * T;
+    const int HD = m.H * m.dk;
+    const size_t mk = r.a.mark();
+    float* x = r.a.alloc<float>(BT * m.D);
+    bf16_t* xn = r.a.alloc<bf16_t>(BT * m.D);
+    bf16_t* qkv = r.a.alloc<bf16_t>(BT * 3 * HD);
+    bf16_t* att = r.a.alloc<bf16_t>(BT * HD);
+    bf16_t* ab = r.a.alloc<bf16_t>(BT * 2 * m.F);
+    bf16_t* hid = r.a.alloc<bf16_t>(BT * m.F);
+    LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_t5_embed(ids, m.embed, x, BT, m.D, m.vocab, m.bad, r.s), "t5_embed");
+    for (const T5Layer& Lw : m.layers) {
+        LAUNCH(r, PC_LAYERNORM, 0.0, 6.0 * BT * m.D, ir_launch_t5_rmsnorm(x, Lw.ln1, xn, nullptr, BT, m.D, 1e-6f, r.s), "t5_rmsnorm");
+        linear(r, Lw.qkv, xn, (int)BT, m.D, qkv, 3 * HD, 0, ACT_NONE, nullptr, 0, 0);
+        LAUNCH(r, PC_OTHER, 4.0 * B * m.H * (double)T * T * m.dk, 0.0, ir_launch_t5_attn(qkv, bias, key_mask, att, B, T, m.H, m.dk, r.s), "t5_attn");
+        linear(r, Lw.o, att, (int)BT, HD, x, m.D, 1, ACT_NONE, x, 1, m.D);
+        LAUNCH(r, PC_LAYERNORM, 0.0, 6.0 * BT * m.D, ir_launch_t5_rmsnorm(x, Lw.ln2, xn, nullptr, BT, m.D, 1e-6f, r.s), "t5_rmsnorm");
+        linear(r, Lw.wi, xn, (int)BT, m.D, ab, 2 * m.F, 0, ACT_NONE, nullptr, 0, 0);
+        LAUNCH(r, PC_OTHER, 0.0, 6.0 * BT * m.F, ir_launch_t5_gated_gelu(ab, hid, BT, m.F, r.s), "t5_gated_gelu");
+        linear(r, Lw.wo, hid, (int)BT, m.F, x, m.D, 1, ACT_NONE, x, 1, m.D);
+    }
+    LAUNCH(r, PC_LAYERNORM, 0.0, 8.0 * BT * m.D, ir_launch_t5_rmsnorm(x, m.final_ln, nullptr, out, BT, m.D, 1e-6f, r.s), "t5_final_norm");
+    r.a.release(mk);
+}
+
+int ir_t5_configure(ir_ctx* c, int n_layers, int d_model, int heads, int d_kv, int d_ff, int vocab) {
+    if (!c || n_layers < 1 || vocab < 1) return fail(c, -1, "ir_t5_configure: bad argument");
+    if ((d_model & 31) || (d_ff & 31) || ((heads * d_kv) & 31) || d_kv > 64 || (d_kv & 1))
+        return fail(c, -1, "ir_t5_configure: unsupported dims (d_model %d, heads %d x %d, d_ff %d)", d_model, heads, d_kv, d_ff);
+    HIPOK(c, hipSetDevice(c->device));
+    Binder b{c};
+    T5Model m;
+    m.L = n_layers; m.D = d_model; m.H = heads; m.dk = d_kv; m.F = d_ff; m.vocab = vocab;
+    const int HD = heads * d_kv;
+    m.embed = (const bf16_t*)b.get("t5.embed", (size_t)vocab * d_model * 2);
+    m.final_ln = b.f32("t5.final_ln", d_model);
+    for (int l = 0; l < n_layers; ++l) {
+        T5Layer L;
+        const std::string p = fmt("t5.l%d", l);
+        L.ln1 = b.f32(p + ".ln1", d_model);
+        L.ln2 = b.f32(p + ".ln2", d_model);
+        L.qkv = b.conv(p + ".qkv", d_model, 3 * HD, 3 * HD, 1);
+        L.o = b.conv(p + ".o", HD, d_model, d_model, 1);
+        L.wi = b.conv(p + ".wi", d_model, 2 * d_ff, 2 * d_ff, 1);
+        L.wo = b.conv(p + ".wo", d_ff, d_model, d_model, 1);
+        m.layers.push_back(L);
+    }
+    if (!b.ok) return fail(c, -2, "ir_t5_configure: tensor %s", b.missing.c_str());
+    if (dev_alloc(c, (void**)&m.bad, 256)) return -100;
+    HIPOK(c, hipMemset(m.bad, 0, 4));
+    m.ok = true;
+    c->t5 = m;
+    ++c->generation;
+    return 0;
+}
+
+int ir_t5_encode(ir_ctx* c, void* stream, const int32_t* ids, const float* key_mask, float* out, int b, int t, void* ws, size_t ws_bytes) {
+    REQUIRE(c && c->t5.ok, "T5 encoder not configured");
+    REQUIRE(ids && out && b > 0 && t > 0 && t <= 512, "ir_t5_encode: bad argument (1 <= tokens <= 512)");
+    auto it = c->t.find(fmt("t5.bias.%d", t));
+    REQUIRE(it != c->t.end() && it->second.bytes >= (size_t)c->t5.H * t * t * 4, "t5.bias table for this length not uploaded");
+    Run r = make_run(c, stream, ws, ws_bytes, false);
+    t5_run(r, ids, key_mask, (const float*)it->second.p, out, b, t);
+    if (int rc = finish(r, c, ws_bytes)) return rc;
+    int bad = 0;   // the producer runs once per prompt: a synchronous check of the id range costs nothing that matters
+    HIPOK(c, hipMemcpyAsync(&bad, c->t5.bad, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPOK(c, hipStreamSynchronize((hipStream_t)stream));
+    if (bad) {
+        HIPOK(c, hipMemset(c->t5.bad, 0, 4));
+        return fail(c, -32, "ir_t5_encode: token id outside [0, %d)", c->t5.vocab);
+    }
     return 0;
 }
 

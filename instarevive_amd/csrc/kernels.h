@@ -93,6 +93,12 @@ int ir_launch_swin_attn(const bf16_t* qkv, bf16_t* out, const float* biasT, int 
 int ir_launch_softmax_rows(const float* x, bf16_t* y, long rows, int cols, long ldx, long ldy, hipStream_t s);
 static inline int ir_attn_dv(int D) { return (D + 31) & ~31; }
 
+// ---- T5 encoder glue (t5.hip)
+int ir_launch_t5_embed(const int* ids, const bf16_t* table, float* x, long rows, int D, int vocab, int* bad, hipStream_t s);
+int ir_launch_t5_rmsnorm(const float* x, const float* w, bf16_t* yb, float* yf, long rows, int D, float eps, hipStream_t s);
+int ir_launch_t5_attn(const bf16_t* qkv, const float* bias, const float* key_mask, bf16_t* out, int B, int T, int H, int dk, hipStream_t s);
+int ir_launch_t5_gated_gelu(const bf16_t* ab, bf16_t* out, long rows, int F, hipStream_t s);
+
 // ---- layout / elementwise (elementwise.hip)
 int ir_launch_u8_to_nchw(const uint8_t* in, float* out, int N, int H, int W, hipStream_t s);
 int ir_launch_swin_prep(const float* x_nchw, bf16_t* out, int N, int H, int W, const float* mean3, float img_range, hipStream_t s);

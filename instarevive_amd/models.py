@@ -517,6 +517,103 @@ class ControlTransformerHalf(_DeviceModule):
         return out
 
 
+# ====================================================================================================== T5 encoder (prompt producer)
+class T5EncoderModel(_DeviceModule):
+    """transformers.T5EncoderModel as the reference's T5Embedder uses it (diffusion/model/t5.py:80,95-100): T5 v1.1 encoder
+    (gated-GELU feed-forward, shared relative-position bias, no biases), state dict in the transformers key layout. The call returns
+    a dict with 'last_hidden_state' [B, T, d_model] (fp32), as the reference indexes it."""
+
+    def __init__(self, d_model=4096, d_kv=64, num_heads=64, d_ff=10240, num_layers=24, vocab_size=32128, relative_attention_num_buckets=32,
+                 relative_attention_max_distance=128, feed_forward_proj="gated-gelu", layer_norm_epsilon=1e-6, **unused):
+        super().__init__()
+        if feed_forward_proj != "gated-gelu" or abs(layer_norm_epsilon - 1e-6) > 1e-12:
+            raise NotImplementedError("the MI355X path implements the T5 v1.1 encoder (gated-gelu, eps 1e-6) of DeepFloyd/t5-v1_1-xxl")
+        self.cfg = dict(d_model=d_model, d_kv=d_kv, num_heads=num_heads, d_ff=d_ff, num_layers=num_layers, vocab_size=vocab_size,
+                        buckets=relative_attention_num_buckets, max_distance=relative_attention_max_distance)
+        self.config = SimpleNamespace(**self.cfg)
+
+    @classmethod
+    def from_pretrained(cls, name_or_path, subfolder=None, **kw):
+        folder = _resolve_pretrained(name_or_path, subfolder)
+        with open(os.path.join(folder, "config.json")) as f:
+            cfg = json.load(f)
+        m = cls(**{k: v for k, v in cfg.items() if not k.startswith("_")})
+        m.load_state_dict(_load_weights_file(folder), strict=False)
+        return m
+
+    def _expected_keys(self):
+        return W.t5_expected_keys(self.cfg)
+
+    def load_state_dict(self, state_dict, strict=True):
+        sd = dict(state_dict)
+        if "shared.weight" not in sd and "encoder.embed_tokens.weight" in sd:
+            sd["shared.weight"] = sd["encoder.embed_tokens.weight"]
+        res = self._check_keys(sd, strict, ignore=("encoder.embed_tokens.weight", "decoder.", "lm_head."))
+        self._sd = {k: v.detach().cpu() for k, v in sd.items() if k in set(self._expected_keys())}
+        if self.ctx is not None:
+            self._upload()
+        return res
+
+    def _upload(self):
+        c = self.cfg
+        self.ctx.upload_all(W.pack_t5(self._sd, c))
+        self.ctx.check(self.ctx.lib.ir_t5_configure(self.ctx.h, c["num_layers"], c["d_model"], c["num_heads"], c["d_kv"], c["d_ff"], c["vocab_size"]),
+                       "ir_t5_configure")
+        self._bias_lengths = set()  # position-bias tables depend on the weights: rebuilt per sequence length after every upload
+
+    @torch.no_grad()
+    def __call__(self, input_ids=None, attention_mask=None, **unused):
+        self._ready()
+        ids = input_ids.to(self.device, torch.int32).contiguous()
+        if ids.ndim != 2 or ids.shape[1] > 512:
+            raise ValueError(f"input_ids must be [B, T] with T <= 512, got {tuple(ids.shape)}")
+        b, t = ids.shape
+        name = f"t5.bias.{t}"
+        if t not in self._bias_lengths:
+            self._bias_lengths.add(t)
+            self.ctx.upload(name, W.t5_position_bias(self._sd["encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"], t,
+                                                     self.cfg["buckets"], self.cfg["max_distance"]))
+        mask = None if attention_mask is None else attention_mask.to(self.device, torch.float32).contiguous()
+        if mask is not None and tuple(mask.shape) != (b, t):
+            raise ValueError("attention_mask must have the shape of input_ids")
+        out = torch.empty(b, t, self.cfg["d_model"], dtype=torch.float32, device=self.device)
+        ws = self.ctx.workspace(self.ctx.ws_bytes(L.STAGE_T5, b, t, 0))
+        self.ctx.check(self.ctx.lib.ir_t5_encode(self.ctx.h, self.ctx.stream(), L.ptr(ids), L.ptr(mask) if mask is not None else None, L.ptr(out), b, t,
+                                                  L.ptr(ws), ws.numel()), "ir_t5_encode")
+        return {"last_hidden_state": out}
+
+    forward = __call__
+
+
+class T5Embedder:
+    """diffusion/model/t5.py:13-101 with the same constructor keywords that matter here and the same get_text_embeddings(texts)
+    -> (embeddings [B, L, 4096], attention_mask [B, L]). The tokenizer is transformers' own (AutoTokenizer over the model folder, as in
+    the reference); the encoder is the HIP T5EncoderModel above. The reference's caption cleaning (clean_caption: ftfy / bs4 / regex
+    rewriting, t5.py:118-233) is not reproduced: use_text_preprocessing=True falls back to its lower().strip() branch (:113-116)."""
+
+    def __init__(self, device, dir_or_name="t5-v1_1-xxl", *, tokenizer=None, model=None, model_max_length=120, use_text_preprocessing=False,
+                 **unused):
+        self.device = torch.device(device)
+        self.model_max_length = model_max_length
+        self.use_text_preprocessing = use_text_preprocessing
+        if tokenizer is None:
+            from transformers import AutoTokenizer  # host-side text -> ids only; needs the tokenizer files in dir_or_name
+            tokenizer = AutoTokenizer.from_pretrained(dir_or_name)
+        self.tokenizer = tokenizer
+        self.model = (model or T5EncoderModel.from_pretrained(dir_or_name)).to(self.device)
+
+    def text_preprocessing(self, text):
+        return text.lower().strip()
+
+    def get_text_embeddings(self, texts):
+        texts = [self.text_preprocessing(t) for t in texts]
+        tok = self.tokenizer(texts, max_length=self.model_max_length, padding="max_length", truncation=True, return_attention_mask=True,
+                             add_special_tokens=True, return_tensors="pt")
+        mask = tok["attention_mask"].to(self.device)
+        embs = self.model(input_ids=tok["input_ids"].to(self.device), attention_mask=mask)["last_hidden_state"].detach()
+        return embs, mask
+
+
 # ====================================================================================================== scheduler
 class DDPMScheduler:
     """Only what the path consumes: alphas_cumprod (generate.py:45). Linear / scaled_linear betas like diffusers."""

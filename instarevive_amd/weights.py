@@ -276,6 +276,46 @@ def pack_dit_control(sd, copy_blocks_num):
     return out
 
 
+# ------------------------------------------------------------------------------------------------ T5 v1.1 encoder (prompt producer)
+def t5_expected_keys(cfg):
+    keys = ["shared.weight", "encoder.final_layer_norm.weight", "encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"]
+    for i in range(cfg["num_layers"]):
+        p = f"encoder.block.{i}.layer."
+        keys += [p + f"0.SelfAttention.{n}.weight" for n in ("q", "k", "v", "o")] + [p + "0.layer_norm.weight", p + "1.layer_norm.weight"]
+        keys += [p + f"1.DenseReluDense.{n}.weight" for n in ("wi_0", "wi_1", "wo")]
+    return keys
+
+
+def pack_t5(sd, cfg):
+    """transformers T5EncoderModel keys -> device tensors of ir_t5_configure (q|k|v and wi_0|wi_1 fused; zero biases)."""
+    out = {"t5.embed": _bf16(sd["shared.weight"].to(torch.float32)), "t5.final_ln": sd["encoder.final_layer_norm.weight"].float().contiguous()}
+    for i in range(cfg["num_layers"]):
+        s_, p = f"encoder.block.{i}.layer.", f"t5.l{i}."
+        out[p + "ln1"] = sd[s_ + "0.layer_norm.weight"].float().contiguous()
+        out[p + "ln2"] = sd[s_ + "1.layer_norm.weight"].float().contiguous()
+        for dst, w in ((p + "qkv", torch.cat([sd[s_ + f"0.SelfAttention.{n}.weight"] for n in ("q", "k", "v")], 0)),
+                       (p + "o", sd[s_ + "0.SelfAttention.o.weight"]),
+                       (p + "wi", torch.cat([sd[s_ + "1.DenseReluDense.wi_0.weight"], sd[s_ + "1.DenseReluDense.wi_1.weight"]], 0)),
+                       (p + "wo", sd[s_ + "1.DenseReluDense.wo.weight"])):
+            _pack_lin(out, dst, w, torch.zeros(w.shape[0]))
+    return out
+
+
+def t5_position_bias(table, T, num_buckets=32, max_distance=128):
+    """relative_attention_bias.weight [buckets, heads] -> additive bias [heads, T, T] (query, key), computed on the host as
+    transformers' T5Attention.compute_bias does (bidirectional buckets: exact up to +-7, log-spaced to max_distance, saturating)."""
+    pos = torch.arange(T)
+    rel = pos[None, :] - pos[:, None]
+    nb = num_buckets // 2
+    ret = (rel > 0).long() * nb
+    n = rel.abs()
+    max_exact = nb // 2
+    large = max_exact + (torch.log(n.float().clamp(min=1) / max_exact) / math.log(max_distance / max_exact) * (nb - max_exact)).long()
+    large = torch.min(large, torch.full_like(large, nb - 1))
+    buckets = ret + torch.where(n < max_exact, n, large)
+    return table.to(torch.float32)[buckets].permute(2, 0, 1).contiguous()
+
+
 def sincos_pos_embed(embed_dim, gh, gw, base_size, interpolation_scale=1.0):
     """2-D sin-cos table regenerated per latent size, as the reference does on the host with numpy
     (PixArtMS.py:177-182 / PixArt.py:258-307; diffusers PatchEmbed cropped/regenerated table). fp32 [gh*gw, D]."""

@@ -211,6 +211,69 @@ def test_dit_control_full_arch_256_tokens():
     check(out, ref, "control dit full arch 32x32", l2=0.03)
 
 
+def make_t5(cfg, seed=707, embed_gain=8.0):
+    from instarevive_amd.models import T5EncoderModel
+    from oracle import t5 as ot5
+    sd = det_state_dict(ot5.state_dict_shapes(cfg), seed=seed)
+    sd["shared.weight"] = sd["shared.weight"] * embed_gain
+    for k in sd:  # q carries the 1/sqrt(d_kv) that T5 folds into its initialisation: logits of a realistic size
+        if k.endswith("SelfAttention.q.weight"):
+            sd[k] = sd[k] * cfg["d_kv"] ** -0.5
+    m = T5EncoderModel(**cfg)
+    m.load_state_dict(sd, strict=True)
+    return m.to("cuda"), sd
+
+
+def test_t5_encoder_vs_transformers_fixture_and_oracle():
+    """SURVEY.md section 8(f) N3, the prompt producer's text encoder: the HIP path against the output of transformers.T5EncoderModel
+    (fixture) and against the oracle at widths nearer the real model (64 heads of 64 would be 4096 wide; here 8 x 64 and 300 tokens)."""
+    from oracle import t5 as ot5
+    from tests.test_oracle_golden import T5_SMALL
+    fx = np.load(os.path.join(G, "t5_small.npz"))
+    m, sd = make_t5(T5_SMALL)
+    ids, mask = torch.from_numpy(fx["ids"]), torch.from_numpy(fx["mask"])
+    out = m(input_ids=ids.cuda(), attention_mask=mask.cuda())["last_hidden_state"]
+    check(out, torch.from_numpy(fx["out"]), "t5 small vs transformers fixture (padding mask)")
+    check(m(input_ids=ids.cuda())["last_hidden_state"], torch.from_numpy(fx["out_nomask"]), "t5 small vs transformers fixture (no mask)")
+    cfg = dict(d_model=512, d_kv=64, num_heads=8, d_ff=1024, num_layers=3, vocab_size=500)
+    m, sd = make_t5(cfg, seed=808)
+    g = np.random.Generator(np.random.PCG64(5))
+    for b, t, valid in ((1, 300, 41), (2, 120, 120)):   # the prompt file's 300 tokens; the reference default max_length 120, batch 2
+        ids = torch.from_numpy(g.integers(1, 500, size=(b, t)))
+        mask = torch.zeros(b, t, dtype=torch.long)
+        mask[:, :valid] = 1
+        ref = ot5.t5_encode(sd, ids, mask, cfg)
+        out = m(input_ids=ids.cuda(), attention_mask=mask.cuda())["last_hidden_state"]
+        check(out[:, :valid], ref[:, :valid], f"t5 512-wide b{b} t{t} (valid tokens)")
+        check(out, ref, f"t5 512-wide b{b} t{t} (all positions)")
+    with pytest.raises(RuntimeError):
+        m(input_ids=torch.full((1, 8), 500).cuda())  # id outside the vocabulary
+
+
+def test_t5_embedder_interface():
+    """T5Embedder.get_text_embeddings (t5.py:82-101) with a stand-in tokenizer: max_length padding, mask, embeddings of the padded batch."""
+    from instarevive_amd.models import T5Embedder
+    from oracle import t5 as ot5
+    from tests.test_oracle_golden import T5_SMALL
+
+    class Tok:  # whitespace "tokenizer" with the call signature the reference uses (t5.py:85-93)
+        def __call__(self, texts, max_length, padding, truncation, return_attention_mask, add_special_tokens, return_tensors):
+            ids = torch.zeros(len(texts), max_length, dtype=torch.long)
+            mask = torch.zeros_like(ids)
+            for i, t in enumerate(texts):
+                w = [2 + (sum(map(ord, x)) % 90) for x in t.split()][: max_length - 1] + [1]  # </s> = 1
+                ids[i, : len(w)] = torch.tensor(w)
+                mask[i, : len(w)] = 1
+            return {"input_ids": ids, "attention_mask": mask}
+
+    m, sd = make_t5(T5_SMALL)
+    emb = T5Embedder("cuda", tokenizer=Tok(), model=m, model_max_length=24)
+    e, msk = emb.get_text_embeddings(["  A portrait photo of a human FACE ", "4k, highly detailed"])
+    assert tuple(e.shape) == (2, 24, 128) and tuple(msk.shape) == (2, 24) and int(msk.sum()) == 8 + 4
+    tok = Tok()(["a portrait photo of a human face", "4k, highly detailed"], 24, "max_length", True, True, True, "pt")
+    check(e, ot5.t5_encode(sd, tok["input_ids"], tok["attention_mask"], T5_SMALL), "T5Embedder.get_text_embeddings")
+
+
 def _small_models():
     return make_swin(SWIN_SMALL), make_vae(VAE_SMALL), make_dit(DIT_SMALL)
 
