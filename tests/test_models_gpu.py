@@ -250,6 +250,21 @@ def test_t5_encoder_vs_transformers_fixture_and_oracle():
         m(input_ids=torch.full((1, 8), 500).cuda())  # id outside the vocabulary
 
 
+def test_t5_one_block_at_xxl_width():
+    """One block at the dimensions of DeepFloyd/t5-v1_1-xxl (4096 wide, 64 heads of 64, d_ff 10240) on the prompt file's 300 tokens:
+    the real model's GEMM shapes and attention LDS footprint (24 such blocks make the 4.7 B parameter encoder)."""
+    from oracle import t5 as ot5
+    cfg = dict(d_model=4096, d_kv=64, num_heads=64, d_ff=10240, num_layers=1, vocab_size=256)
+    m, sd = make_t5(cfg, seed=909)
+    g = np.random.Generator(np.random.PCG64(6))
+    ids = torch.from_numpy(g.integers(1, 256, size=(1, 300)))
+    mask = torch.zeros(1, 300, dtype=torch.long)
+    mask[:, :25] = 1
+    ref = ot5.t5_encode(sd, ids, mask, cfg)
+    out = m(input_ids=ids.cuda(), attention_mask=mask.cuda())["last_hidden_state"]
+    check(out, ref, "t5 one block at XXL width, 300 tokens")
+
+
 def test_t5_embedder_interface():
     """T5Embedder.get_text_embeddings (t5.py:82-101) with a stand-in tokenizer: max_length padding, mask, embeddings of the padded batch."""
     from instarevive_amd.models import T5Embedder
