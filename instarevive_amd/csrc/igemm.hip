@@ -498,6 +498,16 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IGemmParams p) {
 // all nine taps read their A fragments from it with a tap offset on the LDS address; only the weight tile is re-staged per
 // tap. Compared with the generic implicit GEMM above this cuts the activation traffic from L2/HBM ~6x (180 instead of
 // 9 x 128 pixel rows per chunk) and removes all per-tap global address arithmetic.
+// Swizzle key of a halo pixel (a 128-byte LDS row of 8 chunks; chunk c of the pixel in halo column hx is stored at slot
+// c ^ halo_key(hx), on the LDS-DMA source side and on the read side). The key follows the fragment read pattern:
+//  * 32x32x16 MFMAs: the 16 lanes of a ds_read_b128 lane group read the SAME chunk of 16 pixels -> 8 distinct keys per column pair.
+//  * 16x16x32 MFMAs: a lane group reads all 16 columns of one patch row once, columns 4-11 with chunk 4ks + kq and columns 0-3, 12-15
+//    with 4ks + (kq ^ 1) (or the other way round), shifted by the tap's kx. With key = 2 * ((hx >> 1) & 3) the two pixels that share
+//    key bits (columns hx and hx + 8) always sit in opposite chunk sets, whose chunks differ in bit 0, for every kx: conflict-free.
+//    The 32x32 key under this read pattern conflicts for kx = 1, 2 (SQ_LDS_BANK_CONFLICT was 27 % of SQ_LDS_IDX_ACTIVE).
+template <bool M16>
+IR_DEVINL int halo_key(int hx) { return M16 ? ((hx >> 1) & 3) << 1 : (hx >> 1) & 7; }
+
 template <int BN, int UP, bool M16 = false>
 __global__ __launch_bounds__(256, 2) void conv_halo_kernel(IGemmParams p, int tiles_y, int tiles_x) {
     constexpr int BK = 64, ROWB = 128, SP = 8;
@@ -543,7 +553,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(IGemmParams p, int ti
         const bool ok = hp < HP && cy >= 0 && cy < Hc && cx >= 0 && cx < Wc;
         const int iy = min(max(cy, 0), Hc - 1) >> UP, ix = min(max(cx, 0), Wc - 1) >> UP;
         const bf16_t* src = p.in + (((long)img * p.H + iy) * p.W + ix) * p.in_cs;
-        h_ptr[i] = (ok ? src : zero) + ((lslot ^ ((hx >> 1) & 7)) << 3);  // swizzle key from the halo COLUMN: see the read side
+        h_ptr[i] = (ok ? src : zero) + ((lslot ^ halo_key<M16>(hx)) << 3);  // swizzle key from the halo COLUMN: see halo_key
     }
     const bf16_t* b_ptr[B_I];
 #pragma unroll
@@ -620,7 +630,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(IGemmParams p, int ti
             const unsigned char* Hb = smem + cbuf * HALO_BYTES;
             const unsigned char* Bb = smem + 2 * HALO_BYTES + bbuf * BT_BYTES;
             const int ky = tap / 3, kx = tap - ky * 3;
-            const int sw = ((c16 + kx) >> 1) & 7;
+            const int sw = halo_key<true>(c16 + kx);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -690,7 +700,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(IGemmParams p, int ti
             // the halo column alone, the 16 slots are distinct; keyed on the pixel index (18 per row) they collided 2-way
             // (SQ_LDS_BANK_CONFLICT was 30 % of the LDS cycles).
             const int hid = hid0[i] + toff;
-            const int sw = (((r & 15) + kx) >> 1) & 7;
+            const int sw = halo_key<false>((r & 15) + kx);
             af[set][i] = *reinterpret_cast<const bf16x8*>(Hb + hid * ROWB + (((2 * ks + h) ^ sw) << 4));
         }
 #pragma unroll
@@ -805,7 +815,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_pp_kernel(IGemmParams p, int
         const bool ok = hp < HP && cy >= 0 && cy < Hc && cx >= 0 && cx < Wc;
         const int iy = min(max(cy, 0), Hc - 1) >> UP, ix = min(max(cx, 0), Wc - 1) >> UP;
         const bf16_t* src = p.in + (((long)img * p.H + iy) * p.W + ix) * p.in_cs;
-        h_ptr[i] = (ok ? src : zero) + ((lslot ^ ((hx >> 1) & 7)) << 3);  // swizzle key from the halo COLUMN (see conv_halo_kernel)
+        h_ptr[i] = (ok ? src : zero) + ((lslot ^ halo_key<M16>(hx)) << 3);  // swizzle key from the halo COLUMN (see halo_key)
     }
     const bf16_t* b_ptr[B_I];
 #pragma unroll
@@ -881,7 +891,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_pp_kernel(IGemmParams p, int
         const uint32_t Hb = lds0 + (c & 1) * HALO_BYTES;
         const uint32_t Bb = lds0 + 2 * HALO_BYTES + (step % NSB) * BT_BYTES;
         const int ky = tap / 3, kx = tap - ky * 3;
-        const int sw = ((c16 + kx) >> 1) & 7;
+        const int sw = halo_key<true>(c16 + kx);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -910,7 +920,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_pp_kernel(IGemmParams p, int
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int hid = hid0[i] + toff;
-            const int sw = (((r & 15) + kx) >> 1) & 7;
+            const int sw = halo_key<false>((r & 15) + kx);
             af[set][i] = lds_read16<0>(Hb + hid * ROWB + (((2 * ks + h) ^ sw) << 4));
         }
 #pragma unroll
