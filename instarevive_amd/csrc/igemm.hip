@@ -1144,7 +1144,11 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(IGemmParams p) {
     for (int i = 0; i < G::TM; ++i)
 #pragma unroll
         for (int j = 0; j < G::TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#ifndef IR_GKO
+#define IR_GKO 0
+#endif
     auto matrix = [&]() __attribute__((always_inline)) {
+        if (IR_GKO == 1) return;
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int j = 0; j < G::TN; ++j)
@@ -1170,9 +1174,9 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(IGemmParams p) {
                 unsigned char* base = smem + ((kt + 3) & 3) * G::B_BYTES;
                 const int ko = (kt + 3) * G::BK;
 #pragma unroll
-                for (int i = 0; i < 5; ++i) glds16(src[i] + ko, (lds_ptr_t)(base + dst[i]));
+                for (int i = 0; i < 5; ++i) if (IR_GKO != 2) glds16(src[i] + ko, (lds_ptr_t)(base + dst[i]));
             }
-            if (kt + 1 < KT) read_frags(sa1, (kt + 1) & 3);
+            if (kt + 1 < KT && IR_GKO != 3) read_frags(sa1, (kt + 1) & 3);
             sa1 = sa1 == G::NSA - 1 ? 0 : sa1 + 1;
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
@@ -1185,9 +1189,9 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(IGemmParams p) {
                 unsigned char* base = smem + sa4 * G::A_BYTES;
                 const int ko = (kt + 4) * G::BK;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) glds16(src[i] + ko, (lds_ptr_t)(base + dst[i]));
+                for (int i = 0; i < 4; ++i) if (IR_GKO != 2) glds16(src[i] + ko, (lds_ptr_t)(base + dst[i]));
             }
-            read_frags(sa, kt & 3);
+            if (IR_GKO != 3 || kt == 0) read_frags(sa, kt & 3);
             // A(kt+1) has landed; the batches of A(kt+2) .. A(kt+4) may be in flight (fewer at the end of the K loop)
             const int rem = KT - 2 - kt;
             if (rem >= 3) wait_vm<12>(); else if (rem == 2) wait_vm<8>(); else if (rem == 1) wait_vm<4>(); else wait_dma();
