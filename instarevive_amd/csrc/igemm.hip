@@ -1145,8 +1145,8 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(IGemmParams p) {
 #pragma unroll
         for (int j = 0; j < G::TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #ifndef IR_GKO
-#define IR_GKO 0
-#endif
+#define IR_GKO 0  // knock-out builds for timing only (-DIR_GKO=n, results wrong by design; never set in the library): 1 no MFMAs, 2 no
+#endif            // LDS-DMA in the K loop, 3 no fragment reads - DESIGN.md section 7 quotes the three timings
     auto matrix = [&]() __attribute__((always_inline)) {
         if (IR_GKO == 1) return;
         __builtin_amdgcn_s_setprio(1);
