@@ -455,3 +455,16 @@ def test_full_arch_tiled_2048(full_models):
     p = _psnr_u8(fused, staged)
     print(f"2048 tiled fused vs staged: {p:.2f} dB")
     assert p >= 45.0 and fused[0].std() > 1.0
+
+
+def test_fast_vs_plain_kernels_at_awkward_sizes():
+    """A padded 1080p frame (1088 x 1920: 8160 DiT tokens, not a multiple of 64 or 256; 16320-row linears) and a 832 x 1216 one through
+    process() at full architecture, once with the default kernels and once (second process) with the ping-pong / big-tile kernels
+    switched off: the same arithmetic through two independent kernel sets must agree (>= 45 dB on the uint8 result)."""
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(__file__), "..", "tools", "cross_check_sizes.py")
+    r = subprocess.run([sys.executable, tool, "1088x1920", "832x1216"], capture_output=True, text=True, timeout=900)
+    print(r.stdout[-600:])
+    assert r.returncode == 0 and "cross-check ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
