@@ -98,6 +98,33 @@ int ir_color_fix(ir_ctx* ctx, void* stream, int kind /*IR_FLAG_FIX_**/, const fl
 int ir_pipeline(ir_ctx* ctx, void* stream, const uint8_t* in, uint8_t* out, uint8_t* stage1, int n, int h, int w, int flags,
                 int tile_size, int tile_stride, float timestep, float alpha_cumprod, float scaling_factor, void* ws, size_t ws_bytes);
 
+/* process() under --tiled (inference.py:119-153), phase by phase, so that the tiles of ONE image can be sharded over the GPUs of a node
+ * (one process per GPU). Tile i of the reference's loop order (rows of _sliding_windows, inference.py:39-53)
+ * belongs to the caller when i = first + k*step. Sequence per rank:
+ *   ir_tiled_encode        every rank: uint8 -> stage-1 restorer -> VAE encode; control [n,3,h,w] fp32, init = latent*sf [n,4,h/8,w/8]  (:91-109)
+ *   ir_tiled_dit           own tiles: x0 of local tile j -> x0_tiles[j] ([n,4,tile/8,tile/8] each)                                  (:128-131)
+ *   (all-gather of the x0 tiles into loop order)
+ *   ir_tiled_blend_latent  every rank: nb = sum of ALL tiles in loop order / overlap count                                        (:131-136)
+ *   ir_tiled_decode        own tiles: decode nb/sf, /2+0.5, colour fix against the control tile -> px_tiles[j] ([n,3,tile,tile])   (:139-149)
+ *   (gather of the pixel tiles into loop order on one rank)
+ *   ir_tiled_blend_pixels  that rank: sum in loop order / overlap count -> clamp -> uint8 HWC                                      (:150-161)
+ * ir_pipeline with IR_FLAG_TILED is exactly this sequence with first = 0, step = 1, so a sharded run reproduces it bit for bit.
+ * ws: at least ir_workspace_bytes(ctx, IR_STAGE_PIPELINE, n, h, w, flags | IR_FLAG_TILED, tile_size, tile_stride). */
+int ir_tiled_count(int h, int w, int tile_size, int tile_stride);
+int ir_tiled_encode(ir_ctx* ctx, void* stream, const uint8_t* in, uint8_t* stage1, float* control, float* init, int n, int h, int w, int flags,
+                    float scaling_factor, void* ws, size_t ws_bytes);
+int ir_tiled_dit(ir_ctx* ctx, void* stream, const float* init, float* x0_tiles, int n, int h, int w, int tile_size, int tile_stride, int first,
+                 int step, float timestep, float alpha_cumprod, int flags, void* ws, size_t ws_bytes);
+int ir_tiled_blend_latent(ir_ctx* ctx, void* stream, const float* x0_tiles, float* nb, int n, int h, int w, int tile_size, int tile_stride);
+int ir_tiled_decode(ir_ctx* ctx, void* stream, const float* nb, const float* control, float* px_tiles, int n, int h, int w, int tile_size,
+                    int tile_stride, int first, int step, int flags, float scaling_factor, void* ws, size_t ws_bytes);
+int ir_tiled_blend_pixels(ir_ctx* ctx, void* stream, const float* px_tiles, uint8_t* out, int n, int h, int w, int tile_size, int tile_stride,
+                          void* ws, size_t ws_bytes);
+
+/* Diagnostic (no reference counterpart): on != 0 routes every launch through the older 4-wave kernels — an independent second
+ * implementation of the same arithmetic that bench.py ("verified") and the tests cross-check the fast kernels against. Process-wide. */
+int ir_set_plain_kernels(ir_ctx* ctx, int on);
+
 /* Per-launch timing with HIP events recorded on the launch stream (measurement aid for bench.py; no reference
  * counterpart). Classes: 0 conv3x3, 1 linear, 2 flash attention, 3 window attention, 4 groupnorm, 5 layernorm,
  * 6 row softmax, 7 transpose, 8 other. ir_profile_end synchronises the stream and sums per class. */

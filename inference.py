@@ -12,11 +12,15 @@ Same flags, defaults, file naming (`<stem>_<i>.png` under the input's relative p
   * prompt:   {'caption_embeds': [1,300,4096], 'emb_mask': [1,300]} .pth       (override: --prompt_embeds)
   * scheduler: only alphas_cumprod[400] is consumed                            (override: --dit_config folder)
 All compute runs on the MI355X through hand-written HIP kernels; `--device cpu|mps` is rejected (no CPU path).
-With torchrun (WORLD_SIZE > 1) the file list is sharded over the ranks, one process per GPU (images are independent).
+With torchrun (WORLD_SIZE > 1) the file list is sharded over the ranks, one process per GPU (images are independent); with
+--tiled --shard_tiles the tiles of each image are sharded instead (one RCCL all-gather of latent tiles + one gather of pixel tiles).
 """
 import math
 import os
 from argparse import ArgumentParser, Namespace
+from dataclasses import dataclass
+from types import SimpleNamespace
+from typing import Iterable, Iterator, List
 
 import numpy as np
 import torch
@@ -58,6 +62,10 @@ def parse_args() -> Namespace:
     parser.add_argument("--vae", type=str, default="stabilityai/sd-vae-ft-ema")
     parser.add_argument("--dit_config", type=str, default="PixArt-alpha/PixArt-Alpha-DMD-XL-2-512x512")
     parser.add_argument("--prompt_embeds", type=str, default=DEFAULT_PROMPT)
+    # extensions (defaults reproduce the reference's behaviour)
+    parser.add_argument("--batch_size", type=int, default=1, help="consecutive files of equal network-input size per process() call")
+    parser.add_argument("--shard_tiles", action="store_true", help="with --tiled under torchrun: spread the TILES of each image over the "
+                        "GPUs (one large image at a time) instead of spreading the files")
     return parser.parse_args()
 
 
@@ -68,77 +76,129 @@ def check_device(device: str) -> str:
     return device
 
 
-def main() -> None:
+# ---------------------------------------------------------------------------------------------------------------------
+# The reference runs one file at a time through load -> resize -> pad -> process() -> crop -> resize -> save, all on one host thread
+# (test_scripts/inference.py:261-346). Here the same per-file arithmetic is cut into three pieces around the GPU call:
+#   read_job()    everything before process(): decode, --sr_scale bicubic, auto_resize / centre crop, pad to 64       (:263-291)
+#   process_stream()  the GPU path, transfers of neighbouring jobs overlapped with compute
+#   write_job()   everything after: un-pad, LANCZOS back to the LQ size, optional LQ | stage-1 | result strip, PNG    (:323-346)
+# so that a directory streams through the GPU instead of alternating between PIL and the device.
+@dataclass
+class Job:
+    save_path: str
+    lq: Image.Image            # the (sr_scale-d) LQ image: target size of the saved result and left panel of --show_lq
+    net_in: np.ndarray         # what process() receives: HWC uint8, edges multiples of 64 (or 512 x 512 under --use_center_crop)
+    valid_hw: tuple            # un-padded extent of net_in, () under --use_center_crop (nothing to remove)
+
+
+def read_job(file_path: str, repeat: int, args: Namespace) -> Job:
+    from instarevive_amd.utils import auto_resize, center_crop_arr, get_file_name_parts, pad
+    lq = Image.open(file_path).convert("RGB")
+    if args.sr_scale != 1:
+        lq = lq.resize(tuple(math.ceil(edge * args.sr_scale) for edge in lq.size), Image.BICUBIC)
+    if args.use_center_crop and not args.tiled:
+        net_in = np.array(center_crop_arr(lq, 512))
+    else:
+        fitted = auto_resize(lq, args.tile_size if args.tiled else 512)
+        net_in = pad(np.array(fitted), scale=64)
+    # --use_center_crop switches the un-padding / resize-back of the result off, also next to --tiled (inference.py:326-346)
+    valid = () if args.use_center_crop else (fitted.height, fitted.width)
+    folder, stem, _ = get_file_name_parts(os.path.join(args.output, os.path.relpath(file_path, args.input)))
+    return Job(os.path.join(folder, f"{stem}_{repeat}.png"), lq, net_in, valid)
+
+
+def write_job(job: Job, pred: np.ndarray, stage1_pred, args: Namespace) -> None:
+    def back_to_lq(img):
+        if not job.valid_hw:
+            return img
+        img = img[:job.valid_hw[0], :job.valid_hw[1], :]
+        return np.array(Image.fromarray(img).resize(job.lq.size, Image.LANCZOS))
+
+    os.makedirs(os.path.dirname(job.save_path) or ".", exist_ok=True)
+    result = back_to_lq(pred)
+    if args.show_lq:
+        panels = [np.array(job.lq) if job.valid_hw else job.net_in]
+        if not args.disable_preprocess_model:
+            panels.append(back_to_lq(stage1_pred))
+        result = np.concatenate(panels + [result], axis=1)
+    Image.fromarray(result).save(job.save_path)
+    print(f"save to {job.save_path}")
+
+
+def batches_of(jobs: Iterable[Job], limit: int) -> Iterator[List[Job]]:
+    """Consecutive jobs of equal network-input shape, at most `limit` per batch (limit 1 = the reference's one image per call)."""
+    group: List[Job] = []
+    for job in jobs:
+        if group and (len(group) >= limit or job.net_in.shape != group[0].net_in.shape):
+            yield group
+            group = []
+        group.append(job)
+    if group:
+        yield group
+
+
+def load_models(args: Namespace, device: torch.device) -> SimpleNamespace:
     from instarevive_amd.models import AutoencoderKL, DDPMScheduler, Transformer2DModel
-    from instarevive_amd.pipeline import process
-    from instarevive_amd.utils import (auto_resize, center_crop_arr, get_file_name_parts, instantiate_from_config, list_image_files,
-                                       load_state_dict, load_yaml, pad)
+    from instarevive_amd.utils import instantiate_from_config, load_state_dict, load_yaml
+    m = SimpleNamespace()
+    m.noise_scheduler = DDPMScheduler.from_pretrained(args.dit_config, subfolder="scheduler")
+    m.vae = AutoencoderKL.from_pretrained(args.vae).to(torch.float32).to(device)
+    m.model = Transformer2DModel.from_pretrained(args.dit_config, subfolder="transformer")
+    m.model.load_state_dict(torch.load(args.ckpt, map_location="cpu"))
+    m.preprocess_model = instantiate_from_config(load_yaml(args.swinir_config))
+    load_state_dict(m.preprocess_model, torch.load(args.swinir_ckpt, map_location="cpu"), strict=True)
+    m.model.to(device)
+    m.preprocess_model.to(device)
+    prompt = torch.load(args.prompt_embeds, map_location="cpu")
+    embeds = prompt["caption_embeds"]
+    m.y = embeds.to(device, torch.float32).reshape(1, -1, embeds.shape[-1])
+    # [1,1,L]: a 3-D mask reaches the cross-attention as an ADDITIVE bias (diffusers semantics, inference.py:274-277)
+    m.y_mask = prompt["emb_mask"].to(device, torch.float32).reshape(1, 1, -1)
+    return m
+
+
+def main() -> None:
+    from instarevive_amd import parallel
+    from instarevive_amd.pipeline import HipTileEngine, process_stream
+    from instarevive_amd.utils import list_image_files
     args = parse_args()
     torch.manual_seed(args.seed)  # the path is deterministic; kept for surface compatibility (pl.seed_everything)
     args.device = check_device(args.device)
-    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
-    local = int(os.environ.get("LOCAL_RANK", 0))
+    rank, world, local = parallel.init_distributed()
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    m = load_models(args, device)
+    if not os.path.isdir(args.input):
+        raise SystemExit(f"--input {args.input} is not a directory")
+    # os.walk order, like the reference (no sorting); every rank of one node lists the same order
+    files = list_image_files(args.input, follow_links=True)
+    common = dict(color_fix_type=args.color_fix_type, disable_preprocess_model=args.disable_preprocess_model, tile_size=args.tile_size,
+                  tile_stride=args.tile_stride, preprocess_model=m.preprocess_model, vae=m.vae, y=m.y, y_mask=m.y_mask,
+                  noise_scheduler=m.noise_scheduler)
+    if args.shard_tiles and args.tiled and world > 1:
+        # one large image at a time, its tiles spread over the GPUs; rank 0 re-assembles and writes
+        engine = HipTileEngine(m.model, m.vae, m.preprocess_model, m.y, m.y_mask, args.color_fix_type, args.disable_preprocess_model,
+                               args.tile_size, args.tile_stride, m.noise_scheduler)
+        for path in files:
+            for i in range(args.repeat_times):
+                job = read_job(path, i, args)
+                preds, stage1 = parallel.sharded_tiled_process(engine, [job.net_in], rank, world)
+                if rank == 0:
+                    write_job(job, preds[0], stage1[0], args)
+        return
+    mine = parallel.shard(files, rank, world)       # images are independent: no collective on the data path
+    jobs = (read_job(path, i, args) for path in mine for i in range(args.repeat_times))
+    todo: List[List[Job]] = []
 
-    noise_scheduler = DDPMScheduler.from_pretrained(args.dit_config, subfolder="scheduler")
-    vae = AutoencoderKL.from_pretrained(args.vae).to(torch.float32).to(device)
-    model = Transformer2DModel.from_pretrained(args.dit_config, subfolder="transformer")
-    model.load_state_dict(torch.load(args.ckpt, map_location="cpu"))
-    preprocess_model = instantiate_from_config(load_yaml(args.swinir_config))
-    load_state_dict(preprocess_model, torch.load(args.swinir_ckpt, map_location="cpu"), strict=True)
-    model.to(device)
-    preprocess_model.to(device)
+    def feed():
+        for group in batches_of(jobs, max(args.batch_size, 1)):
+            todo.append(group)
+            yield [j.net_in for j in group]
 
-    assert os.path.isdir(args.input)
-    y_null_all = torch.load(args.prompt_embeds, map_location="cpu")
-    y = y_null_all["caption_embeds"].to(device).to(torch.float32).reshape(1, -1, y_null_all["caption_embeds"].shape[-1])
-    y_mask = y_null_all["emb_mask"].to(device).to(torch.float32).reshape(1, 1, -1)  # [1,1,L]: additive bias semantics (inference.py:274-277)
-
-    files = sorted(list_image_files(args.input, follow_links=True))[rank::world]
-    for file_path in files:
-        lq = Image.open(file_path).convert("RGB")
-        if args.sr_scale != 1:
-            lq = lq.resize(tuple(math.ceil(x * args.sr_scale) for x in lq.size), Image.BICUBIC)
-        if not args.tiled:
-            if args.use_center_crop:
-                lq_resized = center_crop_arr(lq, 512)
-                x = np.array(lq_resized)
-            else:
-                lq_resized = auto_resize(lq, 512)
-                x = pad(np.array(lq_resized), scale=64)
-        else:
-            lq_resized = auto_resize(lq, args.tile_size)
-            x = pad(np.array(lq_resized), scale=64)
-        for i in range(args.repeat_times):
-            save_path = os.path.join(args.output, os.path.relpath(file_path, args.input))
-            parent_path, stem, _ = get_file_name_parts(save_path)
-            save_path = os.path.join(parent_path, f"{stem}_{i}.png")
-            os.makedirs(parent_path, exist_ok=True)
-            preds, stage1_preds = process(model, [x], strength=1, color_fix_type=args.color_fix_type,
-                                          disable_preprocess_model=args.disable_preprocess_model, tiled=args.tiled, tile_size=args.tile_size,
-                                          tile_stride=args.tile_stride, vae=vae, preprocess_model=preprocess_model, y=y, y_mask=y_mask,
-                                          noise_scheduler=noise_scheduler)
-            pred, stage1_pred = preds[0], stage1_preds[0]
-            if not args.use_center_crop:
-                height, width = (lq_resized.height, lq_resized.width)
-                pred = pred[:height, :width, :]
-                stage1_pred = stage1_pred[:height, :width, :]
-            if args.show_lq:
-                if not args.use_center_crop:
-                    pred = np.array(Image.fromarray(pred).resize(lq.size, Image.LANCZOS))
-                    stage1_pred = np.array(Image.fromarray(stage1_pred).resize(lq.size, Image.LANCZOS))
-                    lq_arr = np.array(lq)
-                else:
-                    lq_arr = x
-                images = [lq_arr, pred] if args.disable_preprocess_model else [lq_arr, stage1_pred, pred]
-                Image.fromarray(np.concatenate(images, axis=1)).save(save_path)
-            else:
-                if not args.use_center_crop:
-                    Image.fromarray(pred).resize(lq.size, Image.LANCZOS).save(save_path)
-                else:
-                    Image.fromarray(pred).save(save_path)
-            print(f"save to {save_path}")
+    for preds, stage1 in process_stream(m.model, feed(), tiled=args.tiled, return_stage1=args.show_lq and not args.disable_preprocess_model,
+                                        **common):
+        for k, job in enumerate(todo.pop(0)):
+            write_job(job, preds[k], stage1[k] if stage1 else None, args)
 
 
 if __name__ == "__main__":

@@ -20,6 +20,7 @@ SYMBOLS = [
     "ir_pipeline", "ir_u8_to_nchw", "ir_nchw_to_u8", "ir_profile_begin", "ir_profile_end",
     "ir_op_conv", "ir_op_conv_groupnorm", "ir_op_linear", "ir_op_groupnorm", "ir_op_layernorm", "ir_op_attention", "ir_op_swin_attention",
     "ir_op_softmax_rows",
+    "ir_tiled_count", "ir_tiled_encode", "ir_tiled_dit", "ir_tiled_blend_latent", "ir_tiled_decode", "ir_tiled_blend_pixels", "ir_set_plain_kernels",
 ]
 
 STAGE_SWINIR, STAGE_VAE_ENCODE, STAGE_DIT, STAGE_VAE_DECODE, STAGE_PIPELINE, STAGE_COLORFIX, STAGE_T5 = range(7)
@@ -82,6 +83,13 @@ def load_library():
     lib.ir_op_attention.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, i, f, vp, vp, sz]
     lib.ir_op_swin_attention.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, f]
     lib.ir_op_softmax_rows.argtypes = [vp, vp, vp, vp, i, i]
+    lib.ir_tiled_count.argtypes = [i, i, i, i]
+    lib.ir_tiled_encode.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, f, vp, sz]
+    lib.ir_tiled_dit.argtypes = [vp, vp, vp, vp, i, i, i, i, i, i, i, f, f, i, vp, sz]
+    lib.ir_tiled_blend_latent.argtypes = [vp, vp, vp, vp, i, i, i, i, i]
+    lib.ir_tiled_decode.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, f, vp, sz]
+    lib.ir_tiled_blend_pixels.argtypes = [vp, vp, vp, vp, i, i, i, i, i, vp, sz]
+    lib.ir_set_plain_kernels.argtypes = [vp, i]
     for name in SYMBOLS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int and name not in ("ir_abi_version",):

@@ -601,7 +601,7 @@ int ir_launch_flash_attn(const AttnParams& p, hipStream_t s) {
     dim3 grid((p.Tq + 127) / 128, p.Hh, p.B);
     const bool general = p.key_bias != nullptr || (p.Tk & 63);
     static const bool no_pp = getenv("IR_NO_PINGPONG") != nullptr;  // experiment knob
-    if (p.D == 72 && !general && p.Tq >= 256 && p.ovf_flag && !no_pp) {  // the DiT self-attention: ping-pong kernel, 256 queries per workgroup
+    if (p.D == 72 && !general && p.Tq >= 256 && p.ovf_flag && !no_pp && !g_ir_plain_kernels) {  // the DiT self-attention: ping-pong kernel, 256 queries per workgroup
         if (ir_launch_zero_f32(reinterpret_cast<float*>(p.ovf_flag), 1, s)) return -1;
         hipLaunchKernelGGL((flash_attn_pp_kernel<72>), dim3((p.Tq + 255) / 256, p.Hh, p.B), dim3(512), 0, s, p);
         hipLaunchKernelGGL((flash_attn_kernel<72, false>), grid, dim3(256), 0, s, p);  // fallback: returns at once unless flagged

@@ -1326,9 +1326,11 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(IGemmParams p) {
     }
 }
 
+int g_ir_plain_kernels = 0;
+
 static bool takes_gemm_pp(const IGemmParams& p) {
     static const bool off = getenv("IR_NO_GEMM_PP") != nullptr;  // experiment knob
-    if (off || p.taps != 1 || p.force_generic || !p.vec || p.gn_part) return false;
+    if (off || g_ir_plain_kernels || p.taps != 1 || p.force_generic || !p.vec || p.gn_part) return false;
     if (p.Cout != p.Cout_pad || p.Cout % GemmPP::BN || p.Cin % GemmPP::BK || p.Cin < 8 * GemmPP::BK) return false;
     const long span = (long)p.M * std::max(std::max(p.out_cs, p.res ? p.res_cs : 0), p.out2 ? p.out2_cs : 0);
     if (span >= (1L << 31)) return false;  // the epilogue's 32-bit element offsets
@@ -1395,7 +1397,7 @@ static bool takes_halo(const IGemmParams& p) {
 }
 static bool takes_halo_pp(const IGemmParams& p) {  // the 8-wave ping-pong variant: 16 x 16 patches x 128 channels
     static const bool no_pp = getenv("IR_NO_CONV_PP") != nullptr;  // experiment knob
-    return takes_halo(p) && p.Cout_pad % 128 == 0 && p.Cin >= 128 && !no_pp;  // measured with the 16x16x32 MFMAs: +8 % at 512 channels,
+    return takes_halo(p) && p.Cout_pad % 128 == 0 && p.Cin >= 128 && !no_pp && !g_ir_plain_kernels;  // measured with the 16x16x32 MFMAs: +8 % at 512 channels,
                                                                                // +7 % at 256, +2 % at 128 over the 4-wave kernel
 }
 int ir_igemm_gn_chunks(const IGemmParams& p) {

@@ -5,6 +5,9 @@
 
 typedef uint16_t bf16_t;
 
+// 1: launchers pick the older 4-wave kernels only (ir_set_plain_kernels; defined in igemm.hip)
+extern int g_ir_plain_kernels;
+
 // ---- implicit GEMM (igemm.hip)
 struct IGemmParams {
     // A operand: NHWC bf16 activations. taps==1: row m at in + m*in_cs. taps==9: 3x3 window around output pixel.

@@ -80,7 +80,7 @@ class _DeviceModule:
         return self
 
     def cuda(self, device=None):
-        return self.to(torch.device("cuda", device or 0))
+        return self.to(torch.device("cuda", torch.cuda.current_device() if device is None else device))
 
     def _check_keys(self, sd, strict, ignore=()):
         exp = set(self._expected_keys())
@@ -347,10 +347,13 @@ class Transformer2DModel(_DeviceModule):
         """Project the caption and cache all layers' cross-attention K/V (constant across images and tiles)."""
         self._ready()
         y = encoder_hidden_states
-        key = (y.data_ptr(), tuple(y.shape), y._version, None if encoder_attention_mask is None else
-               (encoder_attention_mask.data_ptr(), tuple(encoder_attention_mask.shape), encoder_attention_mask._version))
-        if key == self._prompt_key:
+        # Cache key: the tensor OBJECTS (held strongly, so their storage cannot be recycled for another prompt at the same
+        # address) plus their version counters. Writes that bypass torch (raw pointers, ctypes) need invalidate_prompt().
+        k = self._prompt_key
+        if (k is not None and k[0] is y and k[1] == y._version and k[2] is encoder_attention_mask and
+                k[3] == (None if encoder_attention_mask is None else encoder_attention_mask._version)):
             return
+        key = (y, y._version, encoder_attention_mask, None if encoder_attention_mask is None else encoder_attention_mask._version)
         y = y.detach().to("cpu", torch.float32)
         y = y.reshape(-1, y.shape[-2], y.shape[-1])
         if y.shape[0] != 1:
@@ -370,6 +373,10 @@ class Transformer2DModel(_DeviceModule):
         self.ctx.check(self.ctx.lib.ir_dit_set_prompt(self.ctx.h, self.ctx.stream(), C.c_void_p(y.data_ptr()), C.c_void_p(bias.data_ptr()), n_tok),
                        "ir_dit_set_prompt")
         self._prompt_key = key
+
+    def invalidate_prompt(self):
+        """Forget the cached prompt: the next call projects encoder_hidden_states again even if it is the same tensor object."""
+        self._prompt_key = None
 
     @staticmethod
     def _scalar_timestep(timestep):

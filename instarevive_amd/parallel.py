@@ -1,9 +1,12 @@
 """One process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm, "gloo" in CPU tests).
 
-The path shards by independent units — images (test_scripts/inference.py:261, one process() per file) or, inside one
-large image, tiles (inference.py:128-134,139-152) — so the data path needs NO collective: every rank runs the full
-four-stage path on its own units with replicated weights. The only communication is optional and off the hot path:
-gathering finished uint8 images on rank 0 (gather_uint8) and reducing timings (max_over_ranks)."""
+The path shards by independent units:
+  * images (test_scripts/inference.py:261, one process() per file): every rank runs the full four-stage path on its own images
+    with replicated weights, NO data-path collective; finished uint8 images are gathered on rank 0 (gather_uint8) where the caller
+    wants the batch in one place (BASELINE.json configs[3]);
+  * tiles of one large image under --tiled (inference.py:128-134,139-152): sharded_tiled_process() below, whose only exchange steps
+    are one all-gather of latent tiles between the two loops and the final gather of pixel tiles for re-assembly.
+Timings are reduced with max_over_ranks."""
 import os
 from typing import List, Sequence
 
@@ -70,3 +73,56 @@ def gather_uint8(local: torch.Tensor, dst: int = 0):
     if rank != dst:
         return None
     return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
+
+
+# ------------------------------------------------------------------------------------------------ tile sharding of ONE image
+def _comm_device(local_device):
+    import torch.distributed as dist
+    return local_device if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
+def _exchange_tiles(local: torch.Tensor, n_tiles: int, rank: int, world: int, to_all: bool, dst: int = 0):
+    """local: this rank's tiles [k_r, ...] (tiles rank, rank+world, ... of the loop order). Returns all n_tiles tiles in loop order
+    [n_tiles, ...] on every rank (to_all, one all_gather) or on rank `dst` only (one gather; None elsewhere). Ranks hold
+    ceil/floor(n_tiles / world) tiles, so the buffers are padded to the maximum and the padding is dropped on arrival."""
+    import torch.distributed as dist
+    if world == 1:
+        return local
+    kmax = (n_tiles + world - 1) // world
+    dev = _comm_device(local.device)
+    send = torch.zeros((kmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=dev)
+    send[: local.shape[0]] = local.to(dev)
+    if to_all:
+        parts = [torch.empty_like(send) for _ in range(world)]
+        dist.all_gather(parts, send)
+    else:
+        parts = [torch.empty_like(send) for _ in range(world)] if rank == dst else None
+        dist.gather(send, parts, dst=dst)
+        if rank != dst:
+            return None
+    out = torch.empty((n_tiles,) + tuple(local.shape[1:]), dtype=local.dtype, device=dev)
+    for r in range(world):
+        out[r::world] = parts[r][: len(range(r, n_tiles, world))]   # tile i sits at index i // world of rank i % world
+    return out.to(local.device)
+
+
+def sharded_tiled_process(engine, control_imgs, rank: int = None, world: int = None, dst: int = 0):
+    """process(..., tiled=True) of ONE image batch with its tiles sharded over the ranks (test_scripts/inference.py:119-153; SURVEY.md
+    section 8(e), "tile-level sharding of one large image"). `engine` supplies the five phases (pipeline.HipTileEngine on a GPU).
+    Exchange steps: one all_gather of the x0 latent tiles between the two loops (every rank needs the blended latent for its own
+    decoder tiles) and one gather of the decoded pixel tiles on rank `dst`, which re-assembles the image. Both sums run over ALL
+    tiles in the reference's loop order on the receiving side, so the result equals the single-rank result bit for bit.
+    Returns (preds, stage1_preds) on rank `dst`, (None, None) elsewhere."""
+    import torch.distributed as dist
+    if rank is None or world is None:
+        on = dist.is_available() and dist.is_initialized()
+        rank, world = (dist.get_rank(), dist.get_world_size()) if on else (0, 1)
+    control, init = engine.encode(control_imgs)               # replicated: SwinIR and the VAE encoder are untiled in the reference
+    h, w = control.shape[-2:]
+    n_tiles = engine.count(h, w)
+    x0_all = _exchange_tiles(engine.dit_tiles(init, rank, world), n_tiles, rank, world, to_all=True)
+    nb = engine.blend_latent(x0_all)
+    px_all = _exchange_tiles(engine.decode_tiles(nb, control, rank, world), n_tiles, rank, world, to_all=False, dst=dst)
+    if rank != dst:
+        return None, None
+    return engine.blend_pixels(px_all), engine.stage1()

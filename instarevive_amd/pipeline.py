@@ -6,13 +6,56 @@ When the four models are instarevive_amd objects sharing one context, process() 
 The stage-by-stage form (the reference's literal sequence of Python calls) is kept for drop-in use and for tests.
 """
 import ctypes as C
-from typing import List, Tuple
+from typing import Iterable, Iterator, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
 
 from . import _lib as L
 from .models import AutoencoderKL, ControlTransformerHalf, DDPMScheduler, SwinIR, Transformer2DModel
+
+
+class _Staging:
+    """Host <-> device staging of one image batch shape: page-locked host buffers (so the 12.6 MB per 2048 x 2048 image cross PCIe
+    by DMA at link rate instead of through a pageable bounce copy) and the matching device buffers, kept per shape on the context.
+    `slots` independent sets let process_stream() upload batch i+1 and download batch i-1 while batch i computes."""
+
+    def __init__(self, device, n, h, w, slots=1):
+        shape = (n, h, w, 3)
+        self.shape = shape
+        self.h_in = [torch.empty(shape, dtype=torch.uint8).pin_memory() for _ in range(slots)]
+        self.h_out = [torch.empty(shape, dtype=torch.uint8).pin_memory() for _ in range(slots)]
+        self.h_st1 = [torch.empty(shape, dtype=torch.uint8).pin_memory() for _ in range(slots)]
+        self.d_in = [torch.empty(shape, dtype=torch.uint8, device=device) for _ in range(slots)]
+        self.d_out = [torch.empty(shape, dtype=torch.uint8, device=device) for _ in range(slots)]
+        self.d_st1 = [torch.empty(shape, dtype=torch.uint8, device=device) for _ in range(slots)]
+
+    @staticmethod
+    def get(ctx, n, h, w, slots=1, tag="sync"):
+        pool = ctx.__dict__.setdefault("_staging", {})
+        key = (tag, n, h, w, slots)
+        if key not in pool:
+            if len(pool) >= 8:  # bounded: drop the oldest shape
+                pool.pop(next(iter(pool)))
+            pool[key] = _Staging(ctx.device, n, h, w, slots)
+        return pool[key]
+
+    def fill(self, slot, control_imgs):
+        """Copy the caller's HWC uint8 arrays into the pinned input buffer of `slot` (one pass, no intermediate np.stack)."""
+        dst = self.h_in[slot].numpy()
+        for i, im in enumerate(control_imgs):
+            if im.dtype != np.uint8 or im.shape != self.shape[1:]:
+                raise ValueError("control_imgs must be HWC uint8 RGB arrays of equal size")
+            np.copyto(dst[i], im)
+
+
+def _check_images(control_imgs):
+    if len(control_imgs) == 0:
+        raise ValueError("control_imgs is empty")
+    first = np.asarray(control_imgs[0])
+    if first.dtype != np.uint8 or first.ndim != 3 or first.shape[-1] != 3:
+        raise ValueError("control_imgs must be HWC uint8 RGB arrays")
+    return len(control_imgs), first.shape[0], first.shape[1]
 
 
 def _sliding_windows(h: int, w: int, tile_size: int, tile_stride: int):
@@ -91,55 +134,64 @@ def _fused_ok(model, preprocess_model, vae, disable_preprocess_model):
     return len(ctxs) == 1
 
 
+def _pipeline_flags(model, color_fix_type, disable_preprocess_model, tiled):
+    flags = (L.FLAG_NO_PREPROCESS if disable_preprocess_model else 0) | (L.FLAG_TILED if tiled else 0)
+    if tiled:
+        flags |= {"wavelet": L.FLAG_FIX_WAVELET, "adain": L.FLAG_FIX_ADAIN}.get(color_fix_type, 0)
+    if isinstance(model, ControlTransformerHalf):
+        flags |= L.FLAG_CONTROL_LQ
+    return flags
+
+
+def _prepare_fused(model, y, y_mask, h, w, tiled, tile_size):
+    model.set_prompt(y, y_mask)
+    if tiled:
+        model.ensure_pos(tile_size // 16, tile_size // 16)
+    else:
+        model.ensure_pos(h // 16, w // 16)
+
+
+def _launch_pipeline(ctx, st, slot, n, h, w, flags, tile_size, tile_stride, acp, sf, want_stage1=True):
+    ws = ctx.workspace(ctx.ws_bytes(L.STAGE_PIPELINE, n, h, w, flags, tile_size, tile_stride))
+    ctx.check(ctx.lib.ir_pipeline(ctx.h, ctx.stream(), L.ptr(st.d_in[slot]), L.ptr(st.d_out[slot]), L.ptr(st.d_st1[slot]) if want_stage1 else None,
+                                  n, h, w, flags, tile_size, tile_stride, 400.0, acp, sf, L.ptr(ws), ws.numel()), "ir_pipeline")
+
+
 @torch.no_grad()
 def process(model, control_imgs: List[np.ndarray], strength: float, color_fix_type: str, disable_preprocess_model: bool, tiled: bool,
             tile_size: int, tile_stride: int, preprocess_model=None, vae=None, y=None, y_mask=None, noise_scheduler=None,
-            fused: bool = True, graph: bool = False) -> Tuple[List[np.ndarray], List[np.ndarray]]:
+            fused: bool = True, graph: bool = False, return_stage1: bool = True) -> Tuple[List[np.ndarray], List[np.ndarray]]:
     """test_scripts/inference.py:55-166. control_imgs: list of HWC uint8 RGB arrays of equal size (multiples of 64).
-    Returns (preds, stage1_preds) as lists of HWC uint8 arrays.
+    Returns (preds, stage1_preds) as lists of HWC uint8 arrays (stage1_preds is empty with return_stage1=False, which skips its
+    conversion and download).
 
     Extension (no reference counterpart: the reference's process() never passes c): when `model` is a ControlTransformerHalf, the
     one-step call becomes generate_sample_1step(..., c=<the scaled LQ latent the step starts from>), per tile under `tiled`.
     graph=True (fused form only): the launch sequence is recorded into a hipGraph per image size / flag set and replayed on later
-    calls (staging buffers are kept per size so that the recorded addresses stay valid)."""
+    calls. Images travel through page-locked staging buffers kept per batch shape (which also gives a recorded graph stable
+    device addresses)."""
     noise_scheduler = noise_scheduler or DDPMScheduler()
-    n = len(control_imgs)
-    imgs = np.ascontiguousarray(np.stack(control_imgs))
-    if imgs.dtype != np.uint8 or imgs.ndim != 4 or imgs.shape[-1] != 3:
-        raise ValueError("control_imgs must be HWC uint8 RGB arrays")
-    h, w = imgs.shape[1:3]
+    n, h, w = _check_images(control_imgs)
     device = model.device
     acp = float(noise_scheduler.alphas_cumprod[400])
     sf = float(vae.config.scaling_factor)
     if fused and _fused_ok(model, preprocess_model, vae, disable_preprocess_model):
         ctx = model.ctx
-        with_c = isinstance(model, ControlTransformerHalf)
-        model.set_prompt(y, y_mask)
-        if tiled:
-            model.ensure_pos(tile_size // 16, tile_size // 16)
-        else:
-            model.ensure_pos(h // 16, w // 16)
-        flags = (L.FLAG_NO_PREPROCESS if disable_preprocess_model else 0) | (L.FLAG_TILED if tiled else 0)
-        flags |= {"wavelet": L.FLAG_FIX_WAVELET, "adain": L.FLAG_FIX_ADAIN}.get(color_fix_type, 0) if tiled else 0
-        flags |= L.FLAG_CONTROL_LQ if with_c else 0
-        if graph:  # stable device addresses for the recorded graph: one set of staging buffers per call signature
-            flags |= L.FLAG_GRAPH
-            bufs = ctx.__dict__.setdefault("_graph_bufs", {})
-            key = (n, h, w, flags, tile_size, tile_stride)
-            if key not in bufs:
-                bufs[key] = tuple(torch.empty((n, h, w, 3), dtype=torch.uint8, device=device) for _ in range(3))
-            din, dout, dst1 = bufs[key]
-            din.copy_(torch.from_numpy(imgs))
-        else:
-            din = torch.from_numpy(imgs).to(device)
-            dout = torch.empty_like(din)
-            dst1 = torch.empty_like(din)
-        ws = ctx.workspace(ctx.ws_bytes(L.STAGE_PIPELINE, n, h, w, flags, tile_size, tile_stride))
-        ctx.check(ctx.lib.ir_pipeline(ctx.h, ctx.stream(), L.ptr(din), L.ptr(dout), L.ptr(dst1), n, h, w, flags, tile_size, tile_stride, 400.0, acp,
-                                      sf, L.ptr(ws), ws.numel()), "ir_pipeline")
-        preds, stage1 = dout.cpu().numpy(), dst1.cpu().numpy()
-        return [preds[i] for i in range(n)], [stage1[i] for i in range(n)]
+        _prepare_fused(model, y, y_mask, h, w, tiled, tile_size)
+        flags = _pipeline_flags(model, color_fix_type, disable_preprocess_model, tiled) | (L.FLAG_GRAPH if graph else 0)
+        st = _Staging.get(ctx, n, h, w)
+        st.fill(0, control_imgs)
+        st.d_in[0].copy_(st.h_in[0], non_blocking=True)
+        _launch_pipeline(ctx, st, 0, n, h, w, flags, tile_size, tile_stride, acp, sf, return_stage1)
+        st.h_out[0].copy_(st.d_out[0], non_blocking=True)
+        if return_stage1:
+            st.h_st1[0].copy_(st.d_st1[0], non_blocking=True)
+        torch.cuda.current_stream(device).synchronize()
+        preds = st.h_out[0].clone().numpy()   # the caller owns the result; the pinned buffer is reused by the next call
+        stage1 = st.h_st1[0].clone().numpy() if return_stage1 else None
+        return [preds[i] for i in range(n)], ([stage1[i] for i in range(n)] if return_stage1 else [])
 
+    imgs = np.ascontiguousarray(np.stack(control_imgs))
     # ---- stage-by-stage form: the reference's literal call sequence on NCHW fp32 tensors
     control = torch.tensor(imgs / 255.0, dtype=torch.float32, device=device).clamp_(0, 1).permute(0, 3, 1, 2).contiguous()
     if not disable_preprocess_model:
@@ -176,3 +228,148 @@ def process(model, control_imgs: List[np.ndarray], strength: float, color_fix_ty
     x_samples = (img_buffer.clamp(0, 1).permute(0, 2, 3, 1) * 255).cpu().numpy().clip(0, 255).astype(np.uint8)
     control = (control.permute(0, 2, 3, 1) * 255).cpu().numpy().clip(0, 255).astype(np.uint8)
     return [x_samples[i] for i in range(n)], [control[i] for i in range(n)]
+
+
+@torch.no_grad()
+def process_stream(model, batches: Iterable[Sequence[np.ndarray]], color_fix_type: str, disable_preprocess_model: bool, tiled: bool,
+                   tile_size: int, tile_stride: int, preprocess_model=None, vae=None, y=None, y_mask=None, noise_scheduler=None,
+                   return_stage1: bool = True, graph: bool = False) -> Iterator[Tuple[List[np.ndarray], List[np.ndarray]]]:
+    """process() over a sequence of image batches with the transfers hidden: while batch i computes on the current stream, batch
+    i+1 is uploaded and batch i-1 downloaded on a copy stream (two staging slots per batch shape). Yields process()'s result for
+    every batch, in order. Needs the fused form (all models instarevive_amd objects on one context)."""
+    noise_scheduler = noise_scheduler or DDPMScheduler()
+    if not _fused_ok(model, preprocess_model, vae, disable_preprocess_model):
+        raise TypeError("process_stream needs instarevive_amd models sharing one context")
+    ctx, device = model.ctx, model.device
+    acp, sf = float(noise_scheduler.alphas_cumprod[400]), float(vae.config.scaling_factor)
+    base_flags = _pipeline_flags(model, color_fix_type, disable_preprocess_model, tiled) | (L.FLAG_GRAPH if graph else 0)
+    main, copy = torch.cuda.current_stream(device), ctx.__dict__.setdefault("_copy_stream", torch.cuda.Stream(device))
+    it = iter(batches)
+
+    def upload(imgs, slot):
+        n, h, w = _check_images(imgs)
+        st = _Staging.get(ctx, n, h, w, slots=2, tag="stream")
+        st.fill(slot, imgs)
+        with torch.cuda.stream(copy):
+            st.d_in[slot].copy_(st.h_in[slot], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(copy)
+        return st, slot, (n, h, w), ev
+
+    def download(job):
+        st, slot, (n, h, w), done = job
+        done.synchronize()
+        preds = st.h_out[slot].clone().numpy()
+        stage1 = st.h_st1[slot].clone().numpy() if return_stage1 else None
+        return [preds[i] for i in range(n)], ([stage1[i] for i in range(n)] if return_stage1 else [])
+
+    slot, pending = 0, None
+    nxt = next(it, None)
+    up = upload(nxt, slot) if nxt is not None else None
+    while up is not None:
+        st, cur, (n, h, w), ready = up
+        _prepare_fused(model, y, y_mask, h, w, tiled, tile_size)
+        main.wait_event(ready)
+        _launch_pipeline(ctx, st, cur, n, h, w, base_flags, tile_size, tile_stride, acp, sf, return_stage1)
+        computed = torch.cuda.Event()
+        computed.record(main)
+        # while this batch computes: fetch the previous result, stage the next input into the other slot. The other slot's device
+        # buffers were last read by the previous batch's download, which download() has waited for by then.
+        if pending is not None:
+            yield download(pending)
+        nxt = next(it, None)
+        up = upload(nxt, cur ^ 1) if nxt is not None else None
+        with torch.cuda.stream(copy):
+            copy.wait_event(computed)
+            st.h_out[cur].copy_(st.d_out[cur], non_blocking=True)
+            if return_stage1:
+                st.h_st1[cur].copy_(st.d_st1[cur], non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(copy)
+        pending = (st, cur, (n, h, w), done)
+    if pending is not None:
+        yield download(pending)
+
+
+class HipTileEngine:
+    """The five phases of tiled sampling (ir_tiled_* of the C ABI) on one GPU, in the form parallel.sharded_tiled_process() drives:
+    every rank encodes, each rank runs the DiT / the decoder on ITS tiles, the per-tile results are exchanged between the phases."""
+
+    def __init__(self, model, vae, preprocess_model, y, y_mask, color_fix_type="wavelet", disable_preprocess_model=False, tile_size=512,
+                 tile_stride=448, noise_scheduler=None):
+        if not _fused_ok(model, preprocess_model, vae, disable_preprocess_model):
+            raise TypeError("HipTileEngine needs instarevive_amd models sharing one context")
+        self.model, self.ctx, self.device = model, model.ctx, model.device
+        self.y, self.y_mask = y, y_mask
+        self.tile_size, self.tile_stride = tile_size, tile_stride
+        self.flags = _pipeline_flags(model, color_fix_type, disable_preprocess_model, True)
+        sch = noise_scheduler or DDPMScheduler()
+        self.acp, self.sf = float(sch.alphas_cumprod[400]), float(vae.config.scaling_factor)
+
+    def _ws(self):
+        n, h, w = self.shape
+        return self.ctx.workspace(self.ctx.ws_bytes(L.STAGE_PIPELINE, n, h, w, self.flags, self.tile_size, self.tile_stride))
+
+    def count(self, h, w):
+        k = self.ctx.lib.ir_tiled_count(h, w, self.tile_size, self.tile_stride)
+        if k <= 0:
+            raise ValueError(f"bad tile geometry for a {h}x{w} image: tile {self.tile_size}, stride {self.tile_stride}")
+        return k
+
+    def encode(self, control_imgs):
+        n, h, w = _check_images(control_imgs)
+        self.shape = (n, h, w)
+        _prepare_fused(self.model, self.y, self.y_mask, h, w, True, self.tile_size)
+        st = _Staging.get(self.ctx, n, h, w)
+        st.fill(0, control_imgs)
+        st.d_in[0].copy_(st.h_in[0], non_blocking=True)
+        control = torch.empty((n, 3, h, w), dtype=torch.float32, device=self.device)
+        init = torch.empty((n, 4, h // 8, w // 8), dtype=torch.float32, device=self.device)
+        ws = self._ws()
+        c = self.ctx
+        c.check(c.lib.ir_tiled_encode(c.h, c.stream(), L.ptr(st.d_in[0]), L.ptr(st.d_st1[0]), L.ptr(control), L.ptr(init), n, h, w, self.flags,
+                                      self.sf, L.ptr(ws), ws.numel()), "ir_tiled_encode")
+        self._stage1 = st.d_st1[0]
+        return control, init
+
+    def stage1(self):
+        n = self.shape[0]
+        a = self._stage1.cpu().numpy()
+        return [a[i] for i in range(n)]
+
+    def dit_tiles(self, init, first, step):
+        n, h, w = self.shape
+        k = len(range(first, self.count(h, w), step))
+        tl = self.tile_size // 8
+        x0 = torch.empty((max(k, 1), n, 4, tl, tl), dtype=torch.float32, device=self.device)
+        ws, c = self._ws(), self.ctx
+        c.check(c.lib.ir_tiled_dit(c.h, c.stream(), L.ptr(init), L.ptr(x0), n, h, w, self.tile_size, self.tile_stride, first, step, 400.0, self.acp,
+                                   self.flags, L.ptr(ws), ws.numel()), "ir_tiled_dit")
+        return x0[:k]
+
+    def blend_latent(self, x0_all):
+        n, h, w = self.shape
+        nb = torch.empty((n, 4, h // 8, w // 8), dtype=torch.float32, device=self.device)
+        c = self.ctx
+        c.check(c.lib.ir_tiled_blend_latent(c.h, c.stream(), L.ptr(x0_all.contiguous()), L.ptr(nb), n, h, w, self.tile_size, self.tile_stride),
+                "ir_tiled_blend_latent")
+        return nb
+
+    def decode_tiles(self, nb, control, first, step):
+        n, h, w = self.shape
+        k = len(range(first, self.count(h, w), step))
+        tp = (self.tile_size // 8) * 8
+        px = torch.empty((max(k, 1), n, 3, tp, tp), dtype=torch.float32, device=self.device)
+        ws, c = self._ws(), self.ctx
+        c.check(c.lib.ir_tiled_decode(c.h, c.stream(), L.ptr(nb), L.ptr(control), L.ptr(px), n, h, w, self.tile_size, self.tile_stride, first, step,
+                                      self.flags, self.sf, L.ptr(ws), ws.numel()), "ir_tiled_decode")
+        return px[:k]
+
+    def blend_pixels(self, px_all):
+        n, h, w = self.shape
+        out = torch.empty((n, h, w, 3), dtype=torch.uint8, device=self.device)
+        ws, c = self._ws(), self.ctx
+        c.check(c.lib.ir_tiled_blend_pixels(c.h, c.stream(), L.ptr(px_all.contiguous()), L.ptr(out), n, h, w, self.tile_size, self.tile_stride,
+                                            L.ptr(ws), ws.numel()), "ir_tiled_blend_pixels")
+        a = out.cpu().numpy()
+        return [a[i] for i in range(n)]

@@ -1,92 +1,129 @@
-"""Host-side helpers of the CLI with the reference's names (utils/common.py:7-18,35-51, utils/file.py:20-47,
-utils/image/common.py:12-36,229-249). Pure Python / PIL / numpy plumbing around the GPU path."""
-import importlib
+"""Host-side plumbing of the CLI: the helper functions test_scripts/inference.py imports from the reference's `utils`
+package, re-implemented here with the same names, arguments and results (pinned bit-for-bit by tests/golden/glue.npz and
+tests/test_host_cpu.py):
+
+    instantiate_from_config, get_obj_from_str, load_state_dict   <- utils/common.py:7-18,35-51
+    list_image_files, get_file_name_parts                        <- utils/file.py:20-47
+    center_crop_arr, auto_resize, pad                            <- utils/image/common.py:12-36,229-249
+
+Nothing here touches the GPU.
+"""
+import itertools
 import math
 import os
-from typing import Any, List, Mapping, Tuple
+import pkgutil
+from typing import Any, Iterator, List, Mapping, Sequence, Tuple
 
 import numpy as np
 from PIL import Image
 
-# the reference config names `diffusion.model.swinir.SwinIR`; map reference targets onto this package's classes
-_TARGET_ALIASES = {"diffusion.model.swinir.SwinIR": "instarevive_amd.models.SwinIR"}
+# `target:` strings of the reference's YAML files -> the classes of this package that stand in for them
+TARGET_ALIASES = {"diffusion.model.swinir.SwinIR": "instarevive_amd.models.SwinIR"}
+IMAGE_EXTENSIONS = (".jpg", ".png", ".jpeg", ".arw")
+_DDP_PREFIX = "module."
 
 
-def get_obj_from_str(string: str, reload: bool = False) -> object:
-    string = _TARGET_ALIASES.get(string, string)
-    module, cls = string.rsplit(".", 1)
-    return getattr(importlib.import_module(module, package=None), cls)
+# ------------------------------------------------------------------------------------------------ config -> object
+def get_obj_from_str(string: str, reload: bool = False) -> Any:
+    """Dotted path -> Python object. `reload` is accepted for signature compatibility and ignored (nothing is re-imported)."""
+    dotted = TARGET_ALIASES.get(string, string)
+    module_name, _, attr = dotted.rpartition(".")
+    if not module_name:
+        raise ValueError(f"'{string}' is not a dotted 'package.module.Name' path")
+    return pkgutil.resolve_name(f"{module_name}:{attr}")
 
 
-def instantiate_from_config(config: Mapping[str, Any]) -> object:
-    if "target" not in config:
-        raise KeyError("Expected key `target` to instantiate.")
-    return get_obj_from_str(config["target"])(**config.get("params", dict()))
-
-
-def load_state_dict(model, state_dict: Mapping[str, Any], strict: bool = False) -> None:
-    state_dict = state_dict.get("state_dict", state_dict)
-    is_model_key_starts_with_module = list(model.state_dict().keys())[0].startswith("module.")
-    is_state_dict_key_starts_with_module = list(state_dict.keys())[0].startswith("module.")
-    if is_model_key_starts_with_module and not is_state_dict_key_starts_with_module:
-        state_dict = {f"module.{key}": value for key, value in state_dict.items()}
-    if not is_model_key_starts_with_module and is_state_dict_key_starts_with_module:
-        state_dict = {key[len("module."):]: value for key, value in state_dict.items()}
-    model.load_state_dict(state_dict, strict=strict)
+def instantiate_from_config(config: Mapping[str, Any]) -> Any:
+    """{'target': 'pkg.mod.Class', 'params': {...}} -> Class(**params); a missing 'target' is a KeyError like the reference's."""
+    try:
+        target = config["target"]
+    except KeyError:
+        raise KeyError("Expected key `target` to instantiate.") from None
+    kwargs = config.get("params") or {}
+    return get_obj_from_str(target)(**kwargs)
 
 
 def load_yaml(path: str) -> dict:
-    """OmegaConf.load replacement for configs/swinir.yaml-style files (omegaconf is not a dependency here)."""
+    """Stands in for OmegaConf.load on plain configs such as configs/swinir.yaml (omegaconf is not a dependency here)."""
     import yaml
-    with open(path) as f:
-        return yaml.safe_load(f)
+    with open(path) as fh:
+        return yaml.safe_load(fh)
 
 
-def list_image_files(img_dir: str, exts: Tuple[str, ...] = (".jpg", ".png", ".jpeg", ".arw"), follow_links: bool = False,
-                     log_progress: bool = False, log_every_n_files: int = 10000, max_size: int = -1) -> List[str]:
-    files = []
-    for dir_path, _, file_names in os.walk(img_dir, followlinks=follow_links):
-        early_stop = False
-        for file_name in file_names:
-            if os.path.splitext(file_name)[1].lower() in exts:
-                if max_size >= 0 and len(files) >= max_size:
-                    early_stop = True
-                    break
-                files.append(os.path.join(dir_path, file_name))
-                if log_progress and len(files) % log_every_n_files == 0:
-                    print(f"find {len(files)} images in {img_dir}")
-        if early_stop:
-            break
+# ------------------------------------------------------------------------------------------------ checkpoints
+def _has_ddp_prefix(keys: Sequence[str]) -> bool:
+    return bool(keys) and keys[0].startswith(_DDP_PREFIX)
+
+
+def load_state_dict(model, state_dict: Mapping[str, Any], strict: bool = False) -> None:
+    """Load a checkpoint that may be wrapped in {'state_dict': ...} and may or may not carry DistributedDataParallel's
+    'module.' key prefix: the prefix is added or removed so that it matches what `model` itself reports (decided, like the
+    reference, from the FIRST key on either side)."""
+    weights = state_dict.get("state_dict", state_dict)
+    want = _has_ddp_prefix(list(model.state_dict().keys()))
+    have = _has_ddp_prefix(list(weights.keys()))
+    if want != have:
+        if want:
+            weights = {_DDP_PREFIX + k: v for k, v in weights.items()}
+        else:
+            weights = {k[len(_DDP_PREFIX):]: v for k, v in weights.items()}
+    model.load_state_dict(weights, strict=strict)
+
+
+# ------------------------------------------------------------------------------------------------ files
+def _walk_images(root: str, exts: Tuple[str, ...], follow_links: bool) -> Iterator[str]:
+    for folder, _subdirs, names in os.walk(root, followlinks=follow_links):
+        for name in names:
+            if os.path.splitext(name)[1].lower() in exts:
+                yield os.path.join(folder, name)
+
+
+def list_image_files(img_dir: str, exts: Tuple[str, ...] = IMAGE_EXTENSIONS, follow_links: bool = False, log_progress: bool = False,
+                     log_every_n_files: int = 10000, max_size: int = -1) -> List[str]:
+    """Image files under img_dir in os.walk order (the reference's order: no sorting), filtered by lower-cased extension;
+    at most max_size of them when max_size >= 0."""
+    found = _walk_images(img_dir, tuple(exts), follow_links)
+    if max_size >= 0:
+        found = itertools.islice(found, max_size)
+    files: List[str] = []
+    for path in found:
+        files.append(path)
+        if log_progress and len(files) % log_every_n_files == 0:
+            print(f"find {len(files)} images in {img_dir}")
     return files
 
 
 def get_file_name_parts(file_path: str) -> Tuple[str, str, str]:
-    parent_path, file_name = os.path.split(file_path)
-    stem, ext = os.path.splitext(file_name)
-    return parent_path, stem, ext
+    """'a/b/name.ext' -> ('a/b', 'name', '.ext')."""
+    stem, ext = os.path.splitext(os.path.basename(file_path))
+    return os.path.dirname(file_path), stem, ext
+
+
+# ------------------------------------------------------------------------------------------------ image geometry
+def _scaled_size(size: Tuple[int, int], factor: float, rounding) -> Tuple[int, int]:
+    return tuple(int(rounding(edge * factor)) for edge in size)
 
 
 def auto_resize(img: Image.Image, size: int) -> Image.Image:
-    short_edge = min(img.size)
-    if short_edge < size:
-        r = size / short_edge
-        return img.resize(tuple(math.ceil(x * r) for x in img.size), Image.BICUBIC)
-    return img.copy()
+    """Bicubic upscale so that the SHORT edge reaches `size` (edges rounded up); images that are large enough are copied."""
+    short = min(img.size)
+    if short >= size:
+        return img.copy()
+    return img.resize(_scaled_size(img.size, size / short, math.ceil), Image.BICUBIC)
 
 
 def pad(img: np.ndarray, scale: int) -> np.ndarray:
-    h, w = img.shape[:2]
-    ph = 0 if h % scale == 0 else math.ceil(h / scale) * scale - h
-    pw = 0 if w % scale == 0 else math.ceil(w / scale) * scale - w
-    return np.pad(img, pad_width=((0, ph), (0, pw), (0, 0)), mode="constant", constant_values=0)
+    """Zero-pad an HWC array at the bottom / right up to the next multiples of `scale`."""
+    rows, cols = img.shape[:2]
+    return np.pad(img, ((0, -rows % scale), (0, -cols % scale), (0, 0)), mode="constant", constant_values=0)
 
 
 def center_crop_arr(pil_image: Image.Image, image_size: int) -> np.ndarray:
-    while min(*pil_image.size) >= 2 * image_size:
-        pil_image = pil_image.resize(tuple(x // 2 for x in pil_image.size), resample=Image.BOX)
-    scale = image_size / min(*pil_image.size)
-    pil_image = pil_image.resize(tuple(round(x * scale) for x in pil_image.size), resample=Image.BICUBIC)
-    arr = np.array(pil_image)
-    crop_y = (arr.shape[0] - image_size) // 2
-    crop_x = (arr.shape[1] - image_size) // 2
-    return arr[crop_y: crop_y + image_size, crop_x: crop_x + image_size]
+    """ADM-style centre crop: halve with a box filter while the short edge is at least twice the target, bicubic-resize the
+    short edge to the target (edges rounded to nearest), cut the central image_size x image_size window."""
+    while min(pil_image.size) >= 2 * image_size:
+        pil_image = pil_image.resize(_scaled_size(pil_image.size, 0.5, math.floor), resample=Image.BOX)
+    pil_image = pil_image.resize(_scaled_size(pil_image.size, image_size / min(pil_image.size), round), resample=Image.BICUBIC)
+    pixels = np.array(pil_image)
+    top, left = ((edge - image_size) // 2 for edge in pixels.shape[:2])
+    return pixels[top:top + image_size, left:left + image_size]

@@ -101,3 +101,89 @@ def test_cli_flag_surface():
 def test_scheduler_constant():
     from instarevive_amd.models import DDPMScheduler
     assert abs(float(DDPMScheduler().alphas_cumprod[400]) - 0.193572) < 1e-6
+
+
+def test_list_image_files_and_name_parts(tmp_path):
+    from instarevive_amd import utils
+    for rel in ("b.PNG", "a.jpg", "notes.txt", "sub/c.jpeg", "sub/deep/d.arw", "sub/e.bmp"):
+        p = tmp_path / rel
+        p.parent.mkdir(parents=True, exist_ok=True)
+        p.write_bytes(b"x")
+    got = utils.list_image_files(str(tmp_path))
+    walk = [os.path.join(d, f) for d, _, fs in os.walk(str(tmp_path)) for f in fs if os.path.splitext(f)[1].lower() in (".jpg", ".png", ".jpeg", ".arw")]
+    assert got == walk and len(got) == 4                      # os.walk order (the reference does not sort), lower-cased extension filter
+    assert utils.list_image_files(str(tmp_path), max_size=2) == walk[:2] and utils.list_image_files(str(tmp_path), max_size=0) == []
+    assert utils.list_image_files(str(tmp_path), exts=(".bmp",)) == [os.path.join(str(tmp_path), "sub", "e.bmp")]
+    assert utils.get_file_name_parts("out/x/name.tar.png") == ("out/x", "name.tar", ".png")
+    assert utils.get_file_name_parts("plain") == ("", "plain", "")
+
+
+def test_load_state_dict_prefix_handling():
+    from instarevive_amd import utils
+
+    class Fake:
+        def __init__(self, keys):
+            self.keys, self.loaded, self.strict = keys, None, None
+
+        def state_dict(self):
+            return {k: None for k in self.keys}
+
+        def load_state_dict(self, sd, strict=False):
+            self.loaded, self.strict = dict(sd), strict
+
+    w = {"a.weight": 1, "b.bias": 2}
+    m = Fake(["a.weight", "b.bias"])
+    utils.load_state_dict(m, {"state_dict": {"module." + k: v for k, v in w.items()}}, strict=True)   # wrapped + DDP prefix -> stripped
+    assert m.loaded == w and m.strict is True
+    m = Fake(["module.a.weight", "module.b.bias"])
+    utils.load_state_dict(m, w)                                                                       # bare keys -> prefix added
+    assert m.loaded == {"module." + k: v for k, v in w.items()} and m.strict is False
+    m = Fake(["a.weight", "b.bias"])
+    utils.load_state_dict(m, w)
+    assert m.loaded == w
+    with pytest.raises(KeyError):
+        utils.instantiate_from_config({"params": {}})
+
+
+def test_cli_job_pre_and_post_processing(tmp_path):
+    """read_job / write_job / batches_of of inference.py around a stand-in for process(): the reference's per-file arithmetic
+    (test_scripts/inference.py:263-291, 323-346) without a GPU."""
+    from argparse import Namespace
+    from PIL import Image
+    sys.path.insert(0, ROOT)
+    import importlib
+    inf = importlib.import_module("inference")
+    from tests.golden._det import det_input
+    src = tmp_path / "in" / "sub"
+    src.mkdir(parents=True)
+    img = (det_input(3, (40, 56, 3)) * 255).numpy().astype(np.uint8)
+    Image.fromarray(img).save(src / "x.png")
+    base = dict(input=str(tmp_path / "in"), output=str(tmp_path / "out"), sr_scale=1, tiled=False, tile_size=512, use_center_crop=False,
+                show_lq=False, disable_preprocess_model=False)
+    # default: short edge 40 -> 512 (bicubic, ceil), pad to multiples of 64
+    a = Namespace(**base)
+    job = inf.read_job(str(src / "x.png"), 0, a)
+    assert job.save_path == os.path.join(a.output, "sub", "x_0.png") and job.lq.size == (56, 40)
+    assert job.valid_hw == (512, 717) and job.net_in.shape == (512, 768, 3) and job.net_in[:, 717:].max() == 0
+    inf.write_job(job, job.net_in, job.net_in, a)                       # the "prediction" is the network input itself
+    saved = np.array(Image.open(job.save_path))
+    want = np.array(Image.fromarray(job.net_in[:512, :717]).resize((56, 40), Image.LANCZOS))
+    assert np.array_equal(saved, want)
+    # --sr_scale 2 --tiled --tile_size 64 --show_lq: LQ | stage-1 | result strip at the up-scaled LQ size
+    b = Namespace(**dict(base, sr_scale=2.0, tiled=True, tile_size=64, show_lq=True))
+    job = inf.read_job(str(src / "x.png"), 1, b)
+    assert job.lq.size == (112, 80) and job.valid_hw == (80, 112) and job.net_in.shape == (128, 128, 3) and job.save_path.endswith("x_1.png")
+    inf.write_job(job, job.net_in, 255 - job.net_in, b)
+    strip = np.array(Image.open(job.save_path))
+    assert strip.shape == (80, 336, 3) and np.array_equal(strip[:, :112], np.array(job.lq)) and np.array_equal(strip[:, 224:], np.array(job.lq))
+    # --use_center_crop: 512 x 512 crop, nothing removed or resized afterwards
+    c = Namespace(**dict(base, use_center_crop=True))
+    job = inf.read_job(str(src / "x.png"), 0, c)
+    assert job.valid_hw == () and job.net_in.shape == (512, 512, 3)
+    inf.write_job(job, job.net_in, None, c)
+    assert np.array_equal(np.array(Image.open(job.save_path)), job.net_in)
+    # batching: consecutive equal shapes only, at most `limit`
+    mk = lambda h, w: inf.Job("p", None, np.zeros((h, w, 3), np.uint8), ())
+    groups = list(inf.batches_of([mk(64, 64), mk(64, 64), mk(64, 64), mk(64, 128), mk(64, 64)], 2))
+    assert [len(g) for g in groups] == [2, 1, 1, 1]
+    assert [len(g) for g in inf.batches_of([mk(64, 64)] * 3, 1)] == [1, 1, 1]

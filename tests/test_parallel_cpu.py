@@ -63,3 +63,54 @@ def test_shard_is_a_partition():
         assert sorted(flat) == items
         inv = unshard_order(len(items), world)
         assert [flat[inv[i]] for i in items] == items
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Tile-level sharding of ONE image: parallel.sharded_tiled_process over an oracle-backed engine.
+def _tile_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import torch.distributed as dist
+    from instarevive_amd import parallel as P
+    from tests.golden._det import det_input
+    from tests.support.oracle_engine import OracleTileEngine
+    torch.set_num_threads(2)
+    P.init_distributed("gloo")
+    eng = OracleTileEngine(det_input(9, (1, 20, 64), -1, 1))
+    imgs = [(det_input(150, (128, 192, 3)) * 255).numpy().astype(np.uint8)]   # latent 16 x 24, tile 8, stride 5: 3 x 5 tiles, snapped edges
+    preds, stage1 = P.sharded_tiled_process(eng, imgs)
+    if rank == 0:
+        q.put((preds[0], stage1[0]))
+    else:
+        assert preds is None and stage1 is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_tile_sharding_is_bit_identical_to_one_rank():
+    """Two (and three) gloo ranks share the 15 tiles of one image: the re-assembled uint8 image equals, bit for bit, both the
+    single-rank run of the same five phases and the oracle's process(tiled=True) in one piece."""
+    import numpy as np
+    from instarevive_amd import parallel as P
+    from tests.golden._det import det_input
+    from tests.support.oracle_engine import OracleTileEngine
+    eng = OracleTileEngine(det_input(9, (1, 20, 64), -1, 1))
+    imgs = [(det_input(150, (128, 192, 3)) * 255).numpy().astype(np.uint8)]
+    assert eng.count(128, 192) == 15
+    one, one_s1 = P.sharded_tiled_process(eng, imgs, rank=0, world=1)
+    ref, ref_s1 = eng.reference(imgs)
+    assert np.array_equal(one[0], ref[0]) and np.array_equal(one_s1[0], ref_s1[0])
+    for world in (2, 3):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_tile_worker, args=(r, world, port, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        got, got_s1 = q.get(timeout=600)
+        for p in procs:
+            p.join(timeout=600)
+            assert p.exitcode == 0
+        assert np.array_equal(got, one[0]) and np.array_equal(got_s1, one_s1[0]), world
+    assert one[0].std() > 1.0
