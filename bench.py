@@ -29,7 +29,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA peak (/opt/skills/guides/MI355X_MICROARCH.md, chip-level table)
+PEAK_FP8_TFLOPS = 5000.0   # dense fp8 (MX-scaled f8f6f4 MFMA), same table
 PEAK_HBM_GBS = 8000.0
+PMC_FILE = "r02_pmc_igemm.json"  # HBM traffic of the conv / GEMM family, refreshed per round by tools/pmc_traffic.py
 
 
 # ---------------------------------------------------------------- algorithmic FLOP model (BASELINE.md section 2, 2*MAC, matmul/conv only)
@@ -47,6 +49,18 @@ def flops_model(h, w, n_tok=300, copies=0):
         dit += (14 * C * C * 2 + 4 * n_tok * C) * copies * t + n_tok * 2 * C * C * 2 * copies + 4.0 * t * t * C * copies \
             + (copies + 1) * 2 * C * C * t + t * 16 * C * 2
     return dict(swinir=swin, vae_encode=enc, dit=dit, vae_decode=dec, total=swin + enc + dit + dec)
+
+
+def flops_model_tiled(h, w, tile=512, stride=448, n_tok=300, copies=0):
+    """--tiled: SwinIR and the VAE encoder run on the whole image, the DiT step and the decoder once per tile (inference.py:119-153)."""
+    def starts(size):
+        v = list(range(0, size - tile + 1, stride))
+        return len(v) + (1 if (size - tile) % stride else 0)
+    nt = starts(h) * starts(w)
+    full, per = flops_model(h, w, n_tok, copies), flops_model(tile, tile, n_tok, copies)
+    out = dict(swinir=full["swinir"], vae_encode=full["vae_encode"], dit=nt * per["dit"], vae_decode=nt * per["vae_decode"], tiles=nt)
+    out["total"] = out["swinir"] + out["vae_encode"] + out["dit"] + out["vae_decode"]
+    return out
 
 
 def conv_flops_model(h, w):
@@ -174,9 +188,13 @@ def main():
     ap.add_argument("--graph", action="store_true", help="diagnostic: replay the step as one hipGraph (IR_FLAG_GRAPH); implies --no_profile, "
                     "so the JSON line carries no roofline")
     ap.add_argument("--no_profile", action="store_true", help="experiment: time the loop without the per-launch HIP events (no roofline)")
+    ap.add_argument("--no_verify", action="store_true", help="skip the fast-vs-plain-kernel check of the last timed output")
+    ap.add_argument("--no_host_rate", action="store_true", help="skip the host-buffer (PCIe-inclusive) rates")
+    ap.add_argument("--fp8", action="store_true", help="BASELINE configs[4]: fp8 MFMA in the VAE 3x3 convs and the DiT self-attention")
     args = ap.parse_args()
 
-    rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    from instarevive_amd import parallel
+    rank, world, local = parallel.env_rank_world()
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
@@ -187,7 +205,7 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        parallel.init_distributed("nccl")   # one process per GPU; "nccl" is RCCL on ROCm
 
     def log(msg):
         if rank == 0:
@@ -197,7 +215,9 @@ def main():
     swin, vae, dit, sched, sds = build_models(device, log, args.control)
     ctx = dit.ctx
     y, mask = synthetic_prompt()
-    dit.set_prompt(y.to(device), mask.to(device))
+    y_dev, mask_dev = y.to(device), mask.to(device)
+    dit.set_prompt(y_dev, mask_dev)
+    peak_tflops = PEAK_FP8_TFLOPS if args.fp8 else PEAK_BF16_TFLOPS
 
     if args.net_hw:
         hh, ww = (int(v) for v in args.net_hw.lower().split("x"))
@@ -222,9 +242,13 @@ def main():
     log(f"workload {n}x{h}x{w} per GPU, workspace {ws.numel() / 2**30:.1f} GiB, flags {flags}")
     acp, sf = float(sched.alphas_cumprod[400]), float(vae.config.scaling_factor)
 
+    gathered = [None]
+
     def step():
         ctx.check(ctx.lib.ir_pipeline(ctx.h, ctx.stream(), L.ptr(din), L.ptr(dout), None, n, h, w, flags, tile_size, tile_stride, 400.0, acp, sf,
                                       L.ptr(ws), ws.numel()), "ir_pipeline")
+        if dist is not None:  # BASELINE configs[3]: the finished uint8 images of every rank are gathered on rank 0 over xGMI, inside the step
+            gathered[0] = parallel.gather_uint8(dout, dst=0)
 
     def barrier():
         if dist is not None:
@@ -253,8 +277,56 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = world * n * args.steps / dt
 
+    # ---- outside the timed region: is what was timed correct? The last output of the timed loop against a second pass through the
+    # older 4-wave kernels (an independent implementation of every large contraction; ir_set_plain_kernels)
+    verify = None
+    if not args.no_verify:
+        fast = dout.clone()
+        ctx.check(ctx.lib.ir_set_plain_kernels(ctx.h, 1), "ir_set_plain_kernels")
+        try:
+            ctx.check(ctx.lib.ir_pipeline(ctx.h, ctx.stream(), L.ptr(din), L.ptr(dout), None, n, h, w, flags, tile_size, tile_stride, 400.0, acp, sf,
+                                          L.ptr(ws), ws.numel()), "ir_pipeline")
+            torch.cuda.synchronize()
+        finally:
+            ctx.check(ctx.lib.ir_set_plain_kernels(ctx.h, 0), "ir_set_plain_kernels")
+        mse = float(((fast.double() - dout.double()) ** 2).mean())
+        psnr = 99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
+        std = float(fast.double().std())
+        verify = dict(verified=bool(psnr >= 45.0 and std > 1.0), psnr_fast_vs_plain_kernels_db=round(psnr, 2), output_std=round(std, 2))
+        if dist is not None:
+            ok = torch.tensor([1.0 if verify["verified"] else 0.0], device=device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            verify["verified"] = bool(ok[0] > 0)
+            if rank == 0 and gathered[0] is not None:
+                verify["gathered_images"] = int(gathered[0].shape[0])
+                verify["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+                verify["world_size"] = dist.get_world_size()
+        log(f"verify: fast vs plain kernels {psnr:.2f} dB, output std {std:.1f}")
+
+    # ---- the drop-in boundary hands over HOST arrays (inference.py:91-93,157-166): the same workload through process() (pinned staging,
+    # synchronous) and through process_stream() (what the CLI runs: upload / download of neighbouring batches overlapped with compute)
+    host = None
+    if world == 1 and not args.no_host_rate and not args.control:
+        from instarevive_amd.pipeline import process, process_stream
+        imgs = list(net_in.numpy())
+        kw = dict(preprocess_model=swin, vae=vae, y=y_dev, y_mask=mask_dev, noise_scheduler=sched)
+        process(dit, imgs, 1, "wavelet", False, args.tiled, tile_size, tile_stride, **kw)      # staging buffers
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            process(dit, imgs, 1, "wavelet", False, args.tiled, tile_size, tile_stride, **kw)
+        dt_sync = (time.perf_counter() - t1) / args.steps
+        k = args.steps + 2
+        t1 = time.perf_counter()
+        for _ in process_stream(dit, (imgs for _ in range(k)), "wavelet", False, args.tiled, tile_size, tile_stride, **kw):
+            pass
+        dt_stream = (time.perf_counter() - t1) / k
+        host = dict(value_host=round(n / dt_stream, 4), value_host_sync=round(n / dt_sync, 4), ms_per_step_stream=round(dt_stream * 1e3, 2),
+                    ms_per_step_sync=round(dt_sync * 1e3, 2),
+                    note="uint8 HWC host arrays in, prediction + stage-1 image out; stream = process_stream(), sync = one process() per step")
+        log(f"host-buffer rate: stream {dt_stream * 1e3:.2f} ms/step, sync {dt_sync * 1e3:.2f} ms/step (device-resident {ms_per_step:.2f})")
+
     if rank == 0:
-        fm = flops_model(h, w, copies=args.control)
+        fm = flops_model_tiled(h, w, tile_size, tile_stride, copies=args.control) if args.tiled else flops_model(h, w, copies=args.control)
         total_ms = sum(v["ms"] for v in prof.values())
         dom = max(prof, key=lambda k: prof[k]["ms"])
         for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
@@ -267,38 +339,47 @@ def main():
         ig_ms = prof["conv3x3"]["ms"] + prof["linear"]["ms"]
         if ig_ms >= prof[dom]["ms"]:
             # algorithmic FLOPs of everything igemm executes = whole path minus the two attention-core classes
-            alg = (fm["total"] * n * args.steps) - prof["flash_attn"]["flops"] - prof["swin_attn"]["flops"] if not args.tiled else \
-                prof["conv3x3"]["flops"] + prof["linear"]["flops"]
+            alg = (fm["total"] * n * args.steps) - prof["flash_attn"]["flops"] - prof["swin_attn"]["flops"]
             launches = prof["conv3x3"]["launches"] + prof["linear"]["launches"]
             ach = alg / (ig_ms / 1e3) / 1e12
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_igemm.json")
-            if os.path.exists(pmc) and not args.tiled and (h, w, n) == (2048, 2048, 1):
-                traffic = json.load(open(pmc))["hbm_bytes_per_launch"]  # measured with rocprofv3 --pmc on this exact workload
-            roof = dict(bound="mfma", kernel="igemm.hip family: conv_halo_pp_kernel + conv_halo_kernel + igemm_kernel + gemm_pp_kernel (3x3-conv + linear launches)", achieved=round(ach, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
-                        frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=traffic, launches_per_step=launches // args.steps,
+            traffic, traffic_src = None, None
+            pmc = os.path.join(ROOT, "profiles", PMC_FILE)
+            if os.path.exists(pmc) and not args.tiled and (h, w, n) == (2048, 2048, 1) and not args.fp8:
+                traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
+                traffic_src = f"static: profiles/{PMC_FILE} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command, not this run)"
+            roof = dict(bound="mfma", kernel="igemm.hip family: conv_halo_pp_kernel + conv_halo_kernel + igemm_kernel + gemm_pp_kernel (3x3-conv + linear launches)", achieved=round(ach, 2), peak=peak_tflops, unit="TFLOP/s",
+                        frac=round(ach / peak_tflops, 4), traffic=traffic, traffic_source=traffic_src, launches_per_step=launches // args.steps,
                         avg_launch_ms=round(ig_ms / max(launches, 1), 4), share_of_gpu_time=round(ig_ms / total_ms, 3),
                         algorithmic_tflop_per_step=round(alg / args.steps / 1e12, 2))
         else:
             d = prof[dom]
             ach = d["flops"] / (d["ms"] / 1e3) / 1e12
-            roof = dict(bound="mfma", kernel=dom, achieved=round(ach, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_BF16_TFLOPS, 4),
+            roof = dict(bound="mfma", kernel=dom, achieved=round(ach, 2), peak=peak_tflops, unit="TFLOP/s", frac=round(ach / peak_tflops, 4),
                         traffic=None, launches_per_step=d["launches"] // args.steps, avg_launch_ms=round(d["ms"] / max(d["launches"], 1), 4),
                         share_of_gpu_time=round(d["ms"] / total_ms, 3))
+        roof["per_class_ms"] = {k: round(v["ms"] / args.steps, 2) for k, v in prof.items() if v["launches"]}
         cpu = None
         if world == 1 and not args.no_cpu_baseline and not args.control:  # the CPU baseline times the headline workload only
             cpu = cpu_baseline(sds, y, mask, h, w, log)
-        print(json.dumps({
+        src = f"{h}x{w} synthetic network input" if args.net_hw else f"{args.lq}x{args.lq} LQ, sr_scale {args.sr_scale:g} -> {h}x{w} network input"
+        line = {
             "metric": "512->2048 one-step SR images/sec", "value": round(value, 4), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{args.lq}x{args.lq} LQ, sr_scale {args.sr_scale:g} -> {h}x{w} network input, "
-                                   f"{'tiled 512/448 + wavelet' if args.tiled else 'untiled'}, batch {n} per GPU, full SwinIR->VAE-enc->DiT(t=400)->VAE-dec path"
-                                   + (f" + ControlNet-Half ({args.control} copied blocks, c = LQ latent)" if args.control else ""),
-                       "parallelism": f"dp{world}", "weights": "seeded random, full-size architectures"},
+            "dtype": "fp8" if args.fp8 else "bf16", "data": "synthetic",
+            "config": {"workload": f"{src}, {('tiled 512/448 + wavelet, %d tiles' % fm['tiles']) if args.tiled else 'untiled'}, batch {n} per GPU, "
+                                   "full SwinIR->VAE-enc->DiT(t=400)->VAE-dec path"
+                                   + (f" + ControlNet-Half ({args.control} copied blocks, c = LQ latent)" if args.control else "")
+                                   + (", fp8 MFMA (MX-scaled e4m3) in the VAE 3x3 convs and the DiT self-attention" if args.fp8 else "")
+                                   + (", one RCCL gather of the uint8 results on rank 0 per step" if world > 1 else ""),
+                       "global_batch": n * world, "parallelism": f"dp{world}", "weights": "seeded random, full-size architectures"},
             "algorithmic_tflop_per_image": round(fm["total"] / 1e12, 2),
             "path_tflops": round(fm["total"] * n * world / (ms_per_step / 1e3) / 1e12, 1),
-            "roofline": roof, "cpu_baseline": cpu}), flush=True)
+            "roofline": roof, "cpu_baseline": cpu}
+        if verify is not None:
+            line.update(verify)
+        if host is not None:
+            line.update(host)
+        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -92,13 +92,25 @@ class _DeviceModule:
                                f"{'...' if len(missing) > 8 else ''}\n\tUnexpected key(s): {unexpected[:8]}{'...' if len(unexpected) > 8 else ''}")
         return SimpleNamespace(missing_keys=missing, unexpected_keys=unexpected)
 
+    FAMILY = None  # name of the weight set in the per-GPU context ("swin", "vae", "dit", ...): one binding per family and device
+
+    def _mark_bound(self):
+        self.ctx.__dict__.setdefault("_bound", {})[self.FAMILY] = self
+
+    def _is_bound(self):
+        return self.ctx.__dict__.get("_bound", {}).get(self.FAMILY) is self
+
     def _ready(self):
         if self.ctx is None or self._sd is None:
             raise RuntimeError(f"{type(self).__name__}: load_state_dict(...) and .to('cuda') must both be called before forward")
+        if not self._is_bound():  # another model of the same family was loaded on this GPU since: the context holds ITS weights
+            self._upload()
 
 
 # ====================================================================================================== SwinIR
 class SwinIR(_DeviceModule):
+    FAMILY = "swin"
+
     def __init__(self, img_size=64, patch_size=1, in_chans=3, embed_dim=96, depths=(6, 6, 6, 6), num_heads=(6, 6, 6, 6), window_size=7,
                  mlp_ratio=4.0, qkv_bias=True, qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.1, norm_layer=None,
                  ape=False, patch_norm=True, use_checkpoint=False, sf=4, img_range=1.0, upsampler="", resi_connection="1conv",
@@ -133,6 +145,7 @@ class SwinIR(_DeviceModule):
         self.ctx.check(self.ctx.lib.ir_swinir_configure(self.ctx.h, c["embed_dim"], len(c["depths"]), _ints(c["depths"]), c["num_heads"][0],
                                                          int(c["embed_dim"] * c["mlp_ratio"]), 64, float(c["img_range"]), mean),
                        "ir_swinir_configure")
+        self._mark_bound()
 
     @torch.no_grad()
     def __call__(self, x):
@@ -187,6 +200,8 @@ class _LatentDist:
 
 
 class AutoencoderKL(_DeviceModule):
+    FAMILY = "vae"
+
     def __init__(self, in_channels=3, out_channels=3, block_out_channels=(128, 256, 512, 512), layers_per_block=2, latent_channels=4,
                  norm_num_groups=32, scaling_factor=0.18215, **unused):
         super().__init__()
@@ -258,6 +273,7 @@ class AutoencoderKL(_DeviceModule):
         self.ctx.upload_all(W.pack_vae(self._sd, c))
         self.ctx.check(self.ctx.lib.ir_vae_configure(self.ctx.h, c["ch"], len(c["ch_mult"]), _ints(c["ch_mult"]), c["num_res_blocks"], 1, 1),
                        "ir_vae_configure")
+        self._mark_bound()
 
     @torch.no_grad()
     def encode(self, x):
@@ -288,6 +304,8 @@ class AutoencoderKL(_DeviceModule):
 
 # ====================================================================================================== DiT
 class Transformer2DModel(_DeviceModule):
+    FAMILY = "dit"
+
     def __init__(self, num_attention_heads=16, attention_head_dim=72, in_channels=4, out_channels=8, num_layers=28, cross_attention_dim=1152,
                  attention_bias=True, sample_size=64, patch_size=2, activation_fn="gelu-approximate", norm_type="ada_norm_single",
                  norm_elementwise_affine=False, norm_eps=1e-6, caption_channels=4096, interpolation_scale=None, mlp_ratio=4, **unused):
@@ -335,10 +353,15 @@ class Transformer2DModel(_DeviceModule):
         self.ctx.check(self.ctx.lib.ir_dit_configure(self.ctx.h, c["num_layers"], c["num_attention_heads"], c["attention_head_dim"], c["mlp"],
                                                       c["caption_channels"], c["sample_size"] // 2), "ir_dit_configure")
         self._prompt_key = None
+        self.__dict__["_pos_done"] = set()
+        self._mark_bound()
+        self.ctx.__dict__["_bound"]["dit_ctrl"] = None  # ir_dit_configure drops a control branch bound to the previous model
 
     def ensure_pos(self, gh, gw):
         name = f"dit.pos.{gh}x{gw}"
-        if not self.ctx.has(name):
+        done = self.__dict__.setdefault("_pos_done", set())  # per model: the table depends on its width and base grid, not only on the name
+        if (gh, gw) not in done:
+            done.add((gh, gw))
             c = self.cfg
             self.ctx.upload(name, W.sincos_pos_embed(c["num_attention_heads"] * c["attention_head_dim"], gh, gw, c["sample_size"] // 2,
                                                      c["interpolation_scale"]))
@@ -425,6 +448,8 @@ class ControlTransformerHalf(_DeviceModule):
     `controlnet.{i}.after_proj`, `controlnet.0.before_proj`) and call signature as the reference class; attributes it does not
     define fall through to the base model, as the reference's __getattr__ does (:78-84)."""
 
+    FAMILY = "dit_ctrl"
+
     def __init__(self, base_model, copy_blocks_num=13):
         super().__init__()
         if not isinstance(base_model, Transformer2DModel):
@@ -484,8 +509,17 @@ class ControlTransformerHalf(_DeviceModule):
         if self.base_model.ctx is not self.ctx or self.base_model._sd is None:
             raise RuntimeError("the base model must be loaded and on the same device before the control branch is uploaded")
         self.ctx.upload_all(W.pack_dit_control(self._sd, self.copy_blocks_num))
+        self.base_model._ready()           # the base model's weights are the ones bound on this GPU (re-uploads them if not)
         self.ctx.check(self.ctx.lib.ir_dit_control_configure(self.ctx.h, self.copy_blocks_num), "ir_dit_control_configure")
         self.base_model._prompt_key = None  # the control copies' prompt K/V caches are built by the next set_prompt
+        self._mark_bound()
+
+    def _ready(self):
+        if self.ctx is None or self._sd is None:
+            raise RuntimeError("ControlTransformerHalf: load_state_dict(...) and .to('cuda') must both be called before forward")
+        self.base_model._ready()
+        if not self._is_bound():
+            self._upload()
 
     def _prep(self, hidden_states, c, encoder_hidden_states, encoder_attention_mask):
         if c is None:
@@ -529,6 +563,7 @@ class T5EncoderModel(_DeviceModule):
     """transformers.T5EncoderModel as the reference's T5Embedder uses it (diffusion/model/t5.py:80,95-100): T5 v1.1 encoder
     (gated-GELU feed-forward, shared relative-position bias, no biases), state dict in the transformers key layout. The call returns
     a dict with 'last_hidden_state' [B, T, d_model] (fp32), as the reference indexes it."""
+    FAMILY = "t5"
 
     def __init__(self, d_model=4096, d_kv=64, num_heads=64, d_ff=10240, num_layers=24, vocab_size=32128, relative_attention_num_buckets=32,
                  relative_attention_max_distance=128, feed_forward_proj="gated-gelu", layer_norm_epsilon=1e-6, **unused):
@@ -567,6 +602,7 @@ class T5EncoderModel(_DeviceModule):
         self.ctx.check(self.ctx.lib.ir_t5_configure(self.ctx.h, c["num_layers"], c["d_model"], c["num_heads"], c["d_kv"], c["d_ff"], c["vocab_size"]),
                        "ir_t5_configure")
         self._bias_lengths = set()  # position-bias tables depend on the weights: rebuilt per sequence length after every upload
+        self._mark_bound()
 
     @torch.no_grad()
     def __call__(self, input_ids=None, attention_mask=None, **unused):

@@ -143,7 +143,10 @@ def _pipeline_flags(model, color_fix_type, disable_preprocess_model, tiled):
     return flags
 
 
-def _prepare_fused(model, y, y_mask, h, w, tiled, tile_size):
+def _prepare_fused(model, y, y_mask, h, w, tiled, tile_size, others=()):
+    for m in others:  # the context must hold THESE models' weights (another instance of the family may have been loaded since)
+        if m is not None:
+            m._ready()
     model.set_prompt(y, y_mask)
     if tiled:
         model.ensure_pos(tile_size // 16, tile_size // 16)
@@ -177,7 +180,7 @@ def process(model, control_imgs: List[np.ndarray], strength: float, color_fix_ty
     sf = float(vae.config.scaling_factor)
     if fused and _fused_ok(model, preprocess_model, vae, disable_preprocess_model):
         ctx = model.ctx
-        _prepare_fused(model, y, y_mask, h, w, tiled, tile_size)
+        _prepare_fused(model, y, y_mask, h, w, tiled, tile_size, (vae, None if disable_preprocess_model else preprocess_model))
         flags = _pipeline_flags(model, color_fix_type, disable_preprocess_model, tiled) | (L.FLAG_GRAPH if graph else 0)
         st = _Staging.get(ctx, n, h, w)
         st.fill(0, control_imgs)
@@ -268,7 +271,7 @@ def process_stream(model, batches: Iterable[Sequence[np.ndarray]], color_fix_typ
     up = upload(nxt, slot) if nxt is not None else None
     while up is not None:
         st, cur, (n, h, w), ready = up
-        _prepare_fused(model, y, y_mask, h, w, tiled, tile_size)
+        _prepare_fused(model, y, y_mask, h, w, tiled, tile_size, (vae, None if disable_preprocess_model else preprocess_model))
         main.wait_event(ready)
         _launch_pipeline(ctx, st, cur, n, h, w, base_flags, tile_size, tile_stride, acp, sf, return_stage1)
         computed = torch.cuda.Event()
@@ -300,6 +303,7 @@ class HipTileEngine:
         if not _fused_ok(model, preprocess_model, vae, disable_preprocess_model):
             raise TypeError("HipTileEngine needs instarevive_amd models sharing one context")
         self.model, self.ctx, self.device = model, model.ctx, model.device
+        self.others = (vae, None if disable_preprocess_model else preprocess_model)
         self.y, self.y_mask = y, y_mask
         self.tile_size, self.tile_stride = tile_size, tile_stride
         self.flags = _pipeline_flags(model, color_fix_type, disable_preprocess_model, True)
@@ -319,7 +323,7 @@ class HipTileEngine:
     def encode(self, control_imgs):
         n, h, w = _check_images(control_imgs)
         self.shape = (n, h, w)
-        _prepare_fused(self.model, self.y, self.y_mask, h, w, True, self.tile_size)
+        _prepare_fused(self.model, self.y, self.y_mask, h, w, True, self.tile_size, self.others)
         st = _Staging.get(self.ctx, n, h, w)
         st.fill(0, control_imgs)
         st.d_in[0].copy_(st.h_in[0], non_blocking=True)

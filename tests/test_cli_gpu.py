@@ -86,4 +86,4 @@ def test_cli_matches_oracle(tmp_path):
         assert got.shape == want.shape == v.shape
         p = _psnr_u8([got], [want])
         print(f"cli {k}: PSNR vs oracle {p:.2f} dB")
-        assert p >= 35.0
+        assert p >= 47.0  # measured 52.3 and 53.1 dB on these two files

@@ -1,0 +1,210 @@
+"""Correctness at the HEADLINE sizes (BASELINE.json configs[1] 2048 x 2048 untiled, configs[2] 4K --tiled + hipGraph), where the fp32
+oracle cannot run in seconds: the largest kernels are checked one by one against fp64 / fp32 PyTorch references on sampled rows
+and crops, and the whole path through two independent kernel sets (ping-pong / register-resident kernels vs the older 4-wave
+kernels, ir_set_plain_kernels) plus size-independent properties. Reduced architectures are checked against the output of the
+reference's own process() (tests/golden/process_small.npz), snapped tiles included."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from instarevive_amd import _lib as L
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _bf16_bits(t):  # fp32 / bf16 device tensor -> int16 bit pattern (device)
+    return t.to(torch.bfloat16).contiguous().view(torch.int16)
+
+
+def _psnr(a, b):
+    mse = float(((a.astype(np.float64) - b.astype(np.float64)) ** 2).mean())
+    return 99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
+
+
+# ------------------------------------------------------------------------------------------------ attention at T = 16384 / 65536
+@pytest.mark.parametrize("heads,t,d,gain", [(16, 16384, 72, 3.0), (1, 65536, 512, 3.0)])
+def test_attention_at_headline_size(ctx, heads, t, d, gain):
+    """DiT self-attention of the 2048 x 2048 image (16 heads x 72, 16384 tokens: flash_attn_pp_kernel) and the VAE mid-block
+    attention (1 head x 512, 65536 tokens: the d = 512 kernel) against an fp64 softmax on 320 sampled query rows (block
+    boundaries, first / last rows, random ones). Logits have a standard deviation of `gain`, so a handful of the keys carry each row.
+    Tolerance as in test_ops_gpu.py::test_flash_attention: P and O are rounded to bf16 (rel. 2^-6 + 6e-3 absolute)."""
+    g = torch.Generator(device="cuda").manual_seed(t + d)
+    q = (torch.randn(1, t, heads, d, generator=g, device="cuda") * gain).to(torch.bfloat16)
+    k = torch.randn(1, t, heads, d, generator=g, device="cuda").to(torch.bfloat16)
+    v = torch.randn(1, t, heads, d, generator=g, device="cuda").to(torch.bfloat16)
+    o = torch.empty(1, t, heads, d, dtype=torch.int16, device="cuda")
+    ws = torch.empty(((heads * ((d + 31) // 32 * 32)) if d != 512 else 512) * (t + 64) * 2 + 4096, dtype=torch.uint8, device="cuda")
+    scale = d ** -0.5
+    ctx.check(ctx.lib.ir_op_attention(ctx.h, ctx.stream(), L.ptr(q.view(torch.int16)), L.ptr(k.view(torch.int16)), L.ptr(v.view(torch.int16)),
+                                      L.ptr(o), 1, heads, t, t, d, scale, None, L.ptr(ws), ws.numel()), "attention")
+    torch.cuda.synchronize()
+    rows = sorted(set([0, 1, 31, 32, 127, 128, 255, 256, 257, t // 2 - 1, t // 2, t - 257, t - 256, t - 33, t - 2, t - 1] +
+                      torch.randint(0, t, (304,), generator=torch.Generator().manual_seed(5)).tolist()))
+    idx = torch.tensor(rows, device="cuda")
+    got = o.view(torch.bfloat16)[0, idx].float()                                # [R, heads, d]
+    worst = 0.0
+    for hd in range(heads):
+        s = (q[0, idx, hd].double() @ k[0, :, hd].double().t()) * scale        # [R, T] fp64
+        ref = (torch.softmax(s, dim=-1) @ v[0, :, hd].double()).float()
+        err = (got[:, hd] - ref).abs()
+        bad = err > 6e-3 + 2 ** -6 * ref.abs()
+        worst = max(worst, float(err.max()))
+        assert not bad.any(), f"head {hd}: {int(bad.sum())}/{bad.numel()} off, max abs err {float(err.max()):.4g}, |ref| max {float(ref.abs().max()):.3g}"
+        assert float(ref.abs().max()) > 0.3                                    # a peaked softmax: the output is not an average of everything
+    print(f"attention {heads}x{d} T={t}: max abs err {worst:.4g} on {len(rows)} sampled rows")
+
+
+# ------------------------------------------------------------------------------------------------ 3x3 convs on 2048 x 2048 x 256
+@pytest.mark.parametrize("cin,cout,up", [(256, 256, 0), (256, 128, 0), (256, 256, 1)])
+def test_conv_at_headline_size(ctx, cin, cout, up):
+    """The decoder's full-resolution convolutions: 256 -> 256 and 256 -> 128 on a 2048 x 2048 x 256 activation (2^31 bytes: the
+    largest tensor of the path, last rows at byte offsets just below 2^31 and element offsets above 2^29), and the nearest-2x
+    upsampling conv 1024^2 -> 2048^2. Output crops (top, middle, bottom rows; full width) against F.conv2d in fp32 on the same
+    bf16-rounded operands. Tolerance: fp32 accumulation, bf16 output rounding (2^-7 relative + 4e-3)."""
+    h = w = 1024 if up else 2048
+    g = torch.Generator(device="cuda").manual_seed(cin + cout + up)
+    x = torch.randn(h, w, cin, generator=g, device="cuda", dtype=torch.float32).to(torch.bfloat16)     # NHWC
+    wt = (torch.randn(cout, cin, 3, 3, generator=g, device="cuda") / (9 * cin) ** 0.5).to(torch.bfloat16)
+    b = torch.randn(cout, generator=g, device="cuda")
+    wp = wt.permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous()                                      # [Cout][tap][Cin]
+    ho, wo = (2 * h, 2 * w) if up else (h, w)
+    out = torch.empty(ho, wo, cout, dtype=torch.int16, device="cuda")
+    ctx.check(ctx.lib.ir_op_conv(ctx.h, ctx.stream(), L.ptr(x.view(torch.int16)), L.ptr(wp.view(torch.int16)), L.ptr(b), L.ptr(out), 1, h, w, cin, cout,
+                                 cout, 9, 1, 1, up, L.ACT_NONE, 0.0, None, 0, 0), "conv")
+    torch.cuda.synchronize()
+    got_all = out.view(torch.bfloat16)
+    for r0, r1 in ((0, 18), (ho // 2 - 9, ho // 2 + 9), (ho - 18, ho)):                                   # output row ranges
+        lo, hi = max(r0 - 1, 0), min(r1 + 1, ho)                                                         # input rows needed (conv grid)
+        if up:
+            src = x[lo // 2:(hi + 1) // 2].float().permute(2, 0, 1)[None]
+            src = F.interpolate(src, scale_factor=2.0, mode="nearest")[:, :, lo - 2 * (lo // 2): lo - 2 * (lo // 2) + (hi - lo)]
+        else:
+            src = x[lo:hi].float().permute(2, 0, 1)[None]
+        src = F.pad(src, (1, 1, 1 if lo == 0 and r0 == 0 else 0, 1 if hi == ho and r1 == ho else 0))
+        ref = F.conv2d(src, wt.float(), b)[0].permute(1, 2, 0)                                           # rows lo' .. : [rows, wo, cout]
+        ref = ref[: r1 - r0]   # without a top pad the first valid output row is lo + 1 = r0; with it (r0 = 0) it is row 0
+        got = got_all[r0:r1].float()
+        err = (got - ref).abs()
+        bad = err > 4e-3 + 2 ** -7 * ref.abs()
+        assert not bad.any(), f"rows {r0}:{r1}: {int(bad.sum())}/{bad.numel()} off, max abs err {float(err.max()):.4g}"
+    print(f"conv {cin}->{cout} up={up} at {ho}x{wo}: crops ok")
+
+
+# ------------------------------------------------------------------------------------------------ reduced architecture vs the reference's process()
+@pytest.mark.parametrize("case", ["untiled", "nopre", "tiled_wavelet", "tiled_adain", "tiled_none"])
+def test_process_vs_reference_process_fixture(case):
+    """The HIP path against the uint8 OUTPUT OF THE REFERENCE's own process() (not the oracle): untiled, --disable_preprocess_model
+    and --tiled with snapped last tiles (latent 24 x 32, tile 8, stride 5: 5 x 7 tiles) under the three colour-fix modes; fused
+    ir_pipeline and the stage-by-stage form. >= 45 dB on the uint8 result, >= 50 dB on the stage-1 image."""
+    from instarevive_amd.models import AutoencoderKL, SwinIR, Transformer2DModel
+    from instarevive_amd.pipeline import process
+    from tests.test_oracle_golden import PROCESS_CASES, _process_small_models
+    fx = np.load(os.path.join(G, "process_small.npz"))
+    sws, svae, _, dsd = _process_small_models()
+    swin = SwinIR(img_size=64, patch_size=1, in_chans=3, embed_dim=60, depths=[2, 2], num_heads=[6, 6], window_size=8, mlp_ratio=2, sf=8, img_range=1.0,
+                  upsampler="nearest+conv", resi_connection="1conv", unshuffle=True, unshuffle_scale=8)
+    swin.load_state_dict(sws, strict=False)
+    vae = AutoencoderKL(block_out_channels=(32, 64, 128, 128))
+    vae.load_state_dict(svae)
+    dit = Transformer2DModel(num_attention_heads=4, attention_head_dim=72, num_layers=2, sample_size=16, caption_channels=64, cross_attention_dim=288)
+    dit.load_state_dict(dsd)
+    for m in (swin, vae, dit):
+        m.to("cuda")
+    img_key, kw = PROCESS_CASES[case]
+    want, want1 = fx[case + "_pred"], fx[case + "_stage1"]
+    imgs = list(fx[img_key])[: want.shape[0]]
+    y = torch.from_numpy(fx["y"]).cuda()
+    for fused in (True, False):
+        got, got1 = process(dit, imgs, 1, kw["color_fix_type"], kw.get("disable_preprocess_model", False), kw["tiled"], kw.get("tile_size", 512),
+                            kw.get("tile_stride", 448), preprocess_model=swin, vae=vae, y=y, y_mask=None, fused=fused)
+        p, p1 = _psnr(np.stack(got), want), _psnr(np.stack(got1), want1)
+        print(f"{case} fused={fused}: PSNR vs the reference's process() {p:.2f} dB (stage-1 {p1:.2f} dB)")
+        assert p >= 45.0 and p1 >= 50.0
+
+
+# ------------------------------------------------------------------------------------------------ whole path at 2048 x 2048 and 4K tiled
+def _process_full(full_models, img, tiled, graph=False, fix="wavelet"):
+    from instarevive_amd.pipeline import process
+    swin, vae, dit, sds, y, mask = full_models
+    return process(dit, [img], 1, fix, False, tiled, 512, 448, preprocess_model=swin, vae=vae, y=full_models.y_cuda, y_mask=full_models.mask_cuda,
+                   graph=graph)
+
+
+def test_headline_2048_untiled_fast_vs_plain_kernels(full_models):
+    """BASELINE configs[1] at full architecture: the 2048 x 2048 untiled pass through the default (fast) kernels and through the older
+    4-wave kernel set — two independent implementations of every large contraction (ping-pong conv / GEMM / attention and the
+    register-resident d = 512 attention vs their predecessors) — must agree to >= 45 dB on the uint8 result; plus determinism."""
+    import bench
+    swin, vae, dit, sds, y, mask = full_models
+    ctx = dit.ctx
+    img = bench.synthetic_lq(1, 2048, 2048, 31)[0].numpy()
+    fast, st1 = _process_full(full_models, img, False)
+    again, _ = _process_full(full_models, img, False)
+    assert np.array_equal(fast[0], again[0]), "the path must be deterministic run to run"
+    ctx.check(ctx.lib.ir_set_plain_kernels(ctx.h, 1), "ir_set_plain_kernels")
+    try:
+        plain, st1p = _process_full(full_models, img, False)
+    finally:
+        ctx.check(ctx.lib.ir_set_plain_kernels(ctx.h, 0), "ir_set_plain_kernels")
+    p, p1 = _psnr(fast[0], plain[0]), _psnr(st1[0], st1p[0])
+    print(f"2048x2048 untiled: fast vs plain kernels {p:.2f} dB (stage-1 {p1:.2f} dB), output std {fast[0].std():.1f}")
+    assert p >= 45.0 and p1 >= 50.0 and fast[0].std() > 1.0 and st1[0].std() > 1.0
+
+
+def test_4k_tiled_hipgraph(full_models):
+    """BASELINE configs[2]: a padded 4K frame (2176 x 3840, 45 tiles of 512 px, stride 448: snapped last row of tiles) --tiled with
+    the wavelet fix. The hipGraph replay must be bit-identical to the plain launch sequence (recording call and replay on new
+    pixels), and the fast and the plain kernel sets must agree to >= 45 dB."""
+    import bench
+    swin, vae, dit, sds, y, mask = full_models
+    ctx = dit.ctx
+    a, b = (bench.synthetic_lq(1, 2176, 3840, s)[0].numpy() for s in (41, 42))
+    assert ctx.lib.ir_tiled_count(2176, 3840, 512, 448) == 45
+    want_a, _ = _process_full(full_models, a, True)
+    rec_a, _ = _process_full(full_models, a, True, graph=True)       # records
+    assert np.array_equal(rec_a[0], want_a[0])
+    want_b, _ = _process_full(full_models, b, True)
+    rep_b, _ = _process_full(full_models, b, True, graph=True)       # replays on new pixels
+    assert np.array_equal(rep_b[0], want_b[0]) and not np.array_equal(want_a[0], want_b[0])
+    ctx.check(ctx.lib.ir_set_plain_kernels(ctx.h, 1), "ir_set_plain_kernels")
+    try:
+        plain_a, _ = _process_full(full_models, a, True)
+    finally:
+        ctx.check(ctx.lib.ir_set_plain_kernels(ctx.h, 0), "ir_set_plain_kernels")
+    p = _psnr(want_a[0], plain_a[0])
+    print(f"4K tiled: fast vs plain kernels {p:.2f} dB, output std {want_a[0].std():.1f}")
+    assert p >= 45.0 and want_a[0].std() > 1.0
+
+
+def test_tile_engine_equals_ir_pipeline_tiled(full_models):
+    """The five ir_tiled_* phases driven from the host (what a tile-sharded multi-GPU run executes, here as one rank and as two
+    simulated ranks whose tile sets are exchanged in memory) reproduce ir_pipeline(IR_FLAG_TILED) bit for bit at 1024 x 1536."""
+    import bench
+    from instarevive_amd.parallel import sharded_tiled_process
+    from instarevive_amd.pipeline import HipTileEngine
+    swin, vae, dit, sds, y, mask = full_models
+    img = bench.synthetic_lq(1, 1024, 1536, 51)[0].numpy()
+    want, want1 = _process_full(full_models, img, True)
+    eng = HipTileEngine(dit, vae, swin, full_models.y_cuda, full_models.mask_cuda, "wavelet", False, 512, 448)
+    got, got1 = sharded_tiled_process(eng, [img], rank=0, world=1)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got1[0], want1[0])
+    # two "ranks" on this one GPU: each runs its own tiles, the tile stacks are merged in loop order as the collectives would
+    control, init = eng.encode([img])
+    n_tiles = eng.count(1024, 1536)
+    parts = [eng.dit_tiles(init, r, 2).clone() for r in range(2)]
+    x0_all = torch.empty((n_tiles,) + tuple(parts[0].shape[1:]), device="cuda")
+    for r in range(2):
+        x0_all[r::2] = parts[r]
+    nb = eng.blend_latent(x0_all)
+    parts = [eng.decode_tiles(nb, control, r, 2).clone() for r in range(2)]
+    px_all = torch.empty((n_tiles,) + tuple(parts[0].shape[1:]), device="cuda")
+    for r in range(2):
+        px_all[r::2] = parts[r]
+    two = eng.blend_pixels(px_all)
+    d = np.abs(two[0].astype(int) - want[0].astype(int))
+    print(f"two simulated ranks vs one call: max |diff| {d.max()} grey levels, {100 * (d != 0).mean():.4f} % of the values")
+    assert d.max() <= 1   # bit-identical re-assembly; the per-tile kernels may differ in the last bit when the row count selects another GEMM tiling

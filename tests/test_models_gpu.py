@@ -1,9 +1,12 @@
 """Stage-level and whole-path parity on the GPU: instarevive_amd (HIP, bf16 storage / fp32 accumulation) against the
 oracle (CPU fp32, pinned to the reference by tests/test_oracle_golden.py) on the same seeded inputs and weights.
 
-Tolerance (stated once): activations are stored in bf16 (relative rounding 2^-9) across 10-60 chained kernels, so a
-stage must agree with the fp32 oracle to a relative L2 error <= 2 % and a worst element <= 6 % of the output range;
-the uint8 end result must reach >= 35 dB PSNR against the oracle's uint8 result."""
+Tolerances (stated once; round 1 measured the values in brackets, the gates are those plus a margin): activations are stored in bf16
+(relative rounding 2^-9) across 10-60 chained kernels, so against the fp32 oracle / the reference fixtures a stage must reach
+    SwinIR, DiT (+ ControlNet-Half):  relative L2 <= 0.8 %  [0.23-0.42 %], worst element <= 1.5 % of the output range [0.15-0.78 %]
+    VAE encode / decode:              relative L2 <= 2.0 %  [1.0-1.45 %],  worst element <= 1.5 % of the range        [0.5-0.8 %]
+    T5 encoder:                       relative L2 <= 1.5 %  [0.6-1.0 %],   worst element <= 1.2 % of the range        [0.3-0.6 %]
+and the uint8 end result >= 45 dB PSNR against the oracle's uint8 result [47.7-52.5 dB], the stage-1 image >= 50 dB [53.2-53.7 dB]."""
 import os
 
 import numpy as np
@@ -24,7 +27,13 @@ def rel_l2(a, b):
     return float((a - b).norm() / b.norm())
 
 
-def check(got, ref, what, l2=0.02, worst=0.06):
+TOL_XFMR = dict(l2=0.008, worst=0.015)   # SwinIR, DiT
+TOL_VAE = dict(l2=0.02, worst=0.015)
+TOL_T5 = dict(l2=0.015, worst=0.012)
+PSNR_MIN, PSNR_STAGE1_MIN = 45.0, 50.0
+
+
+def check(got, ref, what, l2, worst):
     got, ref = got.float().cpu(), ref.float().cpu()
     assert got.shape == ref.shape, (what, got.shape, ref.shape)
     assert torch.isfinite(got).all(), what
@@ -75,30 +84,30 @@ def test_swinir_small_vs_golden_and_oracle():
     for k in ("x64", "x128x192"):
         x = torch.from_numpy(fx[k])
         out = m(x.cuda())
-        check(out, torch.from_numpy(fx[k + "_out"]), f"swinir small {k} vs reference fixture")
+        check(out, torch.from_numpy(fx[k + "_out"]), f"swinir small {k} vs reference fixture", **TOL_XFMR)
 
 
 def test_swinir_full_arch_64():
     m, sd = make_swin({}, seed=111)
     x = det_input(21, (1, 3, 64, 64))
-    check(m(x.cuda()), oswin.swinir_forward(sd, x), "swinir full arch 64x64")
+    check(m(x.cuda()), oswin.swinir_forward(sd, x), "swinir full arch 64x64", **TOL_XFMR)
 
 
 def test_vae_small_vs_golden():
     fx = np.load(os.path.join(G, "vae_small.npz"))
     m, sd = make_vae(VAE_SMALL)
     for k in ("x64", "x64x128"):
-        check(m.encode(torch.from_numpy(fx[k]).cuda()).latent_dist.mode(), torch.from_numpy(fx[k + "_mean"]), f"vae encode {k} vs reference fixture")
+        check(m.encode(torch.from_numpy(fx[k]).cuda()).latent_dist.mode(), torch.from_numpy(fx[k + "_mean"]), f"vae encode {k} vs reference fixture", **TOL_VAE)
     for k in ("z8", "z8x16"):
-        check(m.decode(torch.from_numpy(fx[k]).cuda()).sample, torch.from_numpy(fx[k + "_dec"]), f"vae decode {k} vs reference fixture")
+        check(m.decode(torch.from_numpy(fx[k]).cuda()).sample, torch.from_numpy(fx[k + "_dec"]), f"vae decode {k} vs reference fixture", **TOL_VAE)
 
 
 def test_vae_full_arch_128():
     m, sd = make_vae(dict(ch=128), seed=222)
     x = det_input(22, (1, 3, 128, 128), -1, 1)
-    check(m.encode(x.cuda()).latent_dist.mode(), ovae.vae_encode_mean(sd, x), "vae full encode 128")
+    check(m.encode(x.cuda()).latent_dist.mode(), ovae.vae_encode_mean(sd, x), "vae full encode 128", **TOL_VAE)
     z = det_input(23, (1, 4, 16, 16), -3, 3)
-    check(m.decode(z.cuda()).sample, ovae.vae_decode(sd, z), "vae full decode 16->128")
+    check(m.decode(z.cuda()).sample, ovae.vae_decode(sd, z), "vae full decode 16->128", **TOL_VAE)
 
 
 def _prompt(cfg, ntok=20, valid=13, seed=9):
@@ -117,7 +126,7 @@ def test_dit_small_all_mask_forms():
             ref = odit.dit_forward(sd, lat, 400.0, y, mask, DIT_SMALL)
             out = m(lat.cuda(), timestep=torch.full((lat.shape[0],), 400), encoder_hidden_states=y.cuda(),
                     encoder_attention_mask=None if mask is None else mask.cuda(), added_cond_kwargs={"resolution": None, "aspect_ratio": None}).sample
-            check(out, ref, f"dit small {shape} mask={'none' if mask is None else mask.ndim}")
+            check(out, ref, f"dit small {shape} mask={'none' if mask is None else mask.ndim}", **TOL_XFMR)
 
 
 def test_dit_step_matches_eps_to_mu():
@@ -159,8 +168,8 @@ def test_dit_control_vs_reference_fixture():
     m.to("cuda")
     y = fx["y"][None]
     kw = dict(timestep=torch.full((1,), 400), encoder_hidden_states=y.cuda(), added_cond_kwargs={"resolution": None, "aspect_ratio": None})
-    check(m(fx["lat"].cuda(), c=fx["c"].cuda(), **kw), fx["out_c"], "control dit vs reference fixture")
-    check(base(fx["lat"].cuda(), **kw).sample, fx["out_0"], "base dit of the control fixture, c=None")
+    check(m(fx["lat"].cuda(), c=fx["c"].cuda(), **kw), fx["out_c"], "control dit vs reference fixture", **TOL_XFMR)
+    check(base(fx["lat"].cuda(), **kw).sample, fx["out_0"], "base dit of the control fixture, c=None", **TOL_XFMR)
 
 
 def test_dit_control_small_vs_oracle():
@@ -174,7 +183,7 @@ def test_dit_control_small_vs_oracle():
         ref = odit.dit_forward(sd, lat, 400.0, y, mask3, dict(cfg, copy_blocks_num=2), c=c)
         out = m(lat.cuda(), timestep=torch.full((lat.shape[0],), 400), encoder_hidden_states=y.cuda(), encoder_attention_mask=mask3.cuda(),
                 added_cond_kwargs={"resolution": None, "aspect_ratio": None}, c=c.cuda())
-        check(out, ref, f"control dit small {shape}")
+        check(out, ref, f"control dit small {shape}", **TOL_XFMR)
         assert rel_l2(out.cpu(), odit.dit_forward(sd, lat, 400.0, y, mask3, cfg)) > 0.05  # the branch is not a no-op here
     # fused step == forward_model + eps_to_mu through the reference's hook (generate.py:22-51 with c)
     sch, t = DDPMScheduler(), torch.full((1,), 400).long()
@@ -208,7 +217,7 @@ def test_dit_control_full_arch_256_tokens():
     lat, c = det_input(61, (1, 4, 32, 32), -2, 2), det_input(62, (1, 4, 32, 32), -2, 2)
     ref = odit.dit_forward(sd, lat, 400.0, y, mask3, dict(caption_channels=64), c=c)
     out = m(lat.cuda(), timestep=torch.full((1,), 400), encoder_hidden_states=y.cuda(), encoder_attention_mask=mask3.cuda(), c=c.cuda())
-    check(out, ref, "control dit full arch 32x32", l2=0.03)
+    check(out, ref, "control dit full arch 32x32", **TOL_XFMR)
 
 
 def make_t5(cfg, seed=707, embed_gain=8.0):
@@ -233,8 +242,8 @@ def test_t5_encoder_vs_transformers_fixture_and_oracle():
     m, sd = make_t5(T5_SMALL)
     ids, mask = torch.from_numpy(fx["ids"]), torch.from_numpy(fx["mask"])
     out = m(input_ids=ids.cuda(), attention_mask=mask.cuda())["last_hidden_state"]
-    check(out, torch.from_numpy(fx["out"]), "t5 small vs transformers fixture (padding mask)")
-    check(m(input_ids=ids.cuda())["last_hidden_state"], torch.from_numpy(fx["out_nomask"]), "t5 small vs transformers fixture (no mask)")
+    check(out, torch.from_numpy(fx["out"]), "t5 small vs transformers fixture (padding mask)", **TOL_T5)
+    check(m(input_ids=ids.cuda())["last_hidden_state"], torch.from_numpy(fx["out_nomask"]), "t5 small vs transformers fixture (no mask)", **TOL_T5)
     cfg = dict(d_model=512, d_kv=64, num_heads=8, d_ff=1024, num_layers=3, vocab_size=500)
     m, sd = make_t5(cfg, seed=808)
     g = np.random.Generator(np.random.PCG64(5))
@@ -244,8 +253,8 @@ def test_t5_encoder_vs_transformers_fixture_and_oracle():
         mask[:, :valid] = 1
         ref = ot5.t5_encode(sd, ids, mask, cfg)
         out = m(input_ids=ids.cuda(), attention_mask=mask.cuda())["last_hidden_state"]
-        check(out[:, :valid], ref[:, :valid], f"t5 512-wide b{b} t{t} (valid tokens)")
-        check(out, ref, f"t5 512-wide b{b} t{t} (all positions)")
+        check(out[:, :valid], ref[:, :valid], f"t5 512-wide b{b} t{t} (valid tokens)", **TOL_T5)
+        check(out, ref, f"t5 512-wide b{b} t{t} (all positions)", **TOL_T5)
     with pytest.raises(RuntimeError):
         m(input_ids=torch.full((1, 8), 500).cuda())  # id outside the vocabulary
 
@@ -262,7 +271,7 @@ def test_t5_one_block_at_xxl_width():
     mask[:, :25] = 1
     ref = ot5.t5_encode(sd, ids, mask, cfg)
     out = m(input_ids=ids.cuda(), attention_mask=mask.cuda())["last_hidden_state"]
-    check(out, ref, "t5 one block at XXL width, 300 tokens")
+    check(out, ref, "t5 one block at XXL width, 300 tokens", **TOL_T5)
 
 
 def test_t5_embedder_interface():
@@ -286,7 +295,7 @@ def test_t5_embedder_interface():
     e, msk = emb.get_text_embeddings(["  A portrait photo of a human FACE ", "4k, highly detailed"])
     assert tuple(e.shape) == (2, 24, 128) and tuple(msk.shape) == (2, 24) and int(msk.sum()) == 8 + 4
     tok = Tok()(["a portrait photo of a human face", "4k, highly detailed"], 24, "max_length", True, True, True, "pt")
-    check(e, ot5.t5_encode(sd, tok["input_ids"], tok["attention_mask"], T5_SMALL), "T5Embedder.get_text_embeddings")
+    check(e, ot5.t5_encode(sd, tok["input_ids"], tok["attention_mask"], T5_SMALL), "T5Embedder.get_text_embeddings", **TOL_T5)
 
 
 def _small_models():
@@ -316,7 +325,7 @@ def test_process_small_vs_oracle(tiled, fix):
         got, got1 = process(dit, imgs, 1, fix, False, tiled, 64, 32, preprocess_model=sw, vae=vae, y=y.cuda(), y_mask=mask3.cuda(), fused=fused)
         p, p1 = _psnr_u8(got, ref), _psnr_u8(got1, ref1)
         print(f"process tiled={tiled} fix={fix} fused={fused}: PSNR vs oracle {p:.2f} dB (stage-1 {p1:.2f} dB)")
-        assert p >= 35.0 and p1 >= 40.0
+        assert p >= PSNR_MIN and p1 >= PSNR_STAGE1_MIN
 
 
 @pytest.mark.parametrize("tiled", [False, True])
@@ -342,7 +351,7 @@ def test_process_with_control_branch(tiled):
         got, _ = process(ctl, imgs, 1, "wavelet", False, tiled, 64, 32, preprocess_model=sw, vae=vae, y=y.cuda(), y_mask=mask3.cuda(), fused=fused)
         p, q = _psnr_u8(got, ref), _psnr_u8(got, plain)
         print(f"process+control tiled={tiled} fused={fused}: PSNR vs oracle with c {p:.2f} dB, vs oracle without c {q:.2f} dB")
-        assert p >= 35.0 and q < p - 3.0  # matches the conditioned oracle, and the branch visibly changes the image
+        assert p >= PSNR_MIN and q < p - 3.0  # matches the conditioned oracle, and the branch visibly changes the image
 
 
 @pytest.mark.parametrize("tiled", [False, True])
@@ -372,33 +381,11 @@ def test_process_disable_preprocess():
     ref, ref1 = _oracle_process(imgs, sws, svae, sdit, y, mask3, disable_preprocess_model=True)
     got, got1 = process(dit, imgs, 1, "wavelet", True, False, 512, 448, preprocess_model=None, vae=vae, y=y.cuda(), y_mask=mask3.cuda())
     assert np.array_equal(got1[0], imgs[0]) and np.array_equal(ref1[0], imgs[0])  # stage-1 == LQ input, bit exact
-    assert _psnr_u8(got, ref) >= 35.0
+    assert _psnr_u8(got, ref) >= PSNR_MIN
 
 
 # ---------------------------------------------------------------------------------------------------------------------
 # Full-size architectures (SwinIR 15.8 M, VAE 83.7 M, DiT 611 M parameters, 300 x 4096 prompt), seeded random weights.
-@pytest.fixture(scope="module")
-def full_models():
-    import bench
-    from instarevive_amd.models import AutoencoderKL, SwinIR, Transformer2DModel
-    from instarevive_amd import weights as W
-    swin_cfg = dict(embed_dim=180, depths=[6] * 8, num_heads=[6] * 8, window_size=8, mlp_ratio=2)
-    sds = dict(swin=bench.random_state_dict(W.swinir_shapes(swin_cfg), 1),
-               vae=bench.random_state_dict(W.vae_shapes(dict(ch=128, ch_mult=(1, 2, 4, 4), num_res_blocks=2)), 2),
-               dit=bench.random_state_dict(W.dit_shapes(dict(num_layers=28, num_attention_heads=16, attention_head_dim=72, caption_channels=4096)), 3))
-    swin = SwinIR(img_size=64, patch_size=1, in_chans=3, embed_dim=180, depths=[6] * 8, num_heads=[6] * 8, window_size=8, mlp_ratio=2, sf=8,
-                  img_range=1.0, upsampler="nearest+conv", resi_connection="1conv", unshuffle=True, unshuffle_scale=8)
-    swin.load_state_dict(sds["swin"], strict=False)
-    vae = AutoencoderKL()
-    vae.load_state_dict(sds["vae"])
-    dit = Transformer2DModel()
-    dit.load_state_dict(sds["dit"])
-    for m in (swin, vae, dit):
-        m.to("cuda")
-    y, mask = bench.synthetic_prompt()
-    return swin, vae, dit, sds, y, mask
-
-
 def test_full_arch_process_256_vs_oracle(full_models):
     """Whole path at full depth (8x6 Swin blocks, 28 DiT layers, full VAE) on a 256x256 image against the fp32 oracle."""
     import bench
@@ -411,7 +398,7 @@ def test_full_arch_process_256_vs_oracle(full_models):
     got, got1 = process(dit, imgs, 1, "wavelet", False, False, 512, 448, preprocess_model=swin, vae=vae, y=y.cuda(), y_mask=mask.cuda())
     p, p1 = _psnr_u8(got, ref), _psnr_u8(got1, ref1)
     print(f"full-arch 256x256: PSNR vs fp32 oracle {p:.2f} dB (stage-1 {p1:.2f} dB)")
-    assert p >= 35.0 and p1 >= 40.0
+    assert p >= PSNR_MIN and p1 >= PSNR_STAGE1_MIN
     # north_star's acceptance form: PSNR against a ground truth must be within 0.1 dB of the reference path's PSNR against it.
     # Any third image serves as "ground truth" for that comparison; here the LQ input itself.
     gt = [np.asarray(i) for i in imgs]
@@ -421,7 +408,7 @@ def test_full_arch_process_256_vs_oracle(full_models):
     # stage-level: x0 latent of the fused DiT step against the oracle's
     lat = inter["init_noise"].cuda()
     x0 = dit.step(lat, 400.0, float(oglue.alphas_cumprod_diffusers()[400]), y.cuda(), mask.cuda())
-    check(x0, inter["x0"], "full-arch DiT x0 (28 layers)", l2=0.03, worst=0.08)
+    check(x0, inter["x0"], "full-arch DiT x0 (28 layers)", l2=0.012, worst=0.03)  # measured 0.64 % over 28 layers
 
 
 def test_full_arch_size_independent_properties(full_models):
@@ -457,14 +444,23 @@ def test_full_arch_tiled_2048(full_models):
     assert p >= 45.0 and fused[0].std() > 1.0
 
 
-def test_fast_vs_plain_kernels_at_awkward_sizes():
+def test_fast_vs_plain_kernels_at_awkward_sizes(full_models):
     """A padded 1080p frame (1088 x 1920: 8160 DiT tokens, not a multiple of 64 or 256; 16320-row linears) and a 832 x 1216 one through
-    process() at full architecture, once with the default kernels and once (second process) with the ping-pong / big-tile kernels
-    switched off: the same arithmetic through two independent kernel sets must agree (>= 45 dB on the uint8 result)."""
-    import subprocess
-    import sys
-    tool = os.path.join(os.path.dirname(__file__), "..", "tools", "cross_check_sizes.py")
-    r = subprocess.run([sys.executable, tool, "1088x1920", "832x1216"], capture_output=True, text=True, timeout=900)
-    print(r.stdout[-600:])
-    assert r.returncode == 0 and "cross-check ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
-
+    process() at full architecture, once with the default kernels and once with the ping-pong / big-tile kernels switched off
+    (ir_set_plain_kernels): the same arithmetic through two independent kernel sets must agree (>= 45 dB on the uint8 result)."""
+    import bench
+    from instarevive_amd.pipeline import process
+    swin, vae, dit, sds, y, mask = full_models
+    ctx = dit.ctx
+    kw = dict(preprocess_model=swin, vae=vae, y=full_models.y_cuda, y_mask=full_models.mask_cuda)
+    for h, w in ((1088, 1920), (832, 1216)):
+        img = bench.synthetic_lq(1, h, w, 7)[0].numpy()
+        fast, _ = process(dit, [img], 1, "wavelet", False, False, 512, 448, **kw)
+        ctx.check(ctx.lib.ir_set_plain_kernels(ctx.h, 1), "ir_set_plain_kernels")
+        try:
+            plain, _ = process(dit, [img], 1, "wavelet", False, False, 512, 448, **kw)
+        finally:
+            ctx.check(ctx.lib.ir_set_plain_kernels(ctx.h, 0), "ir_set_plain_kernels")
+        p = _psnr_u8(fast, plain)
+        print(f"{h}x{w}: fast vs plain kernels {p:.2f} dB, output std {fast[0].std():.1f}")
+        assert p >= 45.0 and fast[0].std() > 1.0
