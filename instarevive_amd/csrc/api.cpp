@@ -457,6 +457,10 @@ int attnblock(Run& r, const AttnW& w, bf16_t* B[3], int ci, float* gws, int N, i
                              // tile on the same memory channel
     bf16_t* vt = r.a.alloc<bf16_t>(ld * C);
     const bool flash = (C == 512 && (T & 63) == 0);
+    // d = 512 without the redundant score product (attn_d512.hip): the whole batch in one launch, V^T in 32-key tiles
+    const bool v2 = flash && !g_ir_plain_kernels;
+    bf16_t* vtt = v2 ? r.a.alloc<bf16_t>((long)N * T * C) : nullptr;
+    int* flag = v2 ? r.a.alloc<int>(16) : nullptr;
     float* S = flash ? nullptr : r.a.alloc<float>(T * ld);
     bf16_t* P = flash ? nullptr : r.a.alloc<bf16_t>(T * ld);
     groupnorm(r, w.n, B[ci], B[t1], gws, N, T, 0);
@@ -464,19 +468,31 @@ int attnblock(Run& r, const AttnW& w, bf16_t* B[3], int ci, float* gws, int N, i
     linear(r, w.k, B[t1], (int)(N * T), C, k, C, 0, ACT_NONE, nullptr, 0, 0);
     linear(r, w.v, B[t1], (int)(N * T), C, v, C, 0, ACT_NONE, nullptr, 0, 0);
     const int dsub = (C % 128 == 0) ? 128 : (C % 64 == 0 ? 64 : 32);
+    const float sc = 1.0f / sqrtf((float)C);
+    if (v2) {
+        LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_zero_f32(reinterpret_cast<float*>(flag), 1, r.s), "zero");
+        LAUNCH(r, PC_TRANSPOSE, 0.0, 4.0 * (double)N * T * C, ir_launch_transpose_v_tiles(v, vtt, N, (int)T, C, T * C, T * C, r.s), "transpose_v_tiles");
+        LAUNCH(r, PC_FLASH_ATTN, 4.0 * (double)N * T * T * C, 0.0,
+               ir_launch_flash_attn_d512_v2(q, k, vtt, o, N, (int)T, C, C, T * C, T * C, T * C, sc, flag, r.s), "vae_flash_attn");
+    }
     for (int b = 0; b < N; ++b) {
+        if (v2) {  // fallback with the rescaling softmax: both launches return at once unless the kernel above raised the flag
+            LAUNCH(r, PC_TRANSPOSE, 0.0, 0.0, ir_launch_transpose_v(v + b * T * C, vt, 0, C, dsub, 1, C / dsub, (int)T, (int)ld, dsub, dsub, r.s, flag), "transpose_v");
+            LAUNCH(r, PC_FLASH_ATTN, 0.0, 0.0, ir_launch_flash_attn_d512(q + b * T * C, k + b * T * C, vt, o + b * T * C, (int)T, C, C, ld, sc, r.s, flag),
+                   "vae_flash_attn_fallback");
+            continue;
+        }
         LAUNCH(r, PC_TRANSPOSE, 0.0, 4.0 * (double)T * C, ir_launch_transpose_v(v + b * T * C, vt, 0, C, dsub, 1, C / dsub, (int)T, (int)ld, dsub, dsub, r.s),
                "transpose_v");
-        if (C == 512 && (T & 63) == 0) {  // flash path: scores never leave the chip
+        if (flash) {  // flash path: scores never leave the chip
             LAUNCH(r, PC_FLASH_ATTN, 4.0 * (double)T * T * C, 0.0,
-                   ir_launch_flash_attn_d512(q + b * T * C, k + b * T * C, vt, o + b * T * C, (int)T, C, C, ld, 1.0f / sqrtf((float)C), r.s),
-                   "vae_flash_attn");
+                   ir_launch_flash_attn_d512(q + b * T * C, k + b * T * C, vt, o + b * T * C, (int)T, C, C, ld, sc, r.s), "vae_flash_attn");
             continue;
         }
         // generic width (reduced test configurations): scores materialised per image in HBM (fp32 S, bf16 P)
         Conv kw;  // S = q k^T * C^-0.5 : the keys play the role of the weight matrix [T][C]
         kw.w = k + b * T * C; kw.b = nullptr; kw.cin = C; kw.cout = (int)T; kw.cout_pad = (int)T; kw.taps = 1;
-        linear(r, kw, q + b * T * C, (int)T, C, S, (int)ld, 1, ACT_NONE, nullptr, 0, 0, nullptr, 0, nullptr, 0, 1.0f / sqrtf((float)C));
+        linear(r, kw, q + b * T * C, (int)T, C, S, (int)ld, 1, ACT_NONE, nullptr, 0, 0, nullptr, 0, nullptr, 0, sc);
         LAUNCH(r, PC_SOFTMAX, 0.0, 6.0 * (double)T * T, ir_launch_softmax_rows(S, P, T, (int)T, ld, ld, r.s), "softmax_rows");
         Conv vw;  // O = P V : V^T [C][ld] is the weight matrix
         vw.w = vt; vw.b = nullptr; vw.cin = (int)T; vw.cout = C; vw.cout_pad = C; vw.taps = 1; vw.w_rs = ld;
@@ -1653,12 +1669,24 @@ int ir_op_attention(ir_ctx* c, void* stream, const uint16_t* q, const uint16_t* 
     if (c) (void)hipSetDevice(c->device);
     const int DV = ir_attn_dv(d), tkp = ((tk + 63) & ~63) + 64;
     if (heads == 1 && d == 512 && tq == tk && key_bias == nullptr) {  // VAE mid-block form
-        const size_t need512 = (size_t)512 * tkp * 2;
+        const size_t old_vt = ((size_t)512 * tkp * 2 + 255) & ~(size_t)255, tiles = ((size_t)b * tk * 512 * 2 + 255) & ~(size_t)255;
+        const bool v2 = !g_ir_plain_kernels && (tk & 31) == 0;
+        const size_t need512 = old_vt + (v2 ? tiles + 256 : 0);
         if (ws_bytes < need512) return fail(c, -20, "attention workspace too small: need %zu", need512);
-        for (int i = 0; i < b; ++i) {
-            int rc = ir_launch_transpose_v(v + (long)i * tk * 512, (bf16_t*)ws, 0, 512, 128, 1, 4, tk, tkp, 128, 128, (hipStream_t)stream);
+        hipStream_t s = (hipStream_t)stream;
+        int* flag = nullptr;
+        if (v2) {
+            bf16_t* vtt = reinterpret_cast<bf16_t*>((char*)ws + old_vt);
+            flag = reinterpret_cast<int*>((char*)ws + old_vt + tiles);
+            int rc = ir_launch_zero_f32(reinterpret_cast<float*>(flag), 1, s);
+            if (!rc) rc = ir_launch_transpose_v_tiles(v, vtt, b, tk, 512, (long)tk * 512, (long)tk * 512, s);
+            if (!rc) rc = ir_launch_flash_attn_d512_v2(q, k, vtt, o, b, tq, 512, 512, (long)tq * 512, (long)tk * 512, (long)tq * 512, scale, flag, s);
+            if (rc) return fail(c, rc, "flash_attn_d512_v2 failed (%d)", rc);
+        }
+        for (int i = 0; i < b; ++i) {  // v2: the fallback, which returns at once unless the flag was raised
+            int rc = ir_launch_transpose_v(v + (long)i * tk * 512, (bf16_t*)ws, 0, 512, 128, 1, 4, tk, tkp, 128, 128, s, flag);
             if (!rc) rc = ir_launch_flash_attn_d512(q + (long)i * tq * 512, k + (long)i * tk * 512, (const bf16_t*)ws, o + (long)i * tq * 512, tq, 512, 512,
-                                                    tkp, scale, (hipStream_t)stream);
+                                                    tkp, scale, s, flag);
             if (rc) return fail(c, rc, "flash_attn_d512 failed (%d)", rc);
         }
         return 0;

@@ -645,7 +645,9 @@ int ir_launch_flash_attn(const AttnParams& p, hipStream_t s) {
 template <int DSPLIT>
 __global__ __launch_bounds__(256, 1) void flash_attn_d512_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                                   const bf16_t* __restrict__ vt, bf16_t* __restrict__ o, int T, int rs,
-                                                                  int o_rs, long vt_rs, float scale_log2) {
+                                                                  int o_rs, long vt_rs, float scale_log2, const int* __restrict__ only_if) {
+    // launched behind flash_attn_d512_v2_kernel as its fallback: nothing to do unless that kernel flagged a query it could not handle
+    if (only_if && *reinterpret_cast<volatile const int*>(only_if) == 0) return;
     constexpr int D = 512, NKS = D / 16, DVB = D / DSPLIT, NDT = DVB / 32;
     constexpr bool QF_AGPR = DSPLIT > 1;  // DSPLIT 1: the 256 AGPRs are all O^T, the Q^T fragments stay in VGPRs
     constexpr int KROW = 1024 + 16;  // K rows are one DMA instruction each, so they can be padded: (key*65 + c) % 16 is conflict-free
@@ -849,18 +851,19 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d512_kernel(const bf16_t* _
 }
 
 int ir_launch_flash_attn_d512(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* o, int T, int rs, int o_rs, long vt_rs,
-                              float scale, hipStream_t s) {
+                              float scale, hipStream_t s, const int* only_if) {
     if (T <= 0 || (T & 63) || (rs & 7) || (o_rs & 7) || (vt_rs & 7) || vt_rs < T) return -2;
     hipLaunchKernelGGL(flash_attn_d512_kernel<2>, dim3((T + 127) / 128, 2), dim3(256), 0, s, q, k, vt, o, T, rs, o_rs, vt_rs,
-                       scale * 1.44269504088896340736f);
+                       scale * 1.44269504088896340736f, only_if);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 // V[b][t][head*D + d] (row stride v_rs) -> Vt[b][head][DV][Tpad]; rows d >= D and columns t >= T are zero.
 // grid = (Tpad/64, Hh, B), block 256. LDS tile [64 tokens][DV].
 __global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t* __restrict__ v, bf16_t* __restrict__ vt, long v_bs, int v_rs,
-                                                          int v_hs, int T, int Tpad, int D, int DV, int Hh) {
+                                                          int v_hs, int T, int Tpad, int D, int DV, int Hh, const int* __restrict__ only_if) {
     __shared__ bf16_t tile[64][128 + 2];
+    if (only_if && *reinterpret_cast<volatile const int*>(only_if) == 0) return;  // fallback preparation: see ir_launch_flash_attn_d512_v2
     const int t0 = blockIdx.x * 64, head = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
     const bf16_t* src = v + (long)b * v_bs + (long)head * v_hs;
     for (int i = tid; i < 64 * DV; i += 256) {
@@ -879,9 +882,9 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t* __restri
 }
 
 int ir_launch_transpose_v(const bf16_t* v, bf16_t* vt, long v_bs, int v_rs, int v_hs, int B, int Hh, int T, int Tpad, int D,
-                          int DV, hipStream_t s) {
+                          int DV, hipStream_t s, const int* only_if) {
     if (DV > 128 || D > DV || (Tpad & 63) || Tpad < T) return -2;
-    hipLaunchKernelGGL(transpose_v_kernel, dim3(Tpad / 64, Hh, B), dim3(256), 0, s, v, vt, v_bs, v_rs, v_hs, T, Tpad, D, DV, Hh);
+    hipLaunchKernelGGL(transpose_v_kernel, dim3(Tpad / 64, Hh, B), dim3(256), 0, s, v, vt, v_bs, v_rs, v_hs, T, Tpad, D, DV, Hh, only_if);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

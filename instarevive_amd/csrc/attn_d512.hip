@@ -178,8 +178,10 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d512_v2_kernel(const bf16_t
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (DMA && j < 32 && (j & 1)) {  // the next tiles' pieces, one behind every other QK^T MFMA
                 constexpr int pi = j >> 1;
-                if constexpr (pi < 8) { if (t + 2 < NT) k_piece(t + 2, pi, kslot_n); }
-                else { if (t + 1 < NT) v_piece(t + 1, pi - 8, vslot_n); }
+                // a full stream runs only while t + 1 < NT, so V^T(t+1) exists; past the end K(t+2) re-reads the last tile into the free
+                // slot (never used) instead of branching around the DMA
+                if constexpr (pi < 8) k_piece(min(t + 2, NT - 1), pi, kslot_n);
+                else v_piece(t + 1, pi - 8, vslot_n);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if constexpr (SOFTMAX && j >= SM0 && j < SM0 + 16) {  // probability of score e (keys of tile t+1), one per MFMA shadow
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d512_v2_kernel(const bf16_t
                 ovf = fmaxf(ovf, sv);
                 const float p = __builtin_amdgcn_exp2f(sv - m_ref);
                 l_i += p;
-                if constexpr (e & 1) a5_set_word<(e & 7) >> 1>(pn[e >> 3], pack2bf(p_hold, p));
+                if constexpr (e & 1) a5_set_word<((e & 7) >> 1)>(pn[e >> 3], pack2bf(p_hold, p));
                 else p_hold = p;
                 __builtin_amdgcn_sched_barrier(0);
             }

@@ -88,9 +88,14 @@ struct AttnParams {
 };
 int ir_launch_flash_attn(const AttnParams& p, hipStream_t s);
 int ir_launch_flash_attn_d512(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* o, int T, int rs, int o_rs, long vt_rs,
-                              float scale, hipStream_t s);
+                              float scale, hipStream_t s, const int* only_if = nullptr);
+// d = 512 without the redundant score product (attn_d512.hip): V^T in 32-key tiles [B][T/32][512][32]; a set *ovf_flag afterwards
+// means the result must be recomputed by ir_launch_flash_attn_d512 (which is given the flag as `only_if` and returns at once otherwise)
+int ir_launch_transpose_v_tiles(const bf16_t* v, bf16_t* vt, int B, int T, int rs, long v_bs, long vt_bs, hipStream_t s);
+int ir_launch_flash_attn_d512_v2(const bf16_t* q, const bf16_t* k, const bf16_t* vt_tiles, bf16_t* o, int B, int T, int rs, int o_rs, long qk_bs,
+                                 long vt_bs, long o_bs, float scale, int* ovf_flag, hipStream_t s);
 int ir_launch_transpose_v(const bf16_t* v, bf16_t* vt, long v_bs, int v_rs, int v_hs, int B, int Hh, int T, int Tpad, int D,
-                          int DV, hipStream_t s);
+                          int DV, hipStream_t s, const int* only_if = nullptr);
 int ir_launch_swin_attn(const bf16_t* qkv, bf16_t* out, const float* biasT, int B, int H, int W, int heads, int ld, int ldo,
                         int shift, float scale, hipStream_t s);
 int ir_launch_softmax_rows(const float* x, bf16_t* y, long rows, int cols, long ldx, long ldy, hipStream_t s);

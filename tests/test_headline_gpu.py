@@ -36,7 +36,7 @@ def test_attention_at_headline_size(ctx, heads, t, d, gain):
     k = torch.randn(1, t, heads, d, generator=g, device="cuda").to(torch.bfloat16)
     v = torch.randn(1, t, heads, d, generator=g, device="cuda").to(torch.bfloat16)
     o = torch.empty(1, t, heads, d, dtype=torch.int16, device="cuda")
-    ws = torch.empty(((heads * ((d + 31) // 32 * 32)) if d != 512 else 512) * (t + 64) * 2 + 4096, dtype=torch.uint8, device="cuda")
+    ws = torch.empty((heads * ((d + 31) // 32 * 32) if d != 512 else 2 * 512) * (t + 64) * 2 + 8192, dtype=torch.uint8, device="cuda")
     scale = d ** -0.5
     ctx.check(ctx.lib.ir_op_attention(ctx.h, ctx.stream(), L.ptr(q.view(torch.int16)), L.ptr(k.view(torch.int16)), L.ptr(v.view(torch.int16)),
                                       L.ptr(o), 1, heads, t, t, d, scale, None, L.ptr(ws), ws.numel()), "attention")

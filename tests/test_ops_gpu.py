@@ -262,7 +262,7 @@ def test_layernorm(ctx, rows, c, ld):
     (1, 2, 128, 128, 72, False), (2, 3, 200, 200, 72, False), (1, 16, 1024, 1024, 72, False),
     (2, 2, 384, 320, 72, False), (1, 1, 256, 64, 72, False), (1, 2, 300, 128, 72, False),  # ping-pong kernel: ragged Tq, odd / single tile counts
     (2, 2, 130, 300, 72, True), (1, 2, 64, 64, 32, False), (1, 1, 256, 192, 64, True),
-    (1, 1, 256, 256, 512, False), (2, 1, 1024, 1024, 512, False)])
+    (1, 1, 256, 256, 512, False), (2, 1, 1024, 1024, 512, False), (3, 1, 448, 448, 512, False)])  # d = 512: batched, ragged last query block
 def test_flash_attention(ctx, b, heads, tq, tk, d, bias):
     g = torch.Generator().manual_seed(tq + tk + d)
     q = rb(torch.randn(b, tq, heads, d, generator=g))
@@ -304,6 +304,30 @@ def test_flash_attention_spike(ctx, t, gain):
     # for the few queries whose second-largest key is close to the spike; the extreme case is here for the overflow path, not for ulps
     rtol, atol = (2 ** -6, 6e-3) if gain <= 8 else (2 ** -4, 4e-2)
     close(L.from_bf16_bits(o).cpu(), ref, rtol, atol, "flash attention spike")
+
+
+@pytest.mark.parametrize("t,gain", [(512, 2.0), (512, 4.0)])
+def test_flash_attention_d512_spike(ctx, t, gain):
+    """d = 512 kernel with the fixed softmax reference (attn_d512.hip): a late key dominates one query. gain 2: the spike is 2^65 above
+    the first tile's maximum, inside the range the fixed reference covers (2^24 headroom + 2^80); gain 4: 2^130 above -> the overflow
+    flag and the rescaling fallback kernel."""
+    g = torch.Generator().manual_seed(4)
+    d = 512
+    q = rb(torch.randn(1, t, 1, d, generator=g))
+    k = rb(torch.randn(1, t, 1, d, generator=g))
+    v = rb(torch.randn(1, t, 1, d, generator=g))
+    k[0, t - 6, 0] = q[0, 7, 0] * gain
+    k = rb(k)
+    scale = d ** -0.5
+    qd64, kd64, vd64 = (x_.transpose(1, 2).double() for x_ in (q, k, v))
+    ref = (torch.softmax(qd64 @ kd64.transpose(-1, -2) * scale, dim=-1) @ vd64).transpose(1, 2).float()
+    o = torch.empty(1, t, 1, d, dtype=torch.int16, device="cuda")
+    ws = torch.empty(8 << 20, dtype=torch.uint8, device="cuda")
+    ctx.check(ctx.lib.ir_op_attention(ctx.h, ctx.stream(), P(dev_bf16(q)), P(dev_bf16(k)), P(dev_bf16(v)), P(o), 1, 1, t, t, d,
+                                      scale, None, P(ws), ws.numel()), "attention")
+    got = L.from_bf16_bits(o).cpu()
+    assert (got[0, 7, 0] - v[0, t - 6, 0]).abs().max() < 2 ** -6, "the spiked query must return the spiked key's value row"
+    close(got, ref, 2 ** -6, 6e-3, "d512 attention spike")
 
 
 @pytest.mark.parametrize("h,w,shift", [(8, 8, 0), (16, 24, 0), (16, 24, 4), (64, 64, 4)])
