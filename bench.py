@@ -227,7 +227,10 @@ def main():
         net_in = upscale_bicubic(lq, args.sr_scale) if args.sr_scale != 1 else lq    # inference.py:265-269 (host, outside the timed region)
     n, h, w = net_in.shape[:3]
     assert h % 64 == 0 and w % 64 == 0
-    flags = ((L.FLAG_TILED | L.FLAG_FIX_WAVELET) if args.tiled else 0) | (L.FLAG_CONTROL_LQ if args.control else 0)
+    flags = ((L.FLAG_TILED | L.FLAG_FIX_WAVELET) if args.tiled else 0) | (L.FLAG_CONTROL_LQ if args.control else 0) | (L.FLAG_FP8 if args.fp8 else 0)
+    if args.fp8:
+        vae.enable_fp8(True)                                # packs + uploads the fp8 weight forms of the VAE resnet convs
+        ctx.check(ctx.lib.ir_set_fp8(ctx.h, 0), "ir_set_fp8")  # ... the mode itself is switched per call by IR_FLAG_FP8
     if args.graph:
         flags |= L.FLAG_GRAPH
         args.no_profile = True
@@ -282,9 +285,10 @@ def main():
     verify = None
     if not args.no_verify:
         fast = dout.clone()
+        ref_flags = flags & ~L.FLAG_FP8   # fp8 run: the reference pass is the bf16 path (plain kernels), which also prices the fp8 error
         ctx.check(ctx.lib.ir_set_plain_kernels(ctx.h, 1), "ir_set_plain_kernels")
         try:
-            ctx.check(ctx.lib.ir_pipeline(ctx.h, ctx.stream(), L.ptr(din), L.ptr(dout), None, n, h, w, flags, tile_size, tile_stride, 400.0, acp, sf,
+            ctx.check(ctx.lib.ir_pipeline(ctx.h, ctx.stream(), L.ptr(din), L.ptr(dout), None, n, h, w, ref_flags, tile_size, tile_stride, 400.0, acp, sf,
                                           L.ptr(ws), ws.numel()), "ir_pipeline")
             torch.cuda.synchronize()
         finally:
@@ -292,7 +296,10 @@ def main():
         mse = float(((fast.double() - dout.double()) ** 2).mean())
         psnr = 99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
         std = float(fast.double().std())
-        verify = dict(verified=bool(psnr >= 45.0 and std > 1.0), psnr_fast_vs_plain_kernels_db=round(psnr, 2), output_std=round(std, 2))
+        if args.fp8:   # e4m3 operands carry 3 mantissa bits: the gate is "the same image", the number is reported
+            verify = dict(verified=bool(psnr >= 20.0 and std > 1.0), psnr_fp8_vs_bf16_plain_kernels_db=round(psnr, 2), output_std=round(std, 2))
+        else:
+            verify = dict(verified=bool(psnr >= 45.0 and std > 1.0), psnr_fast_vs_plain_kernels_db=round(psnr, 2), output_std=round(std, 2))
         if dist is not None:
             ok = torch.tensor([1.0 if verify["verified"] else 0.0], device=device)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
@@ -306,7 +313,7 @@ def main():
     # ---- the drop-in boundary hands over HOST arrays (inference.py:91-93,157-166): the same workload through process() (pinned staging,
     # synchronous) and through process_stream() (what the CLI runs: upload / download of neighbouring batches overlapped with compute)
     host = None
-    if world == 1 and not args.no_host_rate and not args.control:
+    if world == 1 and not args.no_host_rate and not args.control and not args.fp8:
         from instarevive_amd.pipeline import process, process_stream
         imgs = list(net_in.numpy())
         kw = dict(preprocess_model=swin, vae=vae, y=y_dev, y_mask=mask_dev, noise_scheduler=sched)
@@ -316,6 +323,8 @@ def main():
             process(dit, imgs, 1, "wavelet", False, args.tiled, tile_size, tile_stride, **kw)
         dt_sync = (time.perf_counter() - t1) / args.steps
         k = args.steps + 2
+        for _ in process_stream(dit, (imgs for _ in range(2)), "wavelet", False, args.tiled, tile_size, tile_stride, **kw):   # staging buffers
+            pass
         t1 = time.perf_counter()
         for _ in process_stream(dit, (imgs for _ in range(k)), "wavelet", False, args.tiled, tile_size, tile_stride, **kw):
             pass

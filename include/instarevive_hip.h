@@ -34,7 +34,11 @@ enum { IR_FLAG_NO_PREPROCESS = 1, IR_FLAG_TILED = 2, IR_FLAG_FIX_WAVELET = 4, IR
         * first use and replay it with one hipGraphLaunch afterwards (BASELINE.json configs[2]: "hipGraph-captured per-tile step").
         * The caller keeps in/out/stage1/ws alive and at the same addresses; uploads, *_configure and ir_dit_set_prompt drop the
         * recorded graphs. Ignored while ir_profile_begin is active (per-launch events need individual launches). */
-       IR_FLAG_GRAPH = 32 };
+       IR_FLAG_GRAPH = 32,
+       /* BASELINE.json configs[4]: fp8 (OCP e4m3) MFMA operands in the VAE ResnetBlock 3x3 convolutions (weights quantised per output
+        * channel at load time, GroupNorm+SiLU outputs written as e4m3) and in the DiT self-attention products. Needs the fp8 weight forms
+        * (`*.w8`, `*.g8`, `*.b8`) uploaded; layers without them run in bf16. */
+       IR_FLAG_FP8 = 64 };
 
 int ir_abi_version(void);
 int ir_init(int device, ir_ctx** out);
@@ -124,6 +128,8 @@ int ir_tiled_blend_pixels(ir_ctx* ctx, void* stream, const float* px_tiles, uint
 /* Diagnostic (no reference counterpart): on != 0 routes every launch through the older 4-wave kernels — an independent second
  * implementation of the same arithmetic that bench.py ("verified") and the tests cross-check the fast kernels against. Process-wide. */
 int ir_set_plain_kernels(ir_ctx* ctx, int on);
+/* on != 0: the stage entry points (ir_vae_encode / ir_vae_decode / ir_dit_*) use the fp8 forms as IR_FLAG_FP8 does for ir_pipeline. */
+int ir_set_fp8(ir_ctx* ctx, int on);
 
 /* Per-launch timing with HIP events recorded on the launch stream (measurement aid for bench.py; no reference
  * counterpart). Classes: 0 conv3x3, 1 linear, 2 flash attention, 3 window attention, 4 groupnorm, 5 layernorm,
@@ -146,6 +152,9 @@ int ir_op_conv(ir_ctx* ctx, void* stream, const uint16_t* in, const uint16_t* wg
 int ir_op_conv_groupnorm(ir_ctx* ctx, void* stream, const uint16_t* in, const uint16_t* wgt, const float* bias, uint16_t* conv_out,
                          uint16_t* y, const float* gamma, const float* beta, int n, int h, int w, int cin, int cout, int stride, int up,
                          const void* res, int silu, void* ws, size_t ws_bytes, int* fused);
+/* 3x3 stride-1 conv on fp8 operands: in8 [n][h][w][cin] e4m3, wgt8 [cout][9][cin] e4m3, out = (acc + bias_div[co]) * dequant[co] (+ res) in bf16 */
+int ir_op_conv_fp8(ir_ctx* ctx, void* stream, const uint8_t* in8, const uint8_t* wgt8, const float* dequant, const float* bias_div, uint16_t* out,
+                   int n, int h, int w, int cin, int cout, const uint16_t* res);
 int ir_op_linear(ir_ctx* ctx, void* stream, const uint16_t* in, const uint16_t* wgt, const float* bias, void* out, int m, int k, int n,
                  int n_pad, int act, const float* gate, const void* res, int res_f32, int out_f32, float out_scale);
 int ir_op_groupnorm(ir_ctx* ctx, void* stream, const uint16_t* x, uint16_t* y, const float* gamma, const float* beta, int n, int hw,

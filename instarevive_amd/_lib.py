@@ -20,11 +20,11 @@ SYMBOLS = [
     "ir_pipeline", "ir_u8_to_nchw", "ir_nchw_to_u8", "ir_profile_begin", "ir_profile_end",
     "ir_op_conv", "ir_op_conv_groupnorm", "ir_op_linear", "ir_op_groupnorm", "ir_op_layernorm", "ir_op_attention", "ir_op_swin_attention",
     "ir_op_softmax_rows",
-    "ir_tiled_count", "ir_tiled_encode", "ir_tiled_dit", "ir_tiled_blend_latent", "ir_tiled_decode", "ir_tiled_blend_pixels", "ir_set_plain_kernels",
+    "ir_tiled_count", "ir_tiled_encode", "ir_tiled_dit", "ir_tiled_blend_latent", "ir_tiled_decode", "ir_tiled_blend_pixels", "ir_set_plain_kernels", "ir_set_fp8", "ir_op_conv_fp8",
 ]
 
 STAGE_SWINIR, STAGE_VAE_ENCODE, STAGE_DIT, STAGE_VAE_DECODE, STAGE_PIPELINE, STAGE_COLORFIX, STAGE_T5 = range(7)
-FLAG_NO_PREPROCESS, FLAG_TILED, FLAG_FIX_WAVELET, FLAG_FIX_ADAIN, FLAG_CONTROL_LQ, FLAG_GRAPH = 1, 2, 4, 8, 16, 32
+FLAG_NO_PREPROCESS, FLAG_TILED, FLAG_FIX_WAVELET, FLAG_FIX_ADAIN, FLAG_CONTROL_LQ, FLAG_GRAPH, FLAG_FP8 = 1, 2, 4, 8, 16, 32, 64
 ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_LRELU, ACT_SILU = range(5)
 
 _lib = None
@@ -90,6 +90,8 @@ def load_library():
     lib.ir_tiled_decode.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, f, vp, sz]
     lib.ir_tiled_blend_pixels.argtypes = [vp, vp, vp, vp, i, i, i, i, i, vp, sz]
     lib.ir_set_plain_kernels.argtypes = [vp, i]
+    lib.ir_set_fp8.argtypes = [vp, i]
+    lib.ir_op_conv_fp8.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, vp]
     for name in SYMBOLS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int and name not in ("ir_abi_version",):

@@ -29,7 +29,12 @@ struct Conv {  // packed conv / linear weight: w [cout_pad][taps*cin] bf16, b [c
     const float* b = nullptr;
     int cin = 0, cout = 0, cout_pad = 0, taps = 1;
     long w_rs = 0;  // weight row stride in elements (0: taps*cin, densely packed)
+    // optional fp8 form (BASELINE.json configs[4]): OCP e4m3 weights [cout][9][cin] quantised per output channel, the dequantisation
+    // factor per channel (weight scale / activation scale) and the bias divided by it (see IGemmParams::fp8)
+    const uint8_t* w8 = nullptr;
+    const float *g8 = nullptr, *b8 = nullptr;
 };
+constexpr float FP8_ACT_SCALE = 16.0f;  // GroupNorm+SiLU outputs are stored as e4m3(x * 16): |x| up to 28 without clamping, 3 mantissa bits down to 2^-10
 struct Norm {
     const float *g = nullptr, *b = nullptr;
     int c = 0;
@@ -148,6 +153,7 @@ struct Profiler {
 struct ir_ctx {
     int device = 0;
     Profiler prof;
+    bool fp8 = false;   // ir_set_fp8 / IR_FLAG_FP8: VAE resnet convs with fp8 operands where fp8 weights were uploaded
     std::string err;
     std::unordered_map<std::string, Tensor> t;
     std::vector<void*> owned;  // extra device allocations that live as long as the context
@@ -306,17 +312,46 @@ void linear(Run& r, const Conv& cw, const bf16_t* in, int M, int in_cs, void* ou
             float out_scale = 1.f) {
     conv(r, cw, in, M, 1, 1, in_cs, out, out_cs, out_f32, 1, 0, 0, act, 0.f, res, res_f32, res_cs, out2, out2_cs, gate, res_mod, out_scale);
 }
-void groupnorm(Run& r, const Norm& n, const bf16_t* x, bf16_t* y, float* ws, int N, long HW, int silu) {
+void groupnorm(Run& r, const Norm& n, const bf16_t* x, bf16_t* y, float* ws, int N, long HW, int silu, int out_fp8 = 0) {
     if (!r.live()) return;
+    const double wb = out_fp8 ? 1.0 : 2.0;  // bytes written per element
     if (r.gn_x == x && r.gn_chunks > 0) {  // statistics already produced by the conv that wrote x
         const int chunks = r.gn_chunks;
         r.gn_x = nullptr;
-        LAUNCH(r, PC_GROUPNORM, 0.0, 4.0 * N * (double)HW * n.c,
-               ir_launch_groupnorm_fused(x, y, n.g, n.b, r.gn_buf, ws, N, HW, n.c, 32, chunks, 1e-6f, silu, r.s), "groupnorm_fused");
+        LAUNCH(r, PC_GROUPNORM, 0.0, (2.0 + wb) * N * (double)HW * n.c,
+               ir_launch_groupnorm_fused(x, y, n.g, n.b, r.gn_buf, ws, N, HW, n.c, 32, chunks, 1e-6f, silu, r.s, out_fp8, FP8_ACT_SCALE), "groupnorm_fused");
         return;
     }
     r.gn_x = nullptr;
-    LAUNCH(r, PC_GROUPNORM, 0.0, 6.0 * N * (double)HW * n.c, ir_launch_groupnorm(x, y, n.g, n.b, ws, N, HW, n.c, 32, 1e-6f, silu, r.s), "groupnorm");
+    LAUNCH(r, PC_GROUPNORM, 0.0, (4.0 + wb) * N * (double)HW * n.c,
+           ir_launch_groupnorm(x, y, n.g, n.b, ws, N, HW, n.c, 32, 1e-6f, silu, r.s, out_fp8, FP8_ACT_SCALE), "groupnorm");
+}
+// 3x3 stride-1 conv on fp8 operands (conv_halo_kernel<.., FP8>): in8 holds e4m3(x * FP8_ACT_SCALE) NHWC, cw.w8 / g8 / b8 the weights
+void conv_fp8(Run& r, const Conv& cw, const bf16_t* in8, int N, int H, int W, void* out, int out_cs, const void* res, int res_cs) {
+    if (!r.live()) return;
+    IGemmParams p;
+    memset(&p, 0, sizeof p);
+    p.fp8 = 1;
+    p.in = in8; p.NB = N; p.H = H; p.W = W; p.Cin = cw.cin / 2; p.in_cs = cw.cin / 2;
+    p.taps = 9; p.stride = 1; p.pad = 1; p.up = 0;
+    p.Ho = H; p.Wo = W; p.M = N * H * W;
+    p.wgt = reinterpret_cast<const bf16_t*>(cw.w8); p.wgt_rs = 9L * (cw.cin / 2); p.Cout = cw.cout; p.Cout_pad = cw.cout_pad; p.bias = cw.b8;
+    p.act = ACT_NONE; p.out_scale = 1.f;
+    p.gate = cw.g8; p.gate_stride = 0; p.rows_per_batch = 1 << 30;
+    p.res = res; p.res_f32 = 0; p.res_cs = res_cs;
+    p.out = out; p.out_f32 = 0; p.out_cs = out_cs;
+    if (r.gn_want && r.gn_buf && cw.cout % 32 == 0) {
+        p.gn_cpg = cw.cout / 32;
+        p.gn_chunks = ir_igemm_gn_chunks(p);
+        if (p.gn_chunks > 0) {
+            p.gn_part = r.gn_buf;
+            r.gn_x = out;
+            r.gn_chunks = p.gn_chunks;
+        }
+    }
+    r.gn_want = false;
+    LAUNCH(r, PC_CONV3X3, 2.0 * p.M * (double)cw.cout * 9 * cw.cin, (double)p.M * cw.cin + 2.0 * p.M * cw.cout + (double)cw.cout_pad * 9 * cw.cin,
+           ir_launch_igemm(p, r.s), "igemm_fp8");
 }
 void layernorm(Run& r, const float* x, bf16_t* y, float* yf, const float* a, const float* b, long rows, int C, int ldx, int ldy,
                float eps) {
@@ -345,6 +380,12 @@ struct Binder {
         w.w = (const bf16_t*)get(base + ".w", (size_t)cout_pad * taps * cin * 2);
         w.b = (const float*)get(base + ".b", (size_t)cout_pad * 4);
         return w;
+    }
+    void fp8_optional(Conv& w, const std::string& base) {  // present only when the host packed an fp8 form of this conv
+        auto iw = c->t.find(base + ".w8"), ig = c->t.find(base + ".g8"), ib = c->t.find(base + ".b8");
+        if (iw == c->t.end() || ig == c->t.end() || ib == c->t.end()) return;
+        if (iw->second.bytes < (size_t)w.cout_pad * 9 * w.cin || ig->second.bytes < (size_t)w.cout_pad * 4 || ib->second.bytes < (size_t)w.cout_pad * 4) return;
+        w.w8 = (const uint8_t*)iw->second.p; w.g8 = (const float*)ig->second.p; w.b8 = (const float*)ib->second.p;
     }
     Norm norm(const std::string& base, int c_) {
         Norm n;
@@ -430,6 +471,24 @@ void swinir_run(Run& r, const float* in, float* out, int n, int h, int w) {
 int resblock(Run& r, const ResW& w, bf16_t* B[3], int ci, float* gws, int N, int H, int W, bool gn_after) {
     const int t1 = (ci + 1) % 3, t2 = (ci + 2) % 3;
     const int cin = w.c1.cin, cout = w.c1.cout;
+    if (r.c->fp8 && w.c1.w8 && w.c2.w8 && cin % 128 == 0 && cout % 128 == 0) {
+        // fp8 form: both GroupNorm+SiLU outputs are written as e4m3 (half the bytes) and both convs run on fp8 operands. An fp8
+        // tensor never shares its buffer with the bf16 tensor it was made from (different element sizes: no in-place pass).
+        groupnorm(r, w.n1, B[ci], B[t1], gws, N, (long)H * W, 1, 1);
+        r.gn_want = true;
+        conv_fp8(r, w.c1, B[t1], N, H, W, B[t2], cout, nullptr, 0);
+        if (w.has_sc) {  // shortcut -> B[t1] (the fp8 input of conv1 is dead); norm2 -> B[ci] (the block input is dead after the shortcut)
+            linear(r, w.sc, B[ci], N * H * W, cin, B[t1], cout, 0, ACT_NONE, nullptr, 0, 0);
+            groupnorm(r, w.n2, B[t2], B[ci], gws, N, (long)H * W, 1, 1);
+            r.gn_want = gn_after;
+            conv_fp8(r, w.c2, B[ci], N, H, W, B[t1], cout, B[t1], cout);
+            return t1;
+        }
+        groupnorm(r, w.n2, B[t2], B[t1], gws, N, (long)H * W, 1, 1);  // norm2 -> B[t1]; conv2 -> B[t2] (conv1's output is dead), residual B[ci]
+        r.gn_want = gn_after;
+        conv_fp8(r, w.c2, B[t1], N, H, W, B[t2], cout, B[ci], cout);
+        return t2;
+    }
     groupnorm(r, w.n1, B[ci], B[t1], gws, N, (long)H * W, 1);
     r.gn_want = true;  // conv1's output is norm2's input
     conv(r, w.c1, B[t1], N, H, W, cin, B[t2], cout, 0, 1, 1, 0, ACT_NONE, 0.f, nullptr, 0, 0);
@@ -1016,6 +1075,8 @@ static ResW bind_res(Binder& b, const std::string& p, int cin, int cout) {
     r.c1 = b.conv(p + ".c1", cin, cout, cout, 9);
     r.n2 = b.norm(p + ".n2", cout);
     r.c2 = b.conv(p + ".c2", cout, cout, cout, 9);
+    b.fp8_optional(r.c1, p + ".c1");
+    b.fp8_optional(r.c2, p + ".c2");
     r.has_sc = cin != cout;
     if (r.has_sc) r.sc = b.conv(p + ".sc", cin, cout, cout, 1);
     return r;
@@ -1371,6 +1432,11 @@ int ir_pipeline(ir_ctx* c, void* stream, const uint8_t* in, uint8_t* out, uint8_
     REQUIRE(acp > 0.f && acp < 1.f && sf > 0.f, "pipeline: bad alpha_cumprod / scaling factor");
     REQUIRE(!(flags & IR_FLAG_CONTROL_LQ) || c->dit.ncopy > 0, "pipeline: IR_FLAG_CONTROL_LQ without ir_dit_control_configure");
     if (int e = check_size(c, n, h, w, 64)) return e;
+    struct Fp8Scope {  // IR_FLAG_FP8 holds for this call only (it is part of the graph key through `flags`)
+        ir_ctx* c; bool old;
+        Fp8Scope(ir_ctx* c_, bool on) : c(c_), old(c_->fp8) { c->fp8 = old || on; }
+        ~Fp8Scope() { c->fp8 = old; }
+    } fp8_scope(c, (flags & IR_FLAG_FP8) != 0);
     if (!(flags & IR_FLAG_GRAPH) || c->prof.on) {  // per-launch profiling needs the individual launches
         Run r = make_run(c, stream, ws, ws_bytes, false);
         pipeline_run(r, in, out, stage1, n, h, w, flags, tile_size, tile_stride, timestep, acp, sf);
@@ -1497,6 +1563,13 @@ int ir_tiled_blend_pixels(ir_ctx* c, void* stream, const float* px_tiles, uint8_
 // Diagnostic: 1 = route every launch through the older 4-wave kernels (no ping-pong conv / GEMM / attention, no register-resident
 // d = 512 attention), the independent second implementation of the same arithmetic that bench.py and the tests cross-check the
 // fast kernels against. Process-wide.
+// fp8 mode of the stage entry points (ir_pipeline: IR_FLAG_FP8): VAE resnet convs whose fp8 weights were uploaded run on fp8 operands
+int ir_set_fp8(ir_ctx* c, int on) {
+    if (!c) return -1;
+    c->fp8 = on != 0;
+    return 0;
+}
+
 int ir_set_plain_kernels(ir_ctx* c, int on) {
     (void)c;
     g_ir_plain_kernels = on ? 1 : 0;
@@ -1640,6 +1713,15 @@ int ir_op_conv_groupnorm(ir_ctx* c, void* stream, const uint16_t* in, const uint
     Norm nm;
     nm.c = cout; nm.g = gamma; nm.b = beta;
     groupnorm(r, nm, conv_out, y, (float*)ws + part_floats, n, (long)ho * wo, silu);
+    return finish(r, c, 0);
+}
+int ir_op_conv_fp8(ir_ctx* c, void* stream, const uint8_t* in8, const uint8_t* wgt8, const float* dequant, const float* bias_div, uint16_t* out,
+                   int n, int h, int w, int cin, int cout, const uint16_t* res) {
+    if (!c || (cin % 128) || (cout % 64)) return fail(c, -1, "ir_op_conv_fp8: cin must be a multiple of 128, cout of 64");
+    Run r = make_run(c, stream, nullptr, 0, false);
+    Conv cw;
+    cw.cin = cin; cw.cout = cout; cw.cout_pad = cout; cw.taps = 9; cw.w8 = wgt8; cw.g8 = dequant; cw.b8 = bias_div;
+    conv_fp8(r, cw, reinterpret_cast<const bf16_t*>(in8), n, h, w, out, cout, res, cout);
     return finish(r, c, 0);
 }
 int ir_op_linear(ir_ctx* c, void* stream, const uint16_t* in, const uint16_t* wgt, const float* bias, void* out, int m, int k, int n,

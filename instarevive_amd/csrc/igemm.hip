@@ -508,7 +508,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IGemmParams p) {
 template <bool M16>
 IR_DEVINL int halo_key(int hx) { return M16 ? ((hx >> 1) & 3) << 1 : (hx >> 1) & 7; }
 
-template <int BN, int UP, bool M16 = false>
+template <int BN, int UP, bool M16 = false, bool FP8 = false>
 __global__ __launch_bounds__(256, 2) void conv_halo_kernel(IGemmParams p, int tiles_y, int tiles_x) {
     constexpr int BK = 64, ROWB = 128, SP = 8;
     constexpr int TH = 8, TW = 16, HW = TW + 2, HP = (TH + 2) * HW;  // 180 halo pixels
@@ -605,6 +605,76 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(IGemmParams p, int ti
     wait_dma();
     __syncthreads();
     IR_STAMP(1);
+    if constexpr (FP8) {
+        // fp8 (OCP e4m3) operands through the MX-scaled MFMA with unit block scales, v_mfma_scale_f32_32x32x64_f8f6f4: twice the
+        // FLOPs per byte staged and per MFMA cycle of the bf16 forms (BASELINE.json configs[4]). Everything above addresses memory in
+        // 2-byte units, so a "channel" up there is a PAIR of fp8 channels: the launcher passes Cin = Cin_fp8 / 2 (and the strides
+        // likewise), a 64-unit chunk is 128 fp8 channels in the same 128-byte LDS rows, and staging, swizzles and the bank-conflict
+        // analysis of the 32x32 read pattern carry over unchanged. Lane (r, h) holds row r and k = 32h .. 32h+31 of a 64-wide k-step
+        // (tools/mfma_fp8_probe.hip): the 16-byte chunks 4ks + 2h and 4ks + 2h + 1 of the row. Dequantisation (per-output-channel
+        // weight scale x the activation scale) is the epilogue's per-column multiplier p.gate, the bias arrives pre-divided by it.
+        typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+        typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+        i32x8_t fa[2][TM], fb[2][TN];
+        auto load8 = [&](int cbuf, int bbuf, int tap, int ks, int set) {
+            const unsigned char* Hb = smem + cbuf * HALO_BYTES;
+            const unsigned char* Bb = smem + 2 * HALO_BYTES + bbuf * BT_BYTES;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int toff = ky * HW + kx;
+            const int sw = halo_key<false>((r & 15) + kx);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const unsigned char* row = Hb + (hid0[i] + toff) * ROWB;
+                const i32x4_t lo = *reinterpret_cast<const i32x4_t*>(row + (((4 * ks + 2 * h) ^ sw) << 4));
+                const i32x4_t hi = *reinterpret_cast<const i32x4_t*>(row + (((4 * ks + 2 * h + 1) ^ sw) << 4));
+                fa[set][i] = i32x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int jn = 0; jn < TN; ++jn) {
+                const unsigned char* row = Bb + fb_base[jn];
+                const i32x4_t lo = *reinterpret_cast<const i32x4_t*>(row + (((4 * ks + 2 * h) ^ fb_sw[jn]) << 4));
+                const i32x4_t hi = *reinterpret_cast<const i32x4_t*>(row + (((4 * ks + 2 * h + 1) ^ fb_sw[jn]) << 4));
+                fb[set][jn] = i32x8_t{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+        };
+        auto mfma8 = [&](int set, int first, int last) {
+#pragma unroll
+            for (int e = first; e < last; ++e)
+                acc[e / TN][e % TN] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fa[set][e / TN], fb[set][e % TN], acc[e / TN][e % TN], 0, 0, 0,
+                                                                                      0x7F7F7F7F, 0, 0x7F7F7F7F);
+        };
+        int c = 0, t = 0, c2 = 0, t2 = 2;
+        load8(0, 0, 0, 0, 0);
+        for (int s = 0; s < steps; ++s) {
+            int tn = t + 1, cn = c;
+            if (tn == 9) { tn = 0; cn = c + 1; }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                __builtin_amdgcn_sched_barrier(0);
+                mfma8(ks, 0, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks == 0) {
+                    load8(c & 1, s & 1, t, 1, 1);
+                } else {
+                    wait_dma();
+                    __syncthreads();
+                    if (s + 2 < steps) stage_b(s & 1, t2 * p.Cin + c2 * BK);
+                    if (t == 0 && c + 1 < chunks) stage_halo((c + 1) & 1);
+                    if (s + 1 < steps) load8(cn & 1, (s + 1) & 1, tn, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mfma8(ks, 1, TM * TN);
+            }
+            t = tn; c = cn;
+            if (++t2 == 9) { t2 = 0; ++c2; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        igemm_epilogue<TM, TN, 2>(p, acc, smem, wid, lane, n0 + wn * (BN / 2), n0, img, trem, [&](int i, int row) {
+            const int oy = oy0 + wm * 4 + i * 2 + (row >> 4), ox = ox0 + (row & 15);
+            return (oy < p.Ho && ox < p.Wo) ? (img * p.Ho + oy) * p.Wo + ox : -1;
+        });
+        return;
+    }
     if constexpr (M16) {
         // v_mfma_f32_16x16x32_bf16 form (see igemm_kernel): a 16-row fragment is ONE patch row (16 pixels), lane l holds pixel (l & 15)
         // and 16-byte chunk 4*ks + (l >> 4) of its 64 channels; two k-steps of 32 per (tap, chunk) step.
@@ -1330,7 +1400,7 @@ int g_ir_plain_kernels = 0;
 
 static bool takes_gemm_pp(const IGemmParams& p) {
     static const bool off = getenv("IR_NO_GEMM_PP") != nullptr;  // experiment knob
-    if (off || g_ir_plain_kernels || p.taps != 1 || p.force_generic || !p.vec || p.gn_part) return false;
+    if (off || g_ir_plain_kernels || p.fp8 || p.taps != 1 || p.force_generic || !p.vec || p.gn_part) return false;
     if (p.Cout != p.Cout_pad || p.Cout % GemmPP::BN || p.Cin % GemmPP::BK || p.Cin < 8 * GemmPP::BK) return false;
     const long span = (long)p.M * std::max(std::max(p.out_cs, p.res ? p.res_cs : 0), p.out2 ? p.out2_cs : 0);
     if (span >= (1L << 31)) return false;  // the epilogue's 32-bit element offsets
@@ -1362,6 +1432,11 @@ static int launch_halo(const IGemmParams& p, hipStream_t s) {
     const long MT = (long)p.NB * tiles_y * tiles_x, NT = p.Cout_pad / BN;
     const long grid = ((MT + 7) / 8) * 8 * NT;
     if (grid > 0x7fffffffL) return -12;
+    if (p.fp8) {
+        if (p.up) hipLaunchKernelGGL((conv_halo_kernel<BN, 1, false, true>), dim3((unsigned)grid), dim3(256), 0, s, p, tiles_y, tiles_x);
+        else hipLaunchKernelGGL((conv_halo_kernel<BN, 0, false, true>), dim3((unsigned)grid), dim3(256), 0, s, p, tiles_y, tiles_x);
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
     static const bool m16 = getenv("IR_NO_MFMA16") == nullptr;  // 16x16x32 MFMA form by default (knob: A/B against 32x32x16)
     if (m16 && p.up) hipLaunchKernelGGL((conv_halo_kernel<BN, 1, true>), dim3((unsigned)grid), dim3(256), 0, s, p, tiles_y, tiles_x);
     else if (m16) hipLaunchKernelGGL((conv_halo_kernel<BN, 0, true>), dim3((unsigned)grid), dim3(256), 0, s, p, tiles_y, tiles_x);
@@ -1397,7 +1472,7 @@ static bool takes_halo(const IGemmParams& p) {
 }
 static bool takes_halo_pp(const IGemmParams& p) {  // the 8-wave ping-pong variant: 16 x 16 patches x 128 channels
     static const bool no_pp = getenv("IR_NO_CONV_PP") != nullptr;  // experiment knob
-    return takes_halo(p) && p.Cout_pad % 128 == 0 && p.Cin >= 128 && !no_pp && !g_ir_plain_kernels;  // measured with the 16x16x32 MFMAs: +8 % at 512 channels,
+    return takes_halo(p) && !p.fp8 && p.Cout_pad % 128 == 0 && p.Cin >= 128 && !no_pp && !g_ir_plain_kernels;  // measured with the 16x16x32 MFMAs: +8 % at 512 channels,
                                                                                // +7 % at 256, +2 % at 128 over the 4-wave kernel
 }
 int ir_igemm_gn_chunks(const IGemmParams& p) {
@@ -1434,6 +1509,7 @@ int ir_launch_igemm(const IGemmParams& pin, hipStream_t s) {
         if (p.H <= 0 || p.W <= 0) return -9;
     }
     if (p.gn_part && (!p.vec || p.gn_chunks <= 0 || p.gn_chunks != ir_igemm_gn_chunks(p))) return -13;
+    if (p.fp8 && (!takes_halo(p) || !p.gate || p.act != IR_ACT_NONE)) return -14;  // fp8 operands: stride-1 3x3 halo kernel only
     if (takes_halo_pp(p)) return launch_halo_pp(p, s);
     if (takes_gemm_pp(p)) return launch_gemm_pp(p, s);
     if (takes_halo(p)) {

@@ -37,6 +37,8 @@ struct IGemmParams {
     int out_f32, out_cs;
     bf16_t* out2;       // optional extra bf16 copy of the result
     int out2_cs;
+    int fp8;            // 1: `in` and `wgt` hold OCP e4m3 bytes; Cin / in_cs / wgt_rs count PAIRS of fp8 channels (2-byte units), gate
+                        // carries the dequantisation factor per output channel, bias is pre-divided by it (3x3 stride-1 convs only)
     int force_generic;  // 1: never take the halo-tile conv path (A/B testing)
     int vec;            // set by the launcher: all strides/pointers allow 4-element vector I/O
     // Optional fused GroupNorm statistics of the OUTPUT (the tensor a following GroupNorm normalises): every workgroup writes
@@ -61,12 +63,13 @@ static inline long ir_gn_ws_floats(int N, long HW, int C) {
     const long part = (long)N * ir_gn_chunks(HW) * 2 * C, part2 = (long)N * 256 * 64;  // stand-alone partials | fused second stage
     return (part > part2 ? part : part2) + 2L * N * C;
 }
+// out_fp8 != 0: y receives OCP e4m3 bytes of (result * out_mul) instead of bf16 (the input of an fp8 convolution)
 int ir_launch_groupnorm(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, float* ws, int N, long HW, int C,
-                        int G, float eps, int do_silu, hipStream_t s);
+                        int G, float eps, int do_silu, hipStream_t s, int out_fp8 = 0, float out_mul = 1.f);
 // Same, with the statistics already reduced to per-group partials by the producing conv (IGemmParams::gn_part, `chunks` tiles per
 // image): only the finalise and apply launches run. ws needs 2*N*C + N*256*64 floats (scale, shift, second-stage partials).
 int ir_launch_groupnorm_fused(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, const float* part, float* ws, int N,
-                              long HW, int C, int G, int chunks, float eps, int do_silu, hipStream_t s);
+                              long HW, int C, int G, int chunks, float eps, int do_silu, hipStream_t s, int out_fp8 = 0, float out_mul = 1.f);
 // y (bf16, may be null) and yf (fp32, may be null) both receive xn*a + b; columns C..ldy-1 are written as zero.
 int ir_launch_layernorm(const float* x, bf16_t* y, float* yf, const float* a, const float* b, long rows, int C, int ldx, int ldy,
                         float eps, long rows_per_batch, int ab_stride, hipStream_t s);

@@ -156,9 +156,10 @@ __global__ __launch_bounds__(256) void gn_finalize_groups_kernel(const float* __
 // its 16-byte vectors. The stride (blocks * 256) is a multiple of the vectors per pixel, so a thread always meets the same 8
 // channels: its scale / shift live in registers and the loop has no index arithmetic beyond one add (the first version divided
 // two 64-bit indices per vector and re-read scale / shift for every vector: 3.6 TB/s).
+template <bool FP8>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
-                                                       long HW, int C, long nvec_img, int do_silu) {
+                                                       long HW, int C, long nvec_img, int do_silu, float out_mul) {
     const int vpp = C >> 3;
     const int n = blockIdx.y;
     const int cv = threadIdx.x % vpp;  // blockDim.x * gridDim.x % vpp == 0 (launcher)
@@ -169,18 +170,31 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
         sh[e] = shift[(long)n * C + cv * 8 + e];
     }
     x += (long)n * nvec_img * 8;
-    y += (long)n * nvec_img * 8;
+    y += (long)n * nvec_img * (FP8 ? 4 : 8);  // FP8: 8 output bytes per vector
     auto one = [&](long i, const uint4& v) {
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
         uint32_t o[4];
+        float f[8];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float a = bflo(w[e]) * sc[2 * e] + sh[2 * e];
             float b = bfhi(w[e]) * sc[2 * e + 1] + sh[2 * e + 1];
             if (do_silu) { a = silu(a); b = silu(b); }
             o[e] = pack2bf(a, b);
+            f[2 * e] = a; f[2 * e + 1] = b;
         }
-        *reinterpret_cast<uint4*>(y + i * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+        if constexpr (FP8) {  // OCP e4m3 (max 448), round to nearest even; the consumer conv's epilogue divides out_mul out again
+            int lo = 0, hi = 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = fminf(fmaxf(f[e] * out_mul, -448.f), 448.f);
+            lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
+            lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+            hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
+            hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+            *reinterpret_cast<uint2*>(y + i * 4) = make_uint2((uint32_t)lo, (uint32_t)hi);
+        } else {
+            *reinterpret_cast<uint4*>(y + i * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
     };
     const long stride = (long)gridDim.x * 256;
     long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -195,16 +209,17 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
 }
 
 static void launch_gn_apply(const bf16_t* x, bf16_t* y, const float* scale, const float* shift, int N, long HW, int C, int do_silu,
-                            hipStream_t s) {
+                            hipStream_t s, int out_fp8, float out_mul) {
     const long nvec_img = HW * C / 8;
     long blocks = (nvec_img + 255) / 256;
     const long cap = (256L * 16 + N - 1) / N;  // about 16 blocks per CU over the whole launch
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)blocks, N), dim3(256), 0, s, x, y, scale, shift, HW, C, nvec_img, do_silu);
+    if (out_fp8) hipLaunchKernelGGL(gn_apply_kernel<true>, dim3((unsigned)blocks, N), dim3(256), 0, s, x, y, scale, shift, HW, C, nvec_img, do_silu, out_mul);
+    else hipLaunchKernelGGL(gn_apply_kernel<false>, dim3((unsigned)blocks, N), dim3(256), 0, s, x, y, scale, shift, HW, C, nvec_img, do_silu, 1.f);
 }
 
 int ir_launch_groupnorm(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, float* ws, int N, long HW, int C,
-                        int G, float eps, int do_silu, hipStream_t s) {
+                        int G, float eps, int do_silu, hipStream_t s, int out_fp8, float out_mul) {
     if (C % 8 || C > 512 || G > 64 || C % G || 256 % (C / 8) || 256 % G) return -2;
     if (HW >= (1L << 31)) return -3;
     int chunks = ir_gn_chunks(HW);
@@ -213,7 +228,7 @@ int ir_launch_groupnorm(const bf16_t* x, bf16_t* y, const float* gamma, const fl
     float* shift = scale + (long)N * C;                // [N][C]
     hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, N), dim3(256), 0, s, x, part, (int)HW, C, chunks);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), 0, s, part, gamma, beta, scale, shift, (int)HW, C, G, chunks, eps);
-    launch_gn_apply(x, y, scale, shift, N, HW, C, do_silu, s);
+    launch_gn_apply(x, y, scale, shift, N, HW, C, do_silu, s, out_fp8, out_mul);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -235,7 +250,7 @@ __global__ __launch_bounds__(256) void gn_reduce_groups_kernel(const float* __re
 }
 
 int ir_launch_groupnorm_fused(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, const float* part, float* ws, int N,
-                              long HW, int C, int G, int chunks, float eps, int do_silu, hipStream_t s) {
+                              long HW, int C, int G, int chunks, float eps, int do_silu, hipStream_t s, int out_fp8, float out_mul) {
     if (C % 8 || C > 512 || G > 64 || C % G || 256 % (C / 8) || 256 % G || chunks <= 0) return -2;
     if (HW >= (1L << 31)) return -3;
     float* scale = ws;                 // [N][C]
@@ -249,7 +264,7 @@ int ir_launch_groupnorm_fused(const bf16_t* x, bf16_t* y, const float* gamma, co
         chunks = R;
     }
     hipLaunchKernelGGL(gn_finalize_groups_kernel, dim3(N), dim3(256), 0, s, part, gamma, beta, scale, shift, (int)HW, C, G, chunks, eps);
-    launch_gn_apply(x, y, scale, shift, N, HW, C, do_silu, s);
+    launch_gn_apply(x, y, scale, shift, N, HW, C, do_silu, s, out_fp8, out_mul);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

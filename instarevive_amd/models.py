@@ -268,9 +268,21 @@ class AutoencoderKL(_DeviceModule):
             self._upload()
         return res
 
+    def enable_fp8(self, on=True):
+        """BASELINE.json configs[4]: run the ResnetBlock 3x3 convolutions on fp8 (OCP e4m3) operands. The fp8 weight forms are packed and
+        uploaded on first use; process(..., fp8=True) switches the mode on per call, this switches it on for .encode() / .decode()."""
+        self._fp8 = bool(on)
+        if self.ctx is not None and self._sd is not None:
+            if on and not self.__dict__.get("_fp8_uploaded"):
+                self._upload()
+            self.ctx.check(self.ctx.lib.ir_set_fp8(self.ctx.h, 1 if on else 0), "ir_set_fp8")
+        return self
+
     def _upload(self):
         c = self.cfg
-        self.ctx.upload_all(W.pack_vae(self._sd, c))
+        want8 = bool(self.__dict__.get("_fp8"))
+        self.ctx.upload_all(W.pack_vae(self._sd, c, fp8=want8))
+        self._fp8_uploaded = want8
         self.ctx.check(self.ctx.lib.ir_vae_configure(self.ctx.h, c["ch"], len(c["ch_mult"]), _ints(c["ch_mult"]), c["num_res_blocks"], 1, 1),
                        "ir_vae_configure")
         self._mark_bound()

@@ -163,7 +163,7 @@ def _launch_pipeline(ctx, st, slot, n, h, w, flags, tile_size, tile_stride, acp,
 @torch.no_grad()
 def process(model, control_imgs: List[np.ndarray], strength: float, color_fix_type: str, disable_preprocess_model: bool, tiled: bool,
             tile_size: int, tile_stride: int, preprocess_model=None, vae=None, y=None, y_mask=None, noise_scheduler=None,
-            fused: bool = True, graph: bool = False, return_stage1: bool = True) -> Tuple[List[np.ndarray], List[np.ndarray]]:
+            fused: bool = True, graph: bool = False, return_stage1: bool = True, fp8: bool = False) -> Tuple[List[np.ndarray], List[np.ndarray]]:
     """test_scripts/inference.py:55-166. control_imgs: list of HWC uint8 RGB arrays of equal size (multiples of 64).
     Returns (preds, stage1_preds) as lists of HWC uint8 arrays (stage1_preds is empty with return_stage1=False, which skips its
     conversion and download).
@@ -172,7 +172,8 @@ def process(model, control_imgs: List[np.ndarray], strength: float, color_fix_ty
     one-step call becomes generate_sample_1step(..., c=<the scaled LQ latent the step starts from>), per tile under `tiled`.
     graph=True (fused form only): the launch sequence is recorded into a hipGraph per image size / flag set and replayed on later
     calls. Images travel through page-locked staging buffers kept per batch shape (which also gives a recorded graph stable
-    device addresses)."""
+    device addresses). fp8=True (fused form, BASELINE.json configs[4]): fp8 MFMA operands in the VAE resnet convolutions
+    (vae.enable_fp8() must have uploaded the fp8 weight forms)."""
     noise_scheduler = noise_scheduler or DDPMScheduler()
     n, h, w = _check_images(control_imgs)
     device = model.device
@@ -181,7 +182,7 @@ def process(model, control_imgs: List[np.ndarray], strength: float, color_fix_ty
     if fused and _fused_ok(model, preprocess_model, vae, disable_preprocess_model):
         ctx = model.ctx
         _prepare_fused(model, y, y_mask, h, w, tiled, tile_size, (vae, None if disable_preprocess_model else preprocess_model))
-        flags = _pipeline_flags(model, color_fix_type, disable_preprocess_model, tiled) | (L.FLAG_GRAPH if graph else 0)
+        flags = _pipeline_flags(model, color_fix_type, disable_preprocess_model, tiled) | (L.FLAG_GRAPH if graph else 0) | (L.FLAG_FP8 if fp8 else 0)
         st = _Staging.get(ctx, n, h, w)
         st.fill(0, control_imgs)
         st.d_in[0].copy_(st.h_in[0], non_blocking=True)

@@ -31,6 +31,22 @@ def pack_conv3x3(w, cin_pad, cout_pad, scale=1.0):
     return _bf16(p.reshape(cout_pad, kh * kw * cin_pad))
 
 
+FP8_ACT_SCALE = 16.0   # GroupNorm+SiLU outputs reach the fp8 convs as e4m3(x * 16) (csrc/api.cpp: FP8_ACT_SCALE)
+FP8_MAX = 448.0        # largest finite OCP e4m3 value
+
+
+def pack_conv3x3_fp8(w, bias):
+    """3x3 conv weights [Cout][Cin][3][3] -> (OCP e4m3 bytes [Cout][9*Cin] quantised per OUTPUT channel with scale amax / 448,
+    dequantisation factor per channel = weight scale / activation scale, bias / that factor): the conv epilogue computes
+    (acc + bias') * factor. BASELINE.json configs[4], "fp8 MFMA for ... VAE conv weights"."""
+    co, ci = w.shape[:2]
+    wf = w.to(torch.float32).permute(0, 2, 3, 1).reshape(co, 9 * ci)
+    ws = (wf.abs().amax(dim=1) / FP8_MAX).clamp_min(1e-12)
+    q = (wf / ws[:, None]).clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn).view(torch.uint8).contiguous()
+    factor = (ws / FP8_ACT_SCALE).contiguous()
+    return q, factor, (bias.to(torch.float32) / factor).contiguous()
+
+
 def pack_linear(w, n_pad, k_pad, row_map=None, col_map=None):
     """row_map / col_map: LongTensor giving, for each ORIGINAL row / column, its position in the padded layout."""
     w = w.to(torch.float32).reshape(w.shape[0], -1)
@@ -140,7 +156,7 @@ def _attn_key(sd, p, new, old, leaf):
     return sd[k] if k in sd else sd[f"{p}.{old}.{leaf}"]
 
 
-def pack_vae(sd, cfg, encoder=True, decoder=True):
+def pack_vae(sd, cfg, encoder=True, decoder=True, fp8=False):
     ch, mult, nrb = cfg["ch"], list(cfg["ch_mult"]), cfg["num_res_blocks"]
     nl = len(mult)
     out = {}
@@ -157,6 +173,11 @@ def pack_vae(sd, cfg, encoder=True, decoder=True):
     def res(dst, src):
         norm(dst + ".n1", src + ".norm1"); conv(dst + ".c1", src + ".conv1")
         norm(dst + ".n2", src + ".norm2"); conv(dst + ".c2", src + ".conv2")
+        if fp8:  # fp8 forms of the two 3x3 convs (the halo kernel's fp8 path takes channel counts that are multiples of 128)
+            for cname, sname in ((".c1", ".conv1"), (".c2", ".conv2")):
+                w = sd[src + sname + ".weight"]
+                if w.shape[0] % 128 == 0 and w.shape[1] % 128 == 0:
+                    out[dst + cname + ".w8"], out[dst + cname + ".g8"], out[dst + cname + ".b8"] = pack_conv3x3_fp8(w, sd[src + sname + ".bias"])
         if src + ".conv_shortcut.weight" in sd:
             w = sd[src + ".conv_shortcut.weight"]
             out[dst + ".sc.w"] = pack_linear(w, w.shape[0], w.shape[1])

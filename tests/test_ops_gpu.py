@@ -159,6 +159,29 @@ def test_conv3x3(ctx, case):
     close(out.cpu().permute(0, 3, 1, 2), ref, 1e-4, 1e-3, f"conv {case}")
 
 
+@pytest.mark.parametrize("n,h,w,cin,cout,res", [(1, 16, 16, 128, 128, False), (2, 24, 40, 256, 128, True), (1, 20, 28, 512, 64, False)])
+def test_conv3x3_fp8(ctx, n, h, w, cin, cout, res):
+    """3x3 conv on OCP e4m3 operands through the MX-scaled MFMA (conv_halo_kernel<.., FP8>; BASELINE.json configs[4]). Products of
+    two e4m3 values are exact in fp32, so against a float64 convolution of the DEQUANTISED operands only the fp32 accumulation order
+    and the bf16 rounding of the output remain (2^-7 relative + 2e-3)."""
+    g = torch.Generator().manual_seed(n + h + w + cin + cout)
+    x8 = (torch.randn(n, cin, h, w, generator=g) * 4).clamp(-448, 448).to(torch.float8_e4m3fn)
+    w8 = (torch.randn(cout, cin, 3, 3, generator=g) * 64).clamp(-448, 448).to(torch.float8_e4m3fn)
+    deq = torch.rand(cout, generator=g) * 1e-3 + 1e-4
+    bias = torch.randn(cout, generator=g)
+    r_ = rb(torch.randn(n, cout, h, w, generator=g)) if res else None
+    ref = F.conv2d(x8.double(), w8.double(), None, padding=1) * deq.double()[None, :, None, None] + bias.double()[None, :, None, None]
+    if res:
+        ref = ref + r_.double()
+    xin = x8.permute(0, 2, 3, 1).contiguous().view(torch.uint8).cuda()
+    wp = w8.permute(0, 2, 3, 1).contiguous().view(torch.uint8).cuda()      # [Cout][tap][Cin]
+    out = torch.empty(n, h, w, cout, dtype=torch.int16, device="cuda")
+    rd = dev_bf16(r_.permute(0, 2, 3, 1).contiguous()) if res else None
+    ctx.check(ctx.lib.ir_op_conv_fp8(ctx.h, ctx.stream(), P(xin), P(wp), P(deq.cuda()), P((bias / deq).cuda()), P(out), n, h, w, cin, cout, P(rd)), "conv_fp8")
+    torch.cuda.synchronize()
+    close(L.from_bf16_bits(out).cpu().permute(0, 3, 1, 2).double(), ref, 2 ** -7, 2e-3, "conv fp8")
+
+
 def test_conv_lrelu_residual_bf16(ctx):
     g = torch.Generator().manual_seed(11)
     n, h, w, cin, cout = 1, 16, 16, 64, 64
