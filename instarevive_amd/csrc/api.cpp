@@ -44,6 +44,8 @@ struct SwinBlock {
     Norm n1, n2;
     Conv qkv, proj, fc1, fc2;
     const float* biasT = nullptr;
+    const void* mlp_t = nullptr;   // weight tiles + vectors of the fused LN2 -> fc1 -> GELU -> fc2 -> + x kernel (swin_fused.hip), optional
+    const float* mlp_v = nullptr;
 };
 struct SwinLayer {
     std::vector<SwinBlock> blocks;
@@ -436,9 +438,14 @@ void swinir_run(Run& r, const float* in, float* out, int n, int h, int w) {
             LAUNCH(r, PC_SWIN_ATTN, 4.0 * (double)T * 64 * 32 * m.heads, 0.0,
                    ir_launch_swin_attn(qkv, att, b.biasT, n, gh, gw, m.heads, 3 * m.heads * 32, Cp, (j & 1) ? 4 : 0, scale, r.s), "swin_attn");
             linear(r, b.proj, att, (int)T, Cp, xb, Cp, 1, ACT_NONE, cur, 1, Cp);
-            layernorm(r, xb, xn, nullptr, b.n2.g, b.n2.b, T, m.C, Cp, Cp, 1e-5f);
-            linear(r, b.fc1, xn, (int)T, Cp, hid, m.hid_p, 0, ACT_GELU_ERF, nullptr, 0, 0);
-            linear(r, b.fc2, hid, (int)T, m.hid_p, xb, Cp, 1, ACT_NONE, xb, 1, Cp, last ? xc : nullptr, Cp);
+            if (b.mlp_t && !g_ir_plain_kernels) {  // LN2 -> fc1 -> GELU -> fc2 -> + x in one kernel, the token's state in registers throughout
+                LAUNCH(r, PC_LINEAR, 4.0 * (double)T * m.C * (m.hid_p), 4.0 * (double)T * Cp * 2,
+                       ir_launch_swin_mlp(xb, xb, last ? xc : nullptr, b.mlp_t, b.mlp_v, T, m.C, m.hid_p, 1e-5f, r.s), "swin_mlp");
+            } else {
+                layernorm(r, xb, xn, nullptr, b.n2.g, b.n2.b, T, m.C, Cp, Cp, 1e-5f);
+                linear(r, b.fc1, xn, (int)T, Cp, hid, m.hid_p, 0, ACT_GELU_ERF, nullptr, 0, 0);
+                linear(r, b.fc2, hid, (int)T, m.hid_p, xb, Cp, 1, ACT_NONE, xb, 1, Cp, last ? xc : nullptr, Cp);
+            }
             cur = xb;
         }
         // RSTB tail: conv(x) + input of the RSTB (swinir.py:493)
@@ -1050,6 +1057,14 @@ int ir_swinir_configure(ir_ctx* c, int embed_dim, int n_layers, const int* depth
             k.fc1 = b.conv(p + ".fc1", Cp, m.hid_p, m.hid_p, 1);
             k.fc2 = b.conv(p + ".fc2", m.hid_p, Cp, Cp, 1);
             k.biasT = b.f32(p + ".biasT", (size_t)heads * 4096);
+            {   // optional: present when the host packed the fused-MLP form (Cp = 192 only)
+                auto it = c->t.find(p + ".mlp_t"), iv = c->t.find(p + ".mlp_v");
+                const size_t nj = (size_t)m.hid_p / 32;
+                if (Cp == 192 && it != c->t.end() && iv != c->t.end() && it->second.bytes >= nj * 28672 && iv->second.bytes >= (3 * 192 + nj * 32) * 4) {
+                    k.mlp_t = it->second.p;
+                    k.mlp_v = (const float*)iv->second.p;
+                }
+            }
             L.blocks.push_back(k);
         }
         L.conv = b.conv(fmt("swin.l%d.conv", i), Cp, Cp, Cp, 9);

@@ -104,6 +104,11 @@ int ir_launch_swin_attn(const bf16_t* qkv, bf16_t* out, const float* biasT, int 
 int ir_launch_softmax_rows(const float* x, bf16_t* y, long rows, int cols, long ldx, long ldy, hipStream_t s);
 static inline int ir_attn_dv(int D) { return (D + 31) & ~31; }
 
+// ---- fused SwinIR block halves (swin_fused.hip)
+// out = x + fc2(gelu(fc1(LayerNorm(x)))) on the fp32 residual stream [T][192] (in place allowed); out2: optional bf16 copy
+int ir_launch_swin_mlp(const float* x, float* out, bf16_t* out2, const void* w_tiles, const float* vec, long T, int C, int hid_p, float eps,
+                       hipStream_t s);
+
 // ---- T5 encoder glue (t5.hip)
 int ir_launch_t5_embed(const int* ids, const bf16_t* table, float* x, long rows, int D, int vocab, int* bad, hipStream_t s);
 int ir_launch_t5_rmsnorm(const float* x, const float* w, bf16_t* yb, float* yf, long rows, int D, float eps, hipStream_t s);

@@ -103,6 +103,42 @@ def swinir_expected_keys(cfg):
     return keys
 
 
+def _acc_order(n):
+    """k positions -> source index for the transposed-register kernels (csrc/swin_fused.hip): position 16s + 8h + j of k-step s holds
+    element 16s + 8(j >> 2) + 4h + (j & 3) — the order in which a 32x32 MFMA accumulator tile, packed to bf16, presents its rows."""
+    p = torch.arange(n)
+    s, h, j = p // 16, (p // 8) % 2, p % 8
+    return 16 * s + 8 * (j // 4) + 4 * h + (j % 4)
+
+
+def pack_swin_mlp(fc1_w, fc1_b, fc2_w, fc2_b, n2_g, n2_b, C, Cp, hid_p):
+    """Weight tiles + vectors of swin_mlp_kernel. Per 32 hidden units jt one 28 KB step: W1 tile [32 rows = hidden units][192 k positions]
+    bf16 with 400-byte rows (16 bytes of padding: conflict-free ds_read_b128 across rows) padded to 13 KB, then W2 tile [192 output
+    channels][32 k positions = the tile's hidden units] with 80-byte rows (15 KB). k positions follow _acc_order. Vectors (fp32):
+    LayerNorm gain / bias padded to 192 (zero beyond C: padded channels normalise to exactly 0), fc1 bias padded to hid_p, fc2 bias."""
+    hid = fc1_w.shape[0]
+    nj = hid_p // 32
+    w1 = torch.zeros(hid_p, Cp)
+    w1[:hid, :C] = fc1_w.float()
+    w1 = w1[:, _acc_order(Cp)]                                     # input channels in accumulator order
+    w2 = torch.zeros(Cp, hid_p)
+    w2[:C, :hid] = fc2_w.float()
+    w2 = w2[:, _acc_order(hid_p)]                                  # hidden units in accumulator order (within each 16: tiles of 32 stay intact)
+    tiles = torch.zeros(nj, 13312 + 15360, dtype=torch.uint8)
+    for jt in range(nj):
+        t1 = torch.zeros(32, 200, dtype=torch.int16)               # 400-byte rows
+        t1[:, :Cp] = _bf16(w1[32 * jt:32 * jt + 32])
+        t2 = torch.zeros(Cp, 40, dtype=torch.int16)                # 80-byte rows
+        t2[:, :32] = _bf16(w2[:, 32 * jt:32 * jt + 32])
+        tiles[jt, :12800] = t1.reshape(-1).view(torch.uint8)
+        tiles[jt, 13312:] = t2.reshape(-1).view(torch.uint8)
+    vec = torch.zeros(3 * Cp + hid_p)
+    vec[:C], vec[Cp:Cp + C] = n2_g.float(), n2_b.float()
+    vec[2 * Cp:2 * Cp + hid] = fc1_b.float()
+    vec[2 * Cp + hid_p:2 * Cp + hid_p + C] = fc2_b.float()
+    return tiles.contiguous(), vec.contiguous()
+
+
 def pack_swinir(sd, cfg):
     C, heads = cfg["embed_dim"], cfg["num_heads"][0]
     hd, Cp = C // heads, heads * 32
@@ -132,6 +168,8 @@ def pack_swinir(sd, cfg):
             out[d + "fc1.b"] = pad_vec(sd[s + "mlp.fc1.bias"], hid_p)
             out[d + "fc2.w"] = pack_linear(sd[s + "mlp.fc2.weight"], Cp, hid_p)
             out[d + "fc2.b"] = pad_vec(sd[s + "mlp.fc2.bias"], Cp)
+            out[d + "mlp_t"], out[d + "mlp_v"] = pack_swin_mlp(sd[s + "mlp.fc1.weight"], sd[s + "mlp.fc1.bias"], sd[s + "mlp.fc2.weight"],
+                                                              sd[s + "mlp.fc2.bias"], sd[s + "norm2.weight"], sd[s + "norm2.bias"], C, Cp, hid_p)
             table = sd[s + "attn.relative_position_bias_table"].float()
             bias = table[rpi.view(-1)].view(64, 64, heads)                       # [query][key][head]  (swinir.py:138-140)
             out[d + "biasT"] = (bias.permute(2, 1, 0) * math.log2(math.e)).contiguous()  # [head][key][query], log2 domain
