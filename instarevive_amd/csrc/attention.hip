@@ -603,6 +603,10 @@ int ir_launch_flash_attn(const AttnParams& p, hipStream_t s) {
     static const bool no_pp = getenv("IR_NO_PINGPONG") != nullptr;  // experiment knob
     if (p.D == 72 && !general && p.Tq >= 256 && p.ovf_flag && !no_pp && !g_ir_plain_kernels) {  // the DiT self-attention: ping-pong kernel, 256 queries per workgroup
         if (ir_launch_zero_f32(reinterpret_cast<float*>(p.ovf_flag), 1, s)) return -1;
+        static const bool pp1 = getenv("IR_ATTN_PP1") != nullptr;  // experiment knob: the two-waves-per-SIMD ping-pong kernel
+        if (!pp1) {
+            if (ir_launch_flash_attn_pp2(p, s)) return -1;
+        } else
         hipLaunchKernelGGL((flash_attn_pp_kernel<72>), dim3((p.Tq + 255) / 256, p.Hh, p.B), dim3(512), 0, s, p);
         hipLaunchKernelGGL((flash_attn_kernel<72, false>), grid, dim3(256), 0, s, p);  // fallback: returns at once unless flagged
         return hipGetLastError() == hipSuccess ? 0 : -1;

@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d512_v2_kernel(const bf16_t
                 ovf = fmaxf(ovf, sv);
                 const float p = __builtin_amdgcn_exp2f(sv - m_ref);
                 l_i += p;
-                if constexpr (e & 1) a5_set_word<((e & 7) >> 1)>(pn[e >> 3], pack2bf(p_hold, p));
+                if constexpr (e & 1) a5_set_word<((e & 7) >> 1)>(pn[e >> 3], pack2bf_valu(p_hold, p));   // one v_cvt_pk (operands come from v_exp: no MFMA hazard)
                 else p_hold = p;
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -285,5 +285,330 @@ int ir_launch_flash_attn_d512_v2(const bf16_t* q, const bf16_t* k, const bf16_t*
     if (T <= 0 || (T & 31) || (rs & 7) || (o_rs & 7) || rs < 512 || o_rs < 512 || B <= 0 || !ovf_flag) return -2;
     hipLaunchKernelGGL(flash_attn_d512_v2_kernel, dim3((T + 127) / 128, B), dim3(256), 0, s, q, k, vt_tiles, o, T, rs, o_rs, qk_bs, vt_bs, o_bs,
                        scale * 1.44269504088896340736f, ovf_flag);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// =====================================================================================================================
+// flash_attn_pp2_kernel<72>: the DiT self-attention (16 heads x 72, T % 64 == 0, no key bias; reference PixArt_blocks.py:123-158) in the
+// structure of flash_attn_d512_v2_kernel above - ONE wave per SIMD with the whole register file, one pinned MFMA stream per tile,
+// everything else in the MFMA shadows - instead of the two-waves-per-SIMD ping-pong of flash_attn_pp_kernel (attention.hip), whose
+// matrix and vector segments are kept complementary by two workgroup barriers per tile (phase stamps: the waves wait at them for
+// about a third of a tile).
+// A wave owns TWO groups of 32 queries: O^T (2 x 3 tiles) and the Q^T fragments (2 x 5 k-steps) live in AGPRs, addressed literally.
+// Per 64-key tile one stream of 44 MFMAs: S^T(t+1) of group 0, of group 1 (10 each: -m rides in as the C operand of the first),
+// then O^T += V^T(t) P^T(t) for both groups (24, the V^T fragments shared by the two groups). The exponentials of tile t+1 (no
+// subtraction, no row sum - the denominator comes from the ones row of V^T - no running maximum) follow three MFMAs behind the
+// last score MFMA of their group, two per MFMA shadow; the 19 LDS-DMA pieces of K(t+2) / V^T(t+1) ride behind the score MFMAs. One
+// barrier per tile, K and V^T double-buffered (42 KB of LDS). Same math as the other kernels: S^T = K Q^T with swap23-permuted K
+// rows, P^T registers as the B operand of the second product, reference fixed after the first tile (row maximum + 2^24 headroom).
+// Overflow is detected at the end: a denominator that is not a moderate finite number raises ovf_flag and the rescaling 4-wave
+// kernel, launched behind, recomputes everything.
+// Knock-out builds of flash_attn_pp2_kernel (diagnostic, -DIR_KO_PP2=n, results wrong by design): 1 no per-tile wait + barrier, 2 no LDS-DMA in the
+// stream, 3 no exponentials, 4 no fragment reads, 5 no MFMAs
+#ifndef IR_KO_PP2
+#define IR_KO_PP2 0
+#endif
+namespace pp2 {
+constexpr int D = 72, NKS = 5, NDT = 3, RCH = 9;
+constexpr int KROW = RCH * 16;              // 144-byte K rows, unpadded (9 chunks: conflict-free)
+constexpr int KSLOT = 64 * KROW;            // 9216 B = 9 DMA pieces
+constexpr int VROWS = 96, VSLOT = VROWS * 128;   // V^T tile: 96 rows x 64 keys (rows 73.. are never loaded and never stored)
+constexpr int K_Q = 9, V_Q = (D + 1 + 7) / 8;    // DMA pieces per tile: 9 + 10
+constexpr int V_OFF = 2 * KSLOT;
+constexpr int LDS_MAIN = V_OFF + 2 * VSLOT;      // 43 008 B
+constexpr int OS = 96 + 8;                       // O staging row stride (elements)
+constexpr int LDS_O = 8 * 32 * OS * 2;           // 53 248 B
+constexpr int LDS_BYTES = LDS_MAIN > LDS_O ? LDS_MAIN : LDS_O;
+constexpr int NPC = (K_Q + V_Q + 3) / 4;         // pieces per wave and tile (at most)
+constexpr float MARGIN = 24.0f;
+constexpr int LA = 6, NB = LA + 3;
+constexpr int NQK = 20, NPV = 24, NSTEP = NQK + NPV;
+constexpr int O_BASE = 0, Q_BASE = 96;           // AGPR map: O^T a[0:95] (group g, tile dt at 16*(3g+dt)), Q^T a[96:135] (4*(5g+ks))
+}  // namespace pp2
+
+// Softmax work list of a tile: item n (0..63) -> (query group, score element). The first 20 items are group 0's elements 0..19 (group 1's
+// scores are not finished yet); then three blocks of 12 = 4 of group 0 + 8 of group 1, then the last 8 of group 1. Chunks are even-sized and
+// start at even elements, so the two halves of a bf16 pair are always consecutive items (n even, n odd).
+constexpr int pp2_item_g(int n) { return n < 20 ? 0 : (((n - 20) / 12 < 3 && (n - 20) % 12 < 4) ? 0 : 1); }
+constexpr int pp2_item_e(int n) {
+    if (n < 20) return n;
+    const int m = n - 20, blk = m / 12, pos = m % 12;
+    if (blk < 3 && pos < 4) return 20 + 4 * blk + pos;
+    return blk < 3 ? 8 * blk + pos - 4 : 24 + (m - 36);
+}
+template <int LO>
+IR_DEVINL void pp2_mfma_qk_first(f32x16& s, bf16x8 a, const f32x16& c) {  // s = a x Q^T(AGPR) + c, s and c in different registers
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %4" : "=&v"(s) : "v"(a), "n"(LO), "n"(LO + 3), "v"(c));
+}
+template <int LO>
+IR_DEVINL void pp2_mfma_qk(f32x16& s, bf16x8 a) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, a[%c2:%c3], %0" : "+v"(s) : "v"(a), "n"(LO), "n"(LO + 3));
+}
+template <int LO>
+IR_DEVINL void pp2_mfma_pv(bf16x8 a, bf16x8 b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(a), "v"(b), "n"(LO), "n"(LO + 15));
+}
+template <int I>
+IR_DEVINL void pp2_acc_write(uint32_t x) {
+    asm volatile("v_accvgpr_write_b32 a[%c1], %0" ::"v"(x), "n"(I));
+}
+
+__global__ __launch_bounds__(256, 1) void flash_attn_pp2_kernel(AttnParams p) {
+    using namespace pp2;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wu = __builtin_amdgcn_readfirstlane(wid);
+    const int r = lane & 31, h = lane >> 5;
+    const int q0 = blockIdx.x * 256 + wid * 64, head = blockIdx.y, b = blockIdx.z;
+    const bf16_t* qp = p.q + (long)b * p.q_bs + (long)head * p.q_hs;
+    const bf16_t* kp = p.k + (long)b * p.k_bs + (long)head * p.k_hs;
+    const bf16_t* vtp = p.vt + (long)b * p.vt_bs + (long)head * 96 * p.Tk_pad;
+    const int NT = p.Tk >> 6;
+
+    asm volatile(".set ir_pp2_i, 0\n\t.rept 96\n\tv_accvgpr_write_b32 a[ir_pp2_i], 0\n\t.set ir_pp2_i, ir_pp2_i + 1\n\t.endr" ::: IR_AGPR256_CLOBBERS);
+
+    // LDS-DMA pieces of a tile pair {K, V^T}: piece idx = wave + 4k belongs to this wave (19 pieces: the fifth piece of wave 3 repeats
+    // its fourth - same bytes to the same place - so that the stream issues its pieces without a branch). Per piece: the lane's source
+    // address in tile 0, the element stride from tile to tile, the LDS offset in slot 0, the slot size, and how far ahead of the PV tile
+    // t the piece's tile is (K: t + 2, V^T: t + 1).
+    const bf16_t* pc_src[NPC];
+    long pc_stride[NPC];
+    int pc_dst[NPC], pc_slot[NPC], pc_ahead[NPC];
+#pragma unroll
+    for (int k = 0; k < NPC; ++k) {
+        const int idx = min(wu + 4 * k, K_Q + V_Q - 1);
+        if (idx < K_Q) {
+            const int ci = 64 * idx + lane, row = ci / RCH, ch = ci - row * RCH;
+            pc_src[k] = kp + (long)row * p.k_rs + ch * 8;
+            pc_stride[k] = 64L * p.k_rs;
+            pc_dst[k] = idx * 1024; pc_slot[k] = KSLOT; pc_ahead[k] = 2;
+        } else {
+            const int j = idx - K_Q;
+            const int d = 8 * j + (lane >> 3), c = (lane & 7) ^ ((d >> 1) & 7);
+            pc_src[k] = vtp + (long)d * p.Tk_pad + c * 8;
+            pc_stride[k] = 64;
+            pc_dst[k] = V_OFF + j * 1024; pc_slot[k] = VSLOT; pc_ahead[k] = 1;
+        }
+    }
+    auto issue = [&](auto kc, int t) {  // this wave's k-th piece of the tiles that follow PV tile t (t = -2 / -1: the prologue's K(0), V^T(0) / K(1))
+        constexpr int k = decltype(kc)::value;
+        const int tile = min(t + pc_ahead[k], NT - 1);   // past the end the last tile is re-read into the free slot (never used)
+        a5_glds16(pc_src[k] + tile * pc_stride[k], (a5_lds_t)(smem + (tile & 1) * pc_slot[k] + pc_dst[k]));
+    };
+    // prologue: K(0) -> slot 0 and V^T(0) -> slot 0 (t = -2 for K pieces, -1 for V^T pieces), then K(1) -> slot 1
+    [&]<int... K>(std::integer_sequence<int, K...>) {
+        ((issue(std::integral_constant<int, K>{}, -pc_ahead[K])), ...);
+    }(std::make_integer_sequence<int, NPC>{});
+    if (NT > 1) {
+#pragma unroll
+        for (int k = 0; k < NPC; ++k)
+            if (pc_ahead[k] == 2) a5_glds16(pc_src[k] + pc_stride[k], (a5_lds_t)(smem + pc_slot[k] + pc_dst[k]));
+    }
+    // Q^T fragments -> AGPRs (B operand layout: lane = query, 8 consecutive d per k-step half), scaled; d >= 72 is zero
+    [&]<int... I>(std::integer_sequence<int, I...>) {
+        ([&] {
+            constexpr int g = I / NKS, ks = I % NKS;
+            const bf16_t* qrow = qp + (long)min(q0 + g * 32 + r, p.Tq - 1) * p.q_rs;
+            const int d0 = ks * 16 + h * 8;
+            const uint4 v = *reinterpret_cast<const uint4*>(qrow + (d0 < D ? d0 : 0));
+            const float sc = d0 < D ? p.scale_log2 : 0.f;
+            pp2_acc_write<Q_BASE + 4 * I + 0>(pack2bf(bflo(v.x) * sc, bfhi(v.x) * sc));
+            pp2_acc_write<Q_BASE + 4 * I + 1>(pack2bf(bflo(v.y) * sc, bfhi(v.y) * sc));
+            pp2_acc_write<Q_BASE + 4 * I + 2>(pack2bf(bflo(v.z) * sc, bfhi(v.z) * sc));
+            pp2_acc_write<Q_BASE + 4 * I + 3>(pack2bf(bflo(v.w) * sc, bfhi(v.w) * sc));
+        }(), ...);
+    }(std::make_integer_sequence<int, 2 * NKS>{});
+
+    const uint32_t lds0 = lds_addr(smem);
+    const uint32_t k_addr = lds0 + a5_swap23(r) * KROW + h * 16;           // + slot*KSLOT + kt*32*KROW + ks*32
+    const int vsw = (r >> 1) & 7;
+    uint32_t v_addr[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v_addr[j] = lds0 + V_OFF + r * 128 + ((((2 * j) | h) ^ vsw) << 4);   // + slot*VSLOT + dt*4096 ; j = kt*2 + s2
+
+    f32x16 sacc[2][2], negm[2];
+    uint4 pbA[2][4], pbB[2][4];   // P^T fragments [group][kk] of the tile being multiplied / being exponentiated
+    bf16x8 fr[NB];
+    float p_hold2[2] = {0.f, 0.f}, pend0[2] = {0.f, 0.f}, pend1[2] = {0.f, 0.f};
+    if (IR_KO_PP2 == 4) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) fr[i] = __builtin_bit_cast(bf16x8, make_uint4(lane, 0x3c003c00, 0x3c003c00, 0x3c003c00));
+    }
+    uint32_t ka = k_addr, va[4] = {v_addr[0], v_addr[1], v_addr[2], v_addr[3]};
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) negm[g][e] = 0.f;
+
+    // stream step j: [0, 20) S^T MFMA (group j / 10, key sub-tile (j % 10) / 5, k-step j % 5); [20, 44) PV MFMA (pair (j - 20) >> 1 =
+    // dt*4 + kk, group j & 1)
+    auto frag_read = [&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        if constexpr (IR_KO_PP2 == 4) return;
+        if constexpr (j < NQK) fr[j % NB] = lds_read16<(((j % 10) / 5) * 32 * KROW + (j % 5) * 32)>(ka);
+        else fr[(NQK + ((j - NQK) >> 1)) % NB] = lds_read16<(((j - NQK) >> 3) * 4096)>(va[((j - NQK) >> 1) & 3]);
+    };
+    // fragment slots: score MFMA j uses slot j; PV pair q uses slot NQK + q (one read for the two groups); reads run LA slots ahead
+    auto stream = [&](auto j0c, auto smc, auto dmac, uint4 (&pc)[2][4], uint4 (&pn)[2][4], int t) {
+        constexpr int J0 = decltype(j0c)::value;
+        constexpr bool SOFTMAX = decltype(smc)::value, DMA = decltype(dmac)::value;
+        constexpr int S0 = J0 < NQK ? J0 : NQK + ((J0 - NQK) >> 1), S1 = NQK + NPV / 2;   // fragment slots [S0, S1)
+        auto slot_read = [&](auto sc) {
+            constexpr int sl = decltype(sc)::value;
+            if constexpr (sl < NQK) frag_read(std::integral_constant<int, sl>{});
+            else frag_read(std::integral_constant<int, NQK + 2 * (sl - NQK)>{});
+        };
+        auto step = [&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            constexpr int sl = j < NQK ? j : NQK + ((j - NQK) >> 1);     // fragment slot of this MFMA
+            constexpr bool first_use = j < NQK || ((j - NQK) & 1) == 0;  // a PV pair's fragment is read once, for its first MFMA
+            if constexpr (first_use) {
+                if constexpr (sl + LA < S1) slot_read(std::integral_constant<int, sl + LA>{});
+                wait_lds<(S1 - 1 - sl < LA ? S1 - 1 - sl : LA)>();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (IR_KO_PP2 == 5) {
+                asm volatile("" ::"v"(fr[sl % NB]));
+            } else if constexpr (j < NQK) {
+                constexpr int g = j / 10, kt = (j % 10) / 5, ks = j % 5;
+                if constexpr (ks == 0) pp2_mfma_qk_first<Q_BASE + 4 * (5 * g + ks)>(sacc[g][kt], fr[sl % NB], negm[g]);
+                else pp2_mfma_qk<Q_BASE + 4 * (5 * g + ks)>(sacc[g][kt], fr[sl % NB]);
+            } else {
+                constexpr int q = (j - NQK) >> 1, g = j & 1, dt = q >> 2, kk = q & 3;
+                pp2_mfma_pv<O_BASE + 16 * (3 * g + dt)>(fr[sl % NB], __builtin_bit_cast(bf16x8, pc[g][kk]));
+            }
+            if constexpr (sl - 2 >= S0) asm volatile("" ::"v"(fr[(sl - 2) % NB]));
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (DMA && IR_KO_PP2 != 2 && j < 2 * NPC && (j & 1)) {   // K(t+2) / V^T(t+1) pieces behind the first score MFMAs
+                issue(std::integral_constant<int, (j >> 1)>{}, t);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (SOFTMAX && IR_KO_PP2 != 3 && j >= 13) {   // two exponentials per MFMA shadow: group 0 from step 13 (three MFMAs behind its
+                                                                     // last score MFMA, step 9), group 1 from step 23
+                constexpr int n0 = j < 23 ? 2 * (j - 13) : 20 + (j - 23) * 44 / 21, n1 = j < 23 ? n0 + 2 : 20 + (j - 22) * 44 / 21;
+                [&]<int... E>(std::integer_sequence<int, E...>) {
+                    ([&] {
+                        constexpr int n = n0 + E;
+                        if constexpr (n < n1 && n < 64) {
+                            constexpr int g = pp2_item_g(n), e = pp2_item_e(n);
+                            const float pv = __builtin_amdgcn_exp2f(sacc[g][e >> 4][e & 15]);
+                            if constexpr (e & 1) {
+                                // The pair (e-1, e) is packed one pair LATER, behind the next two exponentials: the v_cvt_pk then never waits
+                                // for the transcendental pipe. Two pending slots alternate.
+                                if constexpr (((n >> 1) & 1) == 0) { pend0[0] = p_hold2[g]; pend0[1] = pv; } else { pend1[0] = p_hold2[g]; pend1[1] = pv; }
+                                if constexpr (n >= 3) {
+                                    constexpr int gp = pp2_item_g(n - 2), ep = pp2_item_e(n - 2);
+                                    if constexpr (((n >> 1) & 1) == 0) a5_set_word<((ep & 7) >> 1)>(pn[gp][ep >> 3], pack2bf_valu(pend1[0], pend1[1]));
+                                    else a5_set_word<((ep & 7) >> 1)>(pn[gp][ep >> 3], pack2bf_valu(pend0[0], pend0[1]));
+                                }
+                            } else {
+                                p_hold2[g] = pv;
+                            }
+                        }
+                    }(), ...);
+                }(std::make_integer_sequence<int, 4>{});
+                if constexpr (j == NSTEP - 1) {   // the last pair (item 63, pending slot 1)
+                    constexpr int gp = pp2_item_g(63), ep = pp2_item_e(63);
+                    a5_set_word<((ep & 7) >> 1)>(pn[gp][ep >> 3], pack2bf_valu(pend1[0], pend1[1]));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        __builtin_amdgcn_sched_barrier(0);
+        [&]<int... I>(std::integer_sequence<int, I...>) { (slot_read(std::integral_constant<int, S0 + I>{}), ...); }(std::make_integer_sequence<int, LA>{});
+        __builtin_amdgcn_sched_barrier(0);
+        [&]<int... I>(std::integer_sequence<int, I...>) { (step(std::integral_constant<int, J0 + I>{}), ...); }(std::make_integer_sequence<int, NSTEP - J0>{});
+    };
+    using J0 = std::integral_constant<int, 0>;
+    using JPV = std::integral_constant<int, NQK>;
+
+    // ---- tile 0: scores of both groups (C = 0), softmax in the open: the reference is fixed here
+    wait_dma();
+    __syncthreads();
+    {
+        __builtin_amdgcn_sched_barrier(0);
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+            ([&] {
+                constexpr int g = I / 10, kt = (I % 10) / 5, ks = I % 5;
+                const bf16x8 a = lds_read16<(kt * 32 * KROW + ks * 32)>(ka);
+                wait_lds<0>();
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (ks == 0) pp2_mfma_qk_first<Q_BASE + 4 * (5 * g + ks)>(sacc[g][kt], a, negm[g]);
+                else pp2_mfma_qk<Q_BASE + 4 * (5 * g + ks)>(sacc[g][kt], a);
+                __builtin_amdgcn_sched_barrier(0);
+            }(), ...);
+        }(std::make_integer_sequence<int, NQK>{});
+    }
+    asm volatile("s_nop 15\n\ts_nop 7" : "+v"(sacc[0][0]), "+v"(sacc[0][1]), "+v"(sacc[1][0]), "+v"(sacc[1][1]));
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sacc[g][kt][e]);
+        const float m_ref = xhalf_max(mx) + MARGIN;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) negm[g][e] = -m_ref;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            float pv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pv[e] = __builtin_amdgcn_exp2f(sacc[g][kk >> 1][(kk & 1) * 8 + e] - m_ref);
+            pbA[g][kk] = make_uint4(pack2bf(pv[0], pv[1]), pack2bf(pv[2], pv[3]), pack2bf(pv[4], pv[5]), pack2bf(pv[6], pv[7]));
+            pbB[g][kk] = make_uint4(0, 0, 0, 0);
+        }
+    }
+    // ---- main loop (two tiles per trip: the P^T buffers swap roles statically)
+    auto tile_step = [&](int t, uint4 (&pc)[2][4], uint4 (&pn)[2][4]) {
+        if (IR_KO_PP2 != 1) {
+            wait_dma();
+            __syncthreads();
+        }
+        ka = k_addr + ((t + 1) & 1) * KSLOT;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) va[j] = v_addr[j] + (t & 1) * VSLOT;
+        if (t + 1 < NT) stream(J0{}, std::true_type{}, std::true_type{}, pc, pn, t);
+        else stream(JPV{}, std::false_type{}, std::false_type{}, pc, pn, t);
+    };
+    for (int t = 0; t < NT; t += 2) {
+        tile_step(t, pbA, pbB);
+        if (t + 1 < NT) tile_step(t + 1, pbB, pbA);
+    }
+    // ---- finalise: O^T[d][q] / l -> LDS [q][d] -> 16-byte row stores; l = O^T row 72 (the ones row of V^T): tile 2, register 4, half 0
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+    __syncthreads();  // every wave has finished reading the K / V^T ring
+    bf16_t* ow = reinterpret_cast<bf16_t*>(smem) + wid * 64 * OS;
+    const float l0 = __shfl(a5_acc_read<O_BASE + 16 * 2 + 4>(), r), l1 = __shfl(a5_acc_read<O_BASE + 16 * 5 + 4>(), r);
+    const bool bad = !(l0 < 1e30f) || !(l1 < 1e30f);   // also catches inf / NaN: the fixed reference was outgrown by about 2^100
+    const float inv0 = 1.0f / l0, inv1 = 1.0f / l1;
+    [&]<int... I>(std::integer_sequence<int, I...>) {
+        ([&] {
+            constexpr int G = I / NDT, DT = I % NDT, A0 = O_BASE + 16 * I;
+            const float inv = G ? inv1 : inv0;
+            const float x[16] = {a5_acc_read<A0 + 0>(), a5_acc_read<A0 + 1>(), a5_acc_read<A0 + 2>(), a5_acc_read<A0 + 3>(),
+                                 a5_acc_read<A0 + 4>(), a5_acc_read<A0 + 5>(), a5_acc_read<A0 + 6>(), a5_acc_read<A0 + 7>(),
+                                 a5_acc_read<A0 + 8>(), a5_acc_read<A0 + 9>(), a5_acc_read<A0 + 10>(), a5_acc_read<A0 + 11>(),
+                                 a5_acc_read<A0 + 12>(), a5_acc_read<A0 + 13>(), a5_acc_read<A0 + 14>(), a5_acc_read<A0 + 15>()};
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) {
+                const uint2 w = make_uint2(pack2bf(x[4 * gg] * inv, x[4 * gg + 1] * inv), pack2bf(x[4 * gg + 2] * inv, x[4 * gg + 3] * inv));
+                *reinterpret_cast<uint2*>(&ow[(G * 32 + r) * OS + DT * 32 + 8 * gg + 4 * h]) = w;
+            }
+        }(), ...);
+    }(std::make_integer_sequence<int, 2 * NDT>{});
+    if (__any(bad) && lane == 0) atomicOr(p.ovf_flag, 1);
+    __syncthreads();
+    bf16_t* op = p.o + (long)b * p.o_bs + (long)head * p.o_hs;
+    for (int c = lane; c < 64 * RCH; c += 64) {
+        const int row = c / RCH, ch = c - row * RCH;
+        const int q = q0 + row;
+        if (q < p.Tq) *reinterpret_cast<uint4*>(op + (long)q * p.o_rs + ch * 8) = *reinterpret_cast<const uint4*>(&ow[row * OS + ch * 8]);
+    }
+}
+
+int ir_launch_flash_attn_pp2(const AttnParams& p, hipStream_t s) {
+    if (p.D != 72 || p.Tq <= 0 || p.Tk < 64 || (p.Tk & 63) || !p.ovf_flag || p.key_bias) return -2;
+    hipLaunchKernelGGL(flash_attn_pp2_kernel, dim3((p.Tq + 255) / 256, p.Hh, p.B), dim3(256), 0, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -23,6 +23,15 @@ IR_DEVINL float bf2f(bf16_t b) {
 IR_DEVINL uint32_t pack2bf(float lo, float hi) {
     return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
 }
+// The same as ONE instruction. hipcc (ROCm 7.2) turns pack2bf into two v_cvt_pk_bf16_f32 (each with a zero second operand), a shift and
+// an or. ONLY for operands produced by ordinary VALU instructions (e.g. v_exp_f32): an asm statement is invisible to hipcc's hazard
+// recogniser, so on operands fresh from an MFMA it reads them before the required wait states (replacing pack2bf globally by this
+// broke every GEMM epilogue: 16 dB).
+IR_DEVINL uint32_t pack2bf_valu(float lo, float hi) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
 IR_DEVINL float bflo(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
 IR_DEVINL float bfhi(uint32_t u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
 

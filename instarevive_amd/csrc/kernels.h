@@ -90,6 +90,8 @@ struct AttnParams {
     int* ovf_flag;             // optional 4 bytes of device scratch: enables the fixed-reference ping-pong kernel (see attention.hip)
 };
 int ir_launch_flash_attn(const AttnParams& p, hipStream_t s);
+// DiT self-attention (D = 72, Tk % 64 == 0, no key bias, ovf_flag set) as one wave per SIMD with two query groups (attn_d512.hip)
+int ir_launch_flash_attn_pp2(const AttnParams& p, hipStream_t s);
 int ir_launch_flash_attn_d512(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* o, int T, int rs, int o_rs, long vt_rs,
                               float scale, hipStream_t s, const int* only_if = nullptr);
 // d = 512 without the redundant score product (attn_d512.hip): V^T in 32-key tiles [B][T/32][512][32]; a set *ovf_flag afterwards
