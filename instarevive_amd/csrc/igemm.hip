@@ -154,7 +154,7 @@ IR_DEVINL void igemm_epilogue(const IGemmParams& p, f32x16 (&acc)[TM][TN], unsig
                 const int m = mrow[i][it];
                 if (m < 0) continue;
                 const f32x4 o = v[i][it] + rres[i][it];
-                const uint2 pk = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+                const uint2 pk = make_uint2(pack2bf_valu(o[0], o[1]), pack2bf_valu(o[2], o[3]));   // o is a VALU result (LDS read + add): no MFMA hazard
                 if (p.out_f32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (long)m * p.out_cs + nbase) = o;
                 else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (long)m * p.out_cs + nbase) = pk;
                 if (p.out2) *reinterpret_cast<uint2*>(p.out2 + (long)m * p.out2_cs + nbase) = pk;

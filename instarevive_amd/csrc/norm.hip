@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
             float a = bflo(w[e]) * sc[2 * e] + sh[2 * e];
             float b = bfhi(w[e]) * sc[2 * e + 1] + sh[2 * e + 1];
             if (do_silu) { a = silu(a); b = silu(b); }
-            o[e] = pack2bf(a, b);
+            o[e] = pack2bf_valu(a, b);   // a, b come out of VALU arithmetic (one v_cvt_pk instead of four instructions)
             f[2 * e] = a; f[2 * e + 1] = b;
         }
         if constexpr (FP8) {  // OCP e4m3 (max 448), round to nearest even; the consumer conv's epilogue divides out_mul out again
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256) void layernorm_v4_kernel(const float* __restri
                 if (ap) o *= *reinterpret_cast<const f32x4*>(ap + 4 * j);
                 if (bp) o += *reinterpret_cast<const f32x4*>(bp + 4 * j);
             }
-            if (y) *reinterpret_cast<uint2*>(y + row * ldy + 4 * j) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+            if (y) *reinterpret_cast<uint2*>(y + row * ldy + 4 * j) = make_uint2(pack2bf_valu(o[0], o[1]), pack2bf_valu(o[2], o[3]));
             if (yf) *reinterpret_cast<f32x4*>(yf + row * ldy + 4 * j) = o;
         }
     }

@@ -87,3 +87,32 @@ def test_cli_matches_oracle(tmp_path):
         p = _psnr_u8([got], [want])
         print(f"cli {k}: PSNR vs oracle {p:.2f} dB")
         assert p >= 47.0  # measured 52.3 and 53.1 dB on these two files
+
+
+def test_eval_batch_harness_matches_oracle(tmp_path):
+    """the batched evaluation harness (eval_batch.py, the role of test_dmd_general.py:112-192) on five images of
+    different sizes in batches of 2 — centre crop (center_crop_arr), B > 1 through process_stream, result + condition folders, .jpg -> .png —
+    against the oracle run image by image."""
+    d = tmp_path
+    sws, svae, sdit, y, mask = _write_artifacts(d)
+    os.makedirs(d / "lq" / "sub", exist_ok=True)
+    srcs = {"a.png": (70, 90), "b.jpg": (64, 64), "sub/c.png": (150, 130), "d.png": (64, 100), "e.png": (97, 71)}
+    for i, (k, hw) in enumerate(srcs.items()):
+        Image.fromarray((det_input(80 + i, hw + (3,)) * 255).numpy().astype(np.uint8)).save(d / "lq" / k, quality=95)
+    cmd = [sys.executable, os.path.join(ROOT, "eval_batch.py"), "--ckpt", str(d / "weights" / "dit.ckpt"), "--input", str(d / "lq"), "--output",
+           str(d / "res"), "--cond_output", str(d / "cond"), "--batch_size", "2", "--image_size", "64", "--swinir_ckpt", str(d / "weights" / "swinir.ckpt"),
+           "--swinir_config", str(d / "swinir.yaml"), "--vae", str(d / "vae"), "--dit_config", str(d / "pixart"), "--prompt_embeds", str(d / "prompt.pth")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    from instarevive_amd.utils import center_crop_arr
+    for k in srcs:
+        name = os.path.splitext(k)[0] + ".png"
+        got, cond = np.array(Image.open(d / "res" / name).convert("RGB")), np.array(Image.open(d / "cond" / name).convert("RGB"))
+        x = center_crop_arr(Image.open(d / "lq" / k).convert("RGB"), 64)
+        ref, ref1 = oglue.process([x], lambda t: oswin.swinir_forward(sws, t, SWIN_SMALL), lambda t: ovae.vae_encode_mean(svae, t, VAE_SMALL),
+                                  lambda lat, tt, yy, mm: odit.dit_forward(sdit, lat, tt, yy, mm, DIT_SMALL), lambda z: ovae.vae_decode(svae, z, VAE_SMALL),
+                                  oglue.alphas_cumprod_diffusers(), y.reshape(1, 20, 64), mask.reshape(1, 1, 20))
+        assert got.shape == (64, 64, 3)
+        p, p1 = _psnr_u8([got], ref), _psnr_u8([cond], ref1)
+        print(f"eval_batch {k}: PSNR vs oracle {p:.2f} dB (condition image {p1:.2f} dB)")
+        assert p >= 45.0 and p1 >= 50.0
