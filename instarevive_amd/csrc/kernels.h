@@ -51,6 +51,11 @@ int ir_launch_igemm(const IGemmParams& p, hipStream_t s);
 // Pixel tiles per image the kernel ir_launch_igemm would pick for p writes statistics for, or 0 if this launch cannot fuse them.
 int ir_igemm_gn_chunks(const IGemmParams& p);
 
+// conv_s1.hip: the one-wave-per-SIMD 3x3 convolution (16 x 32 patches x 128 channels); ir_launch_igemm routes eligible launches to it
+bool ir_conv_s1_takes(const IGemmParams& p);
+int ir_conv_s1_tiles(const IGemmParams& p);   // pixel tiles per image (fused GroupNorm statistics: one partial per tile)
+int ir_launch_conv_s1(const IGemmParams& p, hipStream_t s);
+
 // ---- norms (norm.hip)
 static inline int ir_gn_chunks(long HW) {
     long c = HW / 2048;

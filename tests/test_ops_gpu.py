@@ -223,6 +223,22 @@ def test_groupnorm(ctx, n, hw, c, silu):
 ])
 def test_conv_groupnorm_fused(ctx, n, h, w, cin, cout, stride, up, res, expect_fused):
     """ResnetBlock's conv -> GroupNorm(32)+SiLU with the statistics produced by the conv epilogue (ldm model.py:131-151)."""
+    _conv_groupnorm_case(ctx, n, h, w, cin, cout, stride, up, res, expect_fused)
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,up,res", [
+    (2, 200, 488, 128, 128, 0, True),     # ragged 16 x 32 patches (200 = 12.5 x 16, 488 = 15.25 x 32), two images, residual
+    (1, 100, 120, 256, 256, 1, False),    # nearest-2x folded in -> 200 x 240, two channel tiles, 8 chunks
+    (1, 256, 384, 512, 128, 0, True),     # 16 chunks, whole patches
+])
+def test_conv_s1_kernel(ctx, n, h, w, cin, cout, up, res):
+    """conv_halo_s1_kernel (one wave per SIMD, 16 x 32 patches x 128 channels): sizes with enough patches to be routed to it — the fused
+    statistics come back as one partial per 16 x 32 patch, which is how the test knows which kernel ran."""
+    ho, wo = (2 * h, 2 * w) if up else (h, w)
+    _conv_groupnorm_case(ctx, n, h, w, cin, cout, 1, up, res, True, expect_chunks=((ho + 15) // 16) * ((wo + 31) // 32))
+
+
+def _conv_groupnorm_case(ctx, n, h, w, cin, cout, stride, up, res, expect_fused, expect_chunks=None):
     import ctypes
     g = torch.Generator().manual_seed(h * w + cout + stride)
     x = rb(torch.randn(n, cin, h, w, generator=g))
@@ -252,6 +268,8 @@ def test_conv_groupnorm_fused(ctx, n, h, w, cin, cout, stride, up, res, expect_f
                                            stride, up, P(rd) if res else None, 1, P(ws), ws.numel(), ctypes.byref(fused)), "conv_groupnorm")
     torch.cuda.synchronize()
     assert (fused.value > 0) == expect_fused, fused.value
+    if expect_chunks is not None:
+        assert fused.value == expect_chunks, (fused.value, expect_chunks)
     got_conv = L.from_bf16_bits(conv_out).cpu().permute(0, 3, 1, 2)
     close(got_conv, co, 2 ** -7, 4e-3, "conv (fused-GN launch)")
     # GroupNorm normalises the tensor as stored: reference statistics from the kernel's own conv output (an ulp flip of the conv
