@@ -8,7 +8,8 @@
 // is a quarter of the LDS fragment bytes per MFMA (16 ds_read_b128 per 64 MFMAs), a 1.20x instead of 1.27x halo, and no second
 // workgroup barrier per step.
 // The reduction runs over 32-channel chunks: the 18 x 34 halo of a chunk (612 pixels x 64 B = 39 KB) is brought in ONCE by LDS-DMA
-// (double-buffered, issued during the previous chunk) and all nine taps read their pixel fragments from it with a tap offset on the LDS
+// (three buffers: chunk c+2 is fetched during chunk c, so an HBM miss has nine steps to land - with two buffers the
+// waves stalled about 1 us at every chunk boundary) and all nine taps read their pixel fragments from it with a tap offset on the LDS
 // address; the weight tile of a (chunk, tap) step (128 rows x 64 B) rides a ring of four. Per step every wave issues ONE pinned stream
 // of 64 MFMAs (1024 matrix cycles); the 16 fragment reads of the NEXT step and this wave's 2-4 LDS-DMA pieces sit in the MFMA
 // shadows, so after the single workgroup barrier of a step the next stream starts from registers.
@@ -39,8 +40,9 @@ constexpr int HALO_BYTES = H_Q * 1024;         // 39 936
 constexpr int H_I = 10;                        // halo pieces per wave and chunk (piece q = wave + 4 i, clamped to the last)
 constexpr int BN = 128, WT_BYTES = BN * ROWB;  // 8 192: 8 pieces of 16 rows
 constexpr int NSB = 4;
-constexpr int W_OFF = 2 * HALO_BYTES;          // 79 872
-constexpr int LDS_MAIN = W_OFF + NSB * WT_BYTES;   // 112 640
+constexpr int NHB = 3;                         // halo buffers: chunk c lives in buffer c % 3, chunk c + 2 is fetched during chunk c
+constexpr int W_OFF = NHB * HALO_BYTES;        // 119 808
+constexpr int LDS_MAIN = W_OFF + NSB * WT_BYTES;   // 152 576
 constexpr int SROW = 132;                      // slab row stride in floats (128 + 4)
 constexpr int SLAB = 32 * SROW * 4;            // 16 896 B per wave
 constexpr int RED_OFF = 4 * SLAB;
@@ -52,6 +54,18 @@ constexpr int nh_first(int t) { return t < 4 ? 2 * t : (t < 6 ? 4 + t : 0); }
 constexpr int hkey(int hx) { return ((hx >> 2) & 1) << 1; }
 }  // namespace cs1
 
+#ifndef IR_KO_S1
+#define IR_KO_S1 0   // knock-out builds for timing only (results wrong by design): 1 no epilogue, 2 no main loop, 3 neither,
+                     // 4 no halo DMA in the loop, 5 no weight DMA in the loop, 6 no fragment reads, 7 no per-step barrier
+#endif
+#ifdef IR_S1_STAMPS   // diagnostic build only (tools/conv_s1_stamp.hip): per-workgroup phase sums, never compiled into the library
+__device__ unsigned long long g_s1_stamps[1024 * 8];   // [wg][0..4] s_memrealtime sums (100 MHz): prologue, main, drain, passes, gn; [5] s_memtime over main; [6] tiles
+#define IR_S1_T(v) const unsigned long long v = __builtin_amdgcn_s_memrealtime()
+#define IR_S1_ACC(k, a, b) do { if (tid == 0) g_s1_stamps[blockIdx.x * 8 + (k)] += (b) - (a); } while (0)
+#else
+#define IR_S1_T(v) do { } while (0)
+#define IR_S1_ACC(k, a, b) do { } while (0)
+#endif
 __device__ uint4 g_zero_page_s1[4096];   // 64 KB of zeros: padding taps read from here, the LDS-DMA never needs a mask
 
 typedef __attribute__((address_space(3))) void* cs1_lds_t;
@@ -68,19 +82,24 @@ IR_DEVINL float cs1_acc_read() {
 }
 
 template <int UP>
-__global__ __launch_bounds__(256, 1) void conv_halo_s1_kernel(IGemmParams p, int tiles_y, int tiles_x) {
+__global__ __launch_bounds__(256, 1) void conv_halo_s1_kernel(IGemmParams p, int tiles_y, int tiles_x, int total_vb) {
     using namespace cs1;
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES];   // halo[0] | halo[1] | W ring of 4 ; epilogue: slabs | red
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES];   // halo[0..2] | W ring of 4 ; epilogue: slabs | red
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wu = __builtin_amdgcn_readfirstlane(wid);
     const int c16 = lane & 15, kq = lane >> 4;
 
     const int NT = p.Cout_pad / BN;
     const int MT = p.NB * tiles_y * tiles_x;
-    const int bid = blockIdx.x;
+    // Persistent workgroups (one per CU): with one workgroup per CU nothing else covers the dispatch of the next one, so every
+    // workgroup walks the virtual block ids bid, bid + gridDim.x, ... itself (gridDim.x is a multiple of 8: the XCD of a virtual block
+    // is the XCD of the workgroup that runs it).
+    for (int bid = blockIdx.x; bid < total_vb; bid += gridDim.x) {
     const int xcd = bid & 7, jb = bid >> 3;
     const int mt = (jb / NT) * 8 + xcd, nt = jb % NT;   // an XCD runs the channel tiles of one patch back to back (halo re-read from its L2)
-    if (mt >= MT) return;
+    if (mt >= MT) continue;
+    __syncthreads();   // the previous tile's epilogue has finished with the LDS
+    IR_S1_T(st0);
     const int n0 = nt * BN;
     const int img = mt / (tiles_y * tiles_x), trem = mt - img * tiles_y * tiles_x;
     const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
@@ -136,11 +155,12 @@ __global__ __launch_bounds__(256, 1) void conv_halo_s1_kernel(IGemmParams p, int
 
     bf16x8 fw[2][8], fp[2][8];   // [set][channel fragment] / [set][pixel fragment = a * 2 + mx]
 
-    // ---- prologue: halo of chunk 0, weight tiles of steps 0..3, fragments of step 0
+    // ---- prologue: halo of chunk 0, weight tiles of steps 0..3, halo of chunk 1 (left in flight), fragments of step 0
     [&]<int... I>(std::integer_sequence<int, I...>) { (halo_issue(std::integral_constant<int, I>{}, 0, 0), ...); }(std::make_integer_sequence<int, H_I>{});
 #pragma unroll
     for (int t = 0; t < NSB; ++t) w_issue(0, t, t);
-    wait_dma();
+    [&]<int... I>(std::integer_sequence<int, I...>) { (halo_issue(std::integral_constant<int, I>{}, 1, 1), ...); }(std::make_integer_sequence<int, H_I>{});
+    wait_vm<H_I>();
     __syncthreads();
     [&]<int... R>(std::integer_sequence<int, R...>) {
         ([&] {
@@ -150,22 +170,23 @@ __global__ __launch_bounds__(256, 1) void conv_halo_s1_kernel(IGemmParams p, int
     }(std::make_integer_sequence<int, 16>{});
     wait_lds<0>();
 
-    auto step = [&](auto tc, auto setc, int c) {
+    auto step = [&](auto tc, auto setc, int c, int hbuf) {   // hbuf = c % 3
         constexpr int T = decltype(tc)::value, SET = decltype(setc)::value;
         constexpr int TNX = (T + 1) % 9, KXN = TNX % 3, KYN = TNX / 3;
         const int s = c * 9 + T;
-        const uint32_t hb = (uint32_t)((T == 8 ? (c + 1) : c) & 1) * HALO_BYTES;
+        const uint32_t hb = (uint32_t)(T == 8 ? (hbuf == 2 ? 0 : hbuf + 1) : hbuf) * HALO_BYTES;
+        const int hfill = hbuf == 0 ? 2 : hbuf - 1;   // (c + 2) % 3: the buffer chunk c - 1 was read from
         const uint32_t ha0 = hrd[KXN][0] + hb, ha1 = hrd[KXN][1] + hb;
         const uint32_t wa = wrd + (uint32_t)((s + 1) & 3) * WT_BYTES;
         // weight tile s + 4 = (chunk cw, tap tw), clamped to the last tile
         constexpr int TW4 = (T + 4) % 9;
         int cw = c + (T + 4 >= 9 ? 1 : 0), tw = TW4;
         if (cw >= chunks) { cw = chunks - 1; tw = 8; }
-        const int ch_next = min(c + 1, chunks - 1);
+        const int ch_next = min(c + 2, chunks - 1);
         [&]<int... I>(std::integer_sequence<int, I...>) {
             ([&] {
                 constexpr int PT = I >> 3, CT = I & 7;
-                if constexpr ((I & 3) == 0) {   // one fragment of the next step per four MFMAs, into the other set
+                if constexpr ((I & 3) == 0 && IR_KO_S1 != 6) {   // one fragment of the next step per four MFMAs, into the other set
                     constexpr int R = I >> 2;
                     if constexpr (R < 8) fw[SET ^ 1][R] = lds_read16<R * 1024>(wa);
                     else fp[SET ^ 1][R - 8] = lds_read16<(((R - 8) >> 1) + KYN) * HWD * ROWB>(((R - 8) & 1) ? ha1 : ha0);
@@ -173,15 +194,15 @@ __global__ __launch_bounds__(256, 1) void conv_halo_s1_kernel(IGemmParams p, int
                 __builtin_amdgcn_sched_barrier(0);
                 cs1_mfma<4 * I>(fw[SET][CT], fp[SET][PT]);
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (I == 1 && nh(T) > 0) {
-                    halo_issue(std::integral_constant<int, nh_first(T)>{}, ch_next, (c + 1) & 1);
+                if constexpr (I == 1 && nh(T) > 0 && IR_KO_S1 != 4) {
+                    halo_issue(std::integral_constant<int, nh_first(T)>{}, ch_next, hfill);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if constexpr (I == 5 && nh(T) > 1) {
-                    halo_issue(std::integral_constant<int, (nh(T) > 1 ? nh_first(T) + 1 : 0)>{}, ch_next, (c + 1) & 1);
+                if constexpr (I == 5 && nh(T) > 1 && IR_KO_S1 != 4) {
+                    halo_issue(std::integral_constant<int, (nh(T) > 1 ? nh_first(T) + 1 : 0)>{}, ch_next, hfill);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if constexpr (I == 9) {
+                if constexpr (I == 9 && IR_KO_S1 != 5) {
                     w_issue(cw, tw, s & 3);
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -190,52 +211,71 @@ __global__ __launch_bounds__(256, 1) void conv_halo_s1_kernel(IGemmParams p, int
         wait_lds<0>();
         // everything but the pieces of this step and the previous one has landed: the weight tile of step s + 2 (read during step s + 1)
         // and, before tap 8, the next chunk's halo (its last piece is issued at tap 5)
-        wait_vm<4 + nh((T + 8) % 9) + nh(T)>();
+        wait_vm<(IR_KO_S1 == 5 ? 0 : 4) + (IR_KO_S1 == 4 ? 0 : nh((T + 8) % 9) + nh(T))>();
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
+        if (IR_KO_S1 != 7) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     };
-    for (int c = 0; c < chunks; c += 2) {
-        [&]<int... U>(std::integer_sequence<int, U...>) { (step(std::integral_constant<int, U>{}, std::integral_constant<int, (U & 1)>{}, c), ...); }(std::make_integer_sequence<int, 9>{});
-        [&]<int... U>(std::integer_sequence<int, U...>) { (step(std::integral_constant<int, U>{}, std::integral_constant<int, ((U + 1) & 1)>{}, c + 1), ...); }(std::make_integer_sequence<int, 9>{});
+    IR_S1_T(st1);
+#ifdef IR_S1_STAMPS
+    const unsigned long long sc0 = __builtin_amdgcn_s_memtime();
+#endif
+    if (IR_KO_S1 != 2 && IR_KO_S1 != 3)
+    for (int c = 0, hb3 = 0; c < chunks; c += 2) {
+        const int hb3b = hb3 == 2 ? 0 : hb3 + 1;
+        [&]<int... U>(std::integer_sequence<int, U...>) { (step(std::integral_constant<int, U>{}, std::integral_constant<int, (U & 1)>{}, c, hb3), ...); }(std::make_integer_sequence<int, 9>{});
+        [&]<int... U>(std::integer_sequence<int, U...>) { (step(std::integral_constant<int, U>{}, std::integral_constant<int, ((U + 1) & 1)>{}, c + 1, hb3b), ...); }(std::make_integer_sequence<int, 9>{});
+        hb3 = hb3b == 2 ? 0 : hb3b + 1;
     }
 
     // ---- epilogue
+    IR_S1_T(st2);
+#ifdef IR_S1_STAMPS
+    if (tid == 0) g_s1_stamps[blockIdx.x * 8 + 5] += __builtin_amdgcn_s_memtime() - sc0;
+#endif
     asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // the last MFMA results -> v_accvgpr_read
     wait_dma();        // the re-read pieces past the end must have landed before the slabs overlay the ring
     __syncthreads();
+    IR_S1_T(st3);
     float* slab = reinterpret_cast<float*>(smem + wid * SLAB);
     const int co8 = (lane & 15) * 8, xq = lane >> 4;
-    f32x4 bias4[8];
+    const float osc = p.out_scale;
+    f32x4 bias4[8];   // bias * out_scale: the slab write is one fused multiply-add per value
 #pragma unroll
     for (int ct = 0; ct < 8; ++ct)
-        bias4[ct] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n0 + 16 * ct + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
-    const float osc = p.out_scale;
-    float sA = 0.f, qA = 0.f, sB = 0.f, qB = 0.f;   // GroupNorm partials of channels co8 .. +3 and co8+4 .. +7 over this lane's pixels
-    const bf16_t* resp = reinterpret_cast<const bf16_t*>(p.res);
-    bf16_t* outp = reinterpret_cast<bf16_t*>(p.out);
-    auto pass = [&](auto ac) {
-        constexpr int A = decltype(ac)::value;
-        const int oy = oy0 + 4 * wid + A;
-        long pix[8];
-        bool ok[8];
-        uint4 rr[8];
+        bias4[ct] = (p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n0 + 16 * ct + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f}) * osc;
+    f32x4 sA4 = {0.f, 0.f, 0.f, 0.f}, qA4 = sA4, sB4 = sA4, qB4 = sA4;   // GroupNorm partials, channels co8 .. +3 and co8+4 .. +7
+    // Row it of a pass is pixel (oyw + A, oxl + 4 it): per-lane base pointers once per tile, uniform offsets per pass and row
+    const int oyw = oy0 + 4 * wid, oxl = ox0 + xq;
+    unsigned xm = 0;   // bit it: column oxl + 4 it lies inside the image
+#pragma unroll
+    for (int it = 0; it < 8; ++it) xm |= (oxl + 4 * it < p.Wo ? 1u : 0u) << it;
+    const long pix0 = ((long)img * p.Ho + oyw) * p.Wo + oxl;
+    bf16_t* obase = reinterpret_cast<bf16_t*>(p.out) + pix0 * p.out_cs + n0 + co8;
+    const bf16_t* rbase = reinterpret_cast<const bf16_t*>(p.res) + pix0 * p.res_cs + n0 + co8;
+    const bf16_t* rsafe = reinterpret_cast<const bf16_t*>(p.res) + (((long)img * p.Ho + oy0) * p.Wo + ox0) * p.res_cs + n0 + co8;   // always inside
+    const long o_row = (long)p.Wo * p.out_cs, r_row = (long)p.Wo * p.res_cs;
+    const bool do_gn = p.gn_part != nullptr;
+    uint4 rrb[2][8];   // residual rows of the pass being finished / of the next pass
+    auto res_fetch = [&](int a) {   // rows outside the image read a safe pixel
+        const bool yok = oyw + a < p.Ho;
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
-            const int ox = ox0 + 4 * it + xq;
-            ok[it] = oy < p.Ho && ox < p.Wo;
-            pix[it] = ((long)img * p.Ho + min(oy, p.Ho - 1)) * p.Wo + min(ox, p.Wo - 1);
-            rr[it] = make_uint4(0, 0, 0, 0);
+            const bool v = yok && ((xm >> it) & 1);
+            rrb[a & 1][it] = *reinterpret_cast<const uint4*>(v ? rbase + a * r_row + (long)(4 * it) * p.res_cs : rsafe);
         }
-        if (resp) {   // all residual loads of the pass in flight before the transposes
-#pragma unroll
-            for (int it = 0; it < 8; ++it) rr[it] = *reinterpret_cast<const uint4*>(resp + pix[it] * p.res_cs + n0 + co8);
-        }
+    };
+    auto pass = [&](auto ac, auto resc) {
+        constexpr int A = decltype(ac)::value;
+        constexpr bool RES = decltype(resc)::value;
+        const bool yok = oyw + A < p.Ho;
+        uint4 (&rr)[8] = rrb[A & 1];
+        if constexpr (RES && A < 3) res_fetch(A + 1);   // the next pass's residual rows fly during this pass
         [&]<int... J>(std::integer_sequence<int, J...>) {
             ([&] {
                 constexpr int MX = J >> 3, CT = J & 7, LO = 4 * ((A * 2 + MX) * 8 + CT);
                 f32x4 v = f32x4{cs1_acc_read<LO>(), cs1_acc_read<LO + 1>(), cs1_acc_read<LO + 2>(), cs1_acc_read<LO + 3>()};
-                v = (v + bias4[CT]) * osc;
+                v = v * osc + bias4[CT];
                 *reinterpret_cast<f32x4*>(&slab[(16 * MX + c16) * SROW + 16 * CT + 4 * kq]) = v;
             }(), ...);
         }(std::make_integer_sequence<int, 16>{});
@@ -250,18 +290,18 @@ __global__ __launch_bounds__(256, 1) void conv_halo_s1_kernel(IGemmParams p, int
         }
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
-            const f32x4 a = lo[it] + f32x4{bflo(rr[it].x), bfhi(rr[it].x), bflo(rr[it].y), bfhi(rr[it].y)};
-            const f32x4 b = hi[it] + f32x4{bflo(rr[it].z), bfhi(rr[it].z), bflo(rr[it].w), bfhi(rr[it].w)};
+            f32x4 a = lo[it], b = hi[it];
+            if constexpr (RES) {
+                a += f32x4{bflo(rr[it].x), bfhi(rr[it].x), bflo(rr[it].y), bfhi(rr[it].y)};
+                b += f32x4{bflo(rr[it].z), bfhi(rr[it].z), bflo(rr[it].w), bfhi(rr[it].w)};
+            }
             const uint4 pk = make_uint4(pack2bf_valu(a[0], a[1]), pack2bf_valu(a[2], a[3]), pack2bf_valu(b[0], b[1]), pack2bf_valu(b[2], b[3]));
-            if (ok[it]) {
-                *reinterpret_cast<uint4*>(outp + pix[it] * p.out_cs + n0 + co8) = pk;
-                if (p.gn_part) {   // statistics of the values as stored (bf16-rounded)
-                    const float a0 = bflo(pk.x), a1 = bfhi(pk.x), a2 = bflo(pk.y), a3 = bfhi(pk.y);
-                    const float b0 = bflo(pk.z), b1 = bfhi(pk.z), b2 = bflo(pk.w), b3 = bfhi(pk.w);
-                    sA += (a0 + a1) + (a2 + a3);
-                    qA += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
-                    sB += (b0 + b1) + (b2 + b3);
-                    qB += (b0 * b0 + b1 * b1) + (b2 * b2 + b3 * b3);
+            if (yok && ((xm >> it) & 1)) {
+                *reinterpret_cast<uint4*>(obase + A * o_row + (long)(4 * it) * p.out_cs) = pk;
+                if (do_gn) {   // statistics of the values as stored (bf16-rounded)
+                    const f32x4 ar = {bflo(pk.x), bfhi(pk.x), bflo(pk.y), bfhi(pk.y)}, br = {bflo(pk.z), bfhi(pk.z), bflo(pk.w), bfhi(pk.w)};
+                    sA4 += ar; qA4 += ar * ar;
+                    sB4 += br; qB4 += br * br;
                 }
             }
         }
@@ -269,33 +309,59 @@ __global__ __launch_bounds__(256, 1) void conv_halo_s1_kernel(IGemmParams p, int
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
-    pass(std::integral_constant<int, 0>{});
-    pass(std::integral_constant<int, 1>{});
-    pass(std::integral_constant<int, 2>{});
-    pass(std::integral_constant<int, 3>{});
-    if (p.gn_part) {
-        // Fixed-order workgroup reduction (no atomics, bit-identical run to run): unit u = 4 channels; lane (L = lane & 15) holds units 2L, 2L+1
-        float* red = reinterpret_cast<float*>(smem + RED_OFF);   // [wave][lane][4]
-        *reinterpret_cast<f32x4*>(&red[(wid * 64 + lane) * 4]) = f32x4{sA, qA, sB, qB};
-        __syncthreads();
-        const int upg = p.gn_cpg >> 2;          // units per group
-        const int groups = BN / p.gn_cpg;
-        if (tid < groups) {
-            float a = 0.f, b = 0.f;
-            for (int w = 0; w < 4; ++w)
-                for (int xr = 0; xr < 4; ++xr)
-                    for (int k = 0; k < upg; ++k) {
-                        const int u = tid * upg + k;
-                        const float* e = &red[((w * 64) + xr * 16 + (u >> 1)) * 4 + (u & 1) * 2];
-                        a += e[0];
-                        b += e[1];
-                    }
-            const int G = p.Cout / p.gn_cpg, g = n0 / p.gn_cpg + tid;
-            float* dst = p.gn_part + ((long)img * p.gn_chunks + trem) * 2 * G;
-            dst[g] = a;
-            dst[G + g] = b;
+    if (IR_KO_S1 != 1 && IR_KO_S1 != 3) {
+        if (p.res) {
+            res_fetch(0);
+            pass(std::integral_constant<int, 0>{}, std::true_type{});
+            pass(std::integral_constant<int, 1>{}, std::true_type{});
+            pass(std::integral_constant<int, 2>{}, std::true_type{});
+            pass(std::integral_constant<int, 3>{}, std::true_type{});
+        } else {
+            pass(std::integral_constant<int, 0>{}, std::false_type{});
+            pass(std::integral_constant<int, 1>{}, std::false_type{});
+            pass(std::integral_constant<int, 2>{}, std::false_type{});
+            pass(std::integral_constant<int, 3>{}, std::false_type{});
         }
     }
+    IR_S1_T(st4);
+    const float sA = (sA4[0] + sA4[1]) + (sA4[2] + sA4[3]), qA = (qA4[0] + qA4[1]) + (qA4[2] + qA4[3]);
+    const float sB = (sB4[0] + sB4[1]) + (sB4[2] + sB4[3]), qB = (qB4[0] + qB4[1]) + (qB4[2] + qB4[3]);
+    if (p.gn_part && IR_KO_S1 == 0) {
+        // Fixed-order workgroup reduction (no atomics, bit-identical run to run). Unit u = 4 channels; lane (L = lane & 15) holds units 2L and
+        // 2L+1 over the pixel columns xq, xq + 4, ...: first the four column classes of a wave (lanes L, L+16, L+32, L+48), then the four
+        // waves through LDS, then the units of a group.
+        f32x4 v = {sA, qA, sB, qB};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] += __shfl_xor(v[e], 16);
+            v[e] += __shfl_xor(v[e], 32);
+        }
+        float* red = reinterpret_cast<float*>(smem + RED_OFF);   // [wave][L][4]
+        if (lane < 16) *reinterpret_cast<f32x4*>(&red[(wid * 16 + lane) * 4]) = v;
+        __syncthreads();
+        if (tid < 32) {   // thread u: unit u of the 32 units of this channel tile
+            const int L = tid >> 1, hf = (tid & 1) * 2;
+            float a = (red[(0 * 16 + L) * 4 + hf] + red[(1 * 16 + L) * 4 + hf]) + (red[(2 * 16 + L) * 4 + hf] + red[(3 * 16 + L) * 4 + hf]);
+            float b = (red[(0 * 16 + L) * 4 + hf + 1] + red[(1 * 16 + L) * 4 + hf + 1]) + (red[(2 * 16 + L) * 4 + hf + 1] + red[(3 * 16 + L) * 4 + hf + 1]);
+            const int upg = p.gn_cpg >> 2;   // units per group: 1, 2, 4 or 8 (launcher)
+            for (int m = 1; m < upg; m <<= 1) {
+                a += __shfl_xor(a, m);
+                b += __shfl_xor(b, m);
+            }
+            if ((tid & (upg - 1)) == 0) {
+                const int G = p.Cout / p.gn_cpg, g = n0 / p.gn_cpg + tid / upg;
+                float* dst = p.gn_part + ((long)img * p.gn_chunks + trem) * 2 * G;
+                dst[g] = a;
+                dst[G + g] = b;
+            }
+        }
+    }
+    IR_S1_T(st5);
+    IR_S1_ACC(0, st0, st1); IR_S1_ACC(1, st1, st2); IR_S1_ACC(2, st2, st3); IR_S1_ACC(3, st3, st4); IR_S1_ACC(4, st4, st5);
+#ifdef IR_S1_STAMPS
+    if (tid == 0) g_s1_stamps[blockIdx.x * 8 + 6] += 1;
+#endif
+    }   // persistent loop
 }
 
 // Which launches take this kernel (everything else of the halo family stays with conv_halo_pp_kernel / conv_halo_kernel): plain bf16
@@ -318,12 +384,18 @@ int ir_conv_s1_tiles(const IGemmParams& p) { return ((p.Ho + 15) / 16) * ((p.Wo 
 
 int ir_launch_conv_s1(const IGemmParams& p, hipStream_t s) {
     if (!ir_conv_s1_takes(p)) return -2;
-    if (p.gn_part && (p.gn_cpg < 4 || (p.gn_cpg & 3) || 128 % p.gn_cpg || p.gn_chunks != ir_conv_s1_tiles(p))) return -13;
+    if (p.gn_part && (p.gn_cpg < 4 || p.gn_cpg > 32 || (p.gn_cpg & (p.gn_cpg - 1)) || p.gn_chunks != ir_conv_s1_tiles(p))) return -13;
     const int tiles_y = (p.Ho + 15) / 16, tiles_x = (p.Wo + 31) / 32;
     const long MT = (long)p.NB * tiles_y * tiles_x, NT = p.Cout_pad / 128;
-    const long grid = ((MT + 7) / 8) * 8 * NT;
-    if (grid > 0x7fffffffL) return -12;
-    if (p.up) hipLaunchKernelGGL((conv_halo_s1_kernel<1>), dim3((unsigned)grid), dim3(256), 0, s, p, tiles_y, tiles_x);
-    else hipLaunchKernelGGL((conv_halo_s1_kernel<0>), dim3((unsigned)grid), dim3(256), 0, s, p, tiles_y, tiles_x);
+    const long total = ((MT + 7) / 8) * 8 * NT;
+    if (total > 0x7fffffffL) return -12;
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+        return n & ~7;
+    }();
+    const long grid = total < cus ? total : cus;
+    if (p.up) hipLaunchKernelGGL((conv_halo_s1_kernel<1>), dim3((unsigned)grid), dim3(256), 0, s, p, tiles_y, tiles_x, (int)total);
+    else hipLaunchKernelGGL((conv_halo_s1_kernel<0>), dim3((unsigned)grid), dim3(256), 0, s, p, tiles_y, tiles_x, (int)total);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -1478,7 +1478,7 @@ static bool takes_halo_pp(const IGemmParams& p) {  // the 8-wave ping-pong varia
 int ir_igemm_gn_chunks(const IGemmParams& p) {
     if (p.gn_cpg < 4 || (p.gn_cpg & 3) || p.Cout % p.gn_cpg || p.Cout_pad % 64 || (p.Cout & 3) || p.NB <= 0) return 0;
     if ((p.Cout_pad % 128 == 0 ? 128 : 64) % p.gn_cpg) return 0;
-    if (ir_conv_s1_takes(p)) return ir_conv_s1_tiles(p);
+    if (ir_conv_s1_takes(p)) return (p.gn_cpg <= 32 && !(p.gn_cpg & (p.gn_cpg - 1))) ? ir_conv_s1_tiles(p) : 0;   // its reduction wants 4, 8, 16 or 32 channels per group
     if (takes_halo_pp(p)) return ((p.Ho + 15) / 16) * ((p.Wo + 15) / 16);
     if (takes_halo(p)) return ((p.Ho + 7) / 8) * ((p.Wo + 15) / 16);
     if (p.M % p.NB) return 0;

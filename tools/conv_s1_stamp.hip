@@ -1,0 +1,48 @@
+// Diagnostic: phase times of conv_halo_s1_kernel per workgroup and tile (prologue / main loop / drain + barrier / epilogue passes / GroupNorm
+// reduction) and the in-kernel clock over the main loop.
+// Build:  hipcc --offload-arch=gfx950 -O3 -std=c++20 -ffp-contract=fast -DIR_S1_STAMPS -Iinstarevive_amd/csrc tools/conv_s1_stamp.hip -o tools/conv_s1_stamp
+// Run:    tools/conv_s1_stamp [H W Cin Cout res]
+int g_ir_plain_kernels = 0;
+#include "../instarevive_amd/csrc/conv_s1.hip"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+
+int main(int argc, char** argv) {
+    const int H = argc > 1 ? atoi(argv[1]) : 2048, W = argc > 2 ? atoi(argv[2]) : 2048;
+    const int Cin = argc > 3 ? atoi(argv[3]) : 128, Cout = argc > 4 ? atoi(argv[4]) : 128, use_res = argc > 5 ? atoi(argv[5]) : 0;
+    const size_t nin = (size_t)H * W * Cin, nout = (size_t)H * W * Cout, nw = (size_t)Cout * 9 * Cin;
+    bf16_t *din, *dw, *dout, *dres;
+    float *dbias, *dgn;
+    CK(hipMalloc(&din, nin * 2)); CK(hipMalloc(&dw, nw * 2)); CK(hipMalloc(&dout, nout * 2)); CK(hipMalloc(&dres, nout * 2)); CK(hipMalloc(&dbias, Cout * 4));
+    CK(hipMalloc(&dgn, (size_t)64 << 20));
+    CK(hipMemset(din, 0x3c, nin * 2)); CK(hipMemset(dw, 0x38, nw * 2)); CK(hipMemset(dres, 0x3c, nout * 2)); CK(hipMemset(dbias, 0, Cout * 4));
+    IGemmParams p{};
+    p.in = din; p.NB = 1; p.H = H; p.W = W; p.Cin = Cin; p.in_cs = Cin; p.Ho = H; p.Wo = W; p.taps = 9; p.stride = 1; p.pad = 1;
+    p.wgt = dw; p.wgt_rs = 9 * Cin; p.Cout = Cout; p.Cout_pad = Cout; p.M = H * W; p.bias = dbias; p.act = IR_ACT_NONE; p.out_scale = 1.f;
+    p.out = dout; p.out_cs = Cout;
+    if (use_res) { p.res = dres; p.res_cs = Cout; p.gn_part = dgn; p.gn_cpg = Cout / 32; p.gn_chunks = ir_conv_s1_tiles(p); }
+    hipStream_t st;
+    CK(hipStreamCreate(&st));
+    for (int i = 0; i < 50; ++i) { int rc = ir_launch_conv_s1(p, st); if (rc) { printf("launch rc %d\n", rc); return 1; } }
+    CK(hipStreamSynchronize(st));
+    std::vector<unsigned long long> z(1024 * 8, 0), h(1024 * 8);
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(g_s1_stamps), z.data(), z.size() * 8));
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0, st));
+    for (int i = 0; i < 10; ++i) ir_launch_conv_s1(p, st);
+    CK(hipEventRecord(e1, st));
+    CK(hipStreamSynchronize(st));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= 10;
+    printf("conv %dx%d %d->%d res+gn=%d: %.3f ms  %.1f TFLOP/s\n", H, W, Cin, Cout, use_res, ms, 2.0 * H * W * Cout * 9 * Cin / ms / 1e9);
+    CK(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_s1_stamps), h.size() * 8));
+    double a[6] = {0, 0, 0, 0, 0, 0}, tiles = 0;
+    for (int b = 0; b < 1024; ++b) { for (int k = 0; k < 6; ++k) a[k] += (double)h[b * 8 + k]; tiles += (double)h[b * 8 + 6]; }
+    if (tiles == 0) { printf("no stamps\n"); return 1; }
+    printf("  per tile (us): prologue %.2f, main loop %.2f (%.3f per step), drain+barrier %.2f, passes %.2f, gn reduce %.2f ; sum %.2f\n", a[0] / tiles / 100,
+           a[1] / tiles / 100, a[1] / tiles / 100 / (9.0 * Cin / 32), a[2] / tiles / 100, a[3] / tiles / 100, a[4] / tiles / 100, (a[0] + a[1] + a[2] + a[3] + a[4]) / tiles / 100);
+    printf("  in-kernel clock over the main loop: %.0f MHz ; tiles per workgroup %.1f\n", a[5] / a[1] * 100.0, tiles / 256 / 10);
+    return 0;
+}
