@@ -44,10 +44,10 @@ constexpr int NHB = 3;                         // halo buffers: chunk c lives in
 constexpr int W_OFF = NHB * HALO_BYTES;        // 119 808
 constexpr int LDS_MAIN = W_OFF + NSB * WT_BYTES;   // 152 576
 constexpr int SROW = 132;                      // slab row stride in floats (128 + 4)
-constexpr int SLAB = 32 * SROW * 4;            // 16 896 B per wave
-constexpr int RED_OFF = 4 * SLAB;
-constexpr int LDS_EP = RED_OFF + 4 * 64 * 16;
-constexpr int LDS_BYTES = LDS_MAIN > LDS_EP ? LDS_MAIN : LDS_EP;
+constexpr int SLAB = 16 * SROW * 4;            // 8 448 B per wave: 16 pixels x 128 channels fp32
+constexpr int RED_OFF = 4 * SLAB;              // 33 792; the GroupNorm reduction area (1 KB) follows the slabs inside the same halo buffer
+static_assert(RED_OFF + 4 * 16 * 16 <= HALO_BYTES, "epilogue slabs + reduction area must fit one halo buffer");
+constexpr int LDS_BYTES = LDS_MAIN;
 // halo pieces issued in the step of tap t (10 per chunk, all before tap 6)
 constexpr int nh(int t) { return t < 4 ? 2 : (t < 6 ? 1 : 0); }
 constexpr int nh_first(int t) { return t < 4 ? 2 * t : (t < 6 ? 4 + t : 0); }
@@ -84,284 +84,352 @@ IR_DEVINL float cs1_acc_read() {
 template <int UP>
 __global__ __launch_bounds__(256, 1) void conv_halo_s1_kernel(IGemmParams p, int tiles_y, int tiles_x, int total_vb) {
     using namespace cs1;
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES];   // halo[0..2] | W ring of 4 ; epilogue: slabs | red
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES];   // halo[0..2] | W ring of 4 ; epilogue: slabs + red in ONE halo buffer
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wu = __builtin_amdgcn_readfirstlane(wid);
     const int c16 = lane & 15, kq = lane >> 4;
-
     const int NT = p.Cout_pad / BN;
     const int MT = p.NB * tiles_y * tiles_x;
-    // Persistent workgroups (one per CU): with one workgroup per CU nothing else covers the dispatch of the next one, so every
-    // workgroup walks the virtual block ids bid, bid + gridDim.x, ... itself (gridDim.x is a multiple of 8: the XCD of a virtual block
-    // is the XCD of the workgroup that runs it).
-    for (int bid = blockIdx.x; bid < total_vb; bid += gridDim.x) {
-    const int xcd = bid & 7, jb = bid >> 3;
-    const int mt = (jb / NT) * 8 + xcd, nt = jb % NT;   // an XCD runs the channel tiles of one patch back to back (halo re-read from its L2)
-    if (mt >= MT) continue;
-    __syncthreads();   // the previous tile's epilogue has finished with the LDS
-    IR_S1_T(st0);
-    const int n0 = nt * BN;
-    const int img = mt / (tiles_y * tiles_x), trem = mt - img * tiles_y * tiles_x;
-    const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
-    const int oy0 = ty * TH, ox0 = tx * TW;
     const int Hc = UP ? 2 * p.H : p.H, Wc = UP ? 2 * p.W : p.W;   // conv-input (== output) extent
-    const int chunks = p.Cin / BK;                                  // even (launcher)
-
-    asm volatile(".set ir_cs1_i, 0\n\t.rept 256\n\tv_accvgpr_write_b32 a[ir_cs1_i], 0\n\t.set ir_cs1_i, ir_cs1_i + 1\n\t.endr" ::: IR_AGPR256_CLOBBERS);
-
-    // ---- LDS-DMA sources. Halo piece q covers halo pixels 16q .. 16q+15: lane l -> pixel 16q + (l >> 2), LDS slot l & 3.
+    const int chunks = p.Cin / BK;                                  // a multiple of 4 (launcher): 9 * chunks steps, ring slot = step & 3
     const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page_s1);
-    const bf16_t* h_ptr[H_I];
-#pragma unroll
-    for (int i = 0; i < H_I; ++i) {
-        const int q = min(wu + 4 * i, H_Q - 1);
-        const int hp = q * 16 + (lane >> 2);
-        const int hy = hp / HWD, hx = hp - hy * HWD;
-        const int cy = oy0 + hy - 1, cx = ox0 + hx - 1;
-        const bool ok = hp < HP && cy >= 0 && cy < Hc && cx >= 0 && cx < Wc;
-        const int iy = min(max(cy, 0), Hc - 1) >> UP, ix = min(max(cx, 0), Wc - 1) >> UP;
-        const bf16_t* src = p.in + (((long)img * p.H + iy) * p.W + ix) * p.in_cs;
-        h_ptr[i] = (ok ? src : zero) + (((lane & 3) ^ hkey(hx)) << 3);
-    }
-    const bf16_t* w_ptr[2];   // weight pieces wave, wave + 4: rows 16 j + (l >> 2)
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (wu + 4 * i) * 16 + (lane >> 2);
-        w_ptr[i] = p.wgt + (long)(n0 + row) * p.wgt_rs + (((lane & 3) ^ hkey(row)) << 3);
-    }
-    auto halo_issue = [&](auto ic, int chunk, int buf) {   // piece i of this wave: channels chunk * 32 .. into halo buffer buf
-        constexpr int i = decltype(ic)::value;
-        const int q = min(wu + 4 * i, H_Q - 1);
-        cs1_glds16(h_ptr[i] + chunk * BK, (cs1_lds_t)(smem + buf * HALO_BYTES + q * 1024));
-    };
-    auto w_issue = [&](int chunk, int tap, int slot) {
-        const int koff = tap * p.Cin + chunk * BK;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) cs1_glds16(w_ptr[i] + koff, (cs1_lds_t)(smem + W_OFF + slot * WT_BYTES + (wu + 4 * i) * 1024));
-    };
 
+    // Persistent workgroups (one per CU) walk the virtual block ids bid, bid + gridDim.x, ... (gridDim.x is a multiple of 8: the XCD of a
+    // virtual block is the XCD of the workgroup that runs it), and the LDS-DMA stream runs THROUGH the tile boundary: during the last two
+    // chunks of a tile the "chunk c + 2" fetches bring the first two chunks of the next tile's halo, the last four steps its first four
+    // weight tiles, so the epilogue (whose slabs live in the halo buffer of the tile's last chunk) runs with the next tile's data landing
+    // and there is no prologue between tiles.
+    struct Tile { int img, trem, oy0, ox0, n0; };
+    auto decode = [&](int bid, Tile& t) -> bool {
+        const int xcd = bid & 7, jb = bid >> 3;
+        const int mt = (jb / NT) * 8 + xcd, nt = jb % NT;   // an XCD runs the channel tiles of one patch back to back (halo re-read from its L2)
+        if (bid >= total_vb || mt >= MT) return false;
+        t.n0 = nt * BN;
+        t.img = mt / (tiles_y * tiles_x);
+        t.trem = mt - t.img * tiles_y * tiles_x;
+        const int ty = t.trem / tiles_x, tx = t.trem - ty * tiles_x;
+        t.oy0 = ty * TH; t.ox0 = tx * TW;
+        return true;
+    };
+    // ---- LDS-DMA sources of a tile. Halo piece q covers halo pixels 16q .. 16q+15: lane l -> pixel 16q + (l >> 2), LDS slot l & 3.
+    // Kept as 32-bit offsets in 16-byte units from p.in (bit 31: the pixel is padding -> the same offset into the zero page, which is
+    // only ever the chunk offset): two tiles' worth of descriptors must fit beside 128 fragment registers.
+    auto describe = [&](const Tile& t, uint32_t (&hp)[H_I], uint32_t (&wp)[2]) {
+#pragma unroll
+        for (int i = 0; i < H_I; ++i) {
+            const int q = min(wu + 4 * i, H_Q - 1);
+            const int hpix = q * 16 + (lane >> 2);
+            const int hy = hpix / HWD, hx = hpix - hy * HWD;
+            const int cy = t.oy0 + hy - 1, cx = t.ox0 + hx - 1;
+            const bool ok = hpix < HP && cy >= 0 && cy < Hc && cx >= 0 && cx < Wc;
+            const int iy = min(max(cy, 0), Hc - 1) >> UP, ix = min(max(cx, 0), Wc - 1) >> UP;
+            const long pix = ((long)t.img * p.H + iy) * p.W + ix;
+            const uint32_t sw = (uint32_t)((lane & 3) ^ hkey(hx));
+            hp[i] = ok ? (uint32_t)((pix * p.in_cs) >> 3) + sw : (0x80000000u | sw);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {   // weight pieces wave, wave + 4: rows 16 j + (l >> 2)
+            const int row = (wu + 4 * i) * 16 + (lane >> 2);
+            wp[i] = (uint32_t)(((long)(t.n0 + row) * p.wgt_rs) >> 3) + (uint32_t)((lane & 3) ^ hkey(row));
+        }
+    };
     // ---- fragment read addresses. Pixel fragment (patch row 4w + a, half mx) of tap (ky, kx): halo pixel (4w + a + ky, 16 mx + kx + c16),
     // chunk kq; the row term is an immediate. Weight fragment ct: row 16 ct + c16, chunk kq; ct * 1024 is an immediate.
     const uint32_t lds0 = lds_addr(smem);
-    uint32_t hrd[3][2];
+    uint32_t hrd[3];   // half mx = 1 is 16 pixels = 1024 bytes further (hkey has period 8 in hx): an immediate
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-        for (int mx = 0; mx < 2; ++mx) {
-            const int hx = 16 * mx + kx + c16;
-            hrd[kx][mx] = lds0 + ((4 * wid) * HWD + hx) * ROWB + ((kq ^ hkey(hx)) << 4);
-        }
+    for (int kx = 0; kx < 3; ++kx) {
+        const int hx = kx + c16;
+        hrd[kx] = lds0 + ((4 * wid) * HWD + hx) * ROWB + ((kq ^ hkey(hx)) << 4);
+    }
     const uint32_t wrd = lds0 + W_OFF + c16 * ROWB + ((kq ^ hkey(c16)) << 4);
-
     bf16x8 fw[2][8], fp[2][8];   // [set][channel fragment] / [set][pixel fragment = a * 2 + mx]
 
-    // ---- prologue: halo of chunk 0, weight tiles of steps 0..3, halo of chunk 1 (left in flight), fragments of step 0
+    Tile cur, nxt;
+    int bid = blockIdx.x;
+    while (bid < total_vb && !decode(bid, cur)) bid += gridDim.x;
+    if (bid >= total_vb) return;
+    uint32_t h_ptr[H_I], h_nxt[H_I], w_ptr[2], w_nxt[2];
+    describe(cur, h_ptr, w_ptr);
+
+    auto halo_issue = [&](auto ic, int ci, int buf) {   // piece i of this wave of halo chunk ci (>= chunks: of the next tile) into halo buffer buf
+        constexpr int i = decltype(ic)::value;
+        const int q = min(wu + 4 * i, H_Q - 1);
+        const bool mine = ci < chunks;
+        const uint32_t d = mine ? h_ptr[i] : h_nxt[i];
+        const unsigned char* base = reinterpret_cast<const unsigned char*>((d >> 31) ? zero : p.in);
+        const unsigned char* src = base + ((unsigned long long)(d & 0x7fffffffu) << 4) + (mine ? ci : ci - chunks) * (BK * 2);
+        cs1_glds16(src, (cs1_lds_t)(smem + buf * HALO_BYTES + q * 1024));
+    };
+    auto w_issue = [&](int chunk, int tap, bool mine, int slot) {
+        const int koff = tap * p.Cin + chunk * BK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            cs1_glds16(reinterpret_cast<const unsigned char*>(p.wgt) + ((unsigned long long)(mine ? w_ptr[i] : w_nxt[i]) << 4) + koff * 2,
+                       (cs1_lds_t)(smem + W_OFF + slot * WT_BYTES + (wu + 4 * i) * 1024));
+    };
+
+    // ---- prologue of the FIRST tile only: halo of chunk 0, weight tiles of steps 0..3, halo of chunk 1
+    int hb3 = 0;   // halo buffer of the current chunk; advances by one per chunk, across tiles
     [&]<int... I>(std::integer_sequence<int, I...>) { (halo_issue(std::integral_constant<int, I>{}, 0, 0), ...); }(std::make_integer_sequence<int, H_I>{});
 #pragma unroll
-    for (int t = 0; t < NSB; ++t) w_issue(0, t, t);
+    for (int t = 0; t < NSB; ++t) w_issue(0, t, true, t);
     [&]<int... I>(std::integer_sequence<int, I...>) { (halo_issue(std::integral_constant<int, I>{}, 1, 1), ...); }(std::make_integer_sequence<int, H_I>{});
-    wait_vm<H_I>();
-    __syncthreads();
-    [&]<int... R>(std::integer_sequence<int, R...>) {
-        ([&] {
-            if constexpr (R < 8) fw[0][R] = lds_read16<R * 1024>(wrd);
-            else fp[0][R - 8] = lds_read16<((R - 8) >> 1) * HWD * ROWB>(hrd[0][(R - 8) & 1]);
-        }(), ...);
-    }(std::make_integer_sequence<int, 16>{});
-    wait_lds<0>();
 
-    auto step = [&](auto tc, auto setc, int c, int hbuf) {   // hbuf = c % 3
+    auto step = [&](auto tc, auto setc, int c, int hbuf) {   // hbuf = halo buffer of chunk c
         constexpr int T = decltype(tc)::value, SET = decltype(setc)::value;
         constexpr int TNX = (T + 1) % 9, KXN = TNX % 3, KYN = TNX / 3;
         const int s = c * 9 + T;
         const uint32_t hb = (uint32_t)(T == 8 ? (hbuf == 2 ? 0 : hbuf + 1) : hbuf) * HALO_BYTES;
-        const int hfill = hbuf == 0 ? 2 : hbuf - 1;   // (c + 2) % 3: the buffer chunk c - 1 was read from
-        const uint32_t ha0 = hrd[KXN][0] + hb, ha1 = hrd[KXN][1] + hb;
+        const int hfill = hbuf == 0 ? 2 : hbuf - 1;   // buffer of chunk c + 2 = the one chunk c - 1 was read from
+        const uint32_t ha = hrd[KXN] + hb;
         const uint32_t wa = wrd + (uint32_t)((s + 1) & 3) * WT_BYTES;
-        // weight tile s + 4 = (chunk cw, tap tw), clamped to the last tile
+        // weight tile s + 4 = (chunk cw, tap tw); past the end: tile s + 4 - steps (chunk 0, taps 0..3) of the next tile
         constexpr int TW4 = (T + 4) % 9;
         int cw = c + (T + 4 >= 9 ? 1 : 0), tw = TW4;
-        if (cw >= chunks) { cw = chunks - 1; tw = 8; }
-        const int ch_next = min(c + 2, chunks - 1);
+        const bool wmine = cw < chunks;
+        if (!wmine) cw = 0;
+        // The address arithmetic of this step's LDS-DMA pieces is spread over the MFMA gaps, at most three vector instructions per gap (a
+        // wave issues in order: ten instructions in one gap hold the next MFMA back by about 25 cycles). Halo piece A: gaps 0-3, piece B:
+        // gaps 4-7, weight pieces: gaps 9-10 and 12-13.
+        uint32_t hd[2];
+        const unsigned char* hbase[2];
+        const unsigned char* hsrc[2];
+        const unsigned char* wsrc[2];
+        const bool hmine = c + 2 < chunks;
+        const int hoff = (hmine ? c + 2 : c + 2 - chunks) * (BK * 2);
+        const int wkoff = (tw * p.Cin + cw * BK) * 2;
+        auto halo_stage = [&](auto kc, auto stc) {   // piece k (0 / 1) of this step, stage 0..3
+            constexpr int K = decltype(kc)::value, ST = decltype(stc)::value;
+            constexpr int PI = nh(T) > K ? nh_first(T) + K : 0;
+            if constexpr (ST == 0) hd[K] = hmine ? h_ptr[PI] : h_nxt[PI];
+            if constexpr (ST == 1) hbase[K] = reinterpret_cast<const unsigned char*>((hd[K] >> 31) ? zero : p.in);
+            if constexpr (ST == 2) hsrc[K] = hbase[K] + ((unsigned long long)(hd[K] & 0x7fffffffu) << 4);
+            if constexpr (ST == 3) {
+                const int q = min(wu + 4 * PI, H_Q - 1);
+                cs1_glds16(hsrc[K] + hoff, (cs1_lds_t)(smem + hfill * HALO_BYTES + q * 1024));
+            }
+        };
         [&]<int... I>(std::integer_sequence<int, I...>) {
             ([&] {
                 constexpr int PT = I >> 3, CT = I & 7;
                 if constexpr ((I & 3) == 0 && IR_KO_S1 != 6) {   // one fragment of the next step per four MFMAs, into the other set
                     constexpr int R = I >> 2;
                     if constexpr (R < 8) fw[SET ^ 1][R] = lds_read16<R * 1024>(wa);
-                    else fp[SET ^ 1][R - 8] = lds_read16<(((R - 8) >> 1) + KYN) * HWD * ROWB>(((R - 8) & 1) ? ha1 : ha0);
+                    else fp[SET ^ 1][R - 8] = lds_read16<(((R - 8) >> 1) + KYN) * HWD * ROWB + ((R - 8) & 1) * 1024>(ha);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 cs1_mfma<4 * I>(fw[SET][CT], fp[SET][PT]);
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (I == 1 && nh(T) > 0 && IR_KO_S1 != 4) {
-                    halo_issue(std::integral_constant<int, nh_first(T)>{}, ch_next, hfill);
+                if constexpr (I < 4 && nh(T) > 0 && IR_KO_S1 != 4) {
+                    halo_stage(std::integral_constant<int, 0>{}, std::integral_constant<int, I>{});
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if constexpr (I == 5 && nh(T) > 1 && IR_KO_S1 != 4) {
-                    halo_issue(std::integral_constant<int, (nh(T) > 1 ? nh_first(T) + 1 : 0)>{}, ch_next, hfill);
+                if constexpr (I >= 4 && I < 8 && nh(T) > 1 && IR_KO_S1 != 4) {
+                    halo_stage(std::integral_constant<int, 1>{}, std::integral_constant<int, I - 4>{});
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if constexpr (I == 9 && IR_KO_S1 != 5) {
-                    w_issue(cw, tw, s & 3);
+                if constexpr ((I == 9 || I == 12) && IR_KO_S1 != 5) {
+                    constexpr int K = I == 9 ? 0 : 1;
+                    wsrc[K] = reinterpret_cast<const unsigned char*>(p.wgt) + ((unsigned long long)(wmine ? w_ptr[K] : w_nxt[K]) << 4);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr ((I == 10 || I == 13) && IR_KO_S1 != 5) {
+                    constexpr int K = I == 10 ? 0 : 1;
+                    cs1_glds16(wsrc[K] + wkoff, (cs1_lds_t)(smem + W_OFF + (s & 3) * WT_BYTES + (wu + 4 * K) * 1024));
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }(), ...);
         }(std::make_integer_sequence<int, 64>{});
         wait_lds<0>();
         // everything but the pieces of this step and the previous one has landed: the weight tile of step s + 2 (read during step s + 1)
-        // and, before tap 8, the next chunk's halo (its last piece is issued at tap 5)
+        // and, before tap 8, the next chunk's halo (its last piece was issued a chunk ago)
         wait_vm<(IR_KO_S1 == 5 ? 0 : 4) + (IR_KO_S1 == 4 ? 0 : nh((T + 8) % 9) + nh(T))>();
         __builtin_amdgcn_sched_barrier(0);
         if (IR_KO_S1 != 7) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     };
-    IR_S1_T(st1);
-#ifdef IR_S1_STAMPS
-    const unsigned long long sc0 = __builtin_amdgcn_s_memtime();
-#endif
-    if (IR_KO_S1 != 2 && IR_KO_S1 != 3)
-    for (int c = 0, hb3 = 0; c < chunks; c += 2) {
-        const int hb3b = hb3 == 2 ? 0 : hb3 + 1;
-        [&]<int... U>(std::integer_sequence<int, U...>) { (step(std::integral_constant<int, U>{}, std::integral_constant<int, (U & 1)>{}, c, hb3), ...); }(std::make_integer_sequence<int, 9>{});
-        [&]<int... U>(std::integer_sequence<int, U...>) { (step(std::integral_constant<int, U>{}, std::integral_constant<int, ((U + 1) & 1)>{}, c + 1, hb3b), ...); }(std::make_integer_sequence<int, 9>{});
-        hb3 = hb3b == 2 ? 0 : hb3b + 1;
-    }
 
-    // ---- epilogue
-    IR_S1_T(st2);
-#ifdef IR_S1_STAMPS
-    if (tid == 0) g_s1_stamps[blockIdx.x * 8 + 5] += __builtin_amdgcn_s_memtime() - sc0;
-#endif
-    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // the last MFMA results -> v_accvgpr_read
-    wait_dma();        // the re-read pieces past the end must have landed before the slabs overlay the ring
-    __syncthreads();
-    IR_S1_T(st3);
-    float* slab = reinterpret_cast<float*>(smem + wid * SLAB);
-    const int co8 = (lane & 15) * 8, xq = lane >> 4;
-    const float osc = p.out_scale;
-    f32x4 bias4[8];   // bias * out_scale: the slab write is one fused multiply-add per value
-#pragma unroll
-    for (int ct = 0; ct < 8; ++ct)
-        bias4[ct] = (p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n0 + 16 * ct + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f}) * osc;
-    f32x4 sA4 = {0.f, 0.f, 0.f, 0.f}, qA4 = sA4, sB4 = sA4, qB4 = sA4;   // GroupNorm partials, channels co8 .. +3 and co8+4 .. +7
-    // Row it of a pass is pixel (oyw + A, oxl + 4 it): per-lane base pointers once per tile, uniform offsets per pass and row
-    const int oyw = oy0 + 4 * wid, oxl = ox0 + xq;
-    unsigned xm = 0;   // bit it: column oxl + 4 it lies inside the image
-#pragma unroll
-    for (int it = 0; it < 8; ++it) xm |= (oxl + 4 * it < p.Wo ? 1u : 0u) << it;
-    const long pix0 = ((long)img * p.Ho + oyw) * p.Wo + oxl;
-    bf16_t* obase = reinterpret_cast<bf16_t*>(p.out) + pix0 * p.out_cs + n0 + co8;
-    const bf16_t* rbase = reinterpret_cast<const bf16_t*>(p.res) + pix0 * p.res_cs + n0 + co8;
-    const bf16_t* rsafe = reinterpret_cast<const bf16_t*>(p.res) + (((long)img * p.Ho + oy0) * p.Wo + ox0) * p.res_cs + n0 + co8;   // always inside
-    const long o_row = (long)p.Wo * p.out_cs, r_row = (long)p.Wo * p.res_cs;
-    const bool do_gn = p.gn_part != nullptr;
-    uint4 rrb[2][8];   // residual rows of the pass being finished / of the next pass
-    auto res_fetch = [&](int a) {   // rows outside the image read a safe pixel
-        const bool yok = oyw + a < p.Ho;
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const bool v = yok && ((xm >> it) & 1);
-            rrb[a & 1][it] = *reinterpret_cast<const uint4*>(v ? rbase + a * r_row + (long)(4 * it) * p.res_cs : rsafe);
-        }
-    };
-    auto pass = [&](auto ac, auto resc) {
-        constexpr int A = decltype(ac)::value;
-        constexpr bool RES = decltype(resc)::value;
-        const bool yok = oyw + A < p.Ho;
-        uint4 (&rr)[8] = rrb[A & 1];
-        if constexpr (RES && A < 3) res_fetch(A + 1);   // the next pass's residual rows fly during this pass
-        [&]<int... J>(std::integer_sequence<int, J...>) {
+    for (;;) {
+        IR_S1_T(st0);
+        // the next tile of this workgroup (none: the stream re-reads the current one, into buffers nobody reads again)
+        int nbid = bid + gridDim.x;
+        while (nbid < total_vb && !decode(nbid, nxt)) nbid += gridDim.x;
+        const bool more = nbid < total_vb;
+        if (!more) nxt = cur;
+        describe(nxt, h_nxt, w_nxt);
+        asm volatile(".set ir_cs1_i, 0\n\t.rept 256\n\tv_accvgpr_write_b32 a[ir_cs1_i], 0\n\t.set ir_cs1_i, ir_cs1_i + 1\n\t.endr" ::: IR_AGPR256_CLOBBERS);
+        // everything in flight has landed (first tile: the prologue; later: the pieces fetched through the tile boundary and the previous
+        // epilogue's stores) - chunk 1's halo included, which costs nothing after an epilogue and ~1 us once per workgroup
+        wait_dma();
+        __syncthreads();
+        [&]<int... R>(std::integer_sequence<int, R...>) {
             ([&] {
-                constexpr int MX = J >> 3, CT = J & 7, LO = 4 * ((A * 2 + MX) * 8 + CT);
-                f32x4 v = f32x4{cs1_acc_read<LO>(), cs1_acc_read<LO + 1>(), cs1_acc_read<LO + 2>(), cs1_acc_read<LO + 3>()};
-                v = v * osc + bias4[CT];
-                *reinterpret_cast<f32x4*>(&slab[(16 * MX + c16) * SROW + 16 * CT + 4 * kq]) = v;
+                if constexpr (R < 8) fw[0][R] = lds_read16<R * 1024>(wrd);
+                else fp[0][R - 8] = lds_read16<((R - 8) >> 1) * HWD * ROWB + ((R - 8) & 1) * 1024>(hrd[0] + (uint32_t)hb3 * HALO_BYTES);
             }(), ...);
         }(std::make_integer_sequence<int, 16>{});
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        f32x4 lo[8], hi[8];
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            lo[it] = *reinterpret_cast<const f32x4*>(&slab[(4 * it + xq) * SROW + co8]);
-            hi[it] = *reinterpret_cast<const f32x4*>(&slab[(4 * it + xq) * SROW + co8 + 4]);
+        wait_lds<0>();
+        IR_S1_T(st1);
+#ifdef IR_S1_STAMPS
+        const unsigned long long sc0 = __builtin_amdgcn_s_memtime();
+#endif
+        if (IR_KO_S1 != 2 && IR_KO_S1 != 3)
+        for (int c = 0; c < chunks; c += 2) {
+            const int hb3b = hb3 == 2 ? 0 : hb3 + 1;
+            [&]<int... U>(std::integer_sequence<int, U...>) { (step(std::integral_constant<int, U>{}, std::integral_constant<int, (U & 1)>{}, c, hb3), ...); }(std::make_integer_sequence<int, 9>{});
+            [&]<int... U>(std::integer_sequence<int, U...>) { (step(std::integral_constant<int, U>{}, std::integral_constant<int, ((U + 1) & 1)>{}, c + 1, hb3b), ...); }(std::make_integer_sequence<int, 9>{});
+            hb3 = hb3b == 2 ? 0 : hb3b + 1;
         }
+        // hb3 is now the buffer of the next tile's chunk 0; the last chunk of this tile was read from the one before it
+
+        // ---- epilogue: half a patch row (16 pixels x 128 channels) per wave at a time through a slab in the dead halo buffer
+        IR_S1_T(st2);
+#ifdef IR_S1_STAMPS
+        if (tid == 0) g_s1_stamps[blockIdx.x * 8 + 5] += __builtin_amdgcn_s_memtime() - sc0;
+#endif
+        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // the last MFMA results -> v_accvgpr_read
+        IR_S1_T(st3);
+        unsigned char* ebuf = smem + (hb3 == 0 ? 2 : hb3 - 1) * HALO_BYTES;   // every wave passed the last barrier after its last read of it
+        float* slab = reinterpret_cast<float*>(ebuf + wid * SLAB);
+        const int co8 = (lane & 15) * 8, xq = lane >> 4;
+        const int n0 = cur.n0, img = cur.img, oy0 = cur.oy0, ox0 = cur.ox0;
+        const float osc = p.out_scale;
+        f32x4 bias4[8];   // bias * out_scale: the slab write is one fused multiply-add per value
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            f32x4 a = lo[it], b = hi[it];
-            if constexpr (RES) {
-                a += f32x4{bflo(rr[it].x), bfhi(rr[it].x), bflo(rr[it].y), bfhi(rr[it].y)};
-                b += f32x4{bflo(rr[it].z), bfhi(rr[it].z), bflo(rr[it].w), bfhi(rr[it].w)};
+        for (int ct = 0; ct < 8; ++ct)
+            bias4[ct] = (p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n0 + 16 * ct + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f}) * osc;
+        f32x4 sA4 = {0.f, 0.f, 0.f, 0.f}, qA4 = sA4, sB4 = sA4, qB4 = sA4;   // GroupNorm partials, channels co8 .. +3 and co8+4 .. +7
+        // Row it of a pass is pixel (oyw + A, oxl + 4 it): per-lane base pointers once per tile, uniform offsets per pass and row
+        const int oyw = oy0 + 4 * wid, oxl = ox0 + xq;
+        unsigned xm = 0;   // bit it: column oxl + 4 it lies inside the image
+#pragma unroll
+        for (int it = 0; it < 8; ++it) xm |= (oxl + 4 * it < p.Wo ? 1u : 0u) << it;
+        const long pix0 = ((long)img * p.Ho + oyw) * p.Wo + oxl;
+        bf16_t* obase = reinterpret_cast<bf16_t*>(p.out) + pix0 * p.out_cs + n0 + co8;
+        const bf16_t* rbase = reinterpret_cast<const bf16_t*>(p.res) + pix0 * p.res_cs + n0 + co8;
+        const bf16_t* rsafe = reinterpret_cast<const bf16_t*>(p.res) + (((long)img * p.Ho + oy0) * p.Wo + ox0) * p.res_cs + n0 + co8;   // always inside
+        const long o_row = (long)p.Wo * p.out_cs, r_row = (long)p.Wo * p.res_cs;
+        const bool do_gn = p.gn_part != nullptr;
+        uint4 rrb[2][8];   // residual rows of the pass being finished / of the next pass
+        auto res_fetch = [&](int a) {   // rows outside the image read a safe pixel
+            const bool yok = oyw + a < p.Ho;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const bool v = yok && ((xm >> it) & 1);
+                rrb[a & 1][it] = *reinterpret_cast<const uint4*>(v ? rbase + a * r_row + (long)(4 * it) * p.res_cs : rsafe);
             }
-            const uint4 pk = make_uint4(pack2bf_valu(a[0], a[1]), pack2bf_valu(a[2], a[3]), pack2bf_valu(b[0], b[1]), pack2bf_valu(b[2], b[3]));
-            if (yok && ((xm >> it) & 1)) {
-                *reinterpret_cast<uint4*>(obase + A * o_row + (long)(4 * it) * p.out_cs) = pk;
-                if (do_gn) {   // statistics of the values as stored (bf16-rounded)
-                    const f32x4 ar = {bflo(pk.x), bfhi(pk.x), bflo(pk.y), bfhi(pk.y)}, br = {bflo(pk.z), bfhi(pk.z), bflo(pk.w), bfhi(pk.w)};
-                    sA4 += ar; qA4 += ar * ar;
-                    sB4 += br; qB4 += br * br;
+        };
+        auto pass = [&](auto ac, auto resc) {
+            constexpr int A = decltype(ac)::value;
+            constexpr bool RES = decltype(resc)::value;
+            const bool yok = oyw + A < p.Ho;
+            uint4 (&rr)[8] = rrb[A & 1];
+            if constexpr (RES && A < 3) res_fetch(A + 1);   // the next pass's residual rows fly during this pass
+            [&]<int... MXS>(std::integer_sequence<int, MXS...>) {
+                ([&] {
+                    constexpr int MX = MXS;
+                    [&]<int... CTS>(std::integer_sequence<int, CTS...>) {
+                        ([&] {
+                            constexpr int CT = CTS, LO = 4 * ((A * 2 + MX) * 8 + CT);
+                            f32x4 v = f32x4{cs1_acc_read<LO>(), cs1_acc_read<LO + 1>(), cs1_acc_read<LO + 2>(), cs1_acc_read<LO + 3>()};
+                            v = v * osc + bias4[CT];
+                            *reinterpret_cast<f32x4*>(&slab[c16 * SROW + 16 * CT + 4 * kq]) = v;
+                        }(), ...);
+                    }(std::make_integer_sequence<int, 8>{});
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    f32x4 lo[4], hi[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        lo[j] = *reinterpret_cast<const f32x4*>(&slab[(4 * j + xq) * SROW + co8]);
+                        hi[j] = *reinterpret_cast<const f32x4*>(&slab[(4 * j + xq) * SROW + co8 + 4]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int it = 4 * MX + j;   // pixel column oxl + 4 it
+                        f32x4 a = lo[j], b = hi[j];
+                        if constexpr (RES) {
+                            a += f32x4{bflo(rr[it].x), bfhi(rr[it].x), bflo(rr[it].y), bfhi(rr[it].y)};
+                            b += f32x4{bflo(rr[it].z), bfhi(rr[it].z), bflo(rr[it].w), bfhi(rr[it].w)};
+                        }
+                        const uint4 pk = make_uint4(pack2bf_valu(a[0], a[1]), pack2bf_valu(a[2], a[3]), pack2bf_valu(b[0], b[1]), pack2bf_valu(b[2], b[3]));
+                        if (yok && ((xm >> it) & 1)) {
+                            *reinterpret_cast<uint4*>(obase + A * o_row + (long)(4 * it) * p.out_cs) = pk;
+                            if (do_gn) {   // statistics of the values as stored (bf16-rounded)
+                                const f32x4 ar = {bflo(pk.x), bfhi(pk.x), bflo(pk.y), bfhi(pk.y)}, br = {bflo(pk.z), bfhi(pk.z), bflo(pk.w), bfhi(pk.w)};
+                                sA4 += ar; qA4 += ar * ar;
+                                sB4 += br; qB4 += br * br;
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }(), ...);
+            }(std::make_integer_sequence<int, 2>{});
+        };
+        if (IR_KO_S1 != 1 && IR_KO_S1 != 3) {
+            if (p.res) {
+                res_fetch(0);
+                pass(std::integral_constant<int, 0>{}, std::true_type{});
+                pass(std::integral_constant<int, 1>{}, std::true_type{});
+                pass(std::integral_constant<int, 2>{}, std::true_type{});
+                pass(std::integral_constant<int, 3>{}, std::true_type{});
+            } else {
+                pass(std::integral_constant<int, 0>{}, std::false_type{});
+                pass(std::integral_constant<int, 1>{}, std::false_type{});
+                pass(std::integral_constant<int, 2>{}, std::false_type{});
+                pass(std::integral_constant<int, 3>{}, std::false_type{});
+            }
+        }
+        IR_S1_T(st4);
+        if (p.gn_part && IR_KO_S1 == 0) {
+            // Fixed-order workgroup reduction (no atomics, bit-identical run to run). Unit u = 4 channels; lane (L = lane & 15) holds units 2L and
+            // 2L+1 over the pixel columns xq, xq + 4, ...: first the four column classes of a wave (lanes L, L+16, L+32, L+48), then the four
+            // waves through LDS, then the units of a group.
+            const float sA = (sA4[0] + sA4[1]) + (sA4[2] + sA4[3]), qA = (qA4[0] + qA4[1]) + (qA4[2] + qA4[3]);
+            const float sB = (sB4[0] + sB4[1]) + (sB4[2] + sB4[3]), qB = (qB4[0] + qB4[1]) + (qB4[2] + qB4[3]);
+            f32x4 v = {sA, qA, sB, qB};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[e] += __shfl_xor(v[e], 16);
+                v[e] += __shfl_xor(v[e], 32);
+            }
+            float* red = reinterpret_cast<float*>(ebuf + RED_OFF);   // [wave][L][4]
+            if (lane < 16) *reinterpret_cast<f32x4*>(&red[(wid * 16 + lane) * 4]) = v;
+            __syncthreads();
+            if (tid < 32) {   // thread u: unit u of the 32 units of this channel tile
+                const int L = tid >> 1, hf = (tid & 1) * 2;
+                float a = (red[(0 * 16 + L) * 4 + hf] + red[(1 * 16 + L) * 4 + hf]) + (red[(2 * 16 + L) * 4 + hf] + red[(3 * 16 + L) * 4 + hf]);
+                float b = (red[(0 * 16 + L) * 4 + hf + 1] + red[(1 * 16 + L) * 4 + hf + 1]) + (red[(2 * 16 + L) * 4 + hf + 1] + red[(3 * 16 + L) * 4 + hf + 1]);
+                const int upg = p.gn_cpg >> 2;   // units per group: 1, 2, 4 or 8 (launcher)
+                for (int m = 1; m < upg; m <<= 1) {
+                    a += __shfl_xor(a, m);
+                    b += __shfl_xor(b, m);
+                }
+                if ((tid & (upg - 1)) == 0) {
+                    const int G = p.Cout / p.gn_cpg, g = n0 / p.gn_cpg + tid / upg;
+                    float* dst = p.gn_part + ((long)img * p.gn_chunks + cur.trem) * 2 * G;
+                    dst[g] = a;
+                    dst[G + g] = b;
                 }
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    };
-    if (IR_KO_S1 != 1 && IR_KO_S1 != 3) {
-        if (p.res) {
-            res_fetch(0);
-            pass(std::integral_constant<int, 0>{}, std::true_type{});
-            pass(std::integral_constant<int, 1>{}, std::true_type{});
-            pass(std::integral_constant<int, 2>{}, std::true_type{});
-            pass(std::integral_constant<int, 3>{}, std::true_type{});
-        } else {
-            pass(std::integral_constant<int, 0>{}, std::false_type{});
-            pass(std::integral_constant<int, 1>{}, std::false_type{});
-            pass(std::integral_constant<int, 2>{}, std::false_type{});
-            pass(std::integral_constant<int, 3>{}, std::false_type{});
-        }
-    }
-    IR_S1_T(st4);
-    const float sA = (sA4[0] + sA4[1]) + (sA4[2] + sA4[3]), qA = (qA4[0] + qA4[1]) + (qA4[2] + qA4[3]);
-    const float sB = (sB4[0] + sB4[1]) + (sB4[2] + sB4[3]), qB = (qB4[0] + qB4[1]) + (qB4[2] + qB4[3]);
-    if (p.gn_part && IR_KO_S1 == 0) {
-        // Fixed-order workgroup reduction (no atomics, bit-identical run to run). Unit u = 4 channels; lane (L = lane & 15) holds units 2L and
-        // 2L+1 over the pixel columns xq, xq + 4, ...: first the four column classes of a wave (lanes L, L+16, L+32, L+48), then the four
-        // waves through LDS, then the units of a group.
-        f32x4 v = {sA, qA, sB, qB};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            v[e] += __shfl_xor(v[e], 16);
-            v[e] += __shfl_xor(v[e], 32);
-        }
-        float* red = reinterpret_cast<float*>(smem + RED_OFF);   // [wave][L][4]
-        if (lane < 16) *reinterpret_cast<f32x4*>(&red[(wid * 16 + lane) * 4]) = v;
-        __syncthreads();
-        if (tid < 32) {   // thread u: unit u of the 32 units of this channel tile
-            const int L = tid >> 1, hf = (tid & 1) * 2;
-            float a = (red[(0 * 16 + L) * 4 + hf] + red[(1 * 16 + L) * 4 + hf]) + (red[(2 * 16 + L) * 4 + hf] + red[(3 * 16 + L) * 4 + hf]);
-            float b = (red[(0 * 16 + L) * 4 + hf + 1] + red[(1 * 16 + L) * 4 + hf + 1]) + (red[(2 * 16 + L) * 4 + hf + 1] + red[(3 * 16 + L) * 4 + hf + 1]);
-            const int upg = p.gn_cpg >> 2;   // units per group: 1, 2, 4 or 8 (launcher)
-            for (int m = 1; m < upg; m <<= 1) {
-                a += __shfl_xor(a, m);
-                b += __shfl_xor(b, m);
-            }
-            if ((tid & (upg - 1)) == 0) {
-                const int G = p.Cout / p.gn_cpg, g = n0 / p.gn_cpg + tid / upg;
-                float* dst = p.gn_part + ((long)img * p.gn_chunks + trem) * 2 * G;
-                dst[g] = a;
-                dst[G + g] = b;
-            }
-        }
-    }
-    IR_S1_T(st5);
-    IR_S1_ACC(0, st0, st1); IR_S1_ACC(1, st1, st2); IR_S1_ACC(2, st2, st3); IR_S1_ACC(3, st3, st4); IR_S1_ACC(4, st4, st5);
+        IR_S1_T(st5);
+        IR_S1_ACC(0, st0, st1); IR_S1_ACC(1, st1, st2); IR_S1_ACC(2, st2, st3); IR_S1_ACC(3, st3, st4); IR_S1_ACC(4, st4, st5);
 #ifdef IR_S1_STAMPS
-    if (tid == 0) g_s1_stamps[blockIdx.x * 8 + 6] += 1;
+        if (tid == 0) g_s1_stamps[blockIdx.x * 8 + 6] += 1;
 #endif
-    }   // persistent loop
+        if (!more) break;
+        bid = nbid;
+        cur = nxt;
+#pragma unroll
+        for (int i = 0; i < H_I; ++i) h_ptr[i] = h_nxt[i];
+        w_ptr[0] = w_nxt[0]; w_ptr[1] = w_nxt[1];
+    }
+    wait_dma();   // the stream's last fetches (a re-read of this tile) must not outlive the workgroup's LDS allocation
 }
 
 // Which launches take this kernel (everything else of the halo family stays with conv_halo_pp_kernel / conv_halo_kernel): plain bf16
@@ -370,7 +438,7 @@ __global__ __launch_bounds__(256, 1) void conv_halo_s1_kernel(IGemmParams p, int
 bool ir_conv_s1_takes(const IGemmParams& p) {
     static const bool off = getenv("IR_NO_CONV_S1") != nullptr;   // experiment knob
     if (off || g_ir_plain_kernels || p.fp8 || p.force_generic) return false;
-    if (p.taps != 9 || p.stride != 1 || p.pad != 1 || (p.Cin & 63) || p.Cin < 128) return false;
+    if (p.taps != 9 || p.stride != 1 || p.pad != 1 || (p.Cin & 127)) return false;   // chunks % 4 == 0: the weight ring runs through tile boundaries
     if (p.Cout != p.Cout_pad || p.Cout_pad % 128) return false;
     if (p.act != IR_ACT_NONE || p.gate || p.out2 || p.out_f32) return false;
     if (p.res && (p.res_f32 || p.res_mod > 0 || (p.res_cs & 7) || (reinterpret_cast<uintptr_t>(p.res) & 15))) return false;
