@@ -356,7 +356,7 @@ def main():
             if os.path.exists(pmc) and not args.tiled and (h, w, n) == (2048, 2048, 1) and not args.fp8:
                 traffic = json.load(open(pmc))["hbm_bytes_per_launch"]
                 traffic_src = f"static: profiles/{PMC_FILE} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command, not this run)"
-            roof = dict(bound="mfma", kernel="igemm.hip family: conv_halo_pp_kernel + conv_halo_kernel + igemm_kernel + gemm_pp_kernel + swin_mlp_kernel (3x3-conv + linear launches)", achieved=round(ach, 2), peak=peak_tflops, unit="TFLOP/s",
+            roof = dict(bound="mfma", kernel="conv / GEMM family: conv_halo_s1_kernel + conv_halo_pp_kernel + conv_halo_kernel + igemm_kernel + gemm_pp_kernel + swin_mlp_kernel (3x3-conv + linear launches)", achieved=round(ach, 2), peak=peak_tflops, unit="TFLOP/s",
                         frac=round(ach / peak_tflops, 4), traffic=traffic, traffic_source=traffic_src, launches_per_step=launches // args.steps,
                         avg_launch_ms=round(ig_ms / max(launches, 1), 4), share_of_gpu_time=round(ig_ms / total_ms, 3),
                         algorithmic_tflop_per_step=round(alg / args.steps / 1e12, 2))

@@ -38,7 +38,7 @@ launches = step_launches or sum(fc[k] for k in fam) / passes
 hbm = (2.0 * f_kb + w_kb) * 1024.0
 calib = {k: {"fetch_kb": fetch[k] / fc[k], "write_kb": write[k] / wc[k], "launches": fc[k]} for k in fetch if k.startswith("gn_apply")}
 out = {
-    "workload": "1x2048x2048 untiled", "kernel": "igemm_kernel + conv_halo_kernel + conv_halo_pp_kernel + gemm_pp_kernel + swin_mlp_kernel", "round": int(re.search(r"r(\d+)_", os.path.basename(sys.argv[3])).group(1)) if re.search(r"r(\d+)_", os.path.basename(sys.argv[3])) else None,
+    "workload": "1x2048x2048 untiled", "kernel": "conv_halo_s1_kernel + conv_halo_pp_kernel + conv_halo_kernel + igemm_kernel + gemm_pp_kernel + swin_mlp_kernel", "round": int(re.search(r"r(\d+)_", os.path.basename(sys.argv[3])).group(1)) if re.search(r"r(\d+)_", os.path.basename(sys.argv[3])) else None,
     "fetch_size_kb_per_step": f_kb, "write_size_kb_per_step": w_kb, "launches_per_step": launches,
     "hbm_bytes_per_step": hbm, "hbm_bytes_per_launch": hbm / max(launches, 1),
     "per_kernel_kb": {k: {"fetch_kb_x2": 2 * fetch[k] / passes, "write_kb": write[k] / passes, "launches": fc[k] / passes} for k in sorted(fam)},
