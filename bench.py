@@ -200,12 +200,17 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X GPU; the product path has no CPU fallback")
+    # IR_BENCH_BACKEND=gloo: rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks (ranks share devices, collectives
+    # go through the host); the driver's runs use the default, one process per GPU over RCCL
+    backend = os.environ.get("IR_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        parallel.init_distributed("nccl")   # one process per GPU; "nccl" is RCCL on ROCm
+        parallel.init_distributed(backend)   # one process per GPU; "nccl" is RCCL on ROCm
 
     def log(msg):
         if rank == 0:
@@ -274,7 +279,7 @@ def main():
         return
     prof = ctx.profile_end()
     if dist is not None:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        t = torch.tensor([dt], device=device if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
     ms_per_step = dt / args.steps * 1e3
@@ -301,12 +306,12 @@ def main():
         else:
             verify = dict(verified=bool(psnr >= 45.0 and std > 1.0), psnr_fast_vs_plain_kernels_db=round(psnr, 2), output_std=round(std, 2))
         if dist is not None:
-            ok = torch.tensor([1.0 if verify["verified"] else 0.0], device=device)
+            ok = torch.tensor([1.0 if verify["verified"] else 0.0], device=device if backend == "nccl" else "cpu")
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             verify["verified"] = bool(ok[0] > 0)
             if rank == 0 and gathered[0] is not None:
                 verify["gathered_images"] = int(gathered[0].shape[0])
-                verify["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+                verify["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else backend
                 verify["world_size"] = dist.get_world_size()
         log(f"verify: fast vs plain kernels {psnr:.2f} dB, output std {std:.1f}")
 

@@ -62,17 +62,18 @@ def gather_uint8(local: torch.Tensor, dst: int = 0):
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
         return local
     world, rank = dist.get_world_size(), dist.get_rank()
-    counts = [torch.zeros(1, dtype=torch.int64, device=local.device) for _ in range(world)]
-    dist.all_gather(counts, torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device))
+    dev = _comm_device(local.device)   # RCCL moves device tensors; gloo (CPU tests, single-GPU rehearsals) gathers host tensors
+    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(counts, torch.tensor([local.shape[0]], dtype=torch.int64, device=dev))
     counts = [int(c) for c in counts]
     nmax = max(counts)
-    padded = torch.zeros((nmax,) + tuple(local.shape[1:]), dtype=torch.uint8, device=local.device)
-    padded[: local.shape[0]] = local
+    padded = torch.zeros((nmax,) + tuple(local.shape[1:]), dtype=torch.uint8, device=dev)
+    padded[: local.shape[0]] = local.to(dev)
     bufs = [torch.empty_like(padded) for _ in range(world)] if rank == dst else None
     dist.gather(padded, bufs, dst=dst)
     if rank != dst:
         return None
-    return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
+    return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0).to(local.device)
 
 
 # ------------------------------------------------------------------------------------------------ tile sharding of ONE image
