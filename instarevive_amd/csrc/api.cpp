@@ -46,6 +46,7 @@ struct SwinBlock {
     const float* biasT = nullptr;
     const void* mlp_t = nullptr;   // weight tiles + vectors of the fused LN2 -> fc1 -> GELU -> fc2 -> + x kernel (swin_fused.hip), optional
     const float* mlp_v = nullptr;
+    const void* proj_t = nullptr;  // proj weights with columns in accumulator order for the fused window attention + projection kernel, optional
 };
 struct SwinLayer {
     std::vector<SwinBlock> blocks;
@@ -435,9 +436,14 @@ void swinir_run(Run& r, const float* in, float* out, int n, int h, int w) {
             const bool last = j + 1 == L.blocks.size();
             layernorm(r, cur, xn, nullptr, b.n1.g, b.n1.b, T, m.C, Cp, Cp, 1e-5f);
             linear(r, b.qkv, xn, (int)T, Cp, qkv, 3 * m.heads * 32, 0, ACT_NONE, nullptr, 0, 0);
-            LAUNCH(r, PC_SWIN_ATTN, 4.0 * (double)T * 64 * 32 * m.heads, 0.0,
-                   ir_launch_swin_attn(qkv, att, b.biasT, n, gh, gw, m.heads, 3 * m.heads * 32, Cp, (j & 1) ? 4 : 0, scale, r.s), "swin_attn");
-            linear(r, b.proj, att, (int)T, Cp, xb, Cp, 1, ACT_NONE, cur, 1, Cp);
+            if (b.proj_t && !g_ir_plain_kernels) {  // window attention of all heads -> proj -> + x in one launch, no LDS (swin_fused.hip)
+                LAUNCH(r, PC_SWIN_ATTN, 4.0 * (double)T * 64 * 32 * m.heads + 2.0 * (double)T * m.C * m.C, 0.0,
+                       ir_launch_swin_attn_proj(qkv, cur, xb, b.proj_t, b.proj.b, b.biasT, n, gh, gw, (j & 1) ? 4 : 0, scale, r.s), "swin_attn_proj");
+            } else {
+                LAUNCH(r, PC_SWIN_ATTN, 4.0 * (double)T * 64 * 32 * m.heads, 0.0,
+                       ir_launch_swin_attn(qkv, att, b.biasT, n, gh, gw, m.heads, 3 * m.heads * 32, Cp, (j & 1) ? 4 : 0, scale, r.s), "swin_attn");
+                linear(r, b.proj, att, (int)T, Cp, xb, Cp, 1, ACT_NONE, cur, 1, Cp);
+            }
             if (b.mlp_t && !g_ir_plain_kernels) {  // LN2 -> fc1 -> GELU -> fc2 -> + x in one kernel, the token's state in registers throughout
                 LAUNCH(r, PC_LINEAR, 4.0 * (double)T * m.C * (m.hid_p), 4.0 * (double)T * Cp * 2,
                        ir_launch_swin_mlp(xb, xb, last ? xc : nullptr, b.mlp_t, b.mlp_v, T, m.C, m.hid_p, 1e-5f, r.s), "swin_mlp");
@@ -1064,6 +1070,10 @@ int ir_swinir_configure(ir_ctx* c, int embed_dim, int n_layers, const int* depth
                     k.mlp_t = it->second.p;
                     k.mlp_v = (const float*)iv->second.p;
                 }
+            }
+            {   // optional: the fused attention + projection form (6 heads x 32 = 192 only)
+                auto it = c->t.find(p + ".proj_t");
+                if (Cp == 192 && heads == 6 && k.proj.b && it != c->t.end() && it->second.bytes >= (size_t)192 * 192 * 2) k.proj_t = it->second.p;
             }
             L.blocks.push_back(k);
         }

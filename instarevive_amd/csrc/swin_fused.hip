@@ -220,3 +220,187 @@ int ir_launch_swin_mlp(const float* x, float* out, bf16_t* out2, const void* w_t
                        vec, T, C, NJ, eps);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+
+// =====================================================================================================================
+// swin_attn_proj_kernel: (S)W-MSA of one 8 x 8 window for ALL heads + the output projection + the residual add in one launch
+// (reference diffusion/model/swinir.py:101-165 WindowAttention.forward, :258-290 SwinTransformerBlock.forward up to the first residual).
+// Replaces swin_window_attn_kernel (one workgroup per (window, head), operands staged through LDS with a 2-byte V^T scatter: 53 % LDS
+// bank conflicts, 2 % MFMA busy, bias / mask index arithmetic per element) and the proj GEMM launch behind it.
+//
+// One WAVE per (window, 32-query half); no LDS at all: every MFMA operand is either a 16-byte row piece loaded straight from global
+// memory (a lane's own token row: Q as B operand, K and V rows as A operands, the permuted proj weights as A operands) or a packed
+// accumulator tile (transposed-register formulation, as in swin_mlp_kernel above):
+//   S^T[key][query]   = K Q^T                      2 key tiles x 2 k-steps; lane = query, registers = keys
+//   P^T               = softmax over keys (bias table in the log2 domain, shift mask as a per-lane bit set computed once per wave)
+//   V'[key][d]        = V I                        V rows times the identity: the same values with lane = d, registers = keys - the
+//                                                  A operand the second product needs, without a transpose through LDS (exact in bf16)
+//   O^T[d][query]     = V'^T P^T                   lane = query, registers = d
+//   Y^T[ch][query]   += Wp[:, head] O^T            6 channel tiles x 2 k-steps per head; Wp's columns are stored in accumulator order
+//                                                  (weights.pack_swinir: proj_t), so a packed O^T tile IS the B operand
+// and finally Y + bias + x is written to the fp32 token rows (16-byte pieces: a lane holds 4 consecutive channels per 4 registers).
+// The roll / window partition / reverse of the reference are the token gather tok(): shifted-frame pixel (Y, X) -> source pixel
+// ((Y + s) % H, (X + s) % W), as in swin_window_attn_kernel.
+IR_DEVINL uint4 swa_pack8(const f32x16& v, int lo, float mul) {
+    return make_uint4(pack2bf(v[lo] * mul, v[lo + 1] * mul), pack2bf(v[lo + 2] * mul, v[lo + 3] * mul), pack2bf(v[lo + 4] * mul, v[lo + 5] * mul),
+                      pack2bf(v[lo + 6] * mul, v[lo + 7] * mul));
+}
+
+__global__ __launch_bounds__(256, 2) void swin_attn_proj_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ xres, float* __restrict__ out,
+                                                             const bf16_t* __restrict__ proj_t, const float* __restrict__ proj_b,
+                                                             const float* __restrict__ biasT, int H, int W, int shift, float scale_log2,
+                                                             long n_waves) {
+    constexpr int HEADS = 6, CP = 192, LD = 3 * CP;
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const long wv = (long)blockIdx.x * 4 + (threadIdx.x >> 6);   // wave = (window, query half)
+    if (wv >= n_waves) return;
+    const int g = (int)(wv & 1);
+    long wlin = wv >> 1;
+    const int nwx = W >> 3, nwy = H >> 3;
+    const int wx = (int)(wlin % nwx); wlin /= nwx;
+    const int wy = (int)(wlin % nwy);
+    const long img = wlin / nwy;
+    auto tok = [&](int i) {   // window token i (row-major in the 8 x 8 window) -> token index in the image
+        int y = wy * 8 + (i >> 3) + shift, x = wx * 8 + (i & 7) + shift;
+        if (y >= H) y -= H;
+        if (x >= W) x -= W;
+        return (long)y * W + x;
+    };
+    const long tbase = img * H * W;
+    const long qtok = tbase + tok(32 * g + r);                       // this lane's query (n index of S^T / O^T / Y^T)
+    const long ktok[2] = {tbase + tok(r), tbase + tok(32 + r)};      // this lane's key rows (m index) of the two key tiles
+    // shifted-window mask (swinir.py:227-248): regions of the shifted frame; bit (kt * 16 + reg) set when this lane's key differs in region
+    // from this lane's query. Keys of accumulator register reg: 32 kt + (reg & 3) + 8 (reg >> 2) + 4 h.
+    uint32_t mdiff = 0;
+    if (shift) {
+        auto region = [&](int idx) {
+            const int Y = wy * 8 + (idx >> 3), X = wx * 8 + (idx & 7);
+            const int rh = Y < H - 8 ? 0 : (Y < H - shift ? 1 : 2), rw = X < W - 8 ? 0 : (X < W - shift ? 1 : 2);
+            return rh * 3 + rw;
+        };
+        const int rq = region(32 * g + r);
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int key = 32 * kt + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                mdiff |= (region(key) != rq ? 1u : 0u) << (kt * 16 + reg);
+            }
+    }
+    // identity B operand of the V' product: lane = d = r, k position 16 ks + 8 h + e holds (that position == r)
+    bf16x8 idf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        uint32_t w4[4];
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) {
+            const int c0 = 16 * ks + 8 * h + 2 * e2;
+            w4[e2] = (c0 == r ? 0x3f80u : 0u) | (c0 + 1 == r ? 0x3f800000u : 0u);
+        }
+        idf[ks] = __builtin_bit_cast(bf16x8, make_uint4(w4[0], w4[1], w4[2], w4[3]));
+    }
+    f32x16 yacc[6];
+#pragma unroll
+    for (int ct = 0; ct < 6; ++ct)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) yacc[ct][e] = 0.f;
+    const bf16_t* qrow = qkv + qtok * LD + 8 * h;
+    const bf16_t* krow[2] = {qkv + ktok[0] * LD + CP + 8 * h, qkv + ktok[1] * LD + CP + 8 * h};
+    const bf16_t* vrow[2] = {qkv + ktok[0] * LD + 2 * CP + 8 * h, qkv + ktok[1] * LD + 2 * CP + 8 * h};
+    const float* brow = biasT + 32 * g + r;   // + (head * 64 + key) * 64
+
+#pragma unroll 1
+    for (int hd = 0; hd < HEADS; ++hd) {
+        const int co = hd * 32;
+        bf16x8 qf[2], kf[2][2], vf[2][2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            qf[ks] = *reinterpret_cast<const bf16x8*>(qrow + co + 16 * ks);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                kf[kt][ks] = *reinterpret_cast<const bf16x8*>(krow[kt] + co + 16 * ks);
+                vf[kt][ks] = *reinterpret_cast<const bf16x8*>(vrow[kt] + co + 16 * ks);
+            }
+        }
+        f32x16 s[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s[kt][e] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) s[kt] = mfma32(kf[kt][ks], qf[ks], s[kt]);
+        }
+        // bias (+ mask), softmax over the 64 keys of this query (32 here, 32 in the partner lane)
+        const float* bt = brow + (long)hd * 4096;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int key = 32 * kt + (e & 3) + 8 * (e >> 2) + 4 * h;
+                float v = s[kt][e] * scale_log2 + bt[key * 64];
+                if ((mdiff >> (kt * 16 + e)) & 1) v += -100.0f * 1.44269504088896340736f;
+                s[kt][e] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = xhalf_max(mx);
+        float rs = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float pv = __builtin_amdgcn_exp2f(s[kt][e] - mx);
+                s[kt][e] = pv;
+                rs += pv;
+            }
+        rs += __shfl_xor(rs, 32);
+        // V' = V I (lane = d, registers = keys), then O^T = V'^T P^T
+        f32x16 o;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[e] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            f32x16 vt;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) vt[e] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) vt = mfma32(vf[kt][ks], idf[ks], vt);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+                o = mfma32(__builtin_bit_cast(bf16x8, swa_pack8(vt, 8 * s2, 1.0f)), __builtin_bit_cast(bf16x8, swa_pack8(s[kt], 8 * s2, 1.0f)), o);
+        }
+        const float inv = 1.0f / rs;
+        // Y^T += Wp[:, head] O^T: A = proj_t rows (channel 32 ct + r), 16-byte piece at column head * 32 + 16 s2 + 8 h
+        const bf16x8 ob[2] = {__builtin_bit_cast(bf16x8, swa_pack8(o, 0, inv)), __builtin_bit_cast(bf16x8, swa_pack8(o, 8, inv))};
+#pragma unroll
+        for (int ct = 0; ct < 6; ++ct)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16x8 wp = *reinterpret_cast<const bf16x8*>(proj_t + (long)(32 * ct + r) * CP + co + 16 * s2 + 8 * h);
+                yacc[ct] = mfma32(wp, ob[s2], yacc[ct]);
+            }
+    }
+    // out[token][ch] = Y + bias + x: lane = query token, registers 4 j .. 4 j + 3 of tile ct = channels 32 ct + 8 j + 4 h .. + 3
+    const float* xr = xres + qtok * CP;
+    float* orow = out + qtok * CP;
+#pragma unroll
+    for (int ct = 0; ct < 6; ++ct)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int ch = 32 * ct + 8 * j + 4 * h;
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + ch), bv = *reinterpret_cast<const f32x4*>(proj_b + ch);
+            f32x4 y = {yacc[ct][4 * j], yacc[ct][4 * j + 1], yacc[ct][4 * j + 2], yacc[ct][4 * j + 3]};
+            y = y + bv + xv;
+            *reinterpret_cast<f32x4*>(orow + ch) = y;
+        }
+}
+
+int ir_launch_swin_attn_proj(const bf16_t* qkv, const float* xres, float* out, const void* proj_t, const float* proj_b, const float* biasT, int B,
+                             int H, int W, int shift, float scale, hipStream_t s) {
+    if ((H & 7) || (W & 7) || shift < 0 || shift >= 8 || B <= 0) return -2;
+    const long n_waves = 2L * B * (H >> 3) * (W >> 3);
+    const long blocks = (n_waves + 3) / 4;
+    if (blocks > 0x7fffffffL) return -4;
+    hipLaunchKernelGGL(swin_attn_proj_kernel, dim3((unsigned)blocks), dim3(256), 0, s, qkv, xres, out, reinterpret_cast<const bf16_t*>(proj_t), proj_b,
+                       biasT, H, W, shift, scale * 1.44269504088896340736f, n_waves);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}

@@ -164,6 +164,8 @@ def pack_swinir(sd, cfg):
             out[d + "qkv.b"] = pad_vec(sd[s + "attn.qkv.bias"], 3 * Cp, idx=qmap)
             out[d + "proj.w"] = pack_linear(sd[s + "attn.proj.weight"], Cp, Cp, col_map=hmap)
             out[d + "proj.b"] = pad_vec(sd[s + "attn.proj.bias"], Cp)
+            if Cp == 192:   # fused window attention + projection (swin_attn_proj_kernel): proj input channels in accumulator order
+                out[d + "proj_t"] = out[d + "proj.w"][:, _acc_order(Cp)].contiguous()
             out[d + "fc1.w"] = pack_linear(sd[s + "mlp.fc1.weight"], hid_p, Cp)
             out[d + "fc1.b"] = pad_vec(sd[s + "mlp.fc1.bias"], hid_p)
             out[d + "fc2.w"] = pack_linear(sd[s + "mlp.fc2.weight"], Cp, hid_p)
