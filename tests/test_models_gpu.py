@@ -486,3 +486,30 @@ def test_vae_fp8_resnet_convs(full_models):
         print(f"vae {name}: fp8 vs oracle rel-L2 {rel_l2(f, ref):.4f} (bf16 path {rel_l2(b, ref):.4f}); fp8 vs bf16 {rel_l2(f, b):.4f}")
         assert not torch.equal(f, b), "the fp8 path must actually run"
         assert rel_l2(f, ref) <= 0.15
+
+
+def test_fp8_whole_path_psnr_guard(full_models):
+    """cfg-5, reported separately from bf16 (SURVEY.md section 8(d) PSNR protocol): the whole path with fp8 VAE convs at full network depth
+    against the fp32 oracle on the same LQ input, after the uint8 conversion; north_star's acceptance form |PSNR(ours, GT) - PSNR(oracle, GT)|
+    <= 0.1 dB with the LQ input as the third image. The bf16 path on the same input is printed beside it."""
+    from instarevive_amd.pipeline import process
+    swin, vae, dit, sds, y, mask = full_models
+    import bench
+    imgs = [bench.synthetic_lq(1, 256, 256, 6)[0].numpy()]
+    ref, ref1 = oglue.process(imgs, lambda x: oswin.swinir_forward(sds["swin"], x), lambda x: ovae.vae_encode_mean(sds["vae"], x),
+                              lambda lat, t, yy, mm: odit.dit_forward(sds["dit"], lat, t, yy, mm), lambda z: ovae.vae_decode(sds["vae"], z),
+                              oglue.alphas_cumprod_diffusers(), y, mask)
+    kw = dict(preprocess_model=swin, vae=vae, y=y.cuda(), y_mask=mask.cuda())
+    bf, _ = process(dit, imgs, 1, "wavelet", False, False, 512, 448, **kw)
+    vae.enable_fp8(True)
+    try:
+        f8, _ = process(dit, imgs, 1, "wavelet", False, False, 512, 448, fp8=True, **kw)
+    finally:
+        vae.enable_fp8(False)
+    gt = [np.asarray(i) for i in imgs]
+    p8, pb = _psnr_u8(f8, ref), _psnr_u8(bf, ref)
+    d8, db = abs(_psnr_u8(f8, gt) - _psnr_u8(ref, gt)), abs(_psnr_u8(bf, gt) - _psnr_u8(ref, gt))
+    print(f"fp8 path vs fp32 oracle {p8:.2f} dB (bf16 path {pb:.2f} dB); |PSNR(., GT) - PSNR(oracle, GT)|: fp8 {d8:.4f} dB, bf16 {db:.4f} dB")
+    assert not np.array_equal(f8[0], bf[0]), "the fp8 path must actually run"
+    assert p8 >= 30.0 and d8 <= 0.1
+
