@@ -245,6 +245,12 @@ IR_DEVINL uint4 swa_pack8(const f32x16& v, int lo, float mul) {
                       pack2bf(v[lo + 6] * mul, v[lo + 7] * mul));
 }
 
+IR_DEVINL uint4 swa_pack8_valu(const f32x16& v, int lo, float mul) {   // for values the VALU produced (exponentials, O * 1/sum): one instruction per pair
+    return make_uint4(pack2bf_valu(v[lo] * mul, v[lo + 1] * mul), pack2bf_valu(v[lo + 2] * mul, v[lo + 3] * mul),
+                      pack2bf_valu(v[lo + 4] * mul, v[lo + 5] * mul), pack2bf_valu(v[lo + 6] * mul, v[lo + 7] * mul));
+}
+
+template <bool SHIFTED>
 __global__ __launch_bounds__(256, 2) void swin_attn_proj_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ xres, float* __restrict__ out,
                                                              const bf16_t* __restrict__ proj_t, const float* __restrict__ proj_b,
                                                              const float* __restrict__ biasT, int H, int W, int shift, float scale_log2,
@@ -271,7 +277,7 @@ __global__ __launch_bounds__(256, 2) void swin_attn_proj_kernel(const bf16_t* __
     // shifted-window mask (swinir.py:227-248): regions of the shifted frame; bit (kt * 16 + reg) set when this lane's key differs in region
     // from this lane's query. Keys of accumulator register reg: 32 kt + (reg & 3) + 8 (reg >> 2) + 4 h.
     uint32_t mdiff = 0;
-    if (shift) {
+    if constexpr (SHIFTED) {
         auto region = [&](int idx) {
             const int Y = wy * 8 + (idx >> 3), X = wx * 8 + (idx & 7);
             const int rh = Y < H - 8 ? 0 : (Y < H - shift ? 1 : 2), rw = X < W - 8 ? 0 : (X < W - shift ? 1 : 2);
@@ -338,7 +344,7 @@ __global__ __launch_bounds__(256, 2) void swin_attn_proj_kernel(const bf16_t* __
             for (int e = 0; e < 16; ++e) {
                 const int key = 32 * kt + (e & 3) + 8 * (e >> 2) + 4 * h;
                 float v = s[kt][e] * scale_log2 + bt[key * 64];
-                if ((mdiff >> (kt * 16 + e)) & 1) v += -100.0f * 1.44269504088896340736f;
+                if constexpr (SHIFTED) { if ((mdiff >> (kt * 16 + e)) & 1) v += -100.0f * 1.44269504088896340736f; }
                 s[kt][e] = v;
                 mx = fmaxf(mx, v);
             }
@@ -366,11 +372,11 @@ __global__ __launch_bounds__(256, 2) void swin_attn_proj_kernel(const bf16_t* __
             for (int ks = 0; ks < 2; ++ks) vt = mfma32(vf[kt][ks], idf[ks], vt);
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
-                o = mfma32(__builtin_bit_cast(bf16x8, swa_pack8(vt, 8 * s2, 1.0f)), __builtin_bit_cast(bf16x8, swa_pack8(s[kt], 8 * s2, 1.0f)), o);
+                o = mfma32(__builtin_bit_cast(bf16x8, swa_pack8(vt, 8 * s2, 1.0f)), __builtin_bit_cast(bf16x8, swa_pack8_valu(s[kt], 8 * s2, 1.0f)), o);
         }
         const float inv = 1.0f / rs;
         // Y^T += Wp[:, head] O^T: A = proj_t rows (channel 32 ct + r), 16-byte piece at column head * 32 + 16 s2 + 8 h
-        const bf16x8 ob[2] = {__builtin_bit_cast(bf16x8, swa_pack8(o, 0, inv)), __builtin_bit_cast(bf16x8, swa_pack8(o, 8, inv))};
+        const bf16x8 ob[2] = {__builtin_bit_cast(bf16x8, swa_pack8_valu(o, 0, inv)), __builtin_bit_cast(bf16x8, swa_pack8_valu(o, 8, inv))};
 #pragma unroll
         for (int ct = 0; ct < 6; ++ct)
 #pragma unroll
@@ -400,7 +406,11 @@ int ir_launch_swin_attn_proj(const bf16_t* qkv, const float* xres, float* out, c
     const long n_waves = 2L * B * (H >> 3) * (W >> 3);
     const long blocks = (n_waves + 3) / 4;
     if (blocks > 0x7fffffffL) return -4;
-    hipLaunchKernelGGL(swin_attn_proj_kernel, dim3((unsigned)blocks), dim3(256), 0, s, qkv, xres, out, reinterpret_cast<const bf16_t*>(proj_t), proj_b,
-                       biasT, H, W, shift, scale * 1.44269504088896340736f, n_waves);
+    if (shift)
+        hipLaunchKernelGGL(swin_attn_proj_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, qkv, xres, out, reinterpret_cast<const bf16_t*>(proj_t),
+                           proj_b, biasT, H, W, shift, scale * 1.44269504088896340736f, n_waves);
+    else
+        hipLaunchKernelGGL(swin_attn_proj_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, qkv, xres, out, reinterpret_cast<const bf16_t*>(proj_t),
+                           proj_b, biasT, H, W, shift, scale * 1.44269504088896340736f, n_waves);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
