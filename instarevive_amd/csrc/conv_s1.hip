@@ -433,8 +433,8 @@ __global__ __launch_bounds__(256, 1) void conv_halo_s1_kernel(IGemmParams p, int
 }
 
 // Which launches take this kernel (everything else of the halo family stays with conv_halo_pp_kernel / conv_halo_kernel): plain bf16
-// NHWC in and out, 128-channel output tiles, no activation / gate / second output, a bf16 residual at most, and enough patches to fill
-// the chip (one 512-pixel patch per CU and round).
+// NHWC in and out, 128-channel output tiles, no activation / gate / second output, a bf16 residual at most, and at least 32 patch
+// tiles per image.
 bool ir_conv_s1_takes(const IGemmParams& p) {
     static const bool off = getenv("IR_NO_CONV_S1") != nullptr;   // experiment knob
     if (off || g_ir_plain_kernels || p.fp8 || p.force_generic) return false;
@@ -446,7 +446,7 @@ bool ir_conv_s1_takes(const IGemmParams& p) {
     if (p.bias && (reinterpret_cast<uintptr_t>(p.bias) & 15)) return false;
     // per IMAGE, not per launch: which kernel runs (and with it the summation order) must not depend on an image's batch neighbours
     const long tiles = (long)((p.Ho + 15) / 16) * ((p.Wo + 31) / 32) * (p.Cout_pad / 128);
-    return tiles >= 192;
+    return tiles >= 32;   // a 64 x 64 map at 512 channels and up: batched tiles (--tiled) fill the chip; one such image is a single round either way
 }
 int ir_conv_s1_tiles(const IGemmParams& p) { return ((p.Ho + 15) / 16) * ((p.Wo + 31) / 32); }
 
