@@ -61,6 +61,16 @@ def attn(b, heads, t, d):
     print(f"attn b{b} h{heads} T{t} d{d}: {ms:8.3f} ms  {4.0 * b * heads * t * t * d / ms / 1e9:8.1f} TFLOP/s (incl. V transpose)")
 
 
+def gn(n, hw, c):
+    x = torch.randn(n, hw, c, device="cuda").to(torch.bfloat16).view(torch.int16)
+    y = torch.empty_like(x)
+    g, b = torch.ones(c, device="cuda"), torch.zeros(c, device="cuda")
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    fn = lambda: ctx.check(ctx.lib.ir_op_groupnorm(ctx.h, ctx.stream(), L.ptr(x), L.ptr(y), L.ptr(g), L.ptr(b), n, hw, c, 32, 1e-6, 1, L.ptr(ws), ws.numel()), "gn")
+    ms = timeit(fn)
+    print(f"groupnorm+silu {n}x{hw}x{c}: {ms:8.3f} ms  {6.0 * n * hw * c / ms / 1e9:8.2f} TB/s (partial pass 2 B + apply 4 B per element)")
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["conv", "linear", "attn"]
     if "one" in which:  # the three heaviest shapes of the 2048^2 path (profiling runs)
@@ -92,6 +102,12 @@ if __name__ == "__main__":
         linear(65536, 65536, 512)
         linear(65536, 192, 576)
         linear(4194304, 128, 128)
+    if "gn" in which:
+        gn(1, 2048 * 2048, 128)
+        gn(1, 2048 * 2048, 256)
+        gn(1, 1024 * 1024, 256)
+        gn(1, 1024 * 1024, 512)
+        gn(1, 512 * 512, 512)
     if "attn" in which:
         attn(1, 16, 16384, 72)
         attn(1, 16, 1024, 72)
