@@ -230,6 +230,7 @@ def test_conv_groupnorm_fused(ctx, n, h, w, cin, cout, stride, up, res, expect_f
     (2, 200, 488, 128, 128, 0, True),     # ragged 16 x 32 patches (200 = 12.5 x 16, 488 = 15.25 x 32), two images, residual
     (1, 100, 120, 256, 256, 1, False),    # nearest-2x folded in -> 200 x 240, two channel tiles, 8 chunks
     (1, 256, 384, 512, 128, 0, True),     # 16 chunks, whole patches
+    (3, 64, 128, 256, 512, 0, True),      # four channel tiles, 16 channels per group (group statistics combine four 4-channel units), three images
 ])
 def test_conv_s1_kernel(ctx, n, h, w, cin, cout, up, res):
     """conv_halo_s1_kernel (one wave per SIMD, 16 x 32 patches x 128 channels): sizes with enough patches to be routed to it — the fused
