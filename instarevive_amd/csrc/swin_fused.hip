@@ -227,7 +227,7 @@ int ir_launch_swin_mlp(const float* x, float* out, bf16_t* out2, const void* w_t
 // Replaces swin_window_attn_kernel (one workgroup per (window, head), operands staged through LDS with a 2-byte V^T scatter: 53 % LDS
 // bank conflicts, 2 % MFMA busy, bias / mask index arithmetic per element) and the proj GEMM launch behind it.
 //
-// One WAVE per (window, 32-query half); no LDS at all: every MFMA operand is either a 16-byte row piece loaded straight from global
+// One WAVE per (window, 32-query half); no LDS on the operand side: every MFMA operand is either a 16-byte row piece loaded straight from global
 // memory (a lane's own token row: Q as B operand, K and V rows as A operands, the permuted proj weights as A operands) or a packed
 // accumulator tile (transposed-register formulation, as in swin_mlp_kernel above):
 //   S^T[key][query]   = K Q^T                      2 key tiles x 2 k-steps; lane = query, registers = keys
@@ -236,7 +236,8 @@ int ir_launch_swin_mlp(const float* x, float* out, bf16_t* out2, const void* w_t
 //                                                  A operand the second product needs, without a transpose through LDS (exact in bf16)
 //   O^T[d][query]     = V'^T P^T                   lane = query, registers = d
 //   Y^T[ch][query]   += Wp[:, head] O^T            6 channel tiles x 2 k-steps per head; Wp's columns are stored in accumulator order
-//                                                  (weights.pack_swinir: proj_t), so a packed O^T tile IS the B operand
+//                                                  (weights.pack_swinir: proj_t), so a packed O^T tile IS the B operand, and in
+//                                                  fragment order, so an A-operand load is one contiguous KB (by row it touched 32 lines)
 // and finally Y + bias + x is written to the fp32 token rows (16-byte pieces: a lane holds 4 consecutive channels per 4 registers).
 // The roll / window partition / reverse of the reference are the token gather tok(): shifted-frame pixel (Y, X) -> source pixel
 // ((Y + s) % H, (X + s) % W), as in swin_window_attn_kernel.
@@ -256,6 +257,7 @@ __global__ __launch_bounds__(256, 2) void swin_attn_proj_kernel(const bf16_t* __
                                                              const float* __restrict__ biasT, int H, int W, int shift, float scale_log2,
                                                              long n_waves) {
     constexpr int HEADS = 6, CP = 192, LD = 3 * CP;
+    __shared__ __attribute__((aligned(16))) float yslab[4 * 32 * 36];   // epilogue only: one 32 x 32 output tile per wave (rows padded to 36 floats)
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const long wv = (long)blockIdx.x * 4 + (threadIdx.x >> 6);   // wave = (window, query half)
     if (wv >= n_waves) return;
@@ -381,23 +383,38 @@ __global__ __launch_bounds__(256, 2) void swin_attn_proj_kernel(const bf16_t* __
         for (int ct = 0; ct < 6; ++ct)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const bf16x8 wp = *reinterpret_cast<const bf16x8*>(proj_t + (long)(32 * ct + r) * CP + co + 16 * s2 + 8 * h);
+                const bf16x8 wp = *reinterpret_cast<const bf16x8*>(proj_t + (((hd * 6 + ct) * 2 + s2) * 64 + lane) * 8);   // fragment order: one contiguous KB
                 yacc[ct] = mfma32(wp, ob[s2], yacc[ct]);
             }
     }
-    // out[token][ch] = Y + bias + x: lane = query token, registers 4 j .. 4 j + 3 of tile ct = channels 32 ct + 8 j + 4 h .. + 3
-    const float* xr = xres + qtok * CP;
-    float* orow = out + qtok * CP;
+    // out[token][ch] = Y + bias + x. In the accumulator layout a lane holds 16-byte pieces of ITS token row (32 different rows per store
+    // instruction: the kernel is bound by the texture addresser's line rate, TA busy 83 %), so each 32-channel tile goes through a
+    // wave-private LDS slab and leaves as 128-byte row segments: 8 lanes per token, 8 tokens per instruction.
+    float* ys = &yslab[(threadIdx.x >> 6) * 32 * 36];
+    long rtok[4];
 #pragma unroll
-    for (int ct = 0; ct < 6; ++ct)
+    for (int i = 0; i < 4; ++i) rtok[i] = (tbase + tok(32 * g + 8 * i + (lane >> 3))) * CP + (lane & 7) * 4;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int ch = 32 * ct + 8 * j + 4 * h;
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + ch), bv = *reinterpret_cast<const f32x4*>(proj_b + ch);
-            f32x4 y = {yacc[ct][4 * j], yacc[ct][4 * j + 1], yacc[ct][4 * j + 2], yacc[ct][4 * j + 3]};
-            y = y + bv + xv;
-            *reinterpret_cast<f32x4*>(orow + ch) = y;
+    for (int ct = 0; ct < 6; ++ct) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<f32x4*>(&ys[r * 36 + 8 * j + 4 * h]) = f32x4{yacc[ct][4 * j], yacc[ct][4 * j + 1], yacc[ct][4 * j + 2], yacc[ct][4 * j + 3]};
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(proj_b + 32 * ct + (lane & 7) * 4);
+        f32x4 xv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xv[i] = *reinterpret_cast<const f32x4*>(xres + rtok[i] + 32 * ct);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 y = *reinterpret_cast<const f32x4*>(&ys[(8 * i + (lane >> 3)) * 36 + (lane & 7) * 4]) + bv + xv[i];
+            *reinterpret_cast<f32x4*>(out + rtok[i] + 32 * ct) = y;
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
 }
 
 int ir_launch_swin_attn_proj(const bf16_t* qkv, const float* xres, float* out, const void* proj_t, const float* proj_b, const float* biasT, int B,

@@ -164,8 +164,12 @@ def pack_swinir(sd, cfg):
             out[d + "qkv.b"] = pad_vec(sd[s + "attn.qkv.bias"], 3 * Cp, idx=qmap)
             out[d + "proj.w"] = pack_linear(sd[s + "attn.proj.weight"], Cp, Cp, col_map=hmap)
             out[d + "proj.b"] = pad_vec(sd[s + "attn.proj.bias"], Cp)
-            if Cp == 192:   # fused window attention + projection (swin_attn_proj_kernel): proj input channels in accumulator order
-                out[d + "proj_t"] = out[d + "proj.w"][:, _acc_order(Cp)].contiguous()
+            if Cp == 192:   # fused window attention + projection (swin_attn_proj_kernel): proj input channels in accumulator order, stored
+                # in MFMA-fragment order - block (head, channel tile ct, k-step s2) = the 64 lanes' 16-byte pieces back to back (lane l:
+                # row 32 ct + (l & 31), columns head * 32 + 16 s2 + 8 (l >> 5) .. + 7), so an operand load reads ONE contiguous KB
+                pw = out[d + "proj.w"][:, _acc_order(Cp)]                       # [192 rows][192 permuted columns], bf16 bits
+                pw = pw.reshape(6, 32, 6, 2, 2, 8)                             # [ct][r][head][s2][h][8]
+                out[d + "proj_t"] = pw.permute(2, 0, 3, 4, 1, 5).contiguous()  # [head][ct][s2][h][r][8] -> lane = h * 32 + r
             out[d + "fc1.w"] = pack_linear(sd[s + "mlp.fc1.weight"], hid_p, Cp)
             out[d + "fc1.b"] = pad_vec(sd[s + "mlp.fc1.bias"], hid_p)
             out[d + "fc2.w"] = pack_linear(sd[s + "mlp.fc2.weight"], Cp, hid_p)
