@@ -367,6 +367,64 @@ __global__ __launch_bounds__(256) void layernorm_v4_kernel(const float* __restri
     }
 }
 
+// Short rows (SwinIR: C = 180 in rows of 192): 16 lanes per row, 4 rows per wave, three float4 per lane; the row sums are four DPP
+// steps inside the 16-lane row (quad permutes, half-row mirror, row mirror) instead of six LDS-routed shuffles over a wave that is a
+// quarter empty (layernorm_v4_kernel<1>: 2.9 TB/s).
+IR_DEVINL float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));   // row_mirror
+    return v;
+}
+__global__ __launch_bounds__(256) void layernorm_r16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, float* __restrict__ yf,
+                                                            const float* __restrict__ a, const float* __restrict__ b, long rows, int C, int ldx,
+                                                            int ldy, float eps, long rows_per_batch, int ab_stride) {
+    const int l16 = threadIdx.x & 15;
+    const long row_raw = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool live = row_raw < rows;
+    const long row = live ? row_raw : rows - 1;   // spare 16-lane rows mirror the last row (DPP needs every lane) and store nothing
+    const float* xr = x + row * ldx;
+    const int C4 = C >> 2, L4 = ldy >> 2;
+    f32x4 v[3];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int j = i * 16 + l16;
+        v[i] = *reinterpret_cast<const f32x4*>(xr + 4 * min(j, C4 - 1));
+        if (j >= C4) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    const float mean = row16_sum(sum) / (float)C;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int j = i * 16 + l16;
+        if (j < C4) {
+            const f32x4 d = v[i] - mean;
+            sq += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        }
+    }
+    const float rstd = rsqrtf(row16_sum(sq) / (float)C + eps);
+    const long batch = row / rows_per_batch;
+    const float* ap = a ? a + batch * ab_stride : nullptr;
+    const float* bp = b ? b + batch * ab_stride : nullptr;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int j = i * 16 + l16;
+        if (j < L4 && live) {
+            f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (j < C4) {
+                o = (v[i] - mean) * rstd;
+                if (ap) o *= *reinterpret_cast<const f32x4*>(ap + 4 * j);
+                if (bp) o += *reinterpret_cast<const f32x4*>(bp + 4 * j);
+            }
+            if (y) *reinterpret_cast<uint2*>(y + row * ldy + 4 * j) = make_uint2(pack2bf_valu(o[0], o[1]), pack2bf_valu(o[2], o[3]));
+            if (yf) *reinterpret_cast<f32x4*>(yf + row * ldy + 4 * j) = o;
+        }
+    }
+}
+
 int ir_launch_layernorm(const float* x, bf16_t* y, float* yf, const float* a, const float* b, long rows, int C, int ldx, int ldy,
                         float eps, long rows_per_batch, int ab_stride, hipStream_t s) {
     if (rows <= 0) return 0;
@@ -375,6 +433,11 @@ int ir_launch_layernorm(const float* x, bf16_t* y, float* yf, const float* a, co
     const unsigned grid = (unsigned)((rows + 3) / 4);
     const bool v4 = !((C | ldx | ldy | ab_stride) & 3) && !(reinterpret_cast<uintptr_t>(x) & 15) && !(reinterpret_cast<uintptr_t>(y) & 7) &&
                     !(reinterpret_cast<uintptr_t>(yf) & 15) && !(reinterpret_cast<uintptr_t>(a) & 15) && !(reinterpret_cast<uintptr_t>(b) & 15);
+    if (v4 && ldy <= 192 && rows >= 4096) {
+        hipLaunchKernelGGL(layernorm_r16_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, s, x, y, yf, a, b, rows, C, ldx, ldy, eps, rows_per_batch,
+                           ab_stride);
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
     if (v4 && ldy <= 256) {
         hipLaunchKernelGGL((layernorm_v4_kernel<1>), dim3(grid), dim3(256), 0, s, x, y, yf, a, b, rows, C, ldx, ldy, eps, rows_per_batch, ab_stride);
         return hipGetLastError() == hipSuccess ? 0 : -1;

@@ -286,7 +286,7 @@ def _conv_groupnorm_case(ctx, n, h, w, cin, cout, stride, up, res, expect_fused,
     assert torch.equal(y, y2)
 
 
-@pytest.mark.parametrize("rows,c,ld", [(1000, 180, 192), (513, 1152, 1152), (64, 60, 192)])
+@pytest.mark.parametrize("rows,c,ld", [(1000, 180, 192), (513, 1152, 1152), (64, 60, 192), (5000, 180, 192), (4104, 64, 64)])  # the last two: 16 lanes per row (layernorm_r16_kernel), ragged row count
 def test_layernorm(ctx, rows, c, ld):
     g = torch.Generator().manual_seed(rows)
     x = torch.randn(rows, ld, generator=g) * 3 + 1
