@@ -24,12 +24,20 @@ IR_DEVINL uint32_t pack2bf(float lo, float hi) {
     return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
 }
 // The same as ONE instruction. hipcc (ROCm 7.2) turns pack2bf into two v_cvt_pk_bf16_f32 (each with a zero second operand), a shift and
-// an or. ONLY for operands produced by ordinary VALU instructions (e.g. v_exp_f32): an asm statement is invisible to hipcc's hazard
-// recogniser, so on operands fresh from an MFMA it reads them before the required wait states (replacing pack2bf globally by this
-// broke every GEMM epilogue: 16 dB).
+// an or. ONLY for operands produced by ordinary full-rate VALU instructions at least one instruction earlier: an asm statement is invisible
+// to hipcc's hazard recogniser, so on operands fresh from an MFMA it reads them before the required wait states (replacing pack2bf
+// globally by this broke every GEMM epilogue: 16 dB), and directly behind a transcendental (v_exp_f32 / v_rcp_f32 need one wait state
+// before a VALU reads their result) it packs garbage into one half (seen in a cross-attention experiment: pack2bf_valu(exp2(a), exp2(b))).
+// The attention kernels that pack exponentials keep at least one other instruction between the v_exp and this (attn_d512.hip: the row-sum
+// add / the deferred pair); where that distance is not under control use pack2bf_trans.
 IR_DEVINL uint32_t pack2bf_valu(float lo, float hi) {
     uint32_t r;
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+IR_DEVINL uint32_t pack2bf_trans(float lo, float hi) {   // operands may come straight from v_exp_f32 / v_rcp_f32: one wait state first
+    uint32_t r;
+    asm("s_nop 0\n\tv_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
     return r;
 }
 IR_DEVINL float bflo(uint32_t u) { return __builtin_bit_cast(float, u << 16); }

@@ -246,9 +246,10 @@ IR_DEVINL uint4 swa_pack8(const f32x16& v, int lo, float mul) {
                       pack2bf(v[lo + 6] * mul, v[lo + 7] * mul));
 }
 
-IR_DEVINL uint4 swa_pack8_valu(const f32x16& v, int lo, float mul) {   // for values the VALU produced (exponentials, O * 1/sum): one instruction per pair
-    return make_uint4(pack2bf_valu(v[lo] * mul, v[lo + 1] * mul), pack2bf_valu(v[lo + 2] * mul, v[lo + 3] * mul),
-                      pack2bf_valu(v[lo + 4] * mul, v[lo + 5] * mul), pack2bf_valu(v[lo + 6] * mul, v[lo + 7] * mul));
+IR_DEVINL uint4 swa_pack8_valu(const f32x16& v, int lo, float mul) {   // for values the VALU produced (exponentials, O * 1/sum): one instruction
+    // per pair; with mul = 1 the operands may come straight from v_exp_f32, hence the form with the transcendental-use wait state
+    return make_uint4(pack2bf_trans(v[lo] * mul, v[lo + 1] * mul), pack2bf_trans(v[lo + 2] * mul, v[lo + 3] * mul),
+                      pack2bf_trans(v[lo + 4] * mul, v[lo + 5] * mul), pack2bf_trans(v[lo + 6] * mul, v[lo + 7] * mul));
 }
 
 template <bool SHIFTED>

@@ -61,6 +61,20 @@ def attn(b, heads, t, d):
     print(f"attn b{b} h{heads} T{t} d{d}: {ms:8.3f} ms  {4.0 * b * heads * t * t * d / ms / 1e9:8.1f} TFLOP/s (incl. V transpose)")
 
 
+def xattn(b, heads, tq, tk, d):
+    """cross-attention shape: short key sequence with an additive key bias"""
+    q = torch.randn(b, tq, heads, d, device="cuda").to(torch.bfloat16).view(torch.int16)
+    k = torch.randn(b, tk, heads, d, device="cuda").to(torch.bfloat16).view(torch.int16)
+    v = torch.randn(b, tk, heads, d, device="cuda").to(torch.bfloat16).view(torch.int16)
+    kb = torch.zeros(b, tk, device="cuda")
+    o = torch.empty_like(q)
+    ws = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+    fn = lambda: ctx.check(ctx.lib.ir_op_attention(ctx.h, ctx.stream(), L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(o), b, heads, tq, tk, d, d ** -0.5, L.ptr(kb),
+                                                   L.ptr(ws), ws.numel()), "attn")
+    ms = timeit(fn, iters=20)
+    print(f"cross attn b{b} h{heads} Tq{tq} Tk{tk} d{d}: {ms * 1e3:8.1f} us  {4.0 * b * heads * tq * tk * d / ms / 1e9:8.1f} TFLOP/s (incl. V transpose)")
+
+
 def gn(n, hw, c):
     x = torch.randn(n, hw, c, device="cuda").to(torch.bfloat16).view(torch.int16)
     y = torch.empty_like(x)
@@ -102,6 +116,10 @@ if __name__ == "__main__":
         linear(65536, 65536, 512)
         linear(65536, 192, 576)
         linear(4194304, 128, 128)
+    if "xattn" in which:
+        xattn(1, 16, 16384, 300, 72)
+        xattn(1, 16, 4096, 300, 72)
+        xattn(25, 16, 1024, 300, 72)
     if "gn" in which:
         gn(1, 2048 * 2048, 128)
         gn(1, 2048 * 2048, 256)
