@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d512_v2_kernel(const bf16_t
                 ovf = fmaxf(ovf, sv);
                 const float p = __builtin_amdgcn_exp2f(sv - m_ref);
                 l_i += p;
-                if constexpr (e & 1) a5_set_word<((e & 7) >> 1)>(pn[e >> 3], pack2bf_valu(p_hold, p));   // one v_cvt_pk (operands come from v_exp: no MFMA hazard)
+                if constexpr (e & 1) a5_set_word<((e & 7) >> 1)>(pn[e >> 3], pack2bf_trans(p_hold, p));   // one v_cvt_pk behind the transcendental-use wait state (p is fresh from v_exp)
                 else p_hold = p;
                 __builtin_amdgcn_sched_barrier(0);
             }
