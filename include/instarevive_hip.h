@@ -35,10 +35,13 @@ enum { IR_FLAG_NO_PREPROCESS = 1, IR_FLAG_TILED = 2, IR_FLAG_FIX_WAVELET = 4, IR
         * The caller keeps in/out/stage1/ws alive and at the same addresses; uploads, *_configure and ir_dit_set_prompt drop the
         * recorded graphs. Ignored while ir_profile_begin is active (per-launch events need individual launches). */
        IR_FLAG_GRAPH = 32,
-       /* BASELINE.json configs[4]: fp8 (OCP e4m3) MFMA operands in the VAE ResnetBlock 3x3 convolutions (weights quantised per output
-        * channel at load time, GroupNorm+SiLU outputs written as e4m3) and in the DiT self-attention products. Needs the fp8 weight forms
-        * (`*.w8`, `*.g8`, `*.b8`) uploaded; layers without them run in bf16. */
+       /* BASELINE.json configs[4]: fp8 (OCP e4m3) MFMA operands in the parts ir_fp8_features() reports: the VAE ResnetBlock 3x3
+        * convolutions (weights quantised per output channel at load time, GroupNorm+SiLU outputs written as e4m3; needs the fp8 weight
+        * forms `*.w8`, `*.g8`, `*.b8` uploaded, layers without them run in bf16). */
        IR_FLAG_FP8 = 64 };
+/* which parts of the path IR_FLAG_FP8 / ir_set_fp8 move to fp8 operands in THIS build (bench.py words its workload string from it) */
+enum { IR_FP8_VAE_RESNET_CONVS = 1, IR_FP8_DIT_SELF_ATTENTION = 2 };
+int ir_fp8_features(void);
 
 int ir_abi_version(void);
 int ir_init(int device, ir_ctx** out);
@@ -70,8 +73,9 @@ int ir_dit_set_prompt(ir_ctx* ctx, void* stream, const float* embeds_host, const
  * sequence length is the tensor `t5.bias.{tokens}` [heads][tokens][tokens] fp32 (uploaded by the host mirror on first use). */
 int ir_t5_configure(ir_ctx* ctx, int n_layers, int d_model, int heads, int d_kv, int d_ff, int vocab);
 /* self.model(input_ids=, attention_mask=)['last_hidden_state'] — t5.py:95-100. ids: device int32 [b][tokens]; key_mask: device fp32
- * [b][tokens], 1 = token, 0 = padding (NULL: none); out: device fp32 [b][tokens][d_model]. tokens <= 512. Synchronises the stream
- * (the producer runs once per prompt) and fails on an id outside the vocabulary. */
+ * [b][tokens], 1 = token, 0 = padding (NULL: none); out: device fp32 [b][tokens][d_model]. tokens <= 512. The ONE exception to the
+ * "never synchronises" convention above: it waits for the stream so that it can fail on an id outside the vocabulary, as the
+ * reference's embedding lookup does (the producer runs once per prompt, off the image path). */
 int ir_t5_encode(ir_ctx* ctx, void* stream, const int32_t* ids, const float* key_mask, float* out, int b, int tokens, void* ws, size_t ws_bytes);
 
 size_t ir_workspace_bytes(ir_ctx* ctx, int stage, int n, int h, int w, int flags, int tile_size, int tile_stride);
@@ -125,8 +129,9 @@ int ir_tiled_decode(ir_ctx* ctx, void* stream, const float* nb, const float* con
 int ir_tiled_blend_pixels(ir_ctx* ctx, void* stream, const float* px_tiles, uint8_t* out, int n, int h, int w, int tile_size, int tile_stride,
                           void* ws, size_t ws_bytes);
 
-/* Diagnostic (no reference counterpart): on != 0 routes every launch through the older 4-wave kernels — an independent second
- * implementation of the same arithmetic that bench.py ("verified") and the tests cross-check the fast kernels against. Process-wide. */
+/* Diagnostic (no reference counterpart): on != 0 routes every launch of THIS context through the older 4-wave kernels — an independent
+ * second implementation of the same arithmetic that bench.py ("verified") and the tests cross-check the fast kernels against. Recorded
+ * hipGraphs of the other mode are dropped. */
 int ir_set_plain_kernels(ir_ctx* ctx, int on);
 /* on != 0: the stage entry points (ir_vae_encode / ir_vae_decode / ir_dit_*) use the fp8 forms as IR_FLAG_FP8 does for ir_pipeline. */
 int ir_set_fp8(ir_ctx* ctx, int on);
@@ -136,6 +141,12 @@ int ir_set_fp8(ir_ctx* ctx, int on);
  * 6 row softmax, 7 transpose, 8 other. ir_profile_end synchronises the stream and sums per class. */
 int ir_profile_begin(ir_ctx* ctx);
 int ir_profile_end(ir_ctx* ctx, void* stream, int n_classes, double* ms, double* flops, double* bytes, long long* launches);
+/* The same measurement per KERNEL (ir_profile_kernel_count() rows, named "class/kernel" by ir_profile_kernel_name): milliseconds,
+ * ALGORITHMIC FLOPs (un-padded channel counts / head dims) and bytes, launches of every kernel that ran since ir_profile_begin.
+ * bench.py prints them as roofline.per_kernel. May be called after ir_profile_end (the records live until the next begin). */
+int ir_profile_kernel_count(void);
+const char* ir_profile_kernel_name(int id);
+int ir_profile_end_kernels(ir_ctx* ctx, void* stream, int n_kernels, double* ms, double* flops, double* bytes, long long* launches);
 
 /* image <-> tensor helpers of process() (inference.py:92-93,159-161) */
 int ir_u8_to_nchw(ir_ctx* ctx, void* stream, const uint8_t* in, float* out, int n, int h, int w);
@@ -166,6 +177,10 @@ int ir_op_attention(ir_ctx* ctx, void* stream, const uint16_t* q, const uint16_t
 int ir_op_swin_attention(ir_ctx* ctx, void* stream, const uint16_t* qkv, uint16_t* out, const float* bias_t, int b, int h, int w,
                          int heads, int shift, float scale);
 int ir_op_softmax_rows(ir_ctx* ctx, void* stream, const float* x, uint16_t* y, int rows, int cols);
+/* layout kernels at the two ends of the VAE: fp32 NCHW [n][ch][hw] -> bf16 NHWC [n*hw][cpad] of v*scale+shift (zero padding channels),
+ * and fp32 NHWC rows [n*hw][in_cs] -> fp32 NCHW [n][ch][hw] of v*scale+shift (optionally clamped to [0,1]) */
+int ir_op_nchw_to_nhwc(ir_ctx* ctx, void* stream, const float* in, uint16_t* out, int n, int ch, long hw, int cpad, float scale, float shift);
+int ir_op_nhwc_to_nchw(ir_ctx* ctx, void* stream, const float* in, int in_cs, float* out, int n, int ch, long hw, float scale, float shift, int clamp01);
 
 #ifdef __cplusplus
 }

@@ -170,8 +170,12 @@ def main() -> None:
     m = load_models(args, device)
     if not os.path.isdir(args.input):
         raise SystemExit(f"--input {args.input} is not a directory")
-    # os.walk order, like the reference (no sorting); every rank of one node lists the same order
+    # os.walk order, like the reference (no sorting) for one process. With several ranks the list is what decides which rank owns
+    # which file (and, under --shard_tiles, which image a collective belongs to), and os.walk promises no order across processes:
+    # every rank sorts its listing and checks it against rank 0's.
     files = list_image_files(args.input, follow_links=True)
+    if world > 1:
+        files = parallel.agree_on_list(sorted(files))
     common = dict(color_fix_type=args.color_fix_type, disable_preprocess_model=args.disable_preprocess_model, tile_size=args.tile_size,
                   tile_stride=args.tile_stride, preprocess_model=m.preprocess_model, vae=m.vae, y=m.y, y_mask=m.y_mask,
                   noise_scheduler=m.noise_scheduler)

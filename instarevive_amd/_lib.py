@@ -17,10 +17,11 @@ SYMBOLS = [
     "ir_abi_version", "ir_init", "ir_destroy", "ir_last_error", "ir_upload", "ir_has_tensor",
     "ir_swinir_configure", "ir_vae_configure", "ir_dit_configure", "ir_dit_control_configure", "ir_dit_set_prompt", "ir_t5_configure", "ir_t5_encode", "ir_workspace_bytes",
     "ir_swinir_forward", "ir_vae_encode", "ir_dit_forward", "ir_dit_step", "ir_dit_forward_control", "ir_dit_step_control", "ir_vae_decode", "ir_color_fix",
-    "ir_pipeline", "ir_u8_to_nchw", "ir_nchw_to_u8", "ir_profile_begin", "ir_profile_end",
+    "ir_pipeline", "ir_u8_to_nchw", "ir_nchw_to_u8", "ir_profile_begin", "ir_profile_end", "ir_profile_end_kernels", "ir_profile_kernel_count",
+    "ir_profile_kernel_name",
     "ir_op_conv", "ir_op_conv_groupnorm", "ir_op_linear", "ir_op_groupnorm", "ir_op_layernorm", "ir_op_attention", "ir_op_swin_attention",
-    "ir_op_softmax_rows",
-    "ir_tiled_count", "ir_tiled_encode", "ir_tiled_dit", "ir_tiled_blend_latent", "ir_tiled_decode", "ir_tiled_blend_pixels", "ir_set_plain_kernels", "ir_set_fp8", "ir_op_conv_fp8",
+    "ir_op_softmax_rows", "ir_op_nchw_to_nhwc", "ir_op_nhwc_to_nchw",
+    "ir_tiled_count", "ir_tiled_encode", "ir_tiled_dit", "ir_tiled_blend_latent", "ir_tiled_decode", "ir_tiled_blend_pixels", "ir_set_plain_kernels", "ir_set_fp8", "ir_op_conv_fp8", "ir_fp8_features",
 ]
 
 STAGE_SWINIR, STAGE_VAE_ENCODE, STAGE_DIT, STAGE_VAE_DECODE, STAGE_PIPELINE, STAGE_COLORFIX, STAGE_T5 = range(7)
@@ -73,6 +74,10 @@ def load_library():
     lib.ir_pipeline.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, f, f, f, vp, sz]
     lib.ir_profile_begin.argtypes = [vp]
     lib.ir_profile_end.argtypes = [vp, vp, i, vp, vp, vp, vp]
+    lib.ir_profile_end_kernels.argtypes = [vp, vp, i, vp, vp, vp, vp]
+    lib.ir_profile_kernel_count.argtypes = []
+    lib.ir_profile_kernel_name.argtypes = [i]
+    lib.ir_profile_kernel_name.restype = C.c_char_p
     lib.ir_u8_to_nchw.argtypes = [vp, vp, vp, vp, i, i, i]
     lib.ir_nchw_to_u8.argtypes = [vp, vp, vp, vp, i, i, i]
     lib.ir_op_conv.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, i, i, i, f, vp, i, i]
@@ -83,6 +88,8 @@ def load_library():
     lib.ir_op_attention.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, i, f, vp, vp, sz]
     lib.ir_op_swin_attention.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, f]
     lib.ir_op_softmax_rows.argtypes = [vp, vp, vp, vp, i, i]
+    lib.ir_op_nchw_to_nhwc.argtypes = [vp, vp, vp, vp, i, i, C.c_long, i, f, f]
+    lib.ir_op_nhwc_to_nchw.argtypes = [vp, vp, vp, i, vp, i, i, C.c_long, f, f, i]
     lib.ir_tiled_count.argtypes = [i, i, i, i]
     lib.ir_tiled_encode.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, f, vp, sz]
     lib.ir_tiled_dit.argtypes = [vp, vp, vp, vp, i, i, i, i, i, i, i, f, f, i, vp, sz]
@@ -91,6 +98,7 @@ def load_library():
     lib.ir_tiled_blend_pixels.argtypes = [vp, vp, vp, vp, i, i, i, i, i, vp, sz]
     lib.ir_set_plain_kernels.argtypes = [vp, i]
     lib.ir_set_fp8.argtypes = [vp, i]
+    lib.ir_fp8_features.argtypes = []
     lib.ir_op_conv_fp8.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, vp]
     for name in SYMBOLS:
         fn = getattr(lib, name)
@@ -182,6 +190,13 @@ class Context:
         ms, fl, by, la = (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)(), (C.c_longlong * n)()
         self.check(self.lib.ir_profile_end(self.h, self.stream(), n, ms, fl, by, la), "ir_profile_end")
         return {k: dict(ms=ms[i], flops=fl[i], bytes=by[i], launches=int(la[i])) for i, k in enumerate(self.PROFILE_CLASSES)}
+
+    def profile_end_kernels(self):
+        """-> {"class/kernel": dict(ms, flops, bytes, launches)} of the same measurement, one row per kernel that ran (algorithmic FLOPs / bytes)."""
+        n = int(self.lib.ir_profile_kernel_count())
+        ms, fl, by, la = (C.c_double * n)(), (C.c_double * n)(), (C.c_double * n)(), (C.c_longlong * n)()
+        self.check(self.lib.ir_profile_end_kernels(self.h, self.stream(), n, ms, fl, by, la), "ir_profile_end_kernels")
+        return {self.lib.ir_profile_kernel_name(i).decode(): dict(ms=ms[i], flops=fl[i], bytes=by[i], launches=int(la[i])) for i in range(n) if la[i]}
 
     def ws_bytes(self, stage, n, h, w, flags=0, tile_size=0, tile_stride=0):
         return int(self.lib.ir_workspace_bytes(self.h, stage, n, h, w, flags, tile_size, tile_stride))

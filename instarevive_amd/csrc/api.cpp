@@ -28,6 +28,7 @@ struct Conv {  // packed conv / linear weight: w [cout_pad][taps*cin] bf16, b [c
     const bf16_t* w = nullptr;
     const float* b = nullptr;
     int cin = 0, cout = 0, cout_pad = 0, taps = 1;
+    int cin_r = 0, cout_r = 0;  // un-padded channel counts for the algorithmic FLOP count of the profiler (0: cin / cout)
     long w_rs = 0;  // weight row stride in elements (0: taps*cin, densely packed)
     // optional fp8 form (BASELINE.json configs[4]): OCP e4m3 weights [cout][9][cin] quantised per output channel, the dequantisation
     // factor per channel (weight scale / activation scale) and the bias divided by it (see IGemmParams::fp8)
@@ -54,7 +55,7 @@ struct SwinLayer {
 };
 struct SwinModel {
     bool ok = false;
-    int C = 0, Cp = 0, heads = 0, hid_p = 0, nf = 0;
+    int C = 0, Cp = 0, heads = 0, hid = 0, hid_p = 0, nf = 0;
     float range = 1.f, mean[3] = {0, 0, 0};
     Conv conv_first, after_body, before_up, up1, up2, up3, hr, last;
     Norm pe, norm;
@@ -133,8 +134,24 @@ struct T5Model {
 
 // optional per-launch timing with HIP events on the launch stream (bench.py's roofline numbers come from here)
 enum { PC_CONV3X3 = 0, PC_LINEAR, PC_FLASH_ATTN, PC_SWIN_ATTN, PC_GROUPNORM, PC_LAYERNORM, PC_SOFTMAX, PC_TRANSPOSE, PC_OTHER, PC_COUNT };
+// kernel-level rows of the same measurement (ir_profile_end_kernels): one id per kernel (family) that matters on the 2048 x 2048 path,
+// each with the algorithmic FLOPs (un-padded dims) / bytes of its launches. Keep KERNEL_NAMES and KERNEL_CLASS in step.
+enum { PK_CONV_S1 = 0, PK_CONV_HALO_PP, PK_CONV_HALO, PK_CONV_FP8, PK_CONV_IGEMM, PK_GEMM_PP, PK_LINEAR_IGEMM, PK_SWIN_MLP, PK_ATTN_SELF, PK_ATTN_SELF_FP8,
+       PK_ATTN_D512, PK_ATTN_CROSS, PK_ATTN_OTHER, PK_SWIN_ATTN_PROJ, PK_SWIN_ATTN, PK_GN_APPLY, PK_GN_FULL, PK_LAYERNORM, PK_SOFTMAX, PK_TRANSPOSE, PK_OTHER,
+       PK_COUNT };
+static const char* const KERNEL_NAMES[PK_COUNT] = {
+    "conv3x3/conv_halo_s1_kernel", "conv3x3/conv_halo_pp_kernel", "conv3x3/conv_halo_kernel", "conv3x3/conv_fp8", "conv3x3/igemm_kernel<taps=9>",
+    "linear/gemm_pp_kernel", "linear/igemm_kernel<taps=1>", "linear/swin_mlp_kernel", "flash_attn/flash_attn_pp2_kernel (DiT self-attention)",
+    "flash_attn/flash_attn_fp8_kernel (DiT self-attention, fp8 operands)", "flash_attn/flash_attn_d512_v2_kernel (VAE mid-block)",
+    "flash_attn/flash_attn_kernel<72,true> (DiT cross-attention)", "flash_attn/other", "swin_attn/swin_attn_proj_kernel", "swin_attn/swin_window_attn_kernel",
+    "groupnorm/gn_finalize_groups+gn_apply (statistics from the conv epilogue)", "groupnorm/gn_partial+gn_finalize+gn_apply", "layernorm/layernorm_*_kernel",
+    "softmax_rows/softmax_rows_kernel", "transpose/transpose_v*", "other/layout+glue"};
+static const int KERNEL_CLASS[PK_COUNT] = {PC_CONV3X3, PC_CONV3X3, PC_CONV3X3, PC_CONV3X3, PC_CONV3X3, PC_LINEAR, PC_LINEAR, PC_LINEAR, PC_FLASH_ATTN, PC_FLASH_ATTN,
+                                           PC_FLASH_ATTN, PC_FLASH_ATTN, PC_FLASH_ATTN, PC_SWIN_ATTN, PC_SWIN_ATTN, PC_GROUPNORM, PC_GROUPNORM, PC_LAYERNORM,
+                                           PC_SOFTMAX, PC_TRANSPOSE, PC_OTHER};
+static const int CLASS_DEFAULT_KERNEL[PC_COUNT] = {PK_CONV_IGEMM, PK_LINEAR_IGEMM, PK_ATTN_OTHER, PK_SWIN_ATTN, PK_GN_FULL, PK_LAYERNORM, PK_SOFTMAX, PK_TRANSPOSE, PK_OTHER};
 struct ProfRec {
-    int cls;
+    int cls, kid;
     double flops, bytes;
     hipEvent_t e0, e1;
 };
@@ -157,6 +174,7 @@ struct ir_ctx {
     int device = 0;
     Profiler prof;
     bool fp8 = false;   // ir_set_fp8 / IR_FLAG_FP8: VAE resnet convs with fp8 operands where fp8 weights were uploaded
+    bool plain = false; // ir_set_plain_kernels: this context's launches take the older 4-wave kernels (make_run publishes it to the launchers)
     std::string err;
     std::unordered_map<std::string, Tensor> t;
     std::vector<void*> owned;  // extra device allocations that live as long as the context
@@ -248,7 +266,8 @@ struct Run {
 struct ProfScope {
     Run& r;
     hipEvent_t e1 = nullptr;
-    ProfScope(Run& r_, int cls, double flops, double bytes) : r(r_) {
+    ProfScope(Run& r_, int kid, double flops, double bytes) : r(r_) {
+        const int cls = KERNEL_CLASS[kid];
         Profiler& pf = r.c->prof;
         if (!pf.on) return;
         hipEvent_t e0 = r.chain;
@@ -259,20 +278,21 @@ struct ProfScope {
         }
         e1 = pf.get();
         if (!e1) { r.chain = nullptr; return; }
-        pf.recs.push_back(ProfRec{cls, flops, bytes, e0, e1});
+        pf.recs.push_back(ProfRec{cls, kid, flops, bytes, e0, e1});
     }
     ~ProfScope() {
         if (e1) (void)hipEventRecord(e1, r.s);
         r.chain = e1;
     }
 };
-#define LAUNCH(r, cls, flops, bytes, call, name)          \
+#define LAUNCHK(r, kid, flops, bytes, call, name)         \
     do {                                                  \
         if ((r).live()) {                                 \
-            ProfScope ps_((r), (cls), (flops), (bytes));  \
+            ProfScope ps_((r), (kid), (flops), (bytes));  \
             (r).chk((call), (name));                      \
         }                                                 \
     } while (0)
+#define LAUNCH(r, cls, flops, bytes, call, name) LAUNCHK(r, CLASS_DEFAULT_KERNEL[cls], flops, bytes, call, name)
 
 void conv(Run& r, const Conv& cw, const bf16_t* in, int N, int H, int W, int in_cs, void* out, int out_cs, int out_f32, int stride,
           int pad, int up, int act, float slope, const void* res, int res_f32, int res_cs, bf16_t* out2 = nullptr, int out2_cs = 0,
@@ -306,8 +326,13 @@ void conv(Run& r, const Conv& cw, const bf16_t* in, int N, int H, int W, int in_
         }
     }
     r.gn_want = false;
-    LAUNCH(r, cw.taps == 9 ? PC_CONV3X3 : PC_LINEAR, 2.0 * p.M * (double)cw.cout * cw.taps * cw.cin,
-           2.0 * ((double)p.M * cw.cin + (double)p.M * cw.cout + (double)cw.cout_pad * cw.taps * cw.cin), ir_launch_igemm(p, r.s), "igemm");
+    static const int kid_of[5] = {PK_CONV_S1, PK_CONV_HALO_PP, PK_GEMM_PP, PK_CONV_HALO, -1};
+    int kid = kid_of[ir_igemm_kernel_id(p)];
+    if (kid < 0) kid = cw.taps == 9 ? PK_CONV_IGEMM : PK_LINEAR_IGEMM;
+    const double cin_r = cw.cin_r ? cw.cin_r : cw.cin, cout_r = cw.cout_r ? cw.cout_r : cw.cout;
+    LAUNCHK(r, kid, 2.0 * p.M * cout_r * cw.taps * cin_r,
+            2.0 * ((double)p.M * cin_r + (double)p.M * cout_r + cout_r * cw.taps * cin_r) + (res ? (res_f32 ? 4.0 : 2.0) * p.M * cout_r : 0.0),
+            ir_launch_igemm(p, r.s), "igemm");
 }
 // linear over rows: in [M][in_cs] -> out [M][out_cs]
 void linear(Run& r, const Conv& cw, const bf16_t* in, int M, int in_cs, void* out, int out_cs, int out_f32, int act, const void* res,
@@ -321,7 +346,7 @@ void groupnorm(Run& r, const Norm& n, const bf16_t* x, bf16_t* y, float* ws, int
     if (r.gn_x == x && r.gn_chunks > 0) {  // statistics already produced by the conv that wrote x
         const int chunks = r.gn_chunks;
         r.gn_x = nullptr;
-        LAUNCH(r, PC_GROUPNORM, 0.0, (2.0 + wb) * N * (double)HW * n.c,
+        LAUNCHK(r, PK_GN_APPLY, 0.0, (2.0 + wb) * N * (double)HW * n.c,
                ir_launch_groupnorm_fused(x, y, n.g, n.b, r.gn_buf, ws, N, HW, n.c, 32, chunks, 1e-6f, silu, r.s, out_fp8, FP8_ACT_SCALE), "groupnorm_fused");
         return;
     }
@@ -353,8 +378,8 @@ void conv_fp8(Run& r, const Conv& cw, const bf16_t* in8, int N, int H, int W, vo
         }
     }
     r.gn_want = false;
-    LAUNCH(r, PC_CONV3X3, 2.0 * p.M * (double)cw.cout * 9 * cw.cin, (double)p.M * cw.cin + 2.0 * p.M * cw.cout + (double)cw.cout_pad * 9 * cw.cin,
-           ir_launch_igemm(p, r.s), "igemm_fp8");
+    LAUNCHK(r, PK_CONV_FP8, 2.0 * p.M * (double)cw.cout * 9 * cw.cin, (double)p.M * cw.cin + 2.0 * p.M * cw.cout + (double)cw.cout_pad * 9 * cw.cin,
+            ir_launch_igemm(p, r.s), "igemm_fp8");
 }
 void layernorm(Run& r, const float* x, bf16_t* y, float* yf, const float* a, const float* b, long rows, int C, int ldx, int ldy,
                float eps) {
@@ -377,9 +402,9 @@ struct Binder {
         }
         return it->second.p;
     }
-    Conv conv(const std::string& base, int cin, int cout, int cout_pad, int taps) {
+    Conv conv(const std::string& base, int cin, int cout, int cout_pad, int taps, int cin_r = 0, int cout_r = 0) {
         Conv w;
-        w.cin = cin; w.cout = cout; w.cout_pad = cout_pad; w.taps = taps;
+        w.cin = cin; w.cout = cout; w.cout_pad = cout_pad; w.taps = taps; w.cin_r = cin_r; w.cout_r = cout_r;
         w.w = (const bf16_t*)get(base + ".w", (size_t)cout_pad * taps * cin * 2);
         w.b = (const float*)get(base + ".b", (size_t)cout_pad * 4);
         return w;
@@ -437,15 +462,15 @@ void swinir_run(Run& r, const float* in, float* out, int n, int h, int w) {
             layernorm(r, cur, xn, nullptr, b.n1.g, b.n1.b, T, m.C, Cp, Cp, 1e-5f);
             linear(r, b.qkv, xn, (int)T, Cp, qkv, 3 * m.heads * 32, 0, ACT_NONE, nullptr, 0, 0);
             if (b.proj_t && !g_ir_plain_kernels) {  // window attention of all heads -> proj -> + x in one launch, no LDS (swin_fused.hip)
-                LAUNCH(r, PC_SWIN_ATTN, 4.0 * (double)T * 64 * 32 * m.heads + 2.0 * (double)T * m.C * m.C, 0.0,
+                LAUNCHK(r, PK_SWIN_ATTN_PROJ, 4.0 * (double)T * 64 * m.C + 2.0 * (double)T * m.C * m.C, 0.0,
                        ir_launch_swin_attn_proj(qkv, cur, xb, b.proj_t, b.proj.b, b.biasT, n, gh, gw, (j & 1) ? 4 : 0, scale, r.s), "swin_attn_proj");
             } else {
-                LAUNCH(r, PC_SWIN_ATTN, 4.0 * (double)T * 64 * 32 * m.heads, 0.0,
+                LAUNCHK(r, PK_SWIN_ATTN, 4.0 * (double)T * 64 * m.C, 0.0,
                        ir_launch_swin_attn(qkv, att, b.biasT, n, gh, gw, m.heads, 3 * m.heads * 32, Cp, (j & 1) ? 4 : 0, scale, r.s), "swin_attn");
                 linear(r, b.proj, att, (int)T, Cp, xb, Cp, 1, ACT_NONE, cur, 1, Cp);
             }
             if (b.mlp_t && !g_ir_plain_kernels) {  // LN2 -> fc1 -> GELU -> fc2 -> + x in one kernel, the token's state in registers throughout
-                LAUNCH(r, PC_LINEAR, 4.0 * (double)T * m.C * (m.hid_p), 4.0 * (double)T * Cp * 2,
+                LAUNCHK(r, PK_SWIN_MLP, 4.0 * (double)T * m.C * m.hid, 4.0 * (double)T * m.C * 2,
                        ir_launch_swin_mlp(xb, xb, last ? xc : nullptr, b.mlp_t, b.mlp_v, T, m.C, m.hid_p, 1e-5f, r.s), "swin_mlp");
             } else {
                 layernorm(r, xb, xn, nullptr, b.n2.g, b.n2.b, T, m.C, Cp, Cp, 1e-5f);
@@ -544,7 +569,7 @@ int attnblock(Run& r, const AttnW& w, bf16_t* B[3], int ci, float* gws, int N, i
     if (v2) {
         LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_zero_f32(reinterpret_cast<float*>(flag), 1, r.s), "zero");
         LAUNCH(r, PC_TRANSPOSE, 0.0, 4.0 * (double)N * T * C, ir_launch_transpose_v_tiles(v, vtt, N, (int)T, C, T * C, T * C, r.s), "transpose_v_tiles");
-        LAUNCH(r, PC_FLASH_ATTN, 4.0 * (double)N * T * T * C, 0.0,
+        LAUNCHK(r, PK_ATTN_D512, 4.0 * (double)N * T * T * C, 0.0,
                ir_launch_flash_attn_d512_v2(q, k, vtt, o, N, (int)T, C, C, T * C, T * C, T * C, sc, flag, r.s), "vae_flash_attn");
     }
     for (int b = 0; b < N; ++b) {
@@ -724,7 +749,7 @@ void dit_block(Run& r, const DitLayer& Lw, const float* mod, float* x, const Dit
         p.q_rs = p.k_rs = 3 * C; p.o_rs = C; p.q_hs = p.k_hs = p.o_hs = hd;
         p.B = n; p.Hh = Hh; p.Tq = (int)T; p.Tk = (int)T; p.Tk_pad = Tpad; p.D = hd; p.scale_log2 = sl2;
         p.ovf_flag = b.attn_flag;
-        LAUNCH(r, PC_FLASH_ATTN, 4.0 * n * Hh * (double)T * T * hd, 0.0, ir_launch_flash_attn(p, r.s), "self_attn");
+        LAUNCHK(r, ir_flash_attn_is_pp2(p) ? PK_ATTN_SELF : PK_ATTN_OTHER, 4.0 * n * Hh * (double)T * T * hd, 0.0, ir_launch_flash_attn(p, r.s), "self_attn");
     }
     linear(r, Lw.ao, b.att, (int)BT, C, x, C, 1, ACT_NONE, x, 1, C, b.xb, C, mod + 2 * C);
     // cross attention on the un-normalised stream (PixArtMS.py:76); K/V of the prompt are cached per layer
@@ -737,7 +762,7 @@ void dit_block(Run& r, const DitLayer& Lw, const float* mod, float* x, const Dit
         p.q_rs = C; p.k_rs = 2 * C; p.o_rs = C; p.q_hs = p.k_hs = p.o_hs = hd;
         p.B = n; p.Hh = Hh; p.Tq = (int)T; p.Tk = m.n_tok; p.Tk_pad = m.tok_pad; p.D = hd; p.scale_log2 = sl2;
         p.key_bias = m.key_bias; p.kb_bs = 0;
-        LAUNCH(r, PC_FLASH_ATTN, 4.0 * n * Hh * (double)T * m.n_tok * hd, 0.0, ir_launch_flash_attn(p, r.s), "cross_attn");
+        LAUNCHK(r, PK_ATTN_CROSS, 4.0 * n * Hh * (double)T * m.n_tok * hd, 0.0, ir_launch_flash_attn(p, r.s), "cross_attn");
     }
     linear(r, Lw.co, b.att, (int)BT, C, x, C, 1, ACT_NONE, x, 1, C);
     layernorm(r, x, b.xn, nullptr, mod + 4 * C, mod + 3 * C, BT, C, C, C, 1e-6f);
@@ -983,7 +1008,15 @@ Run make_run(ir_ctx* c, void* stream, void* ws, size_t ws_bytes, bool dry) {
     if (c && !dry && hipSetDevice(c->device) != hipSuccess) r.rc = -3, r.where = "hipSetDevice";
     r.c = c; r.s = (hipStream_t)stream;
     r.a.base = (char*)ws; r.a.cap = ws_bytes; r.a.dry = dry;
+    // the kernel choice of THIS context (a context is driven by one host thread at a time; the launchers read the global)
+    if (c) g_ir_plain_kernels = c->plain ? 1 : 0;
     return r;
+}
+// entry points that launch without a Run: make the context's GPU current and publish its kernel choice
+void use_ctx(ir_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    g_ir_plain_kernels = c->plain ? 1 : 0;
 }
 int check_size(ir_ctx* c, int n, int h, int w, int mult) {
     if (n <= 0 || h <= 0 || w <= 0 || (h % mult) || (w % mult)) return fail(c, -10, "bad size n=%d h=%d w=%d (need multiples of %d)", n, h, w, mult);
@@ -1043,12 +1076,12 @@ int ir_swinir_configure(ir_ctx* c, int embed_dim, int n_layers, const int* depth
                         float img_range, const float* mean3) {
     if (!c || !depths || !mean3 || embed_dim % heads || embed_dim / heads > 32) return fail(c, -1, "ir_swinir_configure: bad argument");
     SwinModel m;
-    m.C = embed_dim; m.Cp = heads * 32; m.heads = heads; m.hid_p = pad32(mlp_hidden); m.nf = num_feat; m.range = img_range;
+    m.C = embed_dim; m.Cp = heads * 32; m.heads = heads; m.hid = mlp_hidden; m.hid_p = pad32(mlp_hidden); m.nf = num_feat; m.range = img_range;
     if (m.Cp < pad32(embed_dim) || (num_feat & 31)) return fail(c, -1, "ir_swinir_configure: unsupported dims");
     for (int i = 0; i < 3; ++i) m.mean[i] = mean3[i];
     Binder b{c};
     const int Cp = m.Cp, qn = 3 * heads * 32;
-    m.conv_first = b.conv("swin.conv_first", 192, Cp, Cp, 9);
+    m.conv_first = b.conv("swin.conv_first", 192, Cp, Cp, 9, 192, embed_dim);
     m.pe = b.norm("swin.pe_norm", embed_dim);
     m.norm = b.norm("swin.norm", embed_dim);
     for (int i = 0; i < n_layers; ++i) {
@@ -1058,15 +1091,16 @@ int ir_swinir_configure(ir_ctx* c, int embed_dim, int n_layers, const int* depth
             const std::string p = fmt("swin.l%d.b%d", i, j);
             k.n1 = b.norm(p + ".n1", embed_dim);
             k.n2 = b.norm(p + ".n2", embed_dim);
-            k.qkv = b.conv(p + ".qkv", Cp, qn, qn, 1);
-            k.proj = b.conv(p + ".proj", Cp, Cp, Cp, 1);
-            k.fc1 = b.conv(p + ".fc1", Cp, m.hid_p, m.hid_p, 1);
-            k.fc2 = b.conv(p + ".fc2", m.hid_p, Cp, Cp, 1);
+            k.qkv = b.conv(p + ".qkv", Cp, qn, qn, 1, embed_dim, 3 * embed_dim);
+            k.proj = b.conv(p + ".proj", Cp, Cp, Cp, 1, embed_dim, embed_dim);
+            k.fc1 = b.conv(p + ".fc1", Cp, m.hid_p, m.hid_p, 1, embed_dim, mlp_hidden);
+            k.fc2 = b.conv(p + ".fc2", m.hid_p, Cp, Cp, 1, mlp_hidden, embed_dim);
             k.biasT = b.f32(p + ".biasT", (size_t)heads * 4096);
             {   // optional: present when the host packed the fused-MLP form (Cp = 192 only)
                 auto it = c->t.find(p + ".mlp_t"), iv = c->t.find(p + ".mlp_v");
                 const size_t nj = (size_t)m.hid_p / 32;
-                if (Cp == 192 && it != c->t.end() && iv != c->t.end() && it->second.bytes >= nj * 28672 && iv->second.bytes >= (3 * 192 + nj * 32) * 4) {
+                if (Cp == 192 && m.hid_p <= 512 && it != c->t.end() && iv != c->t.end() && it->second.bytes >= nj * 28672 &&
+                    iv->second.bytes >= (3 * 192 + nj * 32) * 4) {   // ir_launch_swin_mlp takes hid_p <= 512 only
                     k.mlp_t = it->second.p;
                     k.mlp_v = (const float*)iv->second.p;
                 }
@@ -1077,11 +1111,11 @@ int ir_swinir_configure(ir_ctx* c, int embed_dim, int n_layers, const int* depth
             }
             L.blocks.push_back(k);
         }
-        L.conv = b.conv(fmt("swin.l%d.conv", i), Cp, Cp, Cp, 9);
+        L.conv = b.conv(fmt("swin.l%d.conv", i), Cp, Cp, Cp, 9, embed_dim, embed_dim);
         m.layers.push_back(L);
     }
-    m.after_body = b.conv("swin.after_body", Cp, Cp, Cp, 9);
-    m.before_up = b.conv("swin.before_up", Cp, num_feat, num_feat, 9);
+    m.after_body = b.conv("swin.after_body", Cp, Cp, Cp, 9, embed_dim, embed_dim);
+    m.before_up = b.conv("swin.before_up", Cp, num_feat, num_feat, 9, embed_dim, num_feat);
     m.up1 = b.conv("swin.up1", num_feat, num_feat, num_feat, 9);
     m.up2 = b.conv("swin.up2", num_feat, num_feat, num_feat, 9);
     m.up3 = b.conv("swin.up3", num_feat, num_feat, num_feat, 9);
@@ -1122,7 +1156,7 @@ int ir_vae_configure(ir_ctx* c, int ch, int n_levels, const int* ch_mult, int nu
     VaeModel m;
     if (with_encoder) {
         VaeHalf& e = m.enc;
-        e.conv_in = b.conv("vae.enc.conv_in", 32, ch, ch, 9);
+        e.conv_in = b.conv("vae.enc.conv_in", 32, ch, ch, 9, 3, ch);
         int block_in = ch;
         for (int l = 0; l < n_levels; ++l) {
             VaeLevel L;
@@ -1149,7 +1183,7 @@ int ir_vae_configure(ir_ctx* c, int ch, int n_levels, const int* ch_mult, int nu
     if (with_decoder) {
         VaeHalf& d = m.dec;
         int block_in = ch * ch_mult[n_levels - 1];
-        d.conv_in = b.conv("vae.dec.conv_in", 32, block_in, block_in, 9);
+        d.conv_in = b.conv("vae.dec.conv_in", 32, block_in, block_in, 9, 4, block_in);
         d.mid1 = bind_res(b, "vae.dec.mid.res0", block_in, block_in);
         d.attn = bind_attn(b, "vae.dec.mid.attn", block_in);
         d.mid2 = bind_res(b, "vae.dec.mid.res1", block_in, block_in);
@@ -1217,7 +1251,7 @@ int ir_dit_configure(ir_ctx* c, int n_layers, int heads, int head_dim, int mlp_h
     Binder b{c};
     DitModel m;
     m.L = n_layers; m.heads = heads; m.hd = head_dim; m.C = C; m.mlp = mlp_hidden; m.cap = caption_dim; m.base = base_grid;
-    m.patch = b.conv("dit.patch", 32, C, C, 1);
+    m.patch = b.conv("dit.patch", 32, C, C, 1, 16, C);
     m.cap1 = b.conv("dit.cap1", caption_dim, C, C, 1);
     m.cap2 = b.conv("dit.cap2", C, C, C, 1);
     m.fin = b.conv("dit.final", C, 32, 32, 1);
@@ -1284,12 +1318,16 @@ int ir_dit_set_prompt(ir_ctx* c, void* stream, const float* embeds_host, const f
     hipStream_t s = (hipStream_t)stream;
     const int C = m.C, DV = ir_attn_dv(m.hd);
     const int tok_pad = ((n_tok + 63) & ~63) + 64;
-    float* e32 = nullptr;
-    bf16_t *e16 = nullptr, *y1 = nullptr, *y2 = nullptr;
-    HIPOK(c, hipMalloc((void**)&e32, (size_t)n_tok * m.cap * 4));
-    HIPOK(c, hipMalloc((void**)&e16, (size_t)n_tok * m.cap * 2));
-    HIPOK(c, hipMalloc((void**)&y1, (size_t)n_tok * C * 2));
-    HIPOK(c, hipMalloc((void**)&y2, (size_t)n_tok * C * 2));
+    struct Temps {   // freed on every exit path (the HIPOK early returns included)
+        void* p[4] = {nullptr, nullptr, nullptr, nullptr};
+        ~Temps() { for (void* q : p) if (q) (void)hipFree(q); }
+    } tmp;
+    HIPOK(c, hipMalloc(&tmp.p[0], (size_t)n_tok * m.cap * 4));
+    HIPOK(c, hipMalloc(&tmp.p[1], (size_t)n_tok * m.cap * 2));
+    HIPOK(c, hipMalloc(&tmp.p[2], (size_t)n_tok * C * 2));
+    HIPOK(c, hipMalloc(&tmp.p[3], (size_t)n_tok * C * 2));
+    float* e32 = (float*)tmp.p[0];
+    bf16_t *e16 = (bf16_t*)tmp.p[1], *y1 = (bf16_t*)tmp.p[2], *y2 = (bf16_t*)tmp.p[3];
     HIPOK(c, hipMemcpyAsync(e32, embeds_host, (size_t)n_tok * m.cap * 4, hipMemcpyHostToDevice, s));
     // The caches hold tok_pad rows (>= n_tok), so any prompt of the same 64-token bucket fits; a longer bucket (or a model /
     // control re-bind, which resets prompt_cap) frees the old buffers and allocates new ones. V^T rows have a tok_pad stride, so
@@ -1318,8 +1356,7 @@ int ir_dit_set_prompt(ir_ctx* c, void* stream, const float* embeds_host, const f
             linear(r, L.ckv, y2, n_tok, C, L.kc, 2 * C, 0, ACT_NONE, nullptr, 0, 0);
             LAUNCH(r, PC_TRANSPOSE, 0.0, 0.0, ir_launch_transpose_v(L.kc + C, L.vtc, 0, 2 * C, m.hd, 1, m.heads, n_tok, tok_pad, m.hd, DV, s), "transpose_v");
         }
-    HIPOK(c, hipStreamSynchronize(s));
-    (void)hipFree(e32); (void)hipFree(e16); (void)hipFree(y1); (void)hipFree(y2);
+    HIPOK(c, hipStreamSynchronize(s));   // the temporaries are released when this function returns
     if (r.rc) return fail(c, r.rc, "ir_dit_set_prompt: %s failed", r.where);
     m.n_tok = n_tok; m.tok_pad = tok_pad; m.prompt_ok = true;
     ++c->generation;
@@ -1589,15 +1626,19 @@ int ir_tiled_blend_pixels(ir_ctx* c, void* stream, const float* px_tiles, uint8_
 // d = 512 attention), the independent second implementation of the same arithmetic that bench.py and the tests cross-check the
 // fast kernels against. Process-wide.
 // fp8 mode of the stage entry points (ir_pipeline: IR_FLAG_FP8): VAE resnet convs whose fp8 weights were uploaded run on fp8 operands
+int ir_fp8_features(void) { return IR_FP8_VAE_RESNET_CONVS; }
 int ir_set_fp8(ir_ctx* c, int on) {
     if (!c) return -1;
+    if (c->fp8 != (on != 0)) ++c->generation;   // recorded hipGraphs hold the launches of the mode they were captured in
     c->fp8 = on != 0;
     return 0;
 }
 
 int ir_set_plain_kernels(ir_ctx* c, int on) {
-    (void)c;
-    g_ir_plain_kernels = on ? 1 : 0;
+    if (!c) return -1;
+    if (c->plain != (on != 0)) ++c->generation;
+    c->plain = on != 0;
+    g_ir_plain_kernels = c->plain ? 1 : 0;   // single-kernel entry points that bypass make_run read the global
     return 0;
 }
 
@@ -1697,17 +1738,31 @@ int ir_profile_end(ir_ctx* c, void* stream, int n_classes, double* ms, double* f
         if (hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) continue;
         ms[r.cls] += t; flops[r.cls] += r.flops; bytes[r.cls] += r.bytes; launches[r.cls] += 1;
     }
-    c->prof.recs.clear();
-    c->prof.used = 0;
+    return 0;   // the records stay until the next ir_profile_begin, so ir_profile_end_kernels can read the same measurement
+}
+int ir_profile_kernel_count(void) { return PK_COUNT; }
+const char* ir_profile_kernel_name(int id) { return id >= 0 && id < PK_COUNT ? KERNEL_NAMES[id] : nullptr; }
+int ir_profile_end_kernels(ir_ctx* c, void* stream, int n_kernels, double* ms, double* flops, double* bytes, long long* launches) {
+    if (!c || !ms || !flops || !bytes || !launches) return -1;
+    c->prof.on = false;
+    HIPOK(c, hipSetDevice(c->device));
+    HIPOK(c, hipStreamSynchronize((hipStream_t)stream));
+    for (int i = 0; i < n_kernels; ++i) { ms[i] = flops[i] = bytes[i] = 0.0; launches[i] = 0; }
+    for (const ProfRec& r : c->prof.recs) {
+        if (r.kid >= n_kernels) continue;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) continue;
+        ms[r.kid] += t; flops[r.kid] += r.flops; bytes[r.kid] += r.bytes; launches[r.kid] += 1;
+    }
     return 0;
 }
 
 int ir_u8_to_nchw(ir_ctx* c, void* stream, const uint8_t* in, float* out, int n, int h, int w) {
-    if (c) (void)hipSetDevice(c->device);
+    use_ctx(c);
     return ir_launch_u8_to_nchw(in, out, n, h, w, (hipStream_t)stream) ? fail(c, -1, "u8_to_nchw launch failed") : 0;
 }
 int ir_nchw_to_u8(ir_ctx* c, void* stream, const float* in, uint8_t* out, int n, int h, int w) {
-    if (c) (void)hipSetDevice(c->device);
+    use_ctx(c);
     return ir_launch_nchw_to_u8(in, out, n, (long)h * w, (hipStream_t)stream) ? fail(c, -1, "nchw_to_u8 launch failed") : 0;
 }
 
@@ -1759,21 +1814,21 @@ int ir_op_linear(ir_ctx* c, void* stream, const uint16_t* in, const uint16_t* wg
 }
 int ir_op_groupnorm(ir_ctx* c, void* stream, const uint16_t* x, uint16_t* y, const float* gamma, const float* beta, int n, int hw, int ch,
                     int groups, float eps, int silu, void* ws, size_t ws_bytes) {
-    if (c) (void)hipSetDevice(c->device);
+    use_ctx(c);
     if (ws_bytes < (size_t)ir_gn_ws_floats(n, hw, ch) * 4) return fail(c, -20, "groupnorm workspace too small");
     int rc = ir_launch_groupnorm(x, y, gamma, beta, (float*)ws, n, hw, ch, groups, eps, silu, (hipStream_t)stream);
     return rc ? fail(c, rc, "groupnorm failed (%d)", rc) : 0;
 }
 int ir_op_layernorm(ir_ctx* c, void* stream, const float* x, uint16_t* y, const float* a, const float* b, int rows, int ch, int ldx,
                     int ldy, float eps) {
-    if (c) (void)hipSetDevice(c->device);
+    use_ctx(c);
     int rc = ir_launch_layernorm(x, y, nullptr, a, b, rows, ch, ldx, ldy, eps, 1L << 40, 0, (hipStream_t)stream);
     return rc ? fail(c, rc, "layernorm failed (%d)", rc) : 0;
 }
 int ir_op_attention(ir_ctx* c, void* stream, const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* o, int b, int heads,
                     int tq, int tk, int d, float scale, const float* key_bias, void* ws, size_t ws_bytes) {
     // q/o: [b][tq][heads*d], k/v: [b][tk][heads*d]
-    if (c) (void)hipSetDevice(c->device);
+    use_ctx(c);
     const int DV = ir_attn_dv(d), tkp = ((tk + 63) & ~63) + 64;
     if (heads == 1 && d == 512 && tq == tk && key_bias == nullptr) {  // VAE mid-block form
         const size_t old_vt = ((size_t)512 * tkp * 2 + 255) & ~(size_t)255, tiles = ((size_t)b * tk * 512 * 2 + 255) & ~(size_t)255;
@@ -1817,12 +1872,22 @@ int ir_op_attention(ir_ctx* c, void* stream, const uint16_t* q, const uint16_t* 
 }
 int ir_op_swin_attention(ir_ctx* c, void* stream, const uint16_t* qkv, uint16_t* out, const float* bias_t, int b, int h, int w,
                          int heads, int shift, float scale) {
-    if (c) (void)hipSetDevice(c->device);
+    use_ctx(c);
     int rc = ir_launch_swin_attn(qkv, out, bias_t, b, h, w, heads, 3 * heads * 32, heads * 32, shift, scale, (hipStream_t)stream);
     return rc ? fail(c, rc, "swin_attn failed (%d)", rc) : 0;
 }
+int ir_op_nchw_to_nhwc(ir_ctx* c, void* stream, const float* in, uint16_t* out, int n, int ch, long hw, int cpad, float scale, float shift) {
+    use_ctx(c);
+    int rc = ir_launch_nchw_to_nhwc_bf16(in, out, n, ch, hw, cpad, scale, shift, (hipStream_t)stream);
+    return rc ? fail(c, rc, "nchw_to_nhwc failed (%d)", rc) : 0;
+}
+int ir_op_nhwc_to_nchw(ir_ctx* c, void* stream, const float* in, int in_cs, float* out, int n, int ch, long hw, float scale, float shift, int clamp01) {
+    use_ctx(c);
+    int rc = ir_launch_nhwc_to_nchw(in, in_cs, out, n, ch, hw, scale, shift, clamp01, (hipStream_t)stream);
+    return rc ? fail(c, rc, "nhwc_to_nchw failed (%d)", rc) : 0;
+}
 int ir_op_softmax_rows(ir_ctx* c, void* stream, const float* x, uint16_t* y, int rows, int cols) {
-    if (c) (void)hipSetDevice(c->device);
+    use_ctx(c);
     int rc = ir_launch_softmax_rows(x, y, rows, cols, cols, cols, (hipStream_t)stream);
     return rc ? fail(c, rc, "softmax_rows failed (%d)", rc) : 0;
 }

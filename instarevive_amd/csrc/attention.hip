@@ -591,6 +591,12 @@ __global__ __launch_bounds__(512, 1) void flash_attn_pp_kernel(AttnParams p) {
     }
 }
 
+bool ir_flash_attn_is_pp2(const AttnParams& p) {
+    static const bool no_pp = getenv("IR_NO_PINGPONG") != nullptr, pp1 = getenv("IR_ATTN_PP1") != nullptr;
+    const bool general = p.key_bias != nullptr || (p.Tk & 63);
+    return p.D == 72 && !general && p.Tq >= 256 && p.ovf_flag && !no_pp && !pp1 && !g_ir_plain_kernels;
+}
+
 int ir_launch_flash_attn(const AttnParams& p, hipStream_t s) {
     if (p.Tq <= 0 || p.Tk <= 0 || p.B <= 0 || p.Hh <= 0) return -2;
     if ((p.D & 7) || (p.q_rs & 7) || (p.k_rs & 7) || (p.o_rs & 7) || (p.q_hs & 7) || (p.k_hs & 7) || (p.o_hs & 7) ||

@@ -1487,6 +1487,20 @@ int ir_igemm_gn_chunks(const IGemmParams& p) {
     return (int)(hw / 128);
 }
 
+static bool igemm_vec(const IGemmParams& p) {
+    return !((p.out_cs & 3) || (p.res && (p.res_cs & 3)) || (p.out2 && (p.out2_cs & 3)) || (reinterpret_cast<uintptr_t>(p.res) & 15) ||
+             (reinterpret_cast<uintptr_t>(p.out2) & 7) || (p.gate && (p.gate_stride & 3)));
+}
+int ir_igemm_kernel_id(const IGemmParams& pin) {
+    IGemmParams p = pin;
+    p.vec = igemm_vec(p);
+    if (ir_conv_s1_takes(p)) return 0;
+    if (takes_halo_pp(p)) return 1;
+    if (takes_gemm_pp(p)) return 2;
+    if (takes_halo(p)) return 3;
+    return 4;
+}
+
 // Host launcher. Returns 0 or a negative error code; validates every shape assumption the kernel makes.
 int ir_launch_igemm(const IGemmParams& pin, hipStream_t s) {
     IGemmParams p = pin;
@@ -1496,9 +1510,7 @@ int ir_launch_igemm(const IGemmParams& pin, hipStream_t s) {
     if (p.Cout <= 0 || p.Cout > p.Cout_pad || (p.Cout_pad & 31)) return -4;
     if (p.wgt_rs < (long)p.taps * p.Cin || (p.wgt_rs & 7)) return -10;
     if (p.taps == 9 && (long)p.Cin * 2 + 64 > (long)sizeof(uint4) * 4096) return -11;  // zero page must cover one tap's channels
-    p.vec = !((p.out_cs & 3) || (p.res && (p.res_cs & 3)) || (p.out2 && (p.out2_cs & 3)) ||
-              (reinterpret_cast<uintptr_t>(p.res) & 15) || (reinterpret_cast<uintptr_t>(p.out2) & 7) ||
-              (p.gate && (p.gate_stride & 3)));
+    p.vec = igemm_vec(p);
     if (!p.out) return -5;
     if (p.gate && p.gate_stride != 0) return -6;  // one gate row per launch (single timestep per batch)
     if ((reinterpret_cast<uintptr_t>(p.in) & 15) || (reinterpret_cast<uintptr_t>(p.wgt) & 15) ||

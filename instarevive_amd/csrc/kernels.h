@@ -48,6 +48,8 @@ struct IGemmParams {
     int gn_cpg, gn_chunks;
 };
 int ir_launch_igemm(const IGemmParams& p, hipStream_t s);
+// which kernel ir_launch_igemm picks for p: 0 conv_halo_s1, 1 conv_halo_pp, 2 gemm_pp, 3 conv_halo, 4 igemm_kernel (profiler rows)
+int ir_igemm_kernel_id(const IGemmParams& p);
 // Pixel tiles per image the kernel ir_launch_igemm would pick for p writes statistics for, or 0 if this launch cannot fuse them.
 int ir_igemm_gn_chunks(const IGemmParams& p);
 
@@ -95,6 +97,7 @@ struct AttnParams {
     int* ovf_flag;             // optional 4 bytes of device scratch: enables the fixed-reference ping-pong kernel (see attention.hip)
 };
 int ir_launch_flash_attn(const AttnParams& p, hipStream_t s);
+bool ir_flash_attn_is_pp2(const AttnParams& p);   // ir_launch_flash_attn routes p to flash_attn_pp2_kernel (profiler rows)
 // DiT self-attention (D = 72, Tk % 64 == 0, no key bias, ovf_flag set) as one wave per SIMD with two query groups (attn_d512.hip)
 int ir_launch_flash_attn_pp2(const AttnParams& p, hipStream_t s);
 int ir_launch_flash_attn_d512(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* o, int T, int rs, int o_rs, long vt_rs,

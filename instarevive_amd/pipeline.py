@@ -29,6 +29,7 @@ class _Staging:
         self.d_in = [torch.empty(shape, dtype=torch.uint8, device=device) for _ in range(slots)]
         self.d_out = [torch.empty(shape, dtype=torch.uint8, device=device) for _ in range(slots)]
         self.d_st1 = [torch.empty(shape, dtype=torch.uint8, device=device) for _ in range(slots)]
+        self.h2d_done = [None] * slots   # event behind the last asynchronous upload out of h_in[slot] (see upload())
 
     @staticmethod
     def get(ctx, n, h, w, slots=1, tag="sync"):
@@ -42,11 +43,24 @@ class _Staging:
 
     def fill(self, slot, control_imgs):
         """Copy the caller's HWC uint8 arrays into the pinned input buffer of `slot` (one pass, no intermediate np.stack)."""
+        if self.h2d_done[slot] is not None:   # the previous upload out of this pinned buffer may still be queued behind earlier kernels
+            self.h2d_done[slot].synchronize()
+            self.h2d_done[slot] = None
         dst = self.h_in[slot].numpy()
         for i, im in enumerate(control_imgs):
             if im.dtype != np.uint8 or im.shape != self.shape[1:]:
                 raise ValueError("control_imgs must be HWC uint8 RGB arrays of equal size")
             np.copyto(dst[i], im)
+
+    def upload(self, slot, stream=None):
+        """Asynchronous H2D copy of the pinned input buffer of `slot` on `stream` (default: the current one). The event recorded behind
+        it is what the next fill() of the slot waits for: a caller that never synchronises with the device between two images (a
+        rank that only contributes tiles under --shard_tiles) must not overwrite the pinned buffer while its copy is still queued."""
+        self.d_in[slot].copy_(self.h_in[slot], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(stream if stream is not None else torch.cuda.current_stream(self.d_in[slot].device))
+        self.h2d_done[slot] = ev
+        return ev
 
 
 def _check_images(control_imgs):
@@ -147,6 +161,7 @@ def _prepare_fused(model, y, y_mask, h, w, tiled, tile_size, others=()):
     for m in others:  # the context must hold THESE models' weights (another instance of the family may have been loaded since)
         if m is not None:
             m._ready()
+    model._ready()    # a ControlTransformerHalf re-binds its control branch here (set_prompt below resolves to the base model only)
     model.set_prompt(y, y_mask)
     if tiled:
         model.ensure_pos(tile_size // 16, tile_size // 16)
@@ -179,13 +194,17 @@ def process(model, control_imgs: List[np.ndarray], strength: float, color_fix_ty
     device = model.device
     acp = float(noise_scheduler.alphas_cumprod[400])
     sf = float(vae.config.scaling_factor)
+    if fp8 and not (fused and _fused_ok(model, preprocess_model, vae, disable_preprocess_model)):
+        raise ValueError("process(fp8=True) needs the fused form (instarevive_amd models sharing one context)")
     if fused and _fused_ok(model, preprocess_model, vae, disable_preprocess_model):
+        if fp8 and not vae.__dict__.get("_fp8_uploaded"):
+            raise RuntimeError("process(fp8=True): call vae.enable_fp8() first - without the fp8 weight forms every layer would silently run in bf16")
         ctx = model.ctx
         _prepare_fused(model, y, y_mask, h, w, tiled, tile_size, (vae, None if disable_preprocess_model else preprocess_model))
         flags = _pipeline_flags(model, color_fix_type, disable_preprocess_model, tiled) | (L.FLAG_GRAPH if graph else 0) | (L.FLAG_FP8 if fp8 else 0)
         st = _Staging.get(ctx, n, h, w)
         st.fill(0, control_imgs)
-        st.d_in[0].copy_(st.h_in[0], non_blocking=True)
+        st.upload(0)
         _launch_pipeline(ctx, st, 0, n, h, w, flags, tile_size, tile_stride, acp, sf, return_stage1)
         st.h_out[0].copy_(st.d_out[0], non_blocking=True)
         if return_stage1:
@@ -255,9 +274,7 @@ def process_stream(model, batches: Iterable[Sequence[np.ndarray]], color_fix_typ
         st = _Staging.get(ctx, n, h, w, slots=2, tag="stream")
         st.fill(slot, imgs)
         with torch.cuda.stream(copy):
-            st.d_in[slot].copy_(st.h_in[slot], non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(copy)
+            ev = st.upload(slot, copy)
         return st, slot, (n, h, w), ev
 
     def download(job):
@@ -327,7 +344,7 @@ class HipTileEngine:
         _prepare_fused(self.model, self.y, self.y_mask, h, w, True, self.tile_size, self.others)
         st = _Staging.get(self.ctx, n, h, w)
         st.fill(0, control_imgs)
-        st.d_in[0].copy_(st.h_in[0], non_blocking=True)
+        st.upload(0)
         control = torch.empty((n, 3, h, w), dtype=torch.float32, device=self.device)
         init = torch.empty((n, 4, h // 8, w // 8), dtype=torch.float32, device=self.device)
         ws = self._ws()

@@ -174,8 +174,10 @@ def pack_swinir(sd, cfg):
             out[d + "fc1.b"] = pad_vec(sd[s + "mlp.fc1.bias"], hid_p)
             out[d + "fc2.w"] = pack_linear(sd[s + "mlp.fc2.weight"], Cp, hid_p)
             out[d + "fc2.b"] = pad_vec(sd[s + "mlp.fc2.bias"], Cp)
-            out[d + "mlp_t"], out[d + "mlp_v"] = pack_swin_mlp(sd[s + "mlp.fc1.weight"], sd[s + "mlp.fc1.bias"], sd[s + "mlp.fc2.weight"],
-                                                              sd[s + "mlp.fc2.bias"], sd[s + "norm2.weight"], sd[s + "norm2.bias"], C, Cp, hid_p)
+            if Cp == 192 and hid_p <= 512:   # the fused MLP kernel's tile layout is the 192-channel one and its registers hold <= 512 hidden units;
+                # other widths (num_heads != 6, mlp_ratio >= 3 at embed_dim 180) run LN2 / fc1 / fc2 as separate launches
+                out[d + "mlp_t"], out[d + "mlp_v"] = pack_swin_mlp(sd[s + "mlp.fc1.weight"], sd[s + "mlp.fc1.bias"], sd[s + "mlp.fc2.weight"],
+                                                                  sd[s + "mlp.fc2.bias"], sd[s + "norm2.weight"], sd[s + "norm2.bias"], C, Cp, hid_p)
             table = sd[s + "attn.relative_position_bias_table"].float()
             bias = table[rpi.view(-1)].view(64, 64, heads)                       # [query][key][head]  (swinir.py:138-140)
             out[d + "biasT"] = (bias.permute(2, 1, 0) * math.log2(math.e)).contiguous()  # [head][key][query], log2 domain

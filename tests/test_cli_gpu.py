@@ -116,3 +116,22 @@ def test_eval_batch_harness_matches_oracle(tmp_path):
         p, p1 = _psnr_u8([got], ref), _psnr_u8([cond], ref1)
         print(f"eval_batch {k}: PSNR vs oracle {p:.2f} dB (condition image {p1:.2f} dB)")
         assert p >= 45.0 and p1 >= 50.0
+
+
+def test_bench_self_launches_its_ranks():
+    """BASELINE.json configs[3] control flow: `python bench.py --gpus 2` (no launcher, WORLD_SIZE unset) must start its own two ranks as
+    fresh child processes, shard one batch per rank, gather the uint8 results on rank 0 inside the step and print ONE JSON line.
+    On this one-GPU box the ranks share the device and the collectives go through the host (IR_BENCH_BACKEND=gloo); the driver's
+    multi-GPU runs use one GPU per rank over RCCL with the same code."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["IR_BENCH_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--batch", "2", "--lq", "128", "--sr_scale", "2", "--steps", "2", "--warmup", "1",
+           "--no_cpu_baseline", "--no_host_rate"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["world_size"] == 2 and line["gathered_images"] == 4 and line["verified"] is True
+    assert line["config"]["global_batch"] == 4 and line["config"]["parallelism"] == "dp2" and line["value"] > 0
+    assert "roofline" in line and line["roofline"]["per_kernel"]

@@ -103,6 +103,145 @@ def test_conv_at_headline_size(ctx, cin, cout, up):
     print(f"conv {cin}->{cout} up={up} at {ho}x{wo}: crops ok")
 
 
+# ------------------------------------------------------------------------------------------------ norms and layout kernels at 2048 x 2048
+def _gn_reference_rows(xb, rows, gamma, beta, silu, groups=32):
+    """fp64 GroupNorm statistics over the whole image xb [HW, C] (bf16 device tensor), applied to the sampled rows: -> fp32 [len(rows), C]."""
+    hw, c = xb.shape
+    cpg = c // groups
+    s1 = torch.zeros(groups, dtype=torch.float64, device=xb.device)
+    s2 = torch.zeros_like(s1)
+    for r0 in range(0, hw, 1 << 18):   # chunked: an fp64 copy of the 2^30-element tensor would not fit beside it
+        blk = xb[r0:r0 + (1 << 18)].double().view(-1, groups, cpg)
+        s1 += blk.sum(dim=(0, 2))
+        s2 += (blk * blk).sum(dim=(0, 2))
+    cnt = float(hw) * cpg
+    mean = s1 / cnt
+    rstd = 1.0 / torch.sqrt(s2 / cnt - mean * mean + 1e-6)
+    y = (xb[rows].double().view(-1, groups, cpg) - mean[None, :, None]) * rstd[None, :, None]
+    y = y.view(-1, c) * gamma.double() + beta.double()
+    if silu:
+        y = y * torch.sigmoid(y)
+    return y.float()
+
+
+def _sample_rows(hw, seed):
+    fixed = [0, 1, 2047, 2048, hw // 2 - 1, hw // 2, hw - 2049, hw - 2048, hw - 2, hw - 1]
+    rnd = torch.randint(0, hw, (4096,), generator=torch.Generator().manual_seed(seed)).tolist()
+    return torch.tensor(sorted(set(fixed + rnd)), device="cuda")
+
+
+@pytest.mark.parametrize("n,c", [(1, 128), (2, 256)])
+def test_groupnorm_at_headline_size(ctx, n, c):
+    """gn_partial / gn_finalize / gn_apply on the decoder's full-resolution activations: (1, 2048^2, 128) and (2, 2048^2, 256) - the second
+    is 2 x 2^31 bytes, so image 1 lives wholly past the 2^31-byte mark and every element offset of it is above 2^30. Against fp64
+    statistics over the whole image, on ~4100 sampled pixel rows per image (first / last rows, chunk boundaries, random ones).
+    Tolerance as in test_ops_gpu.py::test_groupnorm: bf16 output rounding, 2^-7 relative + 4e-3."""
+    hw = 2048 * 2048
+    g = torch.Generator(device="cuda").manual_seed(c)
+    x = torch.empty(n, hw, c, dtype=torch.bfloat16, device="cuda")
+    for i in range(n):       # a per-channel offset / gain so that group statistics differ from group to group and image to image
+        for r0 in range(0, hw, 1 << 20):
+            blk = torch.randn(1 << 20, c, generator=g, device="cuda")
+            x[i, r0:r0 + (1 << 20)] = (blk * (1.0 + 0.5 * torch.sin(torch.arange(c, device="cuda") * 0.37 + i)) + 0.25 * (i + 1)).to(torch.bfloat16)
+    gamma, beta = torch.randn(c, generator=g, device="cuda"), torch.randn(c, generator=g, device="cuda")
+    y = torch.empty(n, hw, c, dtype=torch.int16, device="cuda")
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    ctx.check(ctx.lib.ir_op_groupnorm(ctx.h, ctx.stream(), L.ptr(x.view(torch.int16)), L.ptr(y), L.ptr(gamma), L.ptr(beta), n, hw, c, 32, 1e-6, 1,
+                                      L.ptr(ws), ws.numel()), "groupnorm")
+    torch.cuda.synchronize()
+    worst = 0.0
+    for i in range(n):
+        rows = _sample_rows(hw, 7 + i)
+        ref = _gn_reference_rows(x[i], rows, gamma, beta, True)
+        got = y.view(torch.bfloat16)[i, rows].float()
+        err = (got - ref).abs()
+        bad = err > 4e-3 + 2 ** -7 * ref.abs()
+        worst = max(worst, float(err.max()))
+        assert not bad.any(), f"image {i}: {int(bad.sum())}/{bad.numel()} off, max abs err {float(err.max()):.4g}"
+    print(f"groupnorm ({n}, 2048^2, {c}): max abs err {worst:.4g}")
+
+
+def test_conv_groupnorm_fused_statistics_at_headline_size(ctx):
+    """The 128 -> 128 ResnetBlock conv of the 2048 x 2048 level with its GroupNorm statistics produced by the conv epilogue
+    (conv_halo_s1_kernel: 128 x 64 = 8192 patch tiles -> gn_reduce_groups -> gn_finalize_groups -> gn_apply), residual included.
+    The normalised output is checked against fp64 statistics of the kernel's OWN stored conv output (what GroupNorm is defined on),
+    the conv output itself on row crops against F.conv2d."""
+    import ctypes
+    h = w = 2048
+    cin = cout = 128
+    g = torch.Generator(device="cuda").manual_seed(99)
+    x = torch.randn(h, w, cin, generator=g, device="cuda").to(torch.bfloat16)
+    res = torch.randn(h, w, cout, generator=g, device="cuda").to(torch.bfloat16)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g, device="cuda") / (9 * cin) ** 0.5).to(torch.bfloat16)
+    b = torch.randn(cout, generator=g, device="cuda") * 0.1
+    gamma, beta = torch.randn(cout, generator=g, device="cuda"), torch.randn(cout, generator=g, device="cuda")
+    wp = wt.permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous()
+    conv_out = torch.empty(h, w, cout, dtype=torch.int16, device="cuda")
+    y = torch.empty_like(conv_out)
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    fused = ctypes.c_int(-1)
+    ctx.check(ctx.lib.ir_op_conv_groupnorm(ctx.h, ctx.stream(), L.ptr(x.view(torch.int16)), L.ptr(wp.view(torch.int16)), L.ptr(b), L.ptr(conv_out), L.ptr(y),
+                                           L.ptr(gamma), L.ptr(beta), 1, h, w, cin, cout, 1, 0, L.ptr(res.view(torch.int16)), 1, L.ptr(ws), ws.numel(),
+                                           ctypes.byref(fused)), "conv_groupnorm")
+    torch.cuda.synchronize()
+    assert fused.value == (h // 16) * (w // 32), fused.value          # the one-wave-per-SIMD kernel ran and wrote one partial per patch
+    co = conv_out.view(torch.bfloat16)
+    for r0, r1 in ((0, 17), (h // 2 - 8, h // 2 + 9), (h - 17, h)):    # conv crops, as in test_conv_at_headline_size
+        lo, hi = max(r0 - 1, 0), min(r1 + 1, h)
+        src = F.pad(x[lo:hi].float().permute(2, 0, 1)[None], (1, 1, 1 if r0 == 0 else 0, 1 if r1 == h else 0))
+        ref = F.conv2d(src, wt.float(), b)[0].permute(1, 2, 0)[: r1 - r0] + res[r0:r1].float()
+        err = (co[r0:r1].float() - ref).abs()
+        assert not (err > 4e-3 + 2 ** -7 * ref.abs()).any(), f"conv rows {r0}:{r1}: max abs err {float(err.max()):.4g}"
+    rows = _sample_rows(h * w, 3)
+    ref = _gn_reference_rows(co.view(h * w, cout), rows, gamma, beta, True)
+    got = y.view(torch.bfloat16).view(h * w, cout)[rows].float()
+    err = (got - ref).abs()
+    assert not (err > 4e-3 + 2 ** -7 * ref.abs()).any(), f"groupnorm from fused statistics: max abs err {float(err.max()):.4g}"
+    print(f"conv 128->128 + fused GroupNorm statistics at 2048^2: {fused.value} partial tiles, max abs err {float(err.max()):.4g}")
+
+
+@pytest.mark.parametrize("rows,c,ld", [(65536, 180, 192), (65536, 192, 192), (16384, 1152, 1152)])
+def test_layernorm_at_headline_size(ctx, rows, c, ld):
+    """LayerNorm over the token streams of the 2048 x 2048 image: SwinIR's 65 536 tokens x 180 (of 192 stored) channels
+    (layernorm_r16_kernel), the same with all 192 channels live, and the DiT's 16 384 x 1152 (layernorm_v4_kernel). Every row against
+    F.layer_norm in fp32; 2^-7 relative + 2e-3 (bf16 output)."""
+    g = torch.Generator(device="cuda").manual_seed(rows + c)
+    x = torch.randn(rows, ld, generator=g, device="cuda") * 3 + torch.linspace(-2, 2, rows, device="cuda")[:, None]
+    a, b = torch.randn(c, generator=g, device="cuda"), torch.randn(c, generator=g, device="cuda")
+    ref = torch.zeros(rows, ld, device="cuda")
+    ref[:, :c] = F.layer_norm(x[:, :c], (c,), None, None, 1e-6) * a + b
+    y = torch.full((rows, ld), 0x7fff, dtype=torch.int16, device="cuda")
+    ctx.check(ctx.lib.ir_op_layernorm(ctx.h, ctx.stream(), L.ptr(x), L.ptr(y), L.ptr(a), L.ptr(b), rows, c, ld, ld, 1e-6), "layernorm")
+    torch.cuda.synchronize()
+    err = (y.view(torch.bfloat16).float() - ref).abs()
+    assert not (err > 2e-3 + 2 ** -7 * ref.abs()).any(), f"layernorm {rows}x{c}: max abs err {float(err.max()):.4g}"
+
+
+def test_layout_kernels_at_headline_size(ctx):
+    """The image <-> tensor kernels at 3 x 2048 x 2048: uint8 HWC -> fp32 NCHW (/255), fp32 NCHW -> bf16 NHWC padded to 32 channels
+    with the 2x - 1 map of the VAE input, fp32 NHWC[4] -> fp32 NCHW with the /2 + 0.5 map of the decoder output, fp32 NCHW -> uint8
+    HWC (clamp, x255, truncation): each against the same expression in PyTorch, exactly (bf16 rounding where the kernel rounds)."""
+    h = w = 2048
+    hw = h * w
+    g = torch.Generator(device="cuda").manual_seed(5)
+    img = torch.randint(0, 256, (1, h, w, 3), generator=g, device="cuda", dtype=torch.uint8)
+    f = torch.empty(1, 3, h, w, device="cuda")
+    ctx.check(ctx.lib.ir_u8_to_nchw(ctx.h, ctx.stream(), L.ptr(img), L.ptr(f), 1, h, w), "u8_to_nchw")
+    assert torch.equal(f, (img.double() / 255.0).float().permute(0, 3, 1, 2))
+    nhwc = torch.empty(hw, 32, dtype=torch.int16, device="cuda")
+    ctx.check(ctx.lib.ir_op_nchw_to_nhwc(ctx.h, ctx.stream(), L.ptr(f), L.ptr(nhwc), 1, 3, hw, 32, 2.0, -1.0), "nchw_to_nhwc")
+    want = torch.zeros(hw, 32, device="cuda")
+    want[:, :3] = (f[0] * 2.0 - 1.0).view(3, hw).t()
+    assert torch.equal(nhwc.view(torch.bfloat16), want.to(torch.bfloat16))
+    o4 = torch.randn(hw, 4, generator=g, device="cuda") * 1.5
+    nchw = torch.empty(1, 3, h, w, device="cuda")
+    ctx.check(ctx.lib.ir_op_nhwc_to_nchw(ctx.h, ctx.stream(), L.ptr(o4), 4, L.ptr(nchw), 1, 3, hw, 0.5, 0.5, 0), "nhwc_to_nchw")
+    assert torch.allclose(nchw.view(3, hw), (o4[:, :3] * 0.5 + 0.5).t(), rtol=0, atol=1e-7)   # one fma against mul + add
+    u8 = torch.empty(1, h, w, 3, dtype=torch.uint8, device="cuda")
+    ctx.check(ctx.lib.ir_nchw_to_u8(ctx.h, ctx.stream(), L.ptr(nchw), L.ptr(u8), 1, h, w), "nchw_to_u8")
+    assert torch.equal(u8, (nchw.clamp(0, 1) * 255.0).permute(0, 2, 3, 1).to(torch.uint8))
+
+
 # ------------------------------------------------------------------------------------------------ reduced architecture vs the reference's process()
 @pytest.mark.parametrize("case", ["untiled", "nopre", "tiled_wavelet", "tiled_adain", "tiled_none"])
 def test_process_vs_reference_process_fixture(case):
@@ -162,6 +301,27 @@ def test_headline_2048_untiled_fast_vs_plain_kernels(full_models):
     p, p1 = _psnr(fast[0], plain[0]), _psnr(st1[0], st1p[0])
     print(f"2048x2048 untiled: fast vs plain kernels {p:.2f} dB (stage-1 {p1:.2f} dB), output std {fast[0].std():.1f}")
     assert p >= 45.0 and p1 >= 50.0 and fast[0].std() > 1.0 and st1[0].std() > 1.0
+
+
+def test_headline_2048_fp8_vs_bf16(full_models):
+    """BASELINE configs[4] at the workload size of its bench line (2048 x 2048 network input): the fp8 form of the path (e4m3 operands
+    where ir_fp8_features() says so) against the bf16 path on the same image. e4m3 carries 3 mantissa bits; measured 42.5 dB, gate 38."""
+    import bench
+    from instarevive_amd.pipeline import process
+    swin, vae, dit, sds, y, mask = full_models
+    img = bench.synthetic_lq(1, 2048, 2048, 33)[0].numpy()
+    kw = dict(preprocess_model=swin, vae=vae, y=full_models.y_cuda, y_mask=full_models.mask_cuda)
+    bf, _ = process(dit, [img], 1, "wavelet", False, False, 512, 448, **kw)
+    vae.enable_fp8(True)
+    try:
+        f8, _ = process(dit, [img], 1, "wavelet", False, False, 512, 448, fp8=True, **kw)
+    finally:
+        vae.enable_fp8(False)
+    again, _ = process(dit, [img], 1, "wavelet", False, False, 512, 448, **kw)
+    assert np.array_equal(again[0], bf[0]), "switching fp8 off must restore the bf16 result bit for bit"
+    p = _psnr(f8[0], bf[0])
+    print(f"2048x2048 fp8 vs bf16: {p:.2f} dB")
+    assert not np.array_equal(f8[0], bf[0]) and p >= 38.0
 
 
 def test_4k_tiled_hipgraph(full_models):

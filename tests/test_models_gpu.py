@@ -53,7 +53,7 @@ def make_swin(cfg, seed=101):
     sd = det_state_dict(oswin.state_dict_shapes(cfg), seed=seed)
     full = dict(oswin.DEFAULT_CFG, **cfg)
     m = SwinIR(img_size=64, patch_size=1, in_chans=3, embed_dim=full["embed_dim"], depths=full["depths"], num_heads=full["num_heads"], window_size=8,
-               mlp_ratio=2, sf=8, img_range=1.0, upsampler="nearest+conv", resi_connection="1conv", unshuffle=True, unshuffle_scale=8)
+               mlp_ratio=full["mlp_ratio"], sf=8, img_range=1.0, upsampler="nearest+conv", resi_connection="1conv", unshuffle=True, unshuffle_scale=8)
     m.load_state_dict(sd, strict=False)
     return m.to("cuda"), sd
 
@@ -91,6 +91,17 @@ def test_swinir_full_arch_64():
     m, sd = make_swin({}, seed=111)
     x = det_input(21, (1, 3, 64, 64))
     check(m(x.cuda()), oswin.swinir_forward(sd, x), "swinir full arch 64x64", **TOL_XFMR)
+
+
+@pytest.mark.parametrize("cfg", [dict(embed_dim=64, depths=[2], num_heads=[4]),                 # Cp = 128: no fused MLP / attention+proj form
+                                 dict(embed_dim=128, depths=[2], num_heads=[8]),                # Cp = 256
+                                 dict(embed_dim=180, depths=[2], num_heads=[6], mlp_ratio=4)])  # Cp = 192 but 736 hidden units > 512: unfused MLP
+def test_swinir_other_widths_take_the_unfused_kernels(cfg):
+    """SwinIR configurations the fused Swin kernels do not cover (other head counts, mlp_ratio 4) must load and run through the
+    separate LayerNorm / linear / window-attention launches (weights.pack_swinir emits the fused forms for 6 x 32 channels, <= 512 hidden only)."""
+    m, sd = make_swin(cfg, seed=131)
+    x = det_input(24, (1, 3, 64, 128))
+    check(m(x.cuda()), oswin.swinir_forward(sd, x, cfg), f"swinir {cfg}", **TOL_XFMR)
 
 
 def test_vae_small_vs_golden():
@@ -411,6 +422,25 @@ def test_full_arch_process_256_vs_oracle(full_models):
     check(x0, inter["x0"], "full-arch DiT x0 (28 layers)", l2=0.012, worst=0.03)  # measured 0.64 % over 28 layers
 
 
+def test_full_arch_process_512_vs_oracle(full_models):
+    """BASELINE.json configs[0]/[1] network size before the sr_scale: the whole path at full depth on a 512 x 512 image (4096 VAE
+    mid-block tokens, 1024 DiT tokens, 64 x 64 Swin windows) against the fp32 oracle - the same pass bench.py times as its CPU
+    baseline (about 6 s of host time)."""
+    import bench
+    from instarevive_amd.pipeline import process
+    swin, vae, dit, sds, y, mask = full_models
+    imgs = [bench.synthetic_lq(1, 512, 512, 15)[0].numpy()]
+    ref, ref1 = oglue.process(imgs, lambda x: oswin.swinir_forward(sds["swin"], x), lambda x: ovae.vae_encode_mean(sds["vae"], x),
+                              lambda lat, t, yy, mm: odit.dit_forward(sds["dit"], lat, t, yy, mm), lambda z: ovae.vae_decode(sds["vae"], z),
+                              oglue.alphas_cumprod_diffusers(), y, mask)
+    got, got1 = process(dit, imgs, 1, "wavelet", False, False, 512, 448, preprocess_model=swin, vae=vae, y=y.cuda(), y_mask=mask.cuda())
+    p, p1 = _psnr_u8(got, ref), _psnr_u8(got1, ref1)
+    gt = [np.asarray(i) for i in imgs]
+    d = abs(_psnr_u8(got, gt) - _psnr_u8(ref, gt))
+    print(f"full-arch 512x512: PSNR vs fp32 oracle {p:.2f} dB (stage-1 {p1:.2f} dB); |PSNR(ours, GT) - PSNR(oracle, GT)| = {d:.4f} dB")
+    assert p >= PSNR_MIN and p1 >= PSNR_STAGE1_MIN and d <= 0.1
+
+
 def test_full_arch_size_independent_properties(full_models):
     """At a size the oracle cannot finish quickly (1024x1024): determinism, batch independence, single-tile == untiled."""
     import bench
@@ -469,7 +499,7 @@ def test_fast_vs_plain_kernels_at_awkward_sizes(full_models):
 def test_vae_fp8_resnet_convs(full_models):
     """BASELINE.json configs[4] (fp8 VAE conv weights): the full-size VAE with the ResnetBlock 3x3 convs on fp8 (OCP e4m3) operands —
     weights quantised per output channel, GroupNorm+SiLU outputs written as e4m3 — against the fp32 oracle and against the bf16 path.
-    e4m3 keeps 3 mantissa bits (2.6 % relative error per weight tensor), so the gate is loose and the numbers are printed."""
+    e4m3 keeps 3 mantissa bits (2.6 % relative error per weight tensor): measured rel-L2 0.10 (encoder mean) / 0.06 (decoder), gate 0.12."""
     swin, vae, dit, sds, y, mask = full_models
     x = det_input(22, (1, 3, 128, 128), -1, 1)
     z = det_input(23, (1, 4, 16, 16), -3, 3)
@@ -485,7 +515,7 @@ def test_vae_fp8_resnet_convs(full_models):
     for name, f, b, ref in (("encode", f_e, b_e, ref_e), ("decode", f_d, b_d, ref_d)):
         print(f"vae {name}: fp8 vs oracle rel-L2 {rel_l2(f, ref):.4f} (bf16 path {rel_l2(b, ref):.4f}); fp8 vs bf16 {rel_l2(f, b):.4f}")
         assert not torch.equal(f, b), "the fp8 path must actually run"
-        assert rel_l2(f, ref) <= 0.15
+        assert rel_l2(f, ref) <= 0.12
 
 
 def test_fp8_whole_path_psnr_guard(full_models):
@@ -511,5 +541,5 @@ def test_fp8_whole_path_psnr_guard(full_models):
     d8, db = abs(_psnr_u8(f8, gt) - _psnr_u8(ref, gt)), abs(_psnr_u8(bf, gt) - _psnr_u8(ref, gt))
     print(f"fp8 path vs fp32 oracle {p8:.2f} dB (bf16 path {pb:.2f} dB); |PSNR(., GT) - PSNR(oracle, GT)|: fp8 {d8:.4f} dB, bf16 {db:.4f} dB")
     assert not np.array_equal(f8[0], bf[0]), "the fp8 path must actually run"
-    assert p8 >= 30.0 and d8 <= 0.1
+    assert p8 >= 40.0 and d8 <= 0.1   # measured 42.9 dB
 

@@ -20,6 +20,12 @@ def _worker(rank, world, port, n_items, q):
     # stand-in for the per-image path: an image whose pixels encode the unit id
     local = torch.stack([torch.full((4, 6, 3), i, dtype=torch.uint8) for i in mine]) if mine else torch.zeros((0, 4, 6, 3), dtype=torch.uint8)
     out = P.gather_uint8(local, dst=0)
+    plan = P.GatherPlan(local, dst=0)   # the reusable form bench.py keeps in its timed step: counts exchanged once, one gather per call
+    for _ in range(2):
+        again = plan.gather(local)
+        assert (again is None) == (rank != 0)
+        if rank == 0:
+            assert torch.equal(again, out)
     tmax = P.max_over_ranks(1.0 + rank)
     if rank == 0:
         inv = P.unshard_order(n_items, w)
