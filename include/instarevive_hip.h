@@ -37,7 +37,8 @@ enum { IR_FLAG_NO_PREPROCESS = 1, IR_FLAG_TILED = 2, IR_FLAG_FIX_WAVELET = 4, IR
        IR_FLAG_GRAPH = 32,
        /* BASELINE.json configs[4]: fp8 (OCP e4m3) MFMA operands in the parts ir_fp8_features() reports: the VAE ResnetBlock 3x3
         * convolutions (weights quantised per output channel at load time, GroupNorm+SiLU outputs written as e4m3; needs the fp8 weight
-        * forms `*.w8`, `*.g8`, `*.b8` uploaded, layers without them run in bf16). */
+        * forms `*.w8`, `*.g8`, `*.b8` uploaded, layers without them run in bf16) and both products of the DiT self-attention (Q / K / V
+        * quantised per 64-key tile and head on the fly, probabilities per query and 32-key block through the MFMA's E8M0 block scales). */
        IR_FLAG_FP8 = 64 };
 /* which parts of the path IR_FLAG_FP8 / ir_set_fp8 move to fp8 operands in THIS build (bench.py words its workload string from it) */
 enum { IR_FP8_VAE_RESNET_CONVS = 1, IR_FP8_DIT_SELF_ATTENTION = 2 };
@@ -174,6 +175,12 @@ int ir_op_layernorm(ir_ctx* ctx, void* stream, const float* x, uint16_t* y, cons
                     int ldy, float eps);
 int ir_op_attention(ir_ctx* ctx, void* stream, const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* o, int b, int heads,
                     int tq, int tk, int d, float scale, const float* key_bias, void* ws, size_t ws_bytes);
+/* DiT self-attention with both products on fp8 (e4m3) MFMA operands (IR_FP8_DIT_SELF_ATTENTION; attn_fp8.hip): q / k / v / o
+ * [b][t][heads * 72] bf16, t a multiple of 64 (>= 256). ws receives, at its start, the quantised tile images
+ * [b][heads][t / 64][10240 B] (K8 rows of 80 B, then V8^T rows of 64 B in the kernel's key order; row 79 of the V part starts with the
+ * two E8M0 exponent bytes) - tests read them back to build the reference on the dequantised operands. */
+int ir_op_attention_fp8(ir_ctx* ctx, void* stream, const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* o, int b, int heads, int t,
+                        float scale, void* ws, size_t ws_bytes);
 int ir_op_swin_attention(ir_ctx* ctx, void* stream, const uint16_t* qkv, uint16_t* out, const float* bias_t, int b, int h, int w,
                          int heads, int shift, float scale);
 int ir_op_softmax_rows(ir_ctx* ctx, void* stream, const float* x, uint16_t* y, int rows, int cols);

@@ -726,6 +726,7 @@ int dit_update_timestep(Run& r, float t) {
 // scratch of one DiT block, shared by every block of a run
 struct DitBufs {
     bf16_t *xb, *xn, *qkv, *vt, *att, *cq, *hid;
+    uint8_t* f8tiles;   // e4m3 K / V^T tile images of the fp8 self-attention (attn_fp8.hip), or null
     int* attn_flag;
     int n, Tpad, DV;
     long T;
@@ -740,7 +741,21 @@ void dit_block(Run& r, const DitLayer& Lw, const float* mod, float* x, const Dit
     const float sl2 = (1.0f / sqrtf((float)hd)) * 1.44269504088896340736f;
     layernorm(r, x, b.xn, nullptr, mod + C, mod, BT, C, C, C, 1e-6f);
     linear(r, Lw.qkv, b.xn, (int)BT, C, b.qkv, 3 * C, 0, ACT_NONE, nullptr, 0, 0);
-    if (r.live()) {
+    // BASELINE.json configs[4]: both attention products on e4m3 operands (attn_fp8.hip). The bf16 V^T is only built if the kernel's
+    // fixed softmax reference was outgrown (flag), for the rescaling fallback behind it.
+    const bool attn8 = r.c->fp8 && b.f8tiles && hd == 72 && (T & 63) == 0 && T >= 256 && !g_ir_plain_kernels;
+    if (r.live() && attn8) {
+        AttnParams p;
+        memset(&p, 0, sizeof p);
+        p.q = b.qkv; p.k = b.qkv + C; p.vt = b.vt; p.o = b.att;
+        p.q_bs = p.k_bs = T * 3 * C; p.o_bs = T * C; p.vt_bs = (long)Hh * DV * Tpad;
+        p.q_rs = p.k_rs = 3 * C; p.o_rs = C; p.q_hs = p.k_hs = p.o_hs = hd;
+        p.B = n; p.Hh = Hh; p.Tq = (int)T; p.Tk = (int)T; p.Tk_pad = Tpad; p.D = hd; p.scale_log2 = sl2;
+        p.ovf_flag = b.attn_flag;
+        LAUNCHK(r, PK_ATTN_SELF_FP8, 4.0 * n * Hh * (double)T * T * hd, 0.0, ir_launch_flash_attn_fp8(p, b.qkv + 2 * C, b.f8tiles, r.s), "self_attn_fp8");
+        LAUNCH(r, PC_TRANSPOSE, 0.0, 0.0, ir_launch_transpose_v(b.qkv + 2 * C, b.vt, T * 3 * C, 3 * C, hd, n, Hh, (int)T, Tpad, hd, DV, r.s, b.attn_flag), "transpose_v");
+        LAUNCHK(r, PK_ATTN_OTHER, 0.0, 0.0, ir_launch_flash_attn_fallback(p, r.s), "self_attn_fallback");
+    } else if (r.live()) {
         LAUNCH(r, PC_TRANSPOSE, 0.0, 0.0, ir_launch_transpose_v(b.qkv + 2 * C, b.vt, T * 3 * C, 3 * C, hd, n, Hh, (int)T, Tpad, hd, DV, r.s), "transpose_v");
         AttnParams p;
         memset(&p, 0, sizeof p);
@@ -790,6 +805,7 @@ float* dit_tokens_run(Run& r, const float* lat, int n, int h, int w, float times
     b.qkv = r.a.alloc<bf16_t>(BT * 3 * C);
     b.vt = r.a.alloc<bf16_t>((long)n * Hh * b.DV * b.Tpad);
     b.attn_flag = r.a.alloc<int>(16);  // 4 bytes used: overflow flag of the ping-pong self-attention kernel
+    b.f8tiles = (hd == 72 && (T & 63) == 0) ? r.a.alloc<uint8_t>(ir_attn_fp8_tile_bytes(n, Hh, (int)T)) : nullptr;
     b.att = r.a.alloc<bf16_t>(BT * C);
     b.cq = r.a.alloc<bf16_t>(BT * C);
     b.hid = r.a.alloc<bf16_t>(BT * m.mlp);
@@ -1626,7 +1642,7 @@ int ir_tiled_blend_pixels(ir_ctx* c, void* stream, const float* px_tiles, uint8_
 // d = 512 attention), the independent second implementation of the same arithmetic that bench.py and the tests cross-check the
 // fast kernels against. Process-wide.
 // fp8 mode of the stage entry points (ir_pipeline: IR_FLAG_FP8): VAE resnet convs whose fp8 weights were uploaded run on fp8 operands
-int ir_fp8_features(void) { return IR_FP8_VAE_RESNET_CONVS; }
+int ir_fp8_features(void) { return IR_FP8_VAE_RESNET_CONVS | IR_FP8_DIT_SELF_ATTENTION; }
 int ir_set_fp8(ir_ctx* c, int on) {
     if (!c) return -1;
     if (c->fp8 != (on != 0)) ++c->generation;   // recorded hipGraphs hold the launches of the mode they were captured in
@@ -1869,6 +1885,28 @@ int ir_op_attention(ir_ctx* c, void* stream, const uint16_t* q, const uint16_t* 
     p.key_bias = key_bias; p.kb_bs = tk;
     rc = ir_launch_flash_attn(p, s);
     return rc ? fail(c, rc, "flash_attn failed (%d)", rc) : 0;
+}
+int ir_op_attention_fp8(ir_ctx* c, void* stream, const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* o, int b, int heads, int t,
+                        float scale, void* ws, size_t ws_bytes) {
+    // q / k / v / o: [b][t][heads * 72]; ws: tile images | bf16 V^T of the fallback | flag
+    use_ctx(c);
+    if (t < 256 || (t & 63)) return fail(c, -1, "ir_op_attention_fp8: tokens must be a multiple of 64, >= 256");
+    const int d = 72, DV = ir_attn_dv(d), tkp = ((t + 63) & ~63) + 64;
+    const size_t tiles = (ir_attn_fp8_tile_bytes(b, heads, t) + 255) & ~(size_t)255, vt = ((size_t)b * heads * DV * tkp * 2 + 255) & ~(size_t)255;
+    if (ws_bytes < tiles + vt + 256) return fail(c, -20, "attention workspace too small: need %zu", tiles + vt + 256);
+    hipStream_t s = (hipStream_t)stream;
+    AttnParams p;
+    memset(&p, 0, sizeof p);
+    p.q = q; p.k = k; p.vt = reinterpret_cast<bf16_t*>((char*)ws + tiles); p.o = o;
+    p.ovf_flag = reinterpret_cast<int*>((char*)ws + tiles + vt);
+    p.q_bs = p.k_bs = p.o_bs = (long)t * heads * d; p.vt_bs = (long)heads * DV * tkp;
+    p.q_rs = p.k_rs = p.o_rs = heads * d; p.q_hs = p.k_hs = p.o_hs = d;
+    p.B = b; p.Hh = heads; p.Tq = t; p.Tk = t; p.Tk_pad = tkp; p.D = d;
+    p.scale_log2 = scale * 1.44269504088896340736f;
+    int rc = ir_launch_flash_attn_fp8(p, v, (uint8_t*)ws, s);
+    if (!rc) rc = ir_launch_transpose_v(v, const_cast<bf16_t*>(p.vt), (long)t * heads * d, heads * d, d, b, heads, t, tkp, d, DV, s, p.ovf_flag);
+    if (!rc) rc = ir_launch_flash_attn_fallback(p, s);
+    return rc ? fail(c, rc, "flash_attn_fp8 failed (%d)", rc) : 0;
 }
 int ir_op_swin_attention(ir_ctx* c, void* stream, const uint16_t* qkv, uint16_t* out, const float* bias_t, int b, int h, int w,
                          int heads, int shift, float scale) {

@@ -591,6 +591,12 @@ __global__ __launch_bounds__(512, 1) void flash_attn_pp_kernel(AttnParams p) {
     }
 }
 
+int ir_launch_flash_attn_fallback(const AttnParams& p, hipStream_t s) {
+    if (p.D != 72 || !p.ovf_flag || p.key_bias || (p.Tk & 63)) return -2;
+    hipLaunchKernelGGL((flash_attn_kernel<72, false>), dim3((p.Tq + 127) / 128, p.Hh, p.B), dim3(256), 0, s, p);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 bool ir_flash_attn_is_pp2(const AttnParams& p) {
     static const bool no_pp = getenv("IR_NO_PINGPONG") != nullptr, pp1 = getenv("IR_ATTN_PP1") != nullptr;
     const bool general = p.key_bias != nullptr || (p.Tk & 63);

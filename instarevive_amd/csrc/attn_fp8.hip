@@ -1,0 +1,406 @@
+// DiT self-attention (16 heads x 72; reference diffusion/model/nets/PixArt_blocks.py:123-158) on fp8 (OCP e4m3) MFMA operands for gfx950:
+// BASELINE.json configs[4] ("fp8 MFMA for DiT attention"). Both products run on v_mfma_scale_f32_32x32x64_f8f6f4 (k = 64 per
+// instruction at twice the bf16 rate), with the MX block scales (one E8M0 exponent per row / column and 32-k block; a block is bytes
+// 16b .. 16b+15 of the operand registers of the lane pair (l, l ^ 32), its exponent sits in lane (l & 31) + 32 b) doing the range work
+// that fp8 cannot:
+//
+//   S^T = K Q^T     A = K8 (64 keys x d 0..63, e4m3, one exponent per (tile, head) from attn_fp8_prep_kernel), B = Q8 (the lane's own
+//                   query row, quantised when it is loaded, one exponent per (query, scale block)); d 64..71 ride in ONE bf16
+//                   v_mfma_f32_32x32x16_bf16 on the raw bf16 values (k = 16, upper half zero) - 96 matrix cycles per 32 keys
+//                   instead of 160 for the bf16 kernel's five k-steps. -m (the fixed softmax reference) is the C operand.
+//   O^T += V^T P^T  A = V8^T (d x 64 keys, e4m3, per (tile, head) exponent; row 72 = ones with exponent 0: the softmax denominator),
+//                   B = P8: the lane's 32 probabilities of a tile (16 accumulator registers of each of the two 32-key score tiles)
+//                   ARE one k = 64 operand - no data moves between lanes - and score tile kt is scale block kt: its exponent comes
+//                   from the maximum over the lane pair's 2 x 16 registers (v_max3 chain + two v_permlane32_swap), so e4m3 only ever
+//                   sees values relative to its own block: exp2(score - m) may be 2^-60 or 2^+60 against the fixed reference, the
+//                   exponent byte carries that.
+//                   The key order inside a tile is whatever the accumulator layout gives (lane half h, register g of score tile kt
+//                   <-> key 32 kt + (g & 3) + 8 (g >> 2) + 4 h); V8^T is stored in that order by the prep kernel, so no operand is permuted
+//                   at run time. 64 matrix cycles per 32 d-rows and 64 keys instead of 128.
+//
+// Per 64-key tile and 32-query group: 192 + 192 matrix cycles (bf16 kernel: 320 + 384). What is left is the softmax VALU work
+// (32 v_exp + 16 v_max3 + 16 scaled converts per lane, group and tile), which now weighs as much as the matrix work.
+// One wave per SIMD, two groups of 32 queries per wave (as flash_attn_pp2_kernel); K8 / V8^T of a tile are one 10 KB image that is
+// its own LDS image (LDS-DMA, lane-linear), ring of PF + 1 slots, fixed softmax reference with overflow flag + rescaling fallback.
+#include "common.h"
+#include "kernels.h"
+#include <type_traits>
+#include <utility>
+
+typedef __attribute__((address_space(3))) void* f8_lds_t;
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(2))) short s16x2;
+IR_DEVINL void f8_glds16(const void* g, f8_lds_t l) { __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0); }
+
+namespace f8a {
+constexpr int D = 72;
+constexpr int KROW = 80;                       // K8 row: 64 e4m3 bytes (d 0..63) + 8 bf16 (d 64..71); 20 dwords: conflict-free for ds_read_b128
+constexpr int K_BYTES = 64 * KROW;             // 5120
+constexpr int VROWS = 80;                      // V8^T rows: d 0..71, ones row 72, zeros, row 79 = the tile's exponent bytes
+constexpr int V_BYTES = VROWS * 64;            // 5120
+constexpr int TILE_BYTES = K_BYTES + V_BYTES;  // 10 DMA pieces of 1 KB
+constexpr int SCALE_OFF = K_BYTES + 79 * 64;   // dword {K exponent byte, V exponent byte, 0, 0}
+constexpr int PF = 4, NSLOT = PF + 1;          // tile t + PF is issued in iteration t
+constexpr int LDS_MAIN = NSLOT * TILE_BYTES;   // 51 200 B
+constexpr int OS = 96 + 8;                     // O staging row stride (elements)
+constexpr int LDS_O = 8 * 32 * OS * 2;         // 53 248 B
+constexpr int LDS_BYTES = LDS_MAIN > LDS_O ? LDS_MAIN : LDS_O;
+constexpr float MARGIN = 24.0f;                // headroom below the first tile's maximum
+constexpr int E_BIAS = 7;                      // block exponent = exponent of the block maximum - 7: the maximum lands in [128, 256) <= 448
+}  // namespace f8a
+
+// E8M0 byte of a block whose largest magnitude is mx (>= 0): 2^(byte - 127) = 2^(floor(log2 mx) - 7), clamped to a valid byte
+IR_DEVINL int f8_block_byte(float mx) {
+    const int b = (int)(__builtin_bit_cast(uint32_t, mx) >> 23) - f8a::E_BIAS;
+    return b < 1 ? 1 : (b > 254 ? 254 : b);
+}
+// The MFMA's two 32-k scale blocks are BYTE RANGES of the operand registers, not lane halves (tools/fp8_cvt_probe.hip): block b = bytes
+// 16b .. 16b+15 of BOTH lanes (l, l ^ 32) of a row / column, and its exponent is read from lane (l & 31) + 32 b. So a block maximum is a
+// maximum over a lane PAIR. In: the lane's own maxima over its bytes 0..15 (m0) and 16..31 (m1); out: the pair's maxima on both lanes.
+// `own` (the lane's scale register: block 0 on the lower half, block 1 on the upper half) falls out of the first exchange.
+IR_DEVINL void f8_pair_max(float& m0, float& m1, float& own) {
+    float a = m0, b = m1;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));   // lower lanes: {own m0, partner's m0}; upper lanes: {partner's m1, own m1}
+    own = fmaxf(a, b);
+    float x = own, y = own;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));   // x = block-0 maximum everywhere, y = block-1 maximum everywhere
+    m0 = x; m1 = y;
+}
+// two fp32 / 2^(byte - 127) -> two e4m3 bytes in the low or the high half of `old`
+template <bool HI>
+IR_DEVINL uint32_t f8_cvt2(uint32_t old, float a, float b, float scale_f) {
+    return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(__builtin_bit_cast(s16x2, old), a, b, scale_f, HI));
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// K, V [B][T][..] bf16 (token stride rs, head stride hs) -> tile images [B][Hh][T/64][10240 B] (see the header of this file)
+__global__ __launch_bounds__(256) void attn_fp8_prep_kernel(const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, uint8_t* __restrict__ tiles,
+                                                            long kv_bs, int rs, int hs, int NT) {
+    using namespace f8a;
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[64][72 + 8], Vs[64][72 + 8];
+    __shared__ float red[2][4];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int tile = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+    const bf16_t* ksrc = k + (long)b * kv_bs + (long)head * hs + (long)tile * 64 * rs;
+    const bf16_t* vsrc = v + (long)b * kv_bs + (long)head * hs + (long)tile * 64 * rs;
+    float mk = 0.f, mv = 0.f;
+    for (int c = tid; c < 64 * 9; c += 256) {
+        const int row = c / 9, ch = c - row * 9;
+        const uint4 a = *reinterpret_cast<const uint4*>(ksrc + (long)row * rs + ch * 8);
+        const uint4 w = *reinterpret_cast<const uint4*>(vsrc + (long)row * rs + ch * 8);
+        *reinterpret_cast<uint4*>(&Ks[row][ch * 8]) = a;
+        *reinterpret_cast<uint4*>(&Vs[row][ch * 8]) = w;
+        const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (ch < 8) mk = fmaxf(mk, fmaxf(fabsf(bflo(aw[i])), fabsf(bfhi(aw[i]))));   // d 64..71 of K stay bf16: not part of the fp8 block
+            mv = fmaxf(mv, fmaxf(fabsf(bflo(ww[i])), fabsf(bfhi(ww[i]))));
+        }
+    }
+    mk = wave_max(mk); mv = wave_max(mv);
+    if (lane == 0) { red[0][wid] = mk; red[1][wid] = mv; }
+    __syncthreads();
+    mk = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+    mv = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+    const int bk = f8_block_byte(mk), bv = f8_block_byte(mv);
+    const float sk = __builtin_bit_cast(float, (uint32_t)bk << 23), sv = __builtin_bit_cast(float, (uint32_t)bv << 23);
+    uint8_t* dst = tiles + (((long)(b * gridDim.y + head) * NT) + tile) * TILE_BYTES;
+    // K8: 64 rows x 5 chunks of 16 B
+    for (int c = tid; c < 64 * 5; c += 256) {
+        const int row = c / 5, ch = c - row * 5;
+        uint4 o;
+        if (ch == 4) {
+            o = *reinterpret_cast<const uint4*>(&Ks[row][64]);
+        } else {
+            uint32_t w[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bf16_t* s = &Ks[row][ch * 16 + 4 * i];
+                w[i] = f8_cvt2<false>(0u, bf2f(s[0]), bf2f(s[1]), sk);
+                w[i] = f8_cvt2<true>(w[i], bf2f(s[2]), bf2f(s[3]), sk);
+            }
+            o = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        *reinterpret_cast<uint4*>(dst + row * KROW + ch * 16) = o;
+    }
+    // V8^T: 80 rows x 4 chunks of 16 B; logical byte L = 32 h + j of a row <-> key 32 (j >> 4) + (j & 3) + 8 ((j & 15) >> 2) + 4 h;
+    // logical chunk c (16 bytes) sits at physical chunk c ^ ((d >> 2) & 3)
+    for (int c = tid; c < VROWS * 4; c += 256) {
+        const int d = c >> 2, pc = c & 3, lc = pc ^ ((d >> 2) & 3);
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+        if (d < D) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float x[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int L = 16 * lc + 4 * i + e, h = L >> 5, j = L & 31;
+                    const int key = 32 * (j >> 4) + (j & 3) + 8 * ((j & 15) >> 2) + 4 * h;
+                    x[e] = bf2f(Vs[key][d]);
+                }
+                w[i] = f8_cvt2<false>(0u, x[0], x[1], sv);
+                w[i] = f8_cvt2<true>(w[i], x[2], x[3], sv);
+            }
+        } else if (d == D) {
+            w[0] = w[1] = w[2] = w[3] = 0x38383838u;   // 1.0 in e4m3; the kernel multiplies this row with exponent byte 127
+        } else if (d == VROWS - 1 && pc == 0) {
+            w[0] = (uint32_t)bk | ((uint32_t)bv << 8);
+        }
+        *reinterpret_cast<uint4*>(dst + K_BYTES + d * 64 + pc * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+struct AttnF8Params {
+    const bf16_t* q;
+    const uint8_t* tiles;
+    bf16_t* o;
+    long q_bs, o_bs;
+    int q_rs, o_rs, q_hs, o_hs;
+    int Hh, Tq, Tk;
+    float scale_log2;
+    int* ovf_flag;
+};
+
+IR_DEVINL f32x16 f8_mfma(i32x8 a, i32x8 b, f32x16 c, int sa, int sb) {
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, sa, 0, sb);
+}
+IR_DEVINL i32x8 f8_join(bf16x8 lo, bf16x8 hi) {
+    const uint4 a = __builtin_bit_cast(uint4, lo), b = __builtin_bit_cast(uint4, hi);
+    i32x8 r;
+    r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = b.x; r[5] = b.y; r[6] = b.z; r[7] = b.w;
+    return r;
+}
+
+__global__ __launch_bounds__(256, 1) void flash_attn_fp8_kernel(AttnF8Params p) {
+    using namespace f8a;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wu = __builtin_amdgcn_readfirstlane(wid);
+    const int r = lane & 31, h = lane >> 5;
+    const int q0 = blockIdx.x * 256 + wid * 64, head = blockIdx.y, b = blockIdx.z;
+    const int NT = p.Tk >> 6;
+    const bf16_t* qp = p.q + (long)b * p.q_bs + (long)head * p.q_hs;
+    const uint8_t* tp = p.tiles + ((long)(b * p.Hh + head) * NT) * TILE_BYTES + lane * 16;
+
+    // LDS-DMA: the 10 pieces of a tile image, pieces wu, wu + 4, wu + 8 (clamped to 9: a repeated piece writes the same bytes) per wave
+    auto issue_tile = [&](int tile) {
+        tile = min(tile, NT - 1);   // past the end the last tile is fetched again into a free slot (keeps the vmcnt bookkeeping constant)
+        const int slot = tile % NSLOT;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int idx = min(wu + 4 * k, 9);
+            f8_glds16(tp + (long)tile * TILE_BYTES + idx * 1024, (f8_lds_t)(smem + slot * TILE_BYTES + idx * 1024));
+        }
+    };
+#pragma unroll
+    for (int t = 0; t < PF; ++t) issue_tile(t);
+
+    // ---- Q: the lane's own query rows. fp8 part: d 32h .. 32h + 31 scaled by scale * log2(e), one exponent per (query, 32-d block);
+    // bf16 part: d 64..71 (lanes of the upper half hold the zero padding k = 8..15 of that MFMA)
+    i32x8 q8[2];
+    bf16x8 qr[2];
+    int eq[2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        const bf16_t* qrow = qp + (long)min(q0 + g * 32 + r, p.Tq - 1) * p.q_rs;
+        uint4 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const uint4*>(qrow + 32 * h + 8 * i);
+        const uint4 vr = *reinterpret_cast<const uint4*>(qrow + 64);
+        float x[32];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t w[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { x[8 * i + 2 * e] = bflo(w[e]) * p.scale_log2; x[8 * i + 2 * e + 1] = bfhi(w[e]) * p.scale_log2; }
+        }
+        float m0 = 0.f, m1 = 0.f, own;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { m0 = fmaxf(m0, fabsf(x[i])); m1 = fmaxf(m1, fabsf(x[16 + i])); }
+        f8_pair_max(m0, m1, own);
+        eq[g] = f8_block_byte(own);
+        const float sq0 = __builtin_bit_cast(float, (uint32_t)f8_block_byte(m0) << 23), sq1 = __builtin_bit_cast(float, (uint32_t)f8_block_byte(m1) << 23);
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            const float sq = w < 4 ? sq0 : sq1;
+            uint32_t u = f8_cvt2<false>(0u, x[4 * w], x[4 * w + 1], sq);
+            u = f8_cvt2<true>(u, x[4 * w + 2], x[4 * w + 3], sq);
+            q8[g][w] = (int)u;
+        }
+        const float sc = h ? 0.f : p.scale_log2;
+        const uint4 qq = make_uint4(pack2bf(bflo(vr.x) * sc, bfhi(vr.x) * sc), pack2bf(bflo(vr.y) * sc, bfhi(vr.y) * sc),
+                                    pack2bf(bflo(vr.z) * sc, bfhi(vr.z) * sc), pack2bf(bflo(vr.w) * sc, bfhi(vr.w) * sc));
+        qr[g] = __builtin_bit_cast(bf16x8, qq);
+    }
+
+    const uint32_t lds0 = lds_addr(smem);
+    const uint32_t k_lane = lds0 + r * KROW + 32 * h;        // + slot * TILE_BYTES + kt * 32 * KROW (+16 second half); remainder chunk at r * KROW + 64
+    const uint32_t kr_lane = lds0 + r * KROW + 64;
+    // V8^T: row 32 dt + r (dt = 2: rows 64 + (r & 15): rows 80..95 do not exist; their results are never read), logical chunks 2h, 2h + 1
+    uint32_t v_lane[3][2];
+#pragma unroll
+    for (int dt = 0; dt < 3; ++dt) {
+        const int d = dt < 2 ? 32 * dt + r : 64 + (r & 15);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) v_lane[dt][s] = lds0 + K_BYTES + d * 64 + (((2 * h + s) ^ ((d >> 2) & 3)) << 4);
+    }
+    const bool ones_row = (r & 15) == 8;   // d-tile 2, row 72: exponent byte 127 instead of the tile's V exponent
+
+    f32x16 sacc[2][2], negm[2], oacc[2][3];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) negm[g][e] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) oacc[g][dt][e] = 0.f;
+    }
+    i32x8 p8[2];
+    int ep[2];
+
+    // S^T(tile) = K8 Q8 (+ bf16 remainder) - m for both groups
+    auto scores = [&](int tile) {
+        const uint32_t base = (uint32_t)((tile % NSLOT) * TILE_BYTES);
+        int ek;
+        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(ek) : "v"(lds0 + base), "n"(SCALE_OFF));
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            const bf16x8 a0 = lds_read16<0>(k_lane + base + kt * 32 * KROW), a1 = lds_read16<16>(k_lane + base + kt * 32 * KROW);
+            const bf16x8 ar = lds_read16<0>(kr_lane + base + kt * 32 * KROW);
+            wait_lds<0>();
+            __builtin_amdgcn_sched_barrier(0);   // the asm reads are invisible to hipcc's waitcnt insertion: nothing may move above the wait
+            const i32x8 a8 = f8_join(a0, a1);
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                sacc[g][kt] = f8_mfma(a8, q8[g], negm[g], ek, eq[g]);
+                sacc[g][kt] = mfma32(ar, qr[g], sacc[g][kt]);
+            }
+        }
+    };
+    // probabilities of group g (already exponentiated, in sacc[g]) -> one e4m3 k = 64 operand + its exponent byte
+    auto quantise = [&](int g) {
+        float m0 = 0.f, m1 = 0.f, own;   // bytes 0..15 of the operand = score tile 0, bytes 16..31 = score tile 1: one scale block each
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+            m0 = __builtin_fmaxf(__builtin_fmaxf(m0, sacc[g][0][e]), sacc[g][0][e + 1]);
+            m1 = __builtin_fmaxf(__builtin_fmaxf(m1, sacc[g][1][e]), sacc[g][1][e + 1]);
+        }
+        f8_pair_max(m0, m1, own);
+        ep[g] = f8_block_byte(own);
+        const float sp0 = __builtin_bit_cast(float, (uint32_t)f8_block_byte(m0) << 23), sp1 = __builtin_bit_cast(float, (uint32_t)f8_block_byte(m1) << 23);
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            const int kt = w >> 2, e0 = 4 * (w & 3);
+            const float sp = kt ? sp1 : sp0;
+            uint32_t u = f8_cvt2<false>(0u, sacc[g][kt][e0], sacc[g][kt][e0 + 1], sp);
+            u = f8_cvt2<true>(u, sacc[g][kt][e0 + 2], sacc[g][kt][e0 + 3], sp);
+            p8[g][w] = (int)u;
+        }
+    };
+
+    // ---- tile 0: scores with C = 0, the softmax reference is fixed here (row maximum + headroom)
+    wait_vm<3 * (PF - 1)>();
+    __syncthreads();
+    scores(0);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sacc[g][kt][e]);
+        const float m_ref = xhalf_max(mx) + MARGIN;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) negm[g][e] = -m_ref;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sacc[g][kt][e] = __builtin_amdgcn_exp2f(sacc[g][kt][e] - m_ref);
+        quantise(g);
+    }
+
+    // ---- main loop: iteration t multiplies P(t) with V(t) and prepares P(t + 1)
+    for (int t = 0; t < NT; ++t) {
+        wait_vm<3 * (PF - 2)>();   // tile t + 1 has landed (tiles t + 2, t + 3 may still be in flight)
+        __syncthreads();           // ... for every wave, and every wave is done with tile t - 1: its slot takes tile t + PF
+        issue_tile(t + PF);
+        const bool more = t + 1 < NT;
+        if (more) scores(t + 1);
+        {
+            const uint32_t base = (uint32_t)((t % NSLOT) * TILE_BYTES);
+            int esc;
+            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(esc) : "v"(lds0 + base), "n"(SCALE_OFF));
+            wait_lds<0>();
+            __builtin_amdgcn_sched_barrier(0);
+            const int ev = esc >> 8, ev2 = ones_row ? 127 : ev;
+#pragma unroll
+            for (int dt = 0; dt < 3; ++dt) {
+                const bf16x8 a0 = lds_read16<0>(v_lane[dt][0] + base), a1 = lds_read16<0>(v_lane[dt][1] + base);
+                wait_lds<0>();
+                __builtin_amdgcn_sched_barrier(0);
+                const i32x8 a8 = f8_join(a0, a1);
+#pragma unroll
+                for (int g = 0; g < 2; ++g) oacc[g][dt] = f8_mfma(a8, p8[g], oacc[g][dt], dt == 2 ? ev2 : ev, ep[g]);
+            }
+        }
+        if (more) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) sacc[g][kt][e] = __builtin_amdgcn_exp2f(sacc[g][kt][e]);
+                quantise(g);
+            }
+        }
+    }
+
+    // ---- finalise: O^T[d][q] / l -> LDS [q][d] -> 16-byte row stores; l = O^T row 72 (the ones row): d-tile 2, register 4, lane half 0
+    wait_dma();
+    __syncthreads();   // every wave has finished with the tile ring (the staging rows overlay it)
+    bf16_t* ow = reinterpret_cast<bf16_t*>(smem) + wid * 64 * OS;
+    const float l0 = __shfl(oacc[0][2][4], r), l1 = __shfl(oacc[1][2][4], r);
+    const bool bad = !(l0 < 1e30f) || !(l1 < 1e30f) || !(l0 > 0.f) || !(l1 > 0.f);   // also catches inf / NaN: the fixed reference was outgrown
+    const float inv0 = 1.0f / l0, inv1 = 1.0f / l1;
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt) {
+            const float inv = g ? inv1 : inv0;
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) {
+                const uint2 w = make_uint2(pack2bf(oacc[g][dt][4 * gg] * inv, oacc[g][dt][4 * gg + 1] * inv),
+                                           pack2bf(oacc[g][dt][4 * gg + 2] * inv, oacc[g][dt][4 * gg + 3] * inv));
+                *reinterpret_cast<uint2*>(&ow[(g * 32 + r) * OS + dt * 32 + 8 * gg + 4 * h]) = w;
+            }
+        }
+    if (__any(bad) && lane == 0) atomicOr(p.ovf_flag, 1);
+    __syncthreads();
+    bf16_t* op = p.o + (long)b * p.o_bs + (long)head * p.o_hs;
+    for (int c = lane; c < 64 * 9; c += 64) {
+        const int row = c / 9, ch = c - row * 9;
+        const int q = q0 + row;
+        if (q < p.Tq) *reinterpret_cast<uint4*>(op + (long)q * p.o_rs + ch * 8) = *reinterpret_cast<const uint4*>(&ow[row * OS + ch * 8]);
+    }
+}
+
+size_t ir_attn_fp8_tile_bytes(int B, int Hh, int Tk) { return (size_t)B * Hh * (Tk / 64) * f8a::TILE_BYTES; }
+
+// p as for ir_launch_flash_attn's DiT self-attention form (D = 72, Tk % 64 == 0, no key bias, ovf_flag set, p.vt = the bf16 V^T buffer the
+// rescaling fallback uses); v = the V rows (same strides as p.k); tiles = ir_attn_fp8_tile_bytes(...) bytes of scratch.
+int ir_launch_flash_attn_fp8(const AttnParams& p, const bf16_t* v, uint8_t* tiles, hipStream_t s) {
+    if (p.D != 72 || p.Tq <= 0 || p.Tk < 64 || (p.Tk & 63) || !p.ovf_flag || p.key_bias || !v || !tiles) return -2;
+    if ((p.q_rs & 7) || (p.k_rs & 7) || (p.q_hs & 7) || (p.k_hs & 7) || (p.q_bs & 7) || (p.k_bs & 7) || (p.o_rs & 7) || (p.o_hs & 7) || (p.o_bs & 7)) return -3;
+    if ((reinterpret_cast<uintptr_t>(p.q) | reinterpret_cast<uintptr_t>(p.k) | reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(p.o) |
+         reinterpret_cast<uintptr_t>(tiles)) & 15)
+        return -3;
+    const int NT = p.Tk / 64;
+    if (ir_launch_zero_f32(reinterpret_cast<float*>(p.ovf_flag), 1, s)) return -1;
+    hipLaunchKernelGGL(attn_fp8_prep_kernel, dim3(NT, p.Hh, p.B), dim3(256), 0, s, p.k, v, tiles, p.k_bs, p.k_rs, p.k_hs, NT);
+    AttnF8Params f;
+    f.q = p.q; f.tiles = tiles; f.o = p.o; f.q_bs = p.q_bs; f.o_bs = p.o_bs; f.q_rs = p.q_rs; f.o_rs = p.o_rs; f.q_hs = p.q_hs; f.o_hs = p.o_hs;
+    f.Hh = p.Hh; f.Tq = p.Tq; f.Tk = p.Tk; f.scale_log2 = p.scale_log2; f.ovf_flag = p.ovf_flag;
+    hipLaunchKernelGGL(flash_attn_fp8_kernel, dim3((p.Tq + 255) / 256, p.Hh, p.B), dim3(256), 0, s, f);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}

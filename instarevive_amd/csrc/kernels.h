@@ -100,6 +100,13 @@ int ir_launch_flash_attn(const AttnParams& p, hipStream_t s);
 bool ir_flash_attn_is_pp2(const AttnParams& p);   // ir_launch_flash_attn routes p to flash_attn_pp2_kernel (profiler rows)
 // DiT self-attention (D = 72, Tk % 64 == 0, no key bias, ovf_flag set) as one wave per SIMD with two query groups (attn_d512.hip)
 int ir_launch_flash_attn_pp2(const AttnParams& p, hipStream_t s);
+// the rescaling 4-wave kernel alone, as the fallback behind a fixed-reference kernel: returns at once unless *p.ovf_flag is set
+int ir_launch_flash_attn_fallback(const AttnParams& p, hipStream_t s);
+// DiT self-attention on fp8 (e4m3) MFMA operands (attn_fp8.hip; BASELINE.json configs[4]). p as for ir_launch_flash_attn's self-attention form
+// (p.vt: the bf16 V^T buffer, only written / read when the overflow fallback runs); v: the V rows (strides of p.k); tiles: scratch of
+// ir_attn_fp8_tile_bytes(B, Hh, Tk) bytes for the quantised K / V^T tile images.
+size_t ir_attn_fp8_tile_bytes(int B, int Hh, int Tk);
+int ir_launch_flash_attn_fp8(const AttnParams& p, const bf16_t* v, uint8_t* tiles, hipStream_t s);
 int ir_launch_flash_attn_d512(const bf16_t* q, const bf16_t* k, const bf16_t* vt, bf16_t* o, int T, int rs, int o_rs, long vt_rs,
                               float scale, hipStream_t s, const int* only_if = nullptr);
 // d = 512 without the redundant score product (attn_d512.hip): V^T in 32-key tiles [B][T/32][512][32]; a set *ovf_flag afterwards

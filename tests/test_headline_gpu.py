@@ -67,6 +67,50 @@ def test_attention_at_headline_size(ctx, heads, t, d, gain):
     print(f"attention {heads}x{d} T={t}: max abs err {worst:.4g} on {len(rows)} sampled rows")
 
 
+@pytest.mark.parametrize("heads,t,gain", [(2, 1024, 3.0), (16, 16384, 3.0), (4, 4096, 0.5)])
+def test_attention_fp8(ctx, heads, t, gain):
+    """BASELINE.json configs[4], DiT self-attention on e4m3 MFMA operands (flash_attn_fp8_kernel): against an fp64 softmax over the
+    DEQUANTISED operands the kernel's MFMAs saw (K8 / V8^T tile images read back from the workspace, Q quantised as the kernel does),
+    where only the e4m3 rounding of the probabilities (per query and 32-key block, relative 2^-4 at worst) and the bf16 output
+    rounding remain; and against the fp64 softmax of the bf16 operands, which prices the whole fp8 error. T = 16384 is the headline
+    size; gain 0.5 is a flat softmax (thousands of keys carry each row), gain 3 a peaked one."""
+    from tests.support.fp8_tiles import decode_tiles, quantise_q
+    d = 72
+    g = torch.Generator(device="cuda").manual_seed(t + heads)
+    q = (torch.randn(1, t, heads, d, generator=g, device="cuda") * gain).to(torch.bfloat16)
+    k = torch.randn(1, t, heads, d, generator=g, device="cuda").to(torch.bfloat16)
+    v = torch.randn(1, t, heads, d, generator=g, device="cuda").to(torch.bfloat16)
+    o = torch.empty(1, t, heads, d, dtype=torch.int16, device="cuda")
+    ws = torch.zeros(heads * (t // 64) * 10240 + heads * 96 * (t + 128) * 2 + 8192, dtype=torch.uint8, device="cuda")
+    scale = d ** -0.5
+    ctx.check(ctx.lib.ir_op_attention_fp8(ctx.h, ctx.stream(), L.ptr(q.view(torch.int16)), L.ptr(k.view(torch.int16)), L.ptr(v.view(torch.int16)),
+                                          L.ptr(o), 1, heads, t, scale, L.ptr(ws), ws.numel()), "attention_fp8")
+    torch.cuda.synchronize()
+    Kd, Vd = decode_tiles(ws, 1, heads, t)                                     # [1][heads][t][72] fp32
+    # the tile images must be the e4m3 rounding of K / V: relative 2^-4 of the tile maximum at worst
+    for name, deq, src in (("K", Kd, k), ("V", Vd, v)):
+        ref = src[0].float().permute(1, 0, 2)
+        err = (deq[0] - ref).abs().max() / ref.abs().max()
+        assert float(err) <= 2 ** -4, f"{name} tile images: max error {float(err):.4f} of the maximum"
+    assert torch.equal(Kd[0, :, :, 64:], k[0].float().permute(1, 0, 2)[:, :, 64:]), "d 64..71 of K stay bf16"
+    rows = sorted(set([0, 1, 31, 32, 63, 64, 255, 256, t // 2, t - 257, t - 64, t - 1] + torch.randint(0, t, (244,), generator=torch.Generator().manual_seed(5)).tolist()))
+    idx = torch.tensor(rows, device="cuda")
+    got = o.view(torch.bfloat16)[0, idx].float()                               # [R][heads][d]
+    qd = quantise_q(q[0, idx], scale * 1.4426950408889634)                     # [R][heads][72], log2 domain
+    worst, worst_bf, num, den, num_bf = 0.0, 0.0, 0.0, 0.0, 0.0
+    for hd in range(heads):
+        s2 = qd[:, hd].double() @ Kd[0, hd].double().t()
+        ref = (torch.softmax(s2 * 0.6931471805599453, dim=-1) @ Vd[0, hd].double()).float()
+        ref_bf = (torch.softmax((q[0, idx, hd].double() @ k[0, :, hd].double().t()) * scale, dim=-1) @ v[0, :, hd].double()).float()
+        err, err_bf = (got[:, hd] - ref).abs(), (got[:, hd] - ref_bf).abs()
+        worst, worst_bf = max(worst, float(err.max())), max(worst_bf, float(err_bf.max()))
+        num, num_bf, den = num + float((err ** 2).sum()), num_bf + float((err_bf ** 2).sum()), den + float((ref_bf ** 2).sum())
+        assert float(ref_bf.abs().max()) > (0.3 if gain >= 3 else 0.02)
+    r, r_bf = (num / den) ** 0.5, (num_bf / den) ** 0.5
+    print(f"attention fp8 {heads}x72 T={t} gain {gain}: vs dequantised operands rel-L2 {r:.4f} max abs {worst:.4f}; vs bf16 operands rel-L2 {r_bf:.4f} max abs {worst_bf:.4f}")
+    assert r <= 0.03 and r_bf <= 0.12   # measured 0.017 / 0.083 at gain 3 (peaked softmax: the e4m3 rounding of Q and K moves the logits by ~0.08 nat)
+
+
 # ------------------------------------------------------------------------------------------------ 3x3 convs on 2048 x 2048 x 256
 @pytest.mark.parametrize("cin,cout,up", [(256, 256, 0), (256, 128, 0), (256, 256, 1)])
 def test_conv_at_headline_size(ctx, cin, cout, up):

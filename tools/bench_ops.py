@@ -61,6 +61,19 @@ def attn(b, heads, t, d):
     print(f"attn b{b} h{heads} T{t} d{d}: {ms:8.3f} ms  {4.0 * b * heads * t * t * d / ms / 1e9:8.1f} TFLOP/s (incl. V transpose)")
 
 
+def attn8(b, heads, t):
+    """DiT self-attention on e4m3 operands (flash_attn_fp8_kernel + its prep kernel)"""
+    d = 72
+    q = torch.randn(b, t, heads, d, device="cuda").to(torch.bfloat16).view(torch.int16)
+    k = torch.randn(b, t, heads, d, device="cuda").to(torch.bfloat16).view(torch.int16)
+    v = torch.randn(b, t, heads, d, device="cuda").to(torch.bfloat16).view(torch.int16)
+    o = torch.empty_like(q)
+    ws = torch.empty(256 << 20, dtype=torch.uint8, device="cuda")
+    fn = lambda: ctx.check(ctx.lib.ir_op_attention_fp8(ctx.h, ctx.stream(), L.ptr(q), L.ptr(k), L.ptr(v), L.ptr(o), b, heads, t, d ** -0.5, L.ptr(ws), ws.numel()), "attn8")
+    ms = timeit(fn)
+    print(f"attn fp8 b{b} h{heads} T{t} d{d}: {ms:8.3f} ms  {4.0 * b * heads * t * t * d / ms / 1e9:8.1f} TFLOP/s (incl. K / V quantisation pass)")
+
+
 def xattn(b, heads, tq, tk, d):
     """cross-attention shape: short key sequence with an additive key bias"""
     q = torch.randn(b, tq, heads, d, device="cuda").to(torch.bfloat16).view(torch.int16)
@@ -126,6 +139,10 @@ if __name__ == "__main__":
         gn(1, 1024 * 1024, 256)
         gn(1, 1024 * 1024, 512)
         gn(1, 512 * 512, 512)
+    if "attn8" in which:
+        attn8(1, 16, 16384)
+        attn8(1, 16, 1024)
+        attn(1, 16, 16384, 72)
     if "attn" in which:
         attn(1, 16, 16384, 72)
         attn(1, 16, 1024, 72)

@@ -28,6 +28,18 @@ __global__ void scale_probe(const int* sa, const int* sb, float* C) {
     c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, sa[l], 0, sb[l]);
     for (int g = 0; g < 16; ++g) C[((g & 3) + 8 * (g >> 2) + 4 * h) * 32 + r] = c[g];
 }
+// Which bytes of a lane belong to which 32-k scale block? A = 1.0 in bytes 0..15 of every lane and 0 in bytes 16..31, B = 1.0:
+//   blocks by BYTE RANGE (block b = bytes 16b .. 16b+15 of both lane halves): C[i][j] = 32 * 2^(sa[i] - 127) * 2^(sb[j] - 127)
+//   blocks by LANE HALF  (block h = the 32 bytes of lane half h):             C[i][j] = 16 * (2^(sa[i]+sb[j]-254) + 2^(sa[i+32]+sb[j+32]-254))
+__global__ void block_probe(const int* sa, const int* sb, float* C) {
+    const int l = threadIdx.x, r = l & 31, h = l >> 5;
+    i32x8 a, b;
+    for (int w = 0; w < 8; ++w) { a[w] = w < 4 ? 0x38383838 : 0; b[w] = 0x38383838; }
+    f32x16 c;
+    for (int g = 0; g < 16; ++g) c[g] = 0.f;
+    c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, sa[l], 0, sb[l]);
+    for (int g = 0; g < 16; ++g) C[((g & 3) + 8 * (g >> 2) + 4 * h) * 32 + r] = c[g];
+}
 static float f8_to_f(uint8_t v) {
     int s = v >> 7, e = (v >> 3) & 15, m = v & 7;
     float x = e == 0 ? ldexpf((float)m, -9) : ((e == 15 && m == 7) ? NAN : ldexpf(1.f + m / 8.f, e - 7));
@@ -62,5 +74,16 @@ int main() {
         if (ref != C[i * 32 + j]) ++bad;
     }
     printf("per-lane block scales (lane = row/col r + 32 * k-block): %d / 1024 mismatches; C[0][0] = %g C[1][1] = %g C[2][0] = %g\n", bad, C[0], C[33], C[64]);
+    hipLaunchKernelGGL(block_probe, dim3(1), dim3(64), 0, 0, dsa, dsb, dC);
+    hipMemcpy(C.data(), dC, 4096, hipMemcpyDeviceToHost);
+    int bad_range = 0, bad_half = 0;
+    for (int i = 0; i < 32; ++i) for (int j = 0; j < 32; ++j) {
+        const float by_range = 32.f * ldexpf(1.f, sa[i] + sb[j] - 254);
+        const float by_half = 16.f * (ldexpf(1.f, sa[i] + sb[j] - 254) + ldexpf(1.f, sa[i + 32] + sb[j + 32] - 254));
+        if (C[i * 32 + j] != by_range) ++bad_range;
+        if (C[i * 32 + j] != by_half) ++bad_half;
+    }
+    printf("scale-block membership: %d mismatches if block b = bytes [16b, 16b+16) of every lane; %d mismatches if block h = lane half h (C[0][0] = %g)\n",
+           bad_range, bad_half, C[0]);
     return 0;
 }
