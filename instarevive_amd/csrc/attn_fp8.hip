@@ -40,8 +40,9 @@ constexpr int VROWS = 80;                      // V8^T rows: d 0..71, ones row 7
 constexpr int V_BYTES = VROWS * 64;            // 5120
 constexpr int TILE_BYTES = K_BYTES + V_BYTES;  // 10 DMA pieces of 1 KB
 constexpr int SCALE_OFF = K_BYTES + 79 * 64;   // dword {K exponent byte, V exponent byte, 0, 0}
-constexpr int PF = 4, NSLOT = PF + 1;          // tile t + PF is issued in iteration t
-constexpr int LDS_MAIN = NSLOT * TILE_BYTES;   // 51 200 B
+constexpr int ONE_OFF = K_BYTES + 78 * 64;     // 16 bytes: bf16 {1, 0, 0, 0, 0, 0, 0, 0}
+constexpr int PF = 5, NSLOT = PF + 1;          // tile t + PF is issued in iteration t, two iterations before its first use
+constexpr int LDS_MAIN = NSLOT * TILE_BYTES;   // 61 440 B
 constexpr int OS = 96 + 8;                     // O staging row stride (elements)
 constexpr int LDS_O = 8 * 32 * OS * 2;         // 53 248 B
 constexpr int LDS_BYTES = LDS_MAIN > LDS_O ? LDS_MAIN : LDS_O;
@@ -145,6 +146,8 @@ __global__ __launch_bounds__(256) void attn_fp8_prep_kernel(const bf16_t* __rest
             w[0] = w[1] = w[2] = w[3] = 0x38383838u;   // 1.0 in e4m3; the kernel multiplies this row with exponent byte 127
         } else if (d == VROWS - 1 && pc == 0) {
             w[0] = (uint32_t)bk | ((uint32_t)bv << 8);
+        } else if (d == VROWS - 2 && pc == 0) {
+            w[0] = 0x3F80u;   // bf16 {1, 0, 0, ...}: the K-side partner of -m in the remainder MFMA (see flash_attn_fp8_kernel)
         }
         *reinterpret_cast<uint4*>(dst + K_BYTES + d * 64 + pc * 16) = make_uint4(w[0], w[1], w[2], w[3]);
     }
@@ -161,9 +164,40 @@ struct AttnF8Params {
     int* ovf_flag;
 };
 
-IR_DEVINL f32x16 f8_mfma(i32x8 a, i32x8 b, f32x16 c, int sa, int sb) {
-    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, sa, 0, sb);
+// The MFMAs are inline asm: S^T tiles land in arch VGPRs the VALU reads directly, O^T tiles in literal AGPRs. Hazards hipcc cannot see
+// are covered by construction: an MFMA result is read by the VALU a phase (hundreds of cycles) later or behind explicit s_nops; VALU-written
+// operands (P8, exponent bytes) are a phase old; LDS fragments are behind counted lgkmcnt waits; the bf16 remainder MFMA, which reads the
+// e4m3 MFMA's result as its C operand, issues at least 18 wait states behind it (another MFMA plus softmax items sit in between).
+// diagnostic builds: wait states behind the MFMAs of one kind (-DIR_F8_NOP=1: e4m3 score MFMAs, 2: bf16 remainder MFMAs, 4: O^T MFMAs; sums combine)
+#ifndef IR_F8_NOP
+#define IR_F8_NOP 0
+#endif
+IR_DEVINL void f8_mfma_s(f32x16& s, i32x8 a, i32x8 b, int sa, int sb) {   // s = A8 B8 (block scales sa / sb, byte 0), fresh destination
+    if constexpr (IR_F8_NOP & 1) asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, 0, %3, %4 op_sel_hi:[0,0,0]\n\ts_nop 15" : "=&v"(s) : "v"(a), "v"(b), "v"(sa), "v"(sb));
+    else asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, 0, %3, %4 op_sel_hi:[0,0,0]" : "=&v"(s) : "v"(a), "v"(b), "v"(sa), "v"(sb));
 }
+IR_DEVINL void bf_mfma_acc(f32x16& s, bf16x8 a, bf16x8 b) {
+    if constexpr (IR_F8_NOP & 2) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\ts_nop 15" : "+v"(s) : "v"(a), "v"(b));
+    else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s) : "v"(a), "v"(b));
+}
+template <int LO>
+IR_DEVINL void f8_mfma_o(i32x8 a, i32x8 b, int sa, int sb) {   // a[LO : LO + 15] += A8 B8
+    if constexpr (IR_F8_NOP & 4) asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 a[%c4:%c5], %0, %1, a[%c4:%c5], %2, %3 op_sel_hi:[0,0,0]\n\ts_nop 15" ::"v"(a), "v"(b), "v"(sa), "v"(sb), "n"(LO), "n"(LO + 15));
+    else asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 a[%c4:%c5], %0, %1, a[%c4:%c5], %2, %3 op_sel_hi:[0,0,0]" ::"v"(a), "v"(b), "v"(sa), "v"(sb), "n"(LO), "n"(LO + 15));
+}
+// An MFMA reads its A / B registers for a while after it has issued (the 8-register e4m3 operands longest), and nothing stalls a VALU
+// instruction that overwrites them meanwhile: with the fragment registers handed back to hipcc right behind the MFMA, an exponential of the
+// softmax landed in them and the product came out wrong - intermittently. keep() pins a value's registers up to the point where it stands
+// (an empty asm that "reads" it), i.e. past the softmax items that follow the MFMA.
+template <class T>
+IR_DEVINL void keep(const T& x) { asm volatile("" ::"v"(x)); }
+template <int I>
+IR_DEVINL float f8_acc_read() {
+    float x;
+    asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(x) : "n"(I));
+    return x;
+}
+#define IR_AGPR96_CLOBBERS "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31","a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47","a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63","a64","a65","a66","a67","a68","a69","a70","a71","a72","a73","a74","a75","a76","a77","a78","a79","a80","a81","a82","a83","a84","a85","a86","a87","a88","a89","a90","a91","a92","a93","a94","a95"
 IR_DEVINL i32x8 f8_join(bf16x8 lo, bf16x8 hi) {
     const uint4 a = __builtin_bit_cast(uint4, lo), b = __builtin_bit_cast(uint4, hi);
     i32x8 r;
@@ -235,7 +269,10 @@ __global__ __launch_bounds__(256, 1) void flash_attn_fp8_kernel(AttnF8Params p) 
 
     const uint32_t lds0 = lds_addr(smem);
     const uint32_t k_lane = lds0 + r * KROW + 32 * h;        // + slot * TILE_BYTES + kt * 32 * KROW (+16 second half); remainder chunk at r * KROW + 64
-    const uint32_t kr_lane = lds0 + r * KROW + 64;
+    // remainder MFMA (k = 16): lower lanes read d 64..71 of their key row; upper lanes (k = 8..15) read the constant chunk {1, 0, ..}: with
+    // -m in element 0 of the query side's upper lanes that MFMA also subtracts the softmax reference (per query constant, so its bf16
+    // rounding cancels in the normalisation), and the e4m3 MFMA before it can take the inline constant 0 as its C operand
+    const uint32_t kr_lane[2] = {h ? lds0 + ONE_OFF : lds0 + r * KROW + 64, h ? lds0 + ONE_OFF : lds0 + (32 + r) * KROW + 64};
     // V8^T: row 32 dt + r (dt = 2: rows 64 + (r & 15): rows 80..95 do not exist; their results are never read), logical chunks 2h, 2h + 1
     uint32_t v_lane[3][2];
 #pragma unroll
@@ -246,135 +283,243 @@ __global__ __launch_bounds__(256, 1) void flash_attn_fp8_kernel(AttnF8Params p) 
     }
     const bool ones_row = (r & 15) == 8;   // d-tile 2, row 72: exponent byte 127 instead of the tile's V exponent
 
-    f32x16 sacc[2][2], negm[2], oacc[2][3];
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) negm[g][e] = 0.f;
-#pragma unroll
-        for (int dt = 0; dt < 3; ++dt)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) oacc[g][dt][e] = 0.f;
-    }
-    i32x8 p8[2];
-    int ep[2];
+    // O^T accumulators: 2 groups x 3 d-tiles x 16 = a[0:95], addressed literally by the inline-asm MFMAs (hipcc moves accumulators it can
+    // see between the two register files around every MFMA: 1000 v_accvgpr moves per tile in the first version of this kernel). Everything
+    // the compiler sees lives in arch VGPRs (< 256, so it has no reason to touch the AGPR half; the resource-usage remark must say AGPRs: 96).
+    asm volatile(".set ir_f8_i, 0\n\t.rept 96\n\tv_accvgpr_write_b32 a[ir_f8_i], 0\n\t.set ir_f8_i, ir_f8_i + 1\n\t.endr" ::: IR_AGPR96_CLOBBERS);
 
-    // S^T(tile) = K8 Q8 (+ bf16 remainder) - m for both groups
-    auto scores = [&](int tile) {
-        const uint32_t base = (uint32_t)((tile % NSLOT) * TILE_BYTES);
-        int ek;
-        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(ek) : "v"(lds0 + base), "n"(SCALE_OFF));
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-            const bf16x8 a0 = lds_read16<0>(k_lane + base + kt * 32 * KROW), a1 = lds_read16<16>(k_lane + base + kt * 32 * KROW);
-            const bf16x8 ar = lds_read16<0>(kr_lane + base + kt * 32 * KROW);
-            wait_lds<0>();
-            __builtin_amdgcn_sched_barrier(0);   // the asm reads are invisible to hipcc's waitcnt insertion: nothing may move above the wait
-            const i32x8 a8 = f8_join(a0, a1);
-#pragma unroll
-            for (int g = 0; g < 2; ++g) {
-                sacc[g][kt] = f8_mfma(a8, q8[g], negm[g], ek, eq[g]);
-                sacc[g][kt] = mfma32(ar, qr[g], sacc[g][kt]);
-            }
+    // fragment reads (inline asm: invisible to hipcc's waitcnt insertion, so every use is preceded by a counted wait_lds + sched_barrier)
+    auto slot_base = [&](int tile) { return (uint32_t)((min(tile, NT - 1) % NSLOT) * TILE_BYTES); };   // past the end: the last tile again (results unused)
+    struct KF { bf16x8 a0, a1, ar; };
+    struct VF { bf16x8 a0, a1; };
+    auto read_k = [&](KF& f, uint32_t base, auto ktc) {
+        constexpr int kt = decltype(ktc)::value;
+        f.a0 = lds_read16<kt * 32 * KROW>(k_lane + base);
+        f.a1 = lds_read16<kt * 32 * KROW + 16>(k_lane + base);
+        f.ar = lds_read16<0>(kr_lane[kt] + base);
+    };
+    auto read_v = [&](VF& f, uint32_t base, int dt) {
+        f.a0 = lds_read16<0>(v_lane[dt][0] + base);
+        f.a1 = lds_read16<0>(v_lane[dt][1] + base);
+    };
+    auto read_scale = [&](int& e, uint32_t base) { asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(e) : "v"(lds0 + base), "n"(SCALE_OFF)); };
+
+    // the softmax work of one query group and tile, cut into items that ride in the MFMA shadows: S (scores - m of two 32-key tiles)
+    // -> exponentials in place -> block maxima -> exponents -> P8. Item costs (issue cycles): exponential 8, everything else 4,
+    // the pair exchange about 40.
+    struct Sm { float m0, m1, sp0, sp1; };
+    auto sm_item = [&](auto ic, f32x16 (&S)[2], Sm& st, i32x8& P, int& ebyte) {
+        constexpr int I = decltype(ic)::value;
+        if constexpr (I < 16) S[0][I] = __builtin_amdgcn_exp2f(S[0][I]);
+        else if constexpr (I < 24) {
+            constexpr int e = 2 * (I - 16);
+            st.m0 = __builtin_fmaxf(__builtin_fmaxf(I == 16 ? 0.f : st.m0, S[0][e]), S[0][e + 1]);
+        } else if constexpr (I < 40) S[1][I - 24] = __builtin_amdgcn_exp2f(S[1][I - 24]);
+        else if constexpr (I < 48) {
+            constexpr int e = 2 * (I - 40);
+            st.m1 = __builtin_fmaxf(__builtin_fmaxf(I == 40 ? 0.f : st.m1, S[1][e]), S[1][e + 1]);
+        } else if constexpr (I == 48) {
+            float own;
+            f8_pair_max(st.m0, st.m1, own);
+            ebyte = f8_block_byte(own);
+            st.sp0 = __builtin_bit_cast(float, (uint32_t)f8_block_byte(st.m0) << 23);
+            st.sp1 = __builtin_bit_cast(float, (uint32_t)f8_block_byte(st.m1) << 23);
+        } else {
+            constexpr int c = I - 49, w = c >> 1, hi = c & 1, kt = w >> 2, e0 = 4 * (w & 3) + 2 * hi;
+            const float sp = kt ? st.sp1 : st.sp0;
+            if constexpr (hi) P[w] = (int)f8_cvt2<true>((uint32_t)P[w], S[kt][e0], S[kt][e0 + 1], sp);
+            else P[w] = (int)f8_cvt2<false>((uint32_t)P[w], S[kt][e0], S[kt][e0 + 1], sp);   // (the other half is rewritten by the next item: no zeroing)
         }
     };
-    // probabilities of group g (already exponentiated, in sacc[g]) -> one e4m3 k = 64 operand + its exponent byte
-    auto quantise = [&](int g) {
-        float m0 = 0.f, m1 = 0.f, own;   // bytes 0..15 of the operand = score tile 0, bytes 16..31 = score tile 1: one scale block each
-#pragma unroll
-        for (int e = 0; e < 16; e += 2) {
-            m0 = __builtin_fmaxf(__builtin_fmaxf(m0, sacc[g][0][e]), sacc[g][0][e + 1]);
-            m1 = __builtin_fmaxf(__builtin_fmaxf(m1, sacc[g][1][e]), sacc[g][1][e + 1]);
-        }
-        f8_pair_max(m0, m1, own);
-        ep[g] = f8_block_byte(own);
-        const float sp0 = __builtin_bit_cast(float, (uint32_t)f8_block_byte(m0) << 23), sp1 = __builtin_bit_cast(float, (uint32_t)f8_block_byte(m1) << 23);
-#pragma unroll
-        for (int w = 0; w < 8; ++w) {
-            const int kt = w >> 2, e0 = 4 * (w & 3);
-            const float sp = kt ? sp1 : sp0;
-            uint32_t u = f8_cvt2<false>(0u, sacc[g][kt][e0], sacc[g][kt][e0 + 1], sp);
-            u = f8_cvt2<true>(u, sacc[g][kt][e0 + 2], sacc[g][kt][e0 + 3], sp);
-            p8[g][w] = (int)u;
-        }
+    constexpr int SM_ITEMS = 65;
+    auto sm_range = [&](auto lo_c, auto hi_c, f32x16 (&S)[2], Sm& st, i32x8& P, int& ebyte) {
+        constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+            (sm_item(std::integral_constant<int, LO + I>{}, S, st, P, ebyte), ...);
+        }(std::make_integer_sequence<int, (HI > LO ? HI - LO : 0)>{});
     };
 
-    // ---- tile 0: scores with C = 0, the softmax reference is fixed here (row maximum + headroom)
+    f32x16 S0[2], S1a[2], S1b[2];     // scores of group 0 (consumed in the iteration that produced them) / of group 1 (consumed one iteration later: two sets)
+    i32x8 P0a = {0, 0, 0, 0, 0, 0, 0, 0}, P0b = P0a, P1 = P0a;   // P8 of group 0 (two sets: PV(t) reads one while the softmax of tile t + 1 writes the other) / of group 1
+    int e0a = 127, e0b = 127, e1 = 127;
+    Sm st0, st1;
+    KF kf0, kf1;
+    VF vfa, vfb;
+    int ek, esc;
+
+    // ---- tile 0 in the open: scores with C = 0; the softmax reference is fixed here (row maximum + headroom)
     wait_vm<3 * (PF - 1)>();
     __syncthreads();
-    scores(0);
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        float mx = -INFINITY;
+    read_scale(ek, 0);
+    read_k(kf0, 0, std::integral_constant<int, 0>{});
+    read_k(kf1, 0, std::integral_constant<int, 1>{});
+    wait_lds<0>();
+    __builtin_amdgcn_sched_barrier(0);
+    f8_mfma_s(S0[0], f8_join(kf0.a0, kf0.a1), q8[0], ek, eq[0]);
+    f8_mfma_s(S1a[0], f8_join(kf0.a0, kf0.a1), q8[1], ek, eq[1]);
+    f8_mfma_s(S0[1], f8_join(kf1.a0, kf1.a1), q8[0], ek, eq[0]);
+    f8_mfma_s(S1a[1], f8_join(kf1.a0, kf1.a1), q8[1], ek, eq[1]);
+    asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");   // the remainder MFMAs read these results as C: 18 wait states behind the last producer
+    bf_mfma_acc(S0[0], kf0.ar, qr[0]);
+    bf_mfma_acc(S1a[0], kf0.ar, qr[1]);
+    bf_mfma_acc(S0[1], kf1.ar, qr[0]);
+    bf_mfma_acc(S1a[1], kf1.ar, qr[1]);
+    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(S0[0]), "+v"(S0[1]), "+v"(S1a[0]), "+v"(S1a[1]));   // MFMA results -> VALU: the wait states hipcc cannot see
+    {
+        float mx0 = -INFINITY, mx1 = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sacc[g][kt][e]);
-        const float m_ref = xhalf_max(mx) + MARGIN;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) negm[g][e] = -m_ref;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) sacc[g][kt][e] = __builtin_amdgcn_exp2f(sacc[g][kt][e] - m_ref);
-        quantise(g);
-    }
-
-    // ---- main loop: iteration t multiplies P(t) with V(t) and prepares P(t + 1)
-    for (int t = 0; t < NT; ++t) {
-        wait_vm<3 * (PF - 2)>();   // tile t + 1 has landed (tiles t + 2, t + 3 may still be in flight)
-        __syncthreads();           // ... for every wave, and every wave is done with tile t - 1: its slot takes tile t + PF
-        issue_tile(t + PF);
-        const bool more = t + 1 < NT;
-        if (more) scores(t + 1);
-        {
-            const uint32_t base = (uint32_t)((t % NSLOT) * TILE_BYTES);
-            int esc;
-            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(esc) : "v"(lds0 + base), "n"(SCALE_OFF));
-            wait_lds<0>();
-            __builtin_amdgcn_sched_barrier(0);
-            const int ev = esc >> 8, ev2 = ones_row ? 127 : ev;
-#pragma unroll
-            for (int dt = 0; dt < 3; ++dt) {
-                const bf16x8 a0 = lds_read16<0>(v_lane[dt][0] + base), a1 = lds_read16<0>(v_lane[dt][1] + base);
-                wait_lds<0>();
-                __builtin_amdgcn_sched_barrier(0);
-                const i32x8 a8 = f8_join(a0, a1);
-#pragma unroll
-                for (int g = 0; g < 2; ++g) oacc[g][dt] = f8_mfma(a8, p8[g], oacc[g][dt], dt == 2 ? ev2 : ev, ep[g]);
-            }
+            for (int e = 0; e < 16; ++e) { mx0 = fmaxf(mx0, S0[kt][e]); mx1 = fmaxf(mx1, S1a[kt][e]); }
+        // rounded to bf16 once: later tiles get it through the bf16 operand of the remainder MFMA, tile 0 through the subtraction below
+        const float m0 = bf2f(f2bf(xhalf_max(mx0) + MARGIN)), m1 = bf2f(f2bf(xhalf_max(mx1) + MARGIN));
+        if (h) {   // -m into element 0 (k = 8) of the remainder MFMA's query operand on the upper lanes
+            qr[0] = __builtin_bit_cast(bf16x8, make_uint4((uint32_t)f2bf(-m0), 0u, 0u, 0u));
+            qr[1] = __builtin_bit_cast(bf16x8, make_uint4((uint32_t)f2bf(-m1), 0u, 0u, 0u));
         }
-        if (more) {
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
+        for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) sacc[g][kt][e] = __builtin_amdgcn_exp2f(sacc[g][kt][e]);
-                quantise(g);
-            }
+            for (int e = 0; e < 16; ++e) { S0[kt][e] -= m0; S1a[kt][e] -= m1; }   // from here on the scores arrive as score - m
+        sm_range(std::integral_constant<int, 0>{}, std::integral_constant<int, SM_ITEMS>{}, S0, st0, P0a, e0a);
+    }
+    wait_vm<3 * (PF - 2)>();   // tile 1
+    __syncthreads();
+    read_scale(ek, slot_base(1));
+    read_k(kf0, slot_base(1), std::integral_constant<int, 0>{});
+
+    // ---- main loop. Iteration t:
+    //   phase A   8 MFMAs: S(t+1) per 32 keys and group = one e4m3 k = 64 MFMA + the bf16 remainder (which also subtracts m);
+    //             in their shadows the softmax of (tile t, group 1), whose scores the previous iteration left in S1old -> P1
+    //   mid       tile t + 2 has landed for every wave (counted vmcnt + the one barrier of the iteration); tile t + PF is issued
+    //   phase B   6 MFMAs: O^T += V8^T(t) P8(t), d-tile by d-tile, both groups; in their shadows the softmax of (tile t + 1, group 0) -> P0next
+    // Fragments are read one MFMA pair ahead. Item ranges per MFMA shadow: phase A slot weights 2 2 1 1 2 2 1 1 (e4m3 / bf16 MFMA), phase B equal.
+    constexpr int A_LO[9] = {0, 9, 19, 26, 31, 39, 49, 56, 65}, B_LO[7] = {0, 9, 19, 31, 39, 49, 65};   // cut by issue cost (exponential 8, pair exchange 40, others 4)
+    auto tile_step = [&](auto last_c, int t, f32x16 (&S1old)[2], f32x16 (&S1new)[2], i32x8& P0cur, int& e0cur, i32x8& P0next, int& e0next) {
+        constexpr bool LAST = decltype(last_c)::value;
+        auto sm_a = [&](auto jc) {
+            constexpr int J = decltype(jc)::value;
+            sm_range(std::integral_constant<int, A_LO[J]>{}, std::integral_constant<int, A_LO[J + 1]>{}, S1old, st1, P1, e1);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto sm_b = [&](auto jc) {
+            constexpr int J = decltype(jc)::value;
+            if constexpr (!LAST) sm_range(std::integral_constant<int, B_LO[J]>{}, std::integral_constant<int, B_LO[J + 1]>{}, S0, st0, P0next, e0next);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+        using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>; using I6 = std::integral_constant<int, 6>; using I7 = std::integral_constant<int, 7>;
+        const uint32_t vb = slot_base(t), kb = slot_base(t + 1), kb2 = slot_base(t + 2);
+        // ---- phase A (in flight from the previous phase: ek, kf0 of tile t + 1). Order: the two e4m3 MFMAs of a 32-key half (groups 0, 1), then
+        // their two bf16 remainders. A remainder MFMA reads the e4m3 MFMA's result as its C operand, and between MFMAs of DIFFERENT opcodes
+        // nothing forwards or interlocks: the consumer must issue >= 16 passes + 2 wait states behind the producer (hipcc's hazard table; with
+        // them adjacent the scores came out as garbage). Here another 16- / 8-pass MFMA and >= 17 softmax items always sit in between.
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!LAST) read_k(kf1, kb, I1{});
+        read_scale(esc, vb);
+        wait_lds<(LAST ? 1 : 4)>();
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!LAST) { f8_mfma_s(S0[0], f8_join(kf0.a0, kf0.a1), q8[0], ek, eq[0]); __builtin_amdgcn_sched_barrier(0); }
+        sm_a(I0{});
+        if constexpr (!LAST) { f8_mfma_s(S1new[0], f8_join(kf0.a0, kf0.a1), q8[1], ek, eq[1]); __builtin_amdgcn_sched_barrier(0); }
+        sm_a(I1{});
+        keep(kf0.a0); keep(kf0.a1);
+        if constexpr (!LAST) { bf_mfma_acc(S0[0], kf0.ar, qr[0]); __builtin_amdgcn_sched_barrier(0); }
+        sm_a(I2{});
+        if constexpr (!LAST) { bf_mfma_acc(S1new[0], kf0.ar, qr[1]); __builtin_amdgcn_sched_barrier(0); }
+        sm_a(I3{});
+        keep(kf0.ar);
+        wait_lds<0>();    // kf1, esc
+        __builtin_amdgcn_sched_barrier(0);
+        read_v(vfa, vb, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!LAST) { f8_mfma_s(S0[1], f8_join(kf1.a0, kf1.a1), q8[0], ek, eq[0]); __builtin_amdgcn_sched_barrier(0); }
+        sm_a(I4{});
+        if constexpr (!LAST) { f8_mfma_s(S1new[1], f8_join(kf1.a0, kf1.a1), q8[1], ek, eq[1]); __builtin_amdgcn_sched_barrier(0); }
+        sm_a(I5{});
+        keep(kf1.a0); keep(kf1.a1);
+        if constexpr (!LAST) { bf_mfma_acc(S0[1], kf1.ar, qr[0]); __builtin_amdgcn_sched_barrier(0); }
+        sm_a(I6{});
+        if constexpr (!LAST) { bf_mfma_acc(S1new[1], kf1.ar, qr[1]); __builtin_amdgcn_sched_barrier(0); }
+        sm_a(I7{});
+        keep(kf1.ar); keep(ek);
+        const int ev = esc >> 8, ev2 = ones_row ? 127 : ev;
+        // ---- mid
+        wait_lds<0>();            // V(t) d-tile 0
+        wait_vm<3 * (PF - 3)>();  // tile t + 2
+        __builtin_amdgcn_s_barrier();   // bare: __syncthreads() makes hipcc drain vmcnt(0) in front of it, i.e. wait for the tiles still in flight
+        issue_tile(t + PF);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- phase B
+        read_v(vfb, vb, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        f8_mfma_o<0>(f8_join(vfa.a0, vfa.a1), P0cur, ev, e0cur);
+        __builtin_amdgcn_sched_barrier(0);
+        sm_b(I0{});
+        f8_mfma_o<48>(f8_join(vfa.a0, vfa.a1), P1, ev, e1);
+        __builtin_amdgcn_sched_barrier(0);
+        sm_b(I1{});
+        keep(vfa.a0); keep(vfa.a1);
+        wait_lds<0>();
+        __builtin_amdgcn_sched_barrier(0);
+        read_v(vfa, vb, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        f8_mfma_o<16>(f8_join(vfb.a0, vfb.a1), P0cur, ev, e0cur);
+        __builtin_amdgcn_sched_barrier(0);
+        sm_b(I2{});
+        f8_mfma_o<64>(f8_join(vfb.a0, vfb.a1), P1, ev, e1);
+        __builtin_amdgcn_sched_barrier(0);
+        sm_b(I3{});
+        keep(vfb.a0); keep(vfb.a1);
+        wait_lds<0>();
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!LAST) { read_scale(ek, kb2); read_k(kf0, kb2, I0{}); }   // tile t + 2 (landed: the mid barrier): next iteration's first fragments
+        __builtin_amdgcn_sched_barrier(0);
+        f8_mfma_o<32>(f8_join(vfa.a0, vfa.a1), P0cur, ev2, e0cur);
+        __builtin_amdgcn_sched_barrier(0);
+        sm_b(I4{});
+        f8_mfma_o<80>(f8_join(vfa.a0, vfa.a1), P1, ev2, e1);
+        __builtin_amdgcn_sched_barrier(0);
+        sm_b(I5{});
+        keep(vfa.a0); keep(vfa.a1); keep(P0cur); keep(P1); keep(ev); keep(ev2); keep(e0cur); keep(e1);
+    };
+    {
+        int t = 0;
+        for (; t + 2 < NT; t += 2) {
+            tile_step(std::false_type{}, t, S1a, S1b, P0a, e0a, P0b, e0b);
+            tile_step(std::false_type{}, t + 1, S1b, S1a, P0b, e0b, P0a, e0a);
+        }
+        if (t + 1 < NT) {   // two tiles left
+            tile_step(std::false_type{}, t, S1a, S1b, P0a, e0a, P0b, e0b);
+            tile_step(std::true_type{}, t + 1, S1b, S1a, P0b, e0b, P0a, e0a);
+        } else {            // one tile left
+            tile_step(std::true_type{}, t, S1a, S1b, P0a, e0a, P0b, e0b);
         }
     }
 
     // ---- finalise: O^T[d][q] / l -> LDS [q][d] -> 16-byte row stores; l = O^T row 72 (the ones row): d-tile 2, register 4, lane half 0
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     wait_dma();
     __syncthreads();   // every wave has finished with the tile ring (the staging rows overlay it)
     bf16_t* ow = reinterpret_cast<bf16_t*>(smem) + wid * 64 * OS;
-    const float l0 = __shfl(oacc[0][2][4], r), l1 = __shfl(oacc[1][2][4], r);
+    const float l0 = __shfl(f8_acc_read<32 + 4>(), r), l1 = __shfl(f8_acc_read<80 + 4>(), r);
     const bool bad = !(l0 < 1e30f) || !(l1 < 1e30f) || !(l0 > 0.f) || !(l1 > 0.f);   // also catches inf / NaN: the fixed reference was outgrown
     const float inv0 = 1.0f / l0, inv1 = 1.0f / l1;
-#pragma unroll
-    for (int g = 0; g < 2; ++g)
-#pragma unroll
-        for (int dt = 0; dt < 3; ++dt) {
-            const float inv = g ? inv1 : inv0;
+    [&]<int... I>(std::integer_sequence<int, I...>) {
+        ([&] {
+            constexpr int G = I / 3, DT = I % 3, A0 = 16 * I;
+            const float inv = G ? inv1 : inv0;
+            const float x[16] = {f8_acc_read<A0 + 0>(), f8_acc_read<A0 + 1>(), f8_acc_read<A0 + 2>(), f8_acc_read<A0 + 3>(),
+                                 f8_acc_read<A0 + 4>(), f8_acc_read<A0 + 5>(), f8_acc_read<A0 + 6>(), f8_acc_read<A0 + 7>(),
+                                 f8_acc_read<A0 + 8>(), f8_acc_read<A0 + 9>(), f8_acc_read<A0 + 10>(), f8_acc_read<A0 + 11>(),
+                                 f8_acc_read<A0 + 12>(), f8_acc_read<A0 + 13>(), f8_acc_read<A0 + 14>(), f8_acc_read<A0 + 15>()};
 #pragma unroll
             for (int gg = 0; gg < 4; ++gg) {
-                const uint2 w = make_uint2(pack2bf(oacc[g][dt][4 * gg] * inv, oacc[g][dt][4 * gg + 1] * inv),
-                                           pack2bf(oacc[g][dt][4 * gg + 2] * inv, oacc[g][dt][4 * gg + 3] * inv));
-                *reinterpret_cast<uint2*>(&ow[(g * 32 + r) * OS + dt * 32 + 8 * gg + 4 * h]) = w;
+                const uint2 w = make_uint2(pack2bf(x[4 * gg] * inv, x[4 * gg + 1] * inv), pack2bf(x[4 * gg + 2] * inv, x[4 * gg + 3] * inv));
+                *reinterpret_cast<uint2*>(&ow[(G * 32 + r) * OS + DT * 32 + 8 * gg + 4 * h]) = w;
             }
-        }
+        }(), ...);
+    }(std::make_integer_sequence<int, 6>{});
     if (__any(bad) && lane == 0) atomicOr(p.ovf_flag, 1);
     __syncthreads();
     bf16_t* op = p.o + (long)b * p.o_bs + (long)head * p.o_hs;
