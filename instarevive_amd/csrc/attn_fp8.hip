@@ -56,16 +56,16 @@ IR_DEVINL int f8_block_byte(float mx) {
     return b < 1 ? 1 : (b > 254 ? 254 : b);
 }
 // The MFMA's two 32-k scale blocks are BYTE RANGES of the operand registers, not lane halves (tools/fp8_cvt_probe.hip): block b = bytes
-// 16b .. 16b+15 of BOTH lanes (l, l ^ 32) of a row / column, and its exponent is read from lane (l & 31) + 32 b. So a block maximum is a
-// maximum over a lane PAIR. In: the lane's own maxima over its bytes 0..15 (m0) and 16..31 (m1); out: the pair's maxima on both lanes.
-// `own` (the lane's scale register: block 0 on the lower half, block 1 on the upper half) falls out of the first exchange.
-IR_DEVINL void f8_pair_max(float& m0, float& m1, float& own) {
-    float a = m0, b = m1;
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));   // lower lanes: {own m0, partner's m0}; upper lanes: {partner's m1, own m1}
-    own = fmaxf(a, b);
-    float x = own, y = own;
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));   // x = block-0 maximum everywhere, y = block-1 maximum everywhere
-    m0 = x; m1 = y;
+// 16b .. 16b+15 of BOTH lanes (l, l ^ 32) of a row / column, and its exponent is read from lane (l & 31) + 32 b. This kernel gives both
+// blocks of a row / column ONE exponent (e4m3 is a floating format: the shared exponent only has to keep the largest of the 64 values
+// in range, values 2^17 below it do not matter to any sum), so an operand's exponent is the maximum over the lane PAIR's 2 x 32 values.
+// mx: the lane's own maximum (>= 0). Returns 2^(byte - 127) as a float (the convert's scale operand) and the byte for the MFMA.
+IR_DEVINL float f8_pair_scale(float mx, int& byte) {
+    float a = mx, b = mx;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));   // a = {lower half's mx} on both halves, b = {upper half's}
+    const int t = max((int)(__builtin_bit_cast(uint32_t, __builtin_fmaxf(a, b)) >> 23), f8a::E_BIAS + 1);   // biased exponent of the pair maximum, >= 8
+    byte = t - f8a::E_BIAS;
+    return __builtin_bit_cast(float, (uint32_t)byte << 23);
 }
 // two fp32 / 2^(byte - 127) -> two e4m3 bytes in the low or the high half of `old`
 template <bool HI>
@@ -153,6 +153,17 @@ __global__ __launch_bounds__(256) void attn_fp8_prep_kernel(const bf16_t* __rest
     }
 }
 
+#ifdef IR_STAMPS_F8   // diagnostic build (tools/dbg/attn8_stamps.py): per-wave cycle sums of [0] phase A, [1] mid (waits + barrier + DMA issue), [2] phase B.
+// Cycles, not time: this kernel is power-limited (1.70 GHz with every MFMA in place, 2.14 GHz with the score MFMAs knocked out), so
+// knock-out TIMES mostly show the clock moving; only cycle counts say what an instruction group costs (about 95 cycles per tile for the
+// eight score MFMAs, the same for the six PV MFMAs: they do hide behind the softmax).
+__device__ unsigned long long g_f8_stamps[16];
+#define F8_T(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define F8_ACC(k, a, b) st_acc[k] += (b) - (a)
+#else
+#define F8_T(v) do { } while (0)
+#define F8_ACC(k, a, b) do { } while (0)
+#endif
 struct AttnF8Params {
     const bf16_t* q;
     const uint8_t* tiles;
@@ -172,16 +183,23 @@ struct AttnF8Params {
 #ifndef IR_F8_NOP
 #define IR_F8_NOP 0
 #endif
+// knock-out builds (diagnostic, results wrong by design): -DIR_KO_F8=1 no MFMAs, 2 no softmax items, 4 no per-tile barrier + DMA wait, 8 no fragment reads
+#ifndef IR_KO_F8
+#define IR_KO_F8 0
+#endif
 IR_DEVINL void f8_mfma_s(f32x16& s, i32x8 a, i32x8 b, int sa, int sb) {   // s = A8 B8 (block scales sa / sb, byte 0), fresh destination
+    if constexpr (IR_KO_F8 & (1 | 32)) { asm volatile("" : "=v"(s) : "v"(a), "v"(b), "v"(sa), "v"(sb)); return; }
     if constexpr (IR_F8_NOP & 1) asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, 0, %3, %4 op_sel_hi:[0,0,0]\n\ts_nop 15" : "=&v"(s) : "v"(a), "v"(b), "v"(sa), "v"(sb));
     else asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, 0, %3, %4 op_sel_hi:[0,0,0]" : "=&v"(s) : "v"(a), "v"(b), "v"(sa), "v"(sb));
 }
 IR_DEVINL void bf_mfma_acc(f32x16& s, bf16x8 a, bf16x8 b) {
+    if constexpr (IR_KO_F8 & (1 | 16)) { asm volatile("" : "+v"(s) : "v"(a), "v"(b)); return; }
     if constexpr (IR_F8_NOP & 2) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0\n\ts_nop 15" : "+v"(s) : "v"(a), "v"(b));
     else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(s) : "v"(a), "v"(b));
 }
 template <int LO>
 IR_DEVINL void f8_mfma_o(i32x8 a, i32x8 b, int sa, int sb) {   // a[LO : LO + 15] += A8 B8
+    if constexpr (IR_KO_F8 & (1 | 64)) { asm volatile("" ::"v"(a), "v"(b), "v"(sa), "v"(sb)); return; }
     if constexpr (IR_F8_NOP & 4) asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 a[%c4:%c5], %0, %1, a[%c4:%c5], %2, %3 op_sel_hi:[0,0,0]\n\ts_nop 15" ::"v"(a), "v"(b), "v"(sa), "v"(sb), "n"(LO), "n"(LO + 15));
     else asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 a[%c4:%c5], %0, %1, a[%c4:%c5], %2, %3 op_sel_hi:[0,0,0]" ::"v"(a), "v"(b), "v"(sa), "v"(sb), "n"(LO), "n"(LO + 15));
 }
@@ -217,17 +235,16 @@ __global__ __launch_bounds__(256, 1) void flash_attn_fp8_kernel(AttnF8Params p) 
     const uint8_t* tp = p.tiles + ((long)(b * p.Hh + head) * NT) * TILE_BYTES + lane * 16;
 
     // LDS-DMA: the 10 pieces of a tile image, pieces wu, wu + 4, wu + 8 (clamped to 9: a repeated piece writes the same bytes) per wave
-    auto issue_tile = [&](int tile) {
-        tile = min(tile, NT - 1);   // past the end the last tile is fetched again into a free slot (keeps the vmcnt bookkeeping constant)
-        const int slot = tile % NSLOT;
+    auto issue_tile = [&](int tile, auto slot_c) {   // tile (clamped: past the end the last tile is fetched again, which keeps the vmcnt bookkeeping constant) -> ring slot
+        constexpr int slot = decltype(slot_c)::value;
+        const uint8_t* src = tp + (long)min(tile, NT - 1) * TILE_BYTES;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const int idx = min(wu + 4 * k, 9);
-            f8_glds16(tp + (long)tile * TILE_BYTES + idx * 1024, (f8_lds_t)(smem + slot * TILE_BYTES + idx * 1024));
+            f8_glds16(src + idx * 1024, (f8_lds_t)(smem + slot * TILE_BYTES + idx * 1024));
         }
     };
-#pragma unroll
-    for (int t = 0; t < PF; ++t) issue_tile(t);
+    [&]<int... T>(std::integer_sequence<int, T...>) { (issue_tile(T, std::integral_constant<int, T>{}), ...); }(std::make_integer_sequence<int, PF>{});
 
     // ---- Q: the lane's own query rows. fp8 part: d 32h .. 32h + 31 scaled by scale * log2(e), one exponent per (query, 32-d block);
     // bf16 part: d 64..71 (lanes of the upper half hold the zero padding k = 8..15 of that MFMA)
@@ -248,15 +265,12 @@ __global__ __launch_bounds__(256, 1) void flash_attn_fp8_kernel(AttnF8Params p) 
 #pragma unroll
             for (int e = 0; e < 4; ++e) { x[8 * i + 2 * e] = bflo(w[e]) * p.scale_log2; x[8 * i + 2 * e + 1] = bfhi(w[e]) * p.scale_log2; }
         }
-        float m0 = 0.f, m1 = 0.f, own;
+        float mx = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { m0 = fmaxf(m0, fabsf(x[i])); m1 = fmaxf(m1, fabsf(x[16 + i])); }
-        f8_pair_max(m0, m1, own);
-        eq[g] = f8_block_byte(own);
-        const float sq0 = __builtin_bit_cast(float, (uint32_t)f8_block_byte(m0) << 23), sq1 = __builtin_bit_cast(float, (uint32_t)f8_block_byte(m1) << 23);
+        for (int i = 0; i < 32; ++i) mx = fmaxf(mx, fabsf(x[i]));
+        const float sq = f8_pair_scale(mx, eq[g]);   // one exponent for the query's 64 e4m3 values (both scale blocks)
 #pragma unroll
         for (int w = 0; w < 8; ++w) {
-            const float sq = w < 4 ? sq0 : sq1;
             uint32_t u = f8_cvt2<false>(0u, x[4 * w], x[4 * w + 1], sq);
             u = f8_cvt2<true>(u, x[4 * w + 2], x[4 * w + 3], sq);
             q8[g][w] = (int)u;
@@ -288,47 +302,49 @@ __global__ __launch_bounds__(256, 1) void flash_attn_fp8_kernel(AttnF8Params p) 
     // the compiler sees lives in arch VGPRs (< 256, so it has no reason to touch the AGPR half; the resource-usage remark must say AGPRs: 96).
     asm volatile(".set ir_f8_i, 0\n\t.rept 96\n\tv_accvgpr_write_b32 a[ir_f8_i], 0\n\t.set ir_f8_i, ir_f8_i + 1\n\t.endr" ::: IR_AGPR96_CLOBBERS);
 
-    // fragment reads (inline asm: invisible to hipcc's waitcnt insertion, so every use is preceded by a counted wait_lds + sched_barrier)
-    auto slot_base = [&](int tile) { return (uint32_t)((min(tile, NT - 1) % NSLOT) * TILE_BYTES); };   // past the end: the last tile again (results unused)
+    // fragment reads (inline asm: invisible to hipcc's waitcnt insertion, so every use is preceded by a counted wait_lds + sched_barrier).
+    // The ring slot of every read is a compile-time constant (the loop body is six tiles long), so an address is a per-lane register
+    // plus an immediate: no address arithmetic in the stream.
     struct KF { bf16x8 a0, a1, ar; };
     struct VF { bf16x8 a0, a1; };
-    auto read_k = [&](KF& f, uint32_t base, auto ktc) {
-        constexpr int kt = decltype(ktc)::value;
-        f.a0 = lds_read16<kt * 32 * KROW>(k_lane + base);
-        f.a1 = lds_read16<kt * 32 * KROW + 16>(k_lane + base);
-        f.ar = lds_read16<0>(kr_lane[kt] + base);
+    auto read_k = [&](KF& f, auto slot_c, auto ktc) {
+        constexpr int base = decltype(slot_c)::value * TILE_BYTES, kt = decltype(ktc)::value;
+        if constexpr (IR_KO_F8 & 8) { asm volatile("" : "+v"(f.a0), "+v"(f.a1), "+v"(f.ar)); return; }
+        f.a0 = lds_read16<base + kt * 32 * KROW>(k_lane);
+        f.a1 = lds_read16<base + kt * 32 * KROW + 16>(k_lane);
+        f.ar = lds_read16<base>(kr_lane[kt]);
     };
-    auto read_v = [&](VF& f, uint32_t base, int dt) {
-        f.a0 = lds_read16<0>(v_lane[dt][0] + base);
-        f.a1 = lds_read16<0>(v_lane[dt][1] + base);
+    auto read_v = [&](VF& f, auto slot_c, auto dtc) {
+        constexpr int base = decltype(slot_c)::value * TILE_BYTES, dt = decltype(dtc)::value;
+        if constexpr (IR_KO_F8 & 8) { asm volatile("" : "+v"(f.a0), "+v"(f.a1)); return; }
+        f.a0 = lds_read16<base>(v_lane[dt][0]);
+        f.a1 = lds_read16<base>(v_lane[dt][1]);
     };
-    auto read_scale = [&](int& e, uint32_t base) { asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(e) : "v"(lds0 + base), "n"(SCALE_OFF)); };
+    auto read_scale = [&](int& e, auto slot_c) {
+        const uint32_t a = lds0;   // (named outside the asm: clang does not capture a variable that only an asm operand of a generic lambda names)
+        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(e) : "v"(a), "n"(decltype(slot_c)::value * TILE_BYTES + SCALE_OFF));
+    };
 
     // the softmax work of one query group and tile, cut into items that ride in the MFMA shadows: S (scores - m of two 32-key tiles)
-    // -> exponentials in place -> block maxima -> exponents -> P8. Item costs (issue cycles): exponential 8, everything else 4,
-    // the pair exchange about 40.
-    struct Sm { float m0, m1, sp0, sp1; };
+    // -> exponentials in place -> maximum -> exponent -> P8. Measured issue costs (tools/valu_rate_probe.hip): v_exp_f32 and the scaled
+    // convert 8.8 cycles each, v_max3_f32 5, the pair exchange about 35.
+    struct Sm { float mx, sp; };
     auto sm_item = [&](auto ic, f32x16 (&S)[2], Sm& st, i32x8& P, int& ebyte) {
         constexpr int I = decltype(ic)::value;
         if constexpr (I < 16) S[0][I] = __builtin_amdgcn_exp2f(S[0][I]);
         else if constexpr (I < 24) {
             constexpr int e = 2 * (I - 16);
-            st.m0 = __builtin_fmaxf(__builtin_fmaxf(I == 16 ? 0.f : st.m0, S[0][e]), S[0][e + 1]);
+            st.mx = __builtin_fmaxf(__builtin_fmaxf(I == 16 ? 0.f : st.mx, S[0][e]), S[0][e + 1]);
         } else if constexpr (I < 40) S[1][I - 24] = __builtin_amdgcn_exp2f(S[1][I - 24]);
         else if constexpr (I < 48) {
             constexpr int e = 2 * (I - 40);
-            st.m1 = __builtin_fmaxf(__builtin_fmaxf(I == 40 ? 0.f : st.m1, S[1][e]), S[1][e + 1]);
+            st.mx = __builtin_fmaxf(__builtin_fmaxf(st.mx, S[1][e]), S[1][e + 1]);
         } else if constexpr (I == 48) {
-            float own;
-            f8_pair_max(st.m0, st.m1, own);
-            ebyte = f8_block_byte(own);
-            st.sp0 = __builtin_bit_cast(float, (uint32_t)f8_block_byte(st.m0) << 23);
-            st.sp1 = __builtin_bit_cast(float, (uint32_t)f8_block_byte(st.m1) << 23);
+            st.sp = f8_pair_scale(st.mx, ebyte);
         } else {
             constexpr int c = I - 49, w = c >> 1, hi = c & 1, kt = w >> 2, e0 = 4 * (w & 3) + 2 * hi;
-            const float sp = kt ? st.sp1 : st.sp0;
-            if constexpr (hi) P[w] = (int)f8_cvt2<true>((uint32_t)P[w], S[kt][e0], S[kt][e0 + 1], sp);
-            else P[w] = (int)f8_cvt2<false>((uint32_t)P[w], S[kt][e0], S[kt][e0 + 1], sp);   // (the other half is rewritten by the next item: no zeroing)
+            if constexpr (hi) P[w] = (int)f8_cvt2<true>((uint32_t)P[w], S[kt][e0], S[kt][e0 + 1], st.sp);
+            else P[w] = (int)f8_cvt2<false>((uint32_t)P[w], S[kt][e0], S[kt][e0 + 1], st.sp);   // (the other half is rewritten by the next item: no zeroing)
         }
     };
     constexpr int SM_ITEMS = 65;
@@ -346,13 +362,18 @@ __global__ __launch_bounds__(256, 1) void flash_attn_fp8_kernel(AttnF8Params p) 
     KF kf0, kf1;
     VF vfa, vfb;
     int ek, esc;
+#ifdef IR_STAMPS_F8
+    unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+    using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>; using I6 = std::integral_constant<int, 6>; using I7 = std::integral_constant<int, 7>;
 
     // ---- tile 0 in the open: scores with C = 0; the softmax reference is fixed here (row maximum + headroom)
     wait_vm<3 * (PF - 1)>();
     __syncthreads();
-    read_scale(ek, 0);
-    read_k(kf0, 0, std::integral_constant<int, 0>{});
-    read_k(kf1, 0, std::integral_constant<int, 1>{});
+    read_scale(ek, I0{});
+    read_k(kf0, I0{}, I0{});
+    read_k(kf1, I0{}, I1{});
     wait_lds<0>();
     __builtin_amdgcn_sched_barrier(0);
     f8_mfma_s(S0[0], f8_join(kf0.a0, kf0.a1), q8[0], ek, eq[0]);
@@ -381,77 +402,87 @@ __global__ __launch_bounds__(256, 1) void flash_attn_fp8_kernel(AttnF8Params p) 
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int e = 0; e < 16; ++e) { S0[kt][e] -= m0; S1a[kt][e] -= m1; }   // from here on the scores arrive as score - m
-        sm_range(std::integral_constant<int, 0>{}, std::integral_constant<int, SM_ITEMS>{}, S0, st0, P0a, e0a);
+        sm_range(I0{}, std::integral_constant<int, SM_ITEMS>{}, S0, st0, P0a, e0a);
     }
     wait_vm<3 * (PF - 2)>();   // tile 1
     __syncthreads();
-    read_scale(ek, slot_base(1));
-    read_k(kf0, slot_base(1), std::integral_constant<int, 0>{});
+    read_scale(ek, I1{});
+    read_k(kf0, I1{}, I0{});
 
-    // ---- main loop. Iteration t:
+    // ---- main loop. Iteration t (ring slot K = t % 6 is a template argument):
     //   phase A   8 MFMAs: S(t+1) per 32 keys and group = one e4m3 k = 64 MFMA + the bf16 remainder (which also subtracts m);
     //             in their shadows the softmax of (tile t, group 1), whose scores the previous iteration left in S1old -> P1
     //   mid       tile t + 2 has landed for every wave (counted vmcnt + the one barrier of the iteration); tile t + PF is issued
     //   phase B   6 MFMAs: O^T += V8^T(t) P8(t), d-tile by d-tile, both groups; in their shadows the softmax of (tile t + 1, group 0) -> P0next
-    // Fragments are read one MFMA pair ahead. Item ranges per MFMA shadow: phase A slot weights 2 2 1 1 2 2 1 1 (e4m3 / bf16 MFMA), phase B equal.
-    constexpr int A_LO[9] = {0, 9, 19, 26, 31, 39, 49, 56, 65}, B_LO[7] = {0, 9, 19, 31, 39, 49, 65};   // cut by issue cost (exponential 8, pair exchange 40, others 4)
-    auto tile_step = [&](auto last_c, int t, f32x16 (&S1old)[2], f32x16 (&S1new)[2], i32x8& P0cur, int& e0cur, i32x8& P0next, int& e0next) {
-        constexpr bool LAST = decltype(last_c)::value;
+    // Fragments are read one MFMA pair ahead. The last iteration runs the same stream: its "tile t + 1" is whatever the next slot holds
+    // (finite bytes of an older tile), and nothing consumes those scores.
+    // Item ranges per MFMA shadow, cut by issue cost: phase A slot weights 2 2 1 1 2 2 1 1 (e4m3 / bf16 MFMA), phase B equal.
+    constexpr int A_LO[9] = {0, 9, 19, 25, 30, 38, 49, 56, 65}, B_LO[7] = {0, 9, 19, 30, 39, 50, 65};
+    auto tile_step = [&](auto kc, int t, f32x16 (&S1old)[2], f32x16 (&S1new)[2], i32x8& P0cur, int& e0cur, i32x8& P0next, int& e0next) {
+        constexpr int K = decltype(kc)::value;
+        using SV = std::integral_constant<int, K>;                 // slot of tile t
+        using SK = std::integral_constant<int, (K + 1) % NSLOT>;   // of tile t + 1
+        using SK2 = std::integral_constant<int, (K + 2) % NSLOT>;  // of tile t + 2
+        using SF = std::integral_constant<int, (K + PF) % NSLOT>;  // free: tile t - 1 was its last user
         auto sm_a = [&](auto jc) {
             constexpr int J = decltype(jc)::value;
+            if constexpr (IR_KO_F8 & 2) { asm volatile("" : "+v"(S1old[0]), "+v"(S1old[1]), "+v"(P1), "+v"(e1)); return; }
             sm_range(std::integral_constant<int, A_LO[J]>{}, std::integral_constant<int, A_LO[J + 1]>{}, S1old, st1, P1, e1);
             __builtin_amdgcn_sched_barrier(0);
         };
         auto sm_b = [&](auto jc) {
             constexpr int J = decltype(jc)::value;
-            if constexpr (!LAST) sm_range(std::integral_constant<int, B_LO[J]>{}, std::integral_constant<int, B_LO[J + 1]>{}, S0, st0, P0next, e0next);
+            if constexpr (IR_KO_F8 & 2) { asm volatile("" : "+v"(S0[0]), "+v"(S0[1]), "+v"(P0next), "+v"(e0next)); return; }
+            sm_range(std::integral_constant<int, B_LO[J]>{}, std::integral_constant<int, B_LO[J + 1]>{}, S0, st0, P0next, e0next);
             __builtin_amdgcn_sched_barrier(0);
         };
-        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
-        using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>; using I6 = std::integral_constant<int, 6>; using I7 = std::integral_constant<int, 7>;
-        const uint32_t vb = slot_base(t), kb = slot_base(t + 1), kb2 = slot_base(t + 2);
+        F8_T(ta);
         // ---- phase A (in flight from the previous phase: ek, kf0 of tile t + 1). Order: the two e4m3 MFMAs of a 32-key half (groups 0, 1), then
         // their two bf16 remainders. A remainder MFMA reads the e4m3 MFMA's result as its C operand, and between MFMAs of DIFFERENT opcodes
-        // nothing forwards or interlocks: the consumer must issue >= 16 passes + 2 wait states behind the producer (hipcc's hazard table; with
-        // them adjacent the scores came out as garbage). Here another 16- / 8-pass MFMA and >= 17 softmax items always sit in between.
+        // nothing forwards or interlocks: the consumer must issue >= 16 passes + 2 wait states behind the producer (hipcc's hazard table).
+        // Here another 16- / 8-pass MFMA and >= 15 softmax items always sit in between.
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!LAST) read_k(kf1, kb, I1{});
-        read_scale(esc, vb);
-        wait_lds<(LAST ? 1 : 4)>();
+        read_k(kf1, SK{}, I1{});
+        read_scale(esc, SV{});
+        wait_lds<4>();
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!LAST) { f8_mfma_s(S0[0], f8_join(kf0.a0, kf0.a1), q8[0], ek, eq[0]); __builtin_amdgcn_sched_barrier(0); }
+        f8_mfma_s(S0[0], f8_join(kf0.a0, kf0.a1), q8[0], ek, eq[0]); __builtin_amdgcn_sched_barrier(0);
         sm_a(I0{});
-        if constexpr (!LAST) { f8_mfma_s(S1new[0], f8_join(kf0.a0, kf0.a1), q8[1], ek, eq[1]); __builtin_amdgcn_sched_barrier(0); }
+        f8_mfma_s(S1new[0], f8_join(kf0.a0, kf0.a1), q8[1], ek, eq[1]); __builtin_amdgcn_sched_barrier(0);
         sm_a(I1{});
         keep(kf0.a0); keep(kf0.a1);
-        if constexpr (!LAST) { bf_mfma_acc(S0[0], kf0.ar, qr[0]); __builtin_amdgcn_sched_barrier(0); }
+        bf_mfma_acc(S0[0], kf0.ar, qr[0]); __builtin_amdgcn_sched_barrier(0);
         sm_a(I2{});
-        if constexpr (!LAST) { bf_mfma_acc(S1new[0], kf0.ar, qr[1]); __builtin_amdgcn_sched_barrier(0); }
+        bf_mfma_acc(S1new[0], kf0.ar, qr[1]); __builtin_amdgcn_sched_barrier(0);
         sm_a(I3{});
         keep(kf0.ar);
         wait_lds<0>();    // kf1, esc
         __builtin_amdgcn_sched_barrier(0);
-        read_v(vfa, vb, 0);
+        read_v(vfa, SV{}, I0{});
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!LAST) { f8_mfma_s(S0[1], f8_join(kf1.a0, kf1.a1), q8[0], ek, eq[0]); __builtin_amdgcn_sched_barrier(0); }
+        f8_mfma_s(S0[1], f8_join(kf1.a0, kf1.a1), q8[0], ek, eq[0]); __builtin_amdgcn_sched_barrier(0);
         sm_a(I4{});
-        if constexpr (!LAST) { f8_mfma_s(S1new[1], f8_join(kf1.a0, kf1.a1), q8[1], ek, eq[1]); __builtin_amdgcn_sched_barrier(0); }
+        f8_mfma_s(S1new[1], f8_join(kf1.a0, kf1.a1), q8[1], ek, eq[1]); __builtin_amdgcn_sched_barrier(0);
         sm_a(I5{});
         keep(kf1.a0); keep(kf1.a1);
-        if constexpr (!LAST) { bf_mfma_acc(S0[1], kf1.ar, qr[0]); __builtin_amdgcn_sched_barrier(0); }
+        bf_mfma_acc(S0[1], kf1.ar, qr[0]); __builtin_amdgcn_sched_barrier(0);
         sm_a(I6{});
-        if constexpr (!LAST) { bf_mfma_acc(S1new[1], kf1.ar, qr[1]); __builtin_amdgcn_sched_barrier(0); }
+        bf_mfma_acc(S1new[1], kf1.ar, qr[1]); __builtin_amdgcn_sched_barrier(0);
         sm_a(I7{});
         keep(kf1.ar); keep(ek);
         const int ev = esc >> 8, ev2 = ones_row ? 127 : ev;
+        F8_T(tb);
         // ---- mid
         wait_lds<0>();            // V(t) d-tile 0
+        if constexpr (!(IR_KO_F8 & 4)) {
         wait_vm<3 * (PF - 3)>();  // tile t + 2
         __builtin_amdgcn_s_barrier();   // bare: __syncthreads() makes hipcc drain vmcnt(0) in front of it, i.e. wait for the tiles still in flight
-        issue_tile(t + PF);
+        }
+        issue_tile(t + PF, SF{});
         __builtin_amdgcn_sched_barrier(0);
+        F8_T(tc);
         // ---- phase B
-        read_v(vfb, vb, 1);
+        read_v(vfb, SV{}, I1{});
         __builtin_amdgcn_sched_barrier(0);
         f8_mfma_o<0>(f8_join(vfa.a0, vfa.a1), P0cur, ev, e0cur);
         __builtin_amdgcn_sched_barrier(0);
@@ -462,7 +493,7 @@ __global__ __launch_bounds__(256, 1) void flash_attn_fp8_kernel(AttnF8Params p) 
         keep(vfa.a0); keep(vfa.a1);
         wait_lds<0>();
         __builtin_amdgcn_sched_barrier(0);
-        read_v(vfa, vb, 2);
+        read_v(vfa, SV{}, I2{});
         __builtin_amdgcn_sched_barrier(0);
         f8_mfma_o<16>(f8_join(vfb.a0, vfb.a1), P0cur, ev, e0cur);
         __builtin_amdgcn_sched_barrier(0);
@@ -473,7 +504,8 @@ __global__ __launch_bounds__(256, 1) void flash_attn_fp8_kernel(AttnF8Params p) 
         keep(vfb.a0); keep(vfb.a1);
         wait_lds<0>();
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (!LAST) { read_scale(ek, kb2); read_k(kf0, kb2, I0{}); }   // tile t + 2 (landed: the mid barrier): next iteration's first fragments
+        read_scale(ek, SK2{});   // tile t + 2 (landed: the mid barrier): next iteration's first fragments
+        read_k(kf0, SK2{}, I0{});
         __builtin_amdgcn_sched_barrier(0);
         f8_mfma_o<32>(f8_join(vfa.a0, vfa.a1), P0cur, ev2, e0cur);
         __builtin_amdgcn_sched_barrier(0);
@@ -482,21 +514,26 @@ __global__ __launch_bounds__(256, 1) void flash_attn_fp8_kernel(AttnF8Params p) 
         __builtin_amdgcn_sched_barrier(0);
         sm_b(I5{});
         keep(vfa.a0); keep(vfa.a1); keep(P0cur); keep(P1); keep(ev); keep(ev2); keep(e0cur); keep(e1);
+        F8_T(td);
+        F8_ACC(0, ta, tb); F8_ACC(1, tb, tc); F8_ACC(2, tc, td);
     };
-    {
-        int t = 0;
-        for (; t + 2 < NT; t += 2) {
-            tile_step(std::false_type{}, t, S1a, S1b, P0a, e0a, P0b, e0b);
-            tile_step(std::false_type{}, t + 1, S1b, S1a, P0b, e0b, P0a, e0a);
-        }
-        if (t + 1 < NT) {   // two tiles left
-            tile_step(std::false_type{}, t, S1a, S1b, P0a, e0a, P0b, e0b);
-            tile_step(std::true_type{}, t + 1, S1b, S1a, P0b, e0b, P0a, e0a);
-        } else {            // one tile left
-            tile_step(std::true_type{}, t, S1a, S1b, P0a, e0a, P0b, e0b);
-        }
+    for (int t = 0; t < NT; t += NSLOT) {   // six tiles per trip: ring slots and buffer parities are static; a short last trip leaves early
+        tile_step(I0{}, t, S1a, S1b, P0a, e0a, P0b, e0b);
+        if (t + 1 >= NT) break;
+        tile_step(I1{}, t + 1, S1b, S1a, P0b, e0b, P0a, e0a);
+        if (t + 2 >= NT) break;
+        tile_step(I2{}, t + 2, S1a, S1b, P0a, e0a, P0b, e0b);
+        if (t + 3 >= NT) break;
+        tile_step(I3{}, t + 3, S1b, S1a, P0b, e0b, P0a, e0a);
+        if (t + 4 >= NT) break;
+        tile_step(I4{}, t + 4, S1a, S1b, P0a, e0a, P0b, e0b);
+        if (t + 5 >= NT) break;
+        tile_step(I5{}, t + 5, S1b, S1a, P0b, e0b, P0a, e0a);
     }
 
+#ifdef IR_STAMPS_F8
+    if (lane == 0) for (int i = 0; i < 3; ++i) atomicAdd(&g_f8_stamps[i], st_acc[i]);
+#endif
     // ---- finalise: O^T[d][q] / l -> LDS [q][d] -> 16-byte row stores; l = O^T row 72 (the ones row): d-tile 2, register 4, lane half 0
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     wait_dma();
@@ -520,7 +557,7 @@ __global__ __launch_bounds__(256, 1) void flash_attn_fp8_kernel(AttnF8Params p) 
             }
         }(), ...);
     }(std::make_integer_sequence<int, 6>{});
-    if (__any(bad) && lane == 0) atomicOr(p.ovf_flag, 1);
+    if (IR_KO_F8 == 0 && __any(bad) && lane == 0) atomicOr(p.ovf_flag, 1);   // (knock-out builds compute garbage: keep their timing free of the fallback)
     __syncthreads();
     bf16_t* op = p.o + (long)b * p.o_bs + (long)head * p.o_hs;
     for (int c = lane; c < 64 * 9; c += 64) {
@@ -530,6 +567,12 @@ __global__ __launch_bounds__(256, 1) void flash_attn_fp8_kernel(AttnF8Params p) 
     }
 }
 
+#ifdef IR_STAMPS_F8
+extern "C" void ir_f8_stamps(unsigned long long* out, int reset) {
+    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_f8_stamps), z, sizeof z); return; }
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_f8_stamps), 16 * sizeof(unsigned long long));
+}
+#endif
 size_t ir_attn_fp8_tile_bytes(int B, int Hh, int Tk) { return (size_t)B * Hh * (Tk / 64) * f8a::TILE_BYTES; }
 
 // p as for ir_launch_flash_attn's DiT self-attention form (D = 72, Tk % 64 == 0, no key bias, ovf_flag set, p.vt = the bf16 V^T buffer the
