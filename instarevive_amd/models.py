@@ -643,10 +643,10 @@ class T5EncoderModel(_DeviceModule):
 class T5Embedder:
     """diffusion/model/t5.py:13-101 with the same constructor keywords that matter here and the same get_text_embeddings(texts)
     -> (embeddings [B, L, 4096], attention_mask [B, L]). The tokenizer is transformers' own (AutoTokenizer over the model folder, as in
-    the reference); the encoder is the HIP T5EncoderModel above. The reference's caption cleaning (clean_caption: ftfy / bs4 / regex
-    rewriting, t5.py:118-233) is not reproduced: use_text_preprocessing=True falls back to its lower().strip() branch (:113-116)."""
+    the reference); the encoder is the HIP T5EncoderModel above. Caption cleaning (clean_caption twice under use_text_preprocessing,
+    t5.py:106-233) is instarevive_amd.captions, pinned by tests/golden/captions.json."""
 
-    def __init__(self, device, dir_or_name="t5-v1_1-xxl", *, tokenizer=None, model=None, model_max_length=120, use_text_preprocessing=False,
+    def __init__(self, device, dir_or_name="t5-v1_1-xxl", *, tokenizer=None, model=None, model_max_length=120, use_text_preprocessing=True,
                  **unused):
         self.device = torch.device(device)
         self.model_max_length = model_max_length
@@ -658,7 +658,8 @@ class T5Embedder:
         self.model = (model or T5EncoderModel.from_pretrained(dir_or_name)).to(self.device)
 
     def text_preprocessing(self, text):
-        return text.lower().strip()
+        from .captions import text_preprocessing
+        return text_preprocessing(text, self.use_text_preprocessing)
 
     def get_text_embeddings(self, texts):
         texts = [self.text_preprocessing(t) for t in texts]

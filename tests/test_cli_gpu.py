@@ -135,3 +135,51 @@ def test_bench_self_launches_its_ranks():
     assert line["n_gpus"] == 2 and line["world_size"] == 2 and line["gathered_images"] == 4 and line["verified"] is True
     assert line["config"]["global_batch"] == 4 and line["config"]["parallelism"] == "dp2" and line["value"] > 0
     assert "roofline" in line and line["roofline"]["per_kernel"]
+
+
+def test_make_prompt_writes_the_reference_prompt_file(tmp_path):
+    """SURVEY.md section 8(f) N3, the producer of --prompt_embeds: tools/make_prompt.py (tokenizer from a local folder -> HIP T5 encoder ->
+    {'caption_embeds', 'emb_mask'} as test_scripts/test_controlnet.py:389-395 saves them) on a folder in the DeepFloyd layout: a
+    SentencePiece model trained here on a few sentences, config.json and safetensors weights of a reduced T5 v1.1 encoder. The saved
+    embeddings are checked against the oracle on the ids the same tokenizer yields, and the file is fed to the restoration CLI's loader."""
+    import sentencepiece as spm
+    from safetensors.torch import save_file
+    from transformers import T5Tokenizer
+    from oracle import t5 as ot5
+    d = tmp_path / "t5"
+    os.makedirs(d)
+    corpus = d / "corpus.txt"
+    corpus.write_text("\n".join(["a high quality photo of a human face", "highly detailed portrait, sharp focus, 8k", "restore the image cleanly",
+                                 "a photo of a cat and a dog in the garden", "clean, realistic, natural skin texture"] * 4))
+    spm.SentencePieceTrainer.train(input=str(corpus), model_prefix=str(d / "spiece"), vocab_size=60, model_type="unigram", pad_id=0, eos_id=1, unk_id=2,
+                                   bos_id=-1, hard_vocab_limit=False, minloglevel=2)
+    os.remove(corpus)
+    tok = T5Tokenizer.from_pretrained(str(d))   # spiece.model alone, as in the DeepFloyd folder (+ the 100 sentinel ids T5 adds)
+    cfg = dict(d_model=64, d_kv=16, num_heads=4, d_ff=128, num_layers=2, vocab_size=len(tok))
+    sd = det_state_dict(ot5.state_dict_shapes(cfg), seed=717)
+    sd["shared.weight"] = sd["shared.weight"] * 8.0
+    for k in sd:
+        if k.endswith("SelfAttention.q.weight"):
+            sd[k] = sd[k] * cfg["d_kv"] ** -0.5
+    (d / "config.json").write_text(json.dumps(dict(cfg, feed_forward_proj="gated-gelu", layer_norm_epsilon=1e-6, relative_attention_num_buckets=32,
+                                                   relative_attention_max_distance=128, model_type="t5")))
+    save_file({k: v.contiguous() for k, v in sd.items()}, str(d / "model.safetensors"))
+    out = tmp_path / "prompt.pth"
+    prompt = "A high quality PHOTO of a human face, <b>highly detailed</b> https://example.com/x"
+    for clean in (False, True):
+        cmd = [sys.executable, os.path.join(ROOT, "tools", "make_prompt.py"), "--t5", str(d), "--prompt", prompt, "--max_length", "24", "--out", str(out)]
+        r = subprocess.run(cmd + (["--clean"] if clean else []), capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        f = torch.load(out, map_location="cpu")
+        assert set(f) == {"caption_embeds", "emb_mask"} and tuple(f["caption_embeds"].shape) == (1, 24, 64) and tuple(f["emb_mask"].shape) == (1, 24)
+        from instarevive_amd.captions import text_preprocessing
+        want = tok(text_preprocessing(prompt) if clean else prompt, max_length=24, padding="max_length", truncation=True, return_tensors="pt")
+        assert torch.equal(f["emb_mask"], want["attention_mask"]) and 2 < int(f["emb_mask"].sum()) <= 24
+        ref = ot5.t5_encode(sd, want["input_ids"], want["attention_mask"], cfg)
+        n = int(f["emb_mask"].sum())
+        err = float((f["caption_embeds"][:, :n] - ref[:, :n]).norm() / ref[:, :n].norm())
+        print(f"make_prompt clean={clean}: {n} tokens, rel-L2 vs oracle {err:.4f}")
+        assert err <= 0.015
+    # the CLI's loader reshapes it as the reference does (inference.py:256-259,273-277)
+    y = f["caption_embeds"].reshape(1, -1, f["caption_embeds"].shape[-1])
+    assert tuple(y.shape) == (1, 24, 64) and tuple(f["emb_mask"].reshape(1, 1, -1).shape) == (1, 1, 24)

@@ -187,3 +187,18 @@ def test_cli_job_pre_and_post_processing(tmp_path):
     groups = list(inf.batches_of([mk(64, 64), mk(64, 64), mk(64, 64), mk(64, 128), mk(64, 64)], 2))
     assert [len(g) for g in groups] == [2, 1, 1, 1]
     assert [len(g) for g in inf.batches_of([mk(64, 64)] * 3, 1)] == [1, 1, 1]
+
+
+def test_clean_caption_matches_the_reference_fixture():
+    """instarevive_amd.captions against tests/golden/captions.json = outputs of the reference's own T5Embedder.clean_caption /
+    text_preprocessing (diffusion/model/t5.py:106-233) on captions covering every rewrite (URLs, tags, entities, CJK blocks, dashes,
+    quotes, ids, file names, boilerplate, punctuation runs, quote stripping), one pass and the two passes the reference applies."""
+    import json
+    from instarevive_amd.captions import clean_caption, text_preprocessing
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "captions.json"), encoding="utf-8"))
+    assert len(fx["captions"]) >= 15
+    for c, once, twice, plain in zip(fx["captions"], fx["once"], fx["twice"], fx["plain"]):
+        assert clean_caption(c) == once, (c, clean_caption(c), once)
+        assert clean_caption(c, fix=lambda t: t) == once            # the fixture's ftfy stand-in is the identity: these captions do not need repair
+        assert text_preprocessing(c) == twice, (c, text_preprocessing(c), twice)
+        assert text_preprocessing(c, use_text_preprocessing=False) == plain
