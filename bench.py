@@ -294,9 +294,24 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
-    if args.no_profile:
+    if args.no_profile:   # diagnostic forms (--graph / --no_profile): the same JSON line without the per-launch measurements
         if rank == 0:
-            log(f"unprofiled: {dt / args.steps * 1e3:.2f} ms/step")
+            fm = flops_model_tiled(h, w, tile_size, tile_stride, copies=args.control) if args.tiled else flops_model(h, w, copies=args.control)
+            ms = dt / args.steps * 1e3
+            log(f"unprofiled: {ms:.2f} ms/step")
+            src = f"{h}x{w} synthetic network input" if args.net_hw else f"{args.lq}x{args.lq} LQ, sr_scale {args.sr_scale:g} -> {h}x{w} network input"
+            print(json.dumps({
+                "metric": "512->2048 one-step SR images/sec", "value": round(world * n * args.steps / dt, 4), "unit": "images/sec", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "fp8" if args.fp8 else "bf16", "data": "synthetic",
+                "config": {"workload": f"{src}, {('tiled 512/448 + wavelet, %d tiles' % fm['tiles']) if args.tiled else 'untiled'}, batch {n} per GPU, "
+                                       "full SwinIR->VAE-enc->DiT(t=400)->VAE-dec path"
+                                       + (", whole step replayed as ONE hipGraph (IR_FLAG_GRAPH)" if args.graph else ", plain launches, no per-launch events"),
+                           "global_batch": n * world, "parallelism": f"dp{world}", "weights": "seeded random, full-size architectures"},
+                "algorithmic_tflop_per_image": round(fm["total"] / 1e12, 2), "path_tflops": round(fm["total"] * n * world / (ms / 1e3) / 1e12, 1),
+                "roofline": None, "cpu_baseline": None}), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
         return
     prof = ctx.profile_end()
     kprof = ctx.profile_end_kernels()
