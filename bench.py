@@ -434,7 +434,7 @@ def main():
                                    "full SwinIR->VAE-enc->DiT(t=400)->VAE-dec path"
                                    + (f" + ControlNet-Half ({args.control} copied blocks, c = LQ latent)" if args.control else "")
                                    + (fp8_words if args.fp8 else "")
-                                   + (", one RCCL gather of the uint8 results on rank 0 per step" if world > 1 else ""),
+                                   + (f", one {'RCCL' if backend == 'nccl' else backend} gather of the uint8 results on rank 0 per step" if world > 1 else ""),
                        "global_batch": n * world, "parallelism": f"dp{world}", "weights": "seeded random, full-size architectures"},
             "algorithmic_tflop_per_image": round(fm["total"] / 1e12, 2),
             "path_tflops": round(fm["total"] * n * world / (ms_per_step / 1e3) / 1e12, 1),
