@@ -21,7 +21,7 @@ SYMBOLS = [
     "ir_profile_kernel_name",
     "ir_op_conv", "ir_op_conv_groupnorm", "ir_op_linear", "ir_op_groupnorm", "ir_op_layernorm", "ir_op_attention", "ir_op_swin_attention",
     "ir_op_softmax_rows", "ir_op_nchw_to_nhwc", "ir_op_nhwc_to_nchw",
-    "ir_tiled_count", "ir_tiled_encode", "ir_tiled_dit", "ir_tiled_blend_latent", "ir_tiled_decode", "ir_tiled_blend_pixels", "ir_set_plain_kernels", "ir_set_fp8", "ir_op_conv_fp8", "ir_fp8_features", "ir_op_attention_fp8",
+    "ir_tiled_count", "ir_tiled_encode", "ir_tiled_dit", "ir_tiled_blend_latent", "ir_tiled_decode", "ir_tiled_blend_pixels", "ir_set_plain_kernels", "ir_set_fp8", "ir_op_conv_fp8", "ir_op_conv_fp8_route", "ir_fp8_features", "ir_op_attention_fp8",
 ]
 
 STAGE_SWINIR, STAGE_VAE_ENCODE, STAGE_DIT, STAGE_VAE_DECODE, STAGE_PIPELINE, STAGE_COLORFIX, STAGE_T5 = range(7)
@@ -99,6 +99,7 @@ def load_library():
     lib.ir_set_plain_kernels.argtypes = [vp, i]
     lib.ir_set_fp8.argtypes = [vp, i]
     lib.ir_fp8_features.argtypes = []
+    lib.ir_op_conv_fp8_route.argtypes = [vp, i, i, i, i, i, i]
     lib.ir_op_attention_fp8.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, f, vp, sz]
     lib.ir_op_conv_fp8.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, vp]
     for name in SYMBOLS:

@@ -136,17 +136,18 @@ struct T5Model {
 enum { PC_CONV3X3 = 0, PC_LINEAR, PC_FLASH_ATTN, PC_SWIN_ATTN, PC_GROUPNORM, PC_LAYERNORM, PC_SOFTMAX, PC_TRANSPOSE, PC_OTHER, PC_COUNT };
 // kernel-level rows of the same measurement (ir_profile_end_kernels): one id per kernel (family) that matters on the 2048 x 2048 path,
 // each with the algorithmic FLOPs (un-padded dims) / bytes of its launches. Keep KERNEL_NAMES and KERNEL_CLASS in step.
-enum { PK_CONV_S1 = 0, PK_CONV_HALO_PP, PK_CONV_HALO, PK_CONV_FP8, PK_CONV_IGEMM, PK_GEMM_PP, PK_LINEAR_IGEMM, PK_SWIN_MLP, PK_ATTN_SELF, PK_ATTN_SELF_FP8,
+enum { PK_CONV_S1 = 0, PK_CONV_HALO_PP, PK_CONV_HALO, PK_CONV_S1_FP8, PK_CONV_FP8, PK_CONV_IGEMM, PK_GEMM_PP, PK_LINEAR_IGEMM, PK_SWIN_MLP, PK_ATTN_SELF, PK_ATTN_SELF_FP8,
        PK_ATTN_D512, PK_ATTN_CROSS, PK_ATTN_OTHER, PK_SWIN_ATTN_PROJ, PK_SWIN_ATTN, PK_GN_APPLY, PK_GN_FULL, PK_LAYERNORM, PK_SOFTMAX, PK_TRANSPOSE, PK_OTHER,
        PK_COUNT };
 static const char* const KERNEL_NAMES[PK_COUNT] = {
-    "conv3x3/conv_halo_s1_kernel", "conv3x3/conv_halo_pp_kernel", "conv3x3/conv_halo_kernel", "conv3x3/conv_fp8", "conv3x3/igemm_kernel<taps=9>",
+    "conv3x3/conv_halo_s1_kernel", "conv3x3/conv_halo_pp_kernel", "conv3x3/conv_halo_kernel", "conv3x3/conv_halo_s1_fp8_kernel",
+    "conv3x3/conv_halo_kernel<.., fp8>", "conv3x3/igemm_kernel<taps=9>",
     "linear/gemm_pp_kernel", "linear/igemm_kernel<taps=1>", "linear/swin_mlp_kernel", "flash_attn/flash_attn_pp2_kernel (DiT self-attention)",
     "flash_attn/flash_attn_fp8_kernel (DiT self-attention, fp8 operands)", "flash_attn/flash_attn_d512_v2_kernel (VAE mid-block)",
     "flash_attn/flash_attn_kernel<72,true> (DiT cross-attention)", "flash_attn/other", "swin_attn/swin_attn_proj_kernel", "swin_attn/swin_window_attn_kernel",
     "groupnorm/gn_finalize_groups+gn_apply (statistics from the conv epilogue)", "groupnorm/gn_partial+gn_finalize+gn_apply", "layernorm/layernorm_*_kernel",
     "softmax_rows/softmax_rows_kernel", "transpose/transpose_v*", "other/layout+glue"};
-static const int KERNEL_CLASS[PK_COUNT] = {PC_CONV3X3, PC_CONV3X3, PC_CONV3X3, PC_CONV3X3, PC_CONV3X3, PC_LINEAR, PC_LINEAR, PC_LINEAR, PC_FLASH_ATTN, PC_FLASH_ATTN,
+static const int KERNEL_CLASS[PK_COUNT] = {PC_CONV3X3, PC_CONV3X3, PC_CONV3X3, PC_CONV3X3, PC_CONV3X3, PC_CONV3X3, PC_LINEAR, PC_LINEAR, PC_LINEAR, PC_FLASH_ATTN, PC_FLASH_ATTN,
                                            PC_FLASH_ATTN, PC_FLASH_ATTN, PC_FLASH_ATTN, PC_SWIN_ATTN, PC_SWIN_ATTN, PC_GROUPNORM, PC_GROUPNORM, PC_LAYERNORM,
                                            PC_SOFTMAX, PC_TRANSPOSE, PC_OTHER};
 static const int CLASS_DEFAULT_KERNEL[PC_COUNT] = {PK_CONV_IGEMM, PK_LINEAR_IGEMM, PK_ATTN_OTHER, PK_SWIN_ATTN, PK_GN_FULL, PK_LAYERNORM, PK_SOFTMAX, PK_TRANSPOSE, PK_OTHER};
@@ -378,7 +379,7 @@ void conv_fp8(Run& r, const Conv& cw, const bf16_t* in8, int N, int H, int W, vo
         }
     }
     r.gn_want = false;
-    LAUNCHK(r, PK_CONV_FP8, 2.0 * p.M * (double)cw.cout * 9 * cw.cin, (double)p.M * cw.cin + 2.0 * p.M * cw.cout + (double)cw.cout_pad * 9 * cw.cin,
+    LAUNCHK(r, ir_igemm_kernel_id(p) == 0 ? PK_CONV_S1_FP8 : PK_CONV_FP8, 2.0 * p.M * (double)cw.cout * 9 * cw.cin, (double)p.M * cw.cin + 2.0 * p.M * cw.cout + (double)cw.cout_pad * 9 * cw.cin,
             ir_launch_igemm(p, r.s), "igemm_fp8");
 }
 void layernorm(Run& r, const float* x, bf16_t* y, float* yf, const float* a, const float* b, long rows, int C, int ldx, int ldy,
@@ -1819,6 +1820,19 @@ int ir_op_conv_fp8(ir_ctx* c, void* stream, const uint8_t* in8, const uint8_t* w
     cw.cin = cin; cw.cout = cout; cw.cout_pad = cout; cw.taps = 9; cw.w8 = wgt8; cw.g8 = dequant; cw.b8 = bias_div;
     conv_fp8(r, cw, reinterpret_cast<const bf16_t*>(in8), n, h, w, out, cout, res, cout);
     return finish(r, c, 0);
+}
+int ir_op_conv_fp8_route(ir_ctx* c, int n, int h, int w, int cin, int cout, int has_res) {
+    // which kernel ir_op_conv_fp8 launches for this shape: 0 conv_halo_s1_fp8_kernel, 3 conv_halo_kernel<.., FP8> (ir_igemm_kernel_id)
+    use_ctx(c);
+    static float dummy_f[4];
+    IGemmParams p;
+    memset(&p, 0, sizeof p);
+    p.fp8 = 1; p.NB = n; p.H = h; p.W = w; p.Cin = cin / 2; p.in_cs = cin / 2; p.taps = 9; p.stride = 1; p.pad = 1;
+    p.Ho = h; p.Wo = w; p.M = n * h * w; p.wgt_rs = 9L * (cin / 2); p.Cout = cout; p.Cout_pad = cout; p.gate = dummy_f; p.rows_per_batch = 1 << 30;
+    p.in = p.wgt = reinterpret_cast<const bf16_t*>((uintptr_t)0x1000); p.out = reinterpret_cast<void*>((uintptr_t)0x1000);
+    p.res = has_res ? reinterpret_cast<const void*>((uintptr_t)0x1000) : nullptr; p.res_cs = cout; p.out_cs = cout;
+    p.gate = reinterpret_cast<const float*>((uintptr_t)0x1000); p.bias = p.gate;
+    return ir_igemm_kernel_id(p);
 }
 int ir_op_linear(ir_ctx* c, void* stream, const uint16_t* in, const uint16_t* wgt, const float* bias, void* out, int m, int k, int n,
                  int n_pad, int act, const float* gate, const void* res, int res_f32, int out_f32, float out_scale) {

@@ -31,6 +31,7 @@
 #include "agpr256.h"
 #include "common.h"
 #include "kernels.h"
+#include "conv_s1_epi.h"
 
 namespace cs1 {
 constexpr int TH = 16, TW = 32, HWD = TW + 2, HP = (TH + 2) * HWD;   // 612 halo pixels
@@ -43,10 +44,7 @@ constexpr int NSB = 4;
 constexpr int NHB = 3;                         // halo buffers: chunk c lives in buffer c % 3, chunk c + 2 is fetched during chunk c
 constexpr int W_OFF = NHB * HALO_BYTES;        // 119 808
 constexpr int LDS_MAIN = W_OFF + NSB * WT_BYTES;   // 152 576
-constexpr int SROW = 132;                      // slab row stride in floats (128 + 4)
-constexpr int SLAB = 16 * SROW * 4;            // 8 448 B per wave: 16 pixels x 128 channels fp32
-constexpr int RED_OFF = 4 * SLAB;              // 33 792; the GroupNorm reduction area (1 KB) follows the slabs inside the same halo buffer
-static_assert(RED_OFF + 4 * 16 * 16 <= HALO_BYTES, "epilogue slabs + reduction area must fit one halo buffer");
+static_assert(cs1e::BYTES <= HALO_BYTES, "epilogue slabs + reduction area must fit one halo buffer");
 constexpr int LDS_BYTES = LDS_MAIN;
 // halo pieces issued in the step of tap t (10 per chunk, all before tap 6)
 constexpr int nh(int t) { return t < 4 ? 2 : (t < 6 ? 1 : 0); }
@@ -73,12 +71,6 @@ IR_DEVINL void cs1_glds16(const void* g, cs1_lds_t l) { __builtin_amdgcn_global_
 template <int LO>
 IR_DEVINL void cs1_mfma(bf16x8 w, bf16x8 px) {
     asm volatile("v_mfma_f32_16x16x32_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(w), "v"(px), "n"(LO), "n"(LO + 3));
-}
-template <int I>
-IR_DEVINL float cs1_acc_read() {
-    float x;
-    asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(x) : "n"(I));
-    return x;
 }
 
 template <int UP>
@@ -291,132 +283,13 @@ __global__ __launch_bounds__(256, 1) void conv_halo_s1_kernel(IGemmParams p, int
         asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // the last MFMA results -> v_accvgpr_read
         IR_S1_T(st3);
         unsigned char* ebuf = smem + (hb3 == 0 ? 2 : hb3 - 1) * HALO_BYTES;   // every wave passed the last barrier after its last read of it
-        float* slab = reinterpret_cast<float*>(ebuf + wid * SLAB);
-        const int co8 = (lane & 15) * 8, xq = lane >> 4;
-        const int n0 = cur.n0, img = cur.img, oy0 = cur.oy0, ox0 = cur.ox0;
-        const float osc = p.out_scale;
-        f32x4 bias4[8];   // bias * out_scale: the slab write is one fused multiply-add per value
-#pragma unroll
-        for (int ct = 0; ct < 8; ++ct)
-            bias4[ct] = (p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n0 + 16 * ct + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f}) * osc;
-        f32x4 sA4 = {0.f, 0.f, 0.f, 0.f}, qA4 = sA4, sB4 = sA4, qB4 = sA4;   // GroupNorm partials, channels co8 .. +3 and co8+4 .. +7
-        // Row it of a pass is pixel (oyw + A, oxl + 4 it): per-lane base pointers once per tile, uniform offsets per pass and row
-        const int oyw = oy0 + 4 * wid, oxl = ox0 + xq;
-        unsigned xm = 0;   // bit it: column oxl + 4 it lies inside the image
-#pragma unroll
-        for (int it = 0; it < 8; ++it) xm |= (oxl + 4 * it < p.Wo ? 1u : 0u) << it;
-        const long pix0 = ((long)img * p.Ho + oyw) * p.Wo + oxl;
-        bf16_t* obase = reinterpret_cast<bf16_t*>(p.out) + pix0 * p.out_cs + n0 + co8;
-        const bf16_t* rbase = reinterpret_cast<const bf16_t*>(p.res) + pix0 * p.res_cs + n0 + co8;
-        const bf16_t* rsafe = reinterpret_cast<const bf16_t*>(p.res) + (((long)img * p.Ho + oy0) * p.Wo + ox0) * p.res_cs + n0 + co8;   // always inside
-        const long o_row = (long)p.Wo * p.out_cs, r_row = (long)p.Wo * p.res_cs;
-        const bool do_gn = p.gn_part != nullptr;
-        uint4 rrb[2][8];   // residual rows of the pass being finished / of the next pass
-        auto res_fetch = [&](int a) {   // rows outside the image read a safe pixel
-            const bool yok = oyw + a < p.Ho;
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const bool v = yok && ((xm >> it) & 1);
-                rrb[a & 1][it] = *reinterpret_cast<const uint4*>(v ? rbase + a * r_row + (long)(4 * it) * p.res_cs : rsafe);
-            }
-        };
-        auto pass = [&](auto ac, auto resc) {
-            constexpr int A = decltype(ac)::value;
-            constexpr bool RES = decltype(resc)::value;
-            const bool yok = oyw + A < p.Ho;
-            uint4 (&rr)[8] = rrb[A & 1];
-            if constexpr (RES && A < 3) res_fetch(A + 1);   // the next pass's residual rows fly during this pass
-            [&]<int... MXS>(std::integer_sequence<int, MXS...>) {
-                ([&] {
-                    constexpr int MX = MXS;
-                    [&]<int... CTS>(std::integer_sequence<int, CTS...>) {
-                        ([&] {
-                            constexpr int CT = CTS, LO = 4 * ((A * 2 + MX) * 8 + CT);
-                            f32x4 v = f32x4{cs1_acc_read<LO>(), cs1_acc_read<LO + 1>(), cs1_acc_read<LO + 2>(), cs1_acc_read<LO + 3>()};
-                            v = v * osc + bias4[CT];
-                            *reinterpret_cast<f32x4*>(&slab[c16 * SROW + 16 * CT + 4 * kq]) = v;
-                        }(), ...);
-                    }(std::make_integer_sequence<int, 8>{});
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    f32x4 lo[4], hi[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        lo[j] = *reinterpret_cast<const f32x4*>(&slab[(4 * j + xq) * SROW + co8]);
-                        hi[j] = *reinterpret_cast<const f32x4*>(&slab[(4 * j + xq) * SROW + co8 + 4]);
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int it = 4 * MX + j;   // pixel column oxl + 4 it
-                        f32x4 a = lo[j], b = hi[j];
-                        if constexpr (RES) {
-                            a += f32x4{bflo(rr[it].x), bfhi(rr[it].x), bflo(rr[it].y), bfhi(rr[it].y)};
-                            b += f32x4{bflo(rr[it].z), bfhi(rr[it].z), bflo(rr[it].w), bfhi(rr[it].w)};
-                        }
-                        const uint4 pk = make_uint4(pack2bf_valu(a[0], a[1]), pack2bf_valu(a[2], a[3]), pack2bf_valu(b[0], b[1]), pack2bf_valu(b[2], b[3]));
-                        if (yok && ((xm >> it) & 1)) {
-                            *reinterpret_cast<uint4*>(obase + A * o_row + (long)(4 * it) * p.out_cs) = pk;
-                            if (do_gn) {   // statistics of the values as stored (bf16-rounded)
-                                const f32x4 ar = {bflo(pk.x), bfhi(pk.x), bflo(pk.y), bfhi(pk.y)}, br = {bflo(pk.z), bfhi(pk.z), bflo(pk.w), bfhi(pk.w)};
-                                sA4 += ar; qA4 += ar * ar;
-                                sB4 += br; qB4 += br * br;
-                            }
-                        }
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                }(), ...);
-            }(std::make_integer_sequence<int, 2>{});
-        };
-        if (IR_KO_S1 != 1 && IR_KO_S1 != 3) {
-            if (p.res) {
-                res_fetch(0);
-                pass(std::integral_constant<int, 0>{}, std::true_type{});
-                pass(std::integral_constant<int, 1>{}, std::true_type{});
-                pass(std::integral_constant<int, 2>{}, std::true_type{});
-                pass(std::integral_constant<int, 3>{}, std::true_type{});
-            } else {
-                pass(std::integral_constant<int, 0>{}, std::false_type{});
-                pass(std::integral_constant<int, 1>{}, std::false_type{});
-                pass(std::integral_constant<int, 2>{}, std::false_type{});
-                pass(std::integral_constant<int, 3>{}, std::false_type{});
-            }
-        }
-        IR_S1_T(st4);
-        if (p.gn_part && IR_KO_S1 == 0) {
-            // Fixed-order workgroup reduction (no atomics, bit-identical run to run). Unit u = 4 channels; lane (L = lane & 15) holds units 2L and
-            // 2L+1 over the pixel columns xq, xq + 4, ...: first the four column classes of a wave (lanes L, L+16, L+32, L+48), then the four
-            // waves through LDS, then the units of a group.
-            const float sA = (sA4[0] + sA4[1]) + (sA4[2] + sA4[3]), qA = (qA4[0] + qA4[1]) + (qA4[2] + qA4[3]);
-            const float sB = (sB4[0] + sB4[1]) + (sB4[2] + sB4[3]), qB = (qB4[0] + qB4[1]) + (qB4[2] + qB4[3]);
-            f32x4 v = {sA, qA, sB, qB};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v[e] += __shfl_xor(v[e], 16);
-                v[e] += __shfl_xor(v[e], 32);
-            }
-            float* red = reinterpret_cast<float*>(ebuf + RED_OFF);   // [wave][L][4]
-            if (lane < 16) *reinterpret_cast<f32x4*>(&red[(wid * 16 + lane) * 4]) = v;
-            __syncthreads();
-            if (tid < 32) {   // thread u: unit u of the 32 units of this channel tile
-                const int L = tid >> 1, hf = (tid & 1) * 2;
-                float a = (red[(0 * 16 + L) * 4 + hf] + red[(1 * 16 + L) * 4 + hf]) + (red[(2 * 16 + L) * 4 + hf] + red[(3 * 16 + L) * 4 + hf]);
-                float b = (red[(0 * 16 + L) * 4 + hf + 1] + red[(1 * 16 + L) * 4 + hf + 1]) + (red[(2 * 16 + L) * 4 + hf + 1] + red[(3 * 16 + L) * 4 + hf + 1]);
-                const int upg = p.gn_cpg >> 2;   // units per group: 1, 2, 4 or 8 (launcher)
-                for (int m = 1; m < upg; m <<= 1) {
-                    a += __shfl_xor(a, m);
-                    b += __shfl_xor(b, m);
-                }
-                if ((tid & (upg - 1)) == 0) {
-                    const int G = p.Cout / p.gn_cpg, g = n0 / p.gn_cpg + tid / upg;
-                    float* dst = p.gn_part + ((long)img * p.gn_chunks + cur.trem) * 2 * G;
-                    dst[g] = a;
-                    dst[G + g] = b;
-                }
-            }
-        }
+#ifdef IR_S1_STAMPS
+        unsigned long long st4v = 0;
+        cs1_epilogue<false>(p, ebuf, tid, lane, wid, c16, kq, cur.n0, cur.img, cur.oy0, cur.ox0, cur.trem, IR_KO_S1 != 1 && IR_KO_S1 != 3, IR_KO_S1 == 0, &st4v);
+        const unsigned long long st4 = st4v;
+#else
+        cs1_epilogue<false>(p, ebuf, tid, lane, wid, c16, kq, cur.n0, cur.img, cur.oy0, cur.ox0, cur.trem, IR_KO_S1 != 1 && IR_KO_S1 != 3, IR_KO_S1 == 0, nullptr);
+#endif
         IR_S1_T(st5);
         IR_S1_ACC(0, st0, st1); IR_S1_ACC(1, st1, st2); IR_S1_ACC(2, st2, st3); IR_S1_ACC(3, st3, st4); IR_S1_ACC(4, st4, st5);
 #ifdef IR_S1_STAMPS

@@ -1,0 +1,168 @@
+// Epilogue of the one-wave-per-SIMD 3x3 convolution kernels (conv_s1.hip bf16, conv_s1_fp8.hip e4m3): the 64 accumulator tiles of a wave
+// (a[0:255]; tile (patch row A, half MX, channel tile CT) at 4 * ((2A + MX) * 8 + CT), a lane holding 4 consecutive channels of one pixel)
+// -> bias / per-channel gate -> wave-private fp32 slab in LDS -> rows read back as 8-channel vectors -> + bf16 residual -> bf16 -> 16-byte
+// stores, plus the fused GroupNorm statistics of the values as stored (fixed-order reduction: bit-identical run to run). Same contract as
+// igemm_epilogue (igemm.hip). GATE: out = (acc + bias) * gate[channel] (the fp8 kernel's dequantisation; bias arrives divided by gate),
+// otherwise out = acc * out_scale + bias * out_scale.
+#pragma once
+#include "common.h"
+#include "kernels.h"
+
+namespace cs1e {
+constexpr int SROW = 132;                      // slab row stride in floats (128 + 4)
+constexpr int SLAB = 16 * SROW * 4;            // 8 448 B per wave: 16 pixels x 128 channels fp32
+constexpr int RED_OFF = 4 * SLAB;              // 33 792; the GroupNorm reduction area (1 KB) follows the slabs
+constexpr int BYTES = RED_OFF + 4 * 16 * 16;   // what the epilogue needs of the LDS buffer it is given
+}  // namespace cs1e
+
+template <int I>
+IR_DEVINL float cs1_acc_read() {
+    float x;
+    asm volatile("v_accvgpr_read_b32 %0, a[%c1]" : "=v"(x) : "n"(I));
+    return x;
+}
+
+// ebuf: an LDS buffer of cs1e::BYTES bytes that no wave reads any more; t_*: the tile (first channel, image, patch origin, patch index in
+// the image). do_passes / do_stats / mid_stamp: diagnostics of the callers' knock-out and stamp builds (true, true, nullptr in the product).
+template <bool GATE>
+IR_DEVINL void cs1_epilogue(const IGemmParams& p, unsigned char* ebuf, int tid, int lane, int wid, int c16, int kq, int t_n0, int t_img, int t_oy0,
+                            int t_ox0, int t_trem, bool do_passes, bool do_stats, unsigned long long* mid_stamp) {
+    using namespace cs1e;
+    float* slab = reinterpret_cast<float*>(ebuf + wid * SLAB);
+    const int co8 = (lane & 15) * 8, xq = lane >> 4;
+    const int n0 = t_n0, img = t_img, oy0 = t_oy0, ox0 = t_ox0;
+    const float osc = p.out_scale;
+    // plain: bias * out_scale per accumulator tile, the slab write is one fused multiply-add per value. GATE: the accumulators go to the
+    // slab as they are and gate / bias are applied on the read-back side, where a lane keeps the same 8 channels for the whole tile
+    // (16 registers instead of 64)
+    f32x4 bias4[GATE ? 1 : 8], g_lo, g_hi, b_lo, b_hi;
+    if constexpr (GATE) {
+        g_lo = *reinterpret_cast<const f32x4*>(p.gate + n0 + co8);
+        g_hi = *reinterpret_cast<const f32x4*>(p.gate + n0 + co8 + 4);
+        b_lo = (p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n0 + co8) : f32x4{0.f, 0.f, 0.f, 0.f}) * g_lo;
+        b_hi = (p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n0 + co8 + 4) : f32x4{0.f, 0.f, 0.f, 0.f}) * g_hi;
+    } else {
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct)
+            bias4[ct] = (p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n0 + 16 * ct + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f}) * osc;
+    }
+    f32x4 sA4 = {0.f, 0.f, 0.f, 0.f}, qA4 = sA4, sB4 = sA4, qB4 = sA4;   // GroupNorm partials, channels co8 .. +3 and co8+4 .. +7
+    // Row it of a pass is pixel (oyw + A, oxl + 4 it): per-lane base pointers once per tile, uniform offsets per pass and row
+    const int oyw = oy0 + 4 * wid, oxl = ox0 + xq;
+    unsigned xm = 0;   // bit it: column oxl + 4 it lies inside the image
+#pragma unroll
+    for (int it = 0; it < 8; ++it) xm |= (oxl + 4 * it < p.Wo ? 1u : 0u) << it;
+    const long pix0 = ((long)img * p.Ho + oyw) * p.Wo + oxl;
+    bf16_t* obase = reinterpret_cast<bf16_t*>(p.out) + pix0 * p.out_cs + n0 + co8;
+    const bf16_t* rbase = reinterpret_cast<const bf16_t*>(p.res) + pix0 * p.res_cs + n0 + co8;
+    const bf16_t* rsafe = reinterpret_cast<const bf16_t*>(p.res) + (((long)img * p.Ho + oy0) * p.Wo + ox0) * p.res_cs + n0 + co8;   // always inside
+    const long o_row = (long)p.Wo * p.out_cs, r_row = (long)p.Wo * p.res_cs;
+    const bool do_gn = p.gn_part != nullptr;
+    uint4 rrb[2][8];   // residual rows of the pass being finished / of the next pass
+    auto res_fetch = [&](int a) {   // rows outside the image read a safe pixel
+        const bool yok = oyw + a < p.Ho;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const bool v = yok && ((xm >> it) & 1);
+            rrb[a & 1][it] = *reinterpret_cast<const uint4*>(v ? rbase + a * r_row + (long)(4 * it) * p.res_cs : rsafe);
+        }
+    };
+    auto pass = [&](auto ac, auto resc) {
+        constexpr int A = decltype(ac)::value;
+        constexpr bool RES = decltype(resc)::value;
+        const bool yok = oyw + A < p.Ho;
+        uint4 (&rr)[8] = rrb[A & 1];
+        if constexpr (RES && A < 3) res_fetch(A + 1);   // the next pass's residual rows fly during this pass
+        [&]<int... MXS>(std::integer_sequence<int, MXS...>) {
+            ([&] {
+                constexpr int MX = MXS;
+                [&]<int... CTS>(std::integer_sequence<int, CTS...>) {
+                    ([&] {
+                        constexpr int CT = CTS, LO = 4 * ((A * 2 + MX) * 8 + CT);
+                        f32x4 v = f32x4{cs1_acc_read<LO>(), cs1_acc_read<LO + 1>(), cs1_acc_read<LO + 2>(), cs1_acc_read<LO + 3>()};
+                        if constexpr (!GATE) v = v * osc + bias4[CT];
+                        *reinterpret_cast<f32x4*>(&slab[c16 * SROW + 16 * CT + 4 * kq]) = v;
+                    }(), ...);
+                }(std::make_integer_sequence<int, 8>{});
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                f32x4 lo[4], hi[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    lo[j] = *reinterpret_cast<const f32x4*>(&slab[(4 * j + xq) * SROW + co8]);
+                    hi[j] = *reinterpret_cast<const f32x4*>(&slab[(4 * j + xq) * SROW + co8 + 4]);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int it = 4 * MX + j;   // pixel column oxl + 4 it
+                    f32x4 a = lo[j], b = hi[j];
+                    if constexpr (GATE) { a = a * g_lo + b_lo; b = b * g_hi + b_hi; }
+                    if constexpr (RES) {
+                        a += f32x4{bflo(rr[it].x), bfhi(rr[it].x), bflo(rr[it].y), bfhi(rr[it].y)};
+                        b += f32x4{bflo(rr[it].z), bfhi(rr[it].z), bflo(rr[it].w), bfhi(rr[it].w)};
+                    }
+                    const uint4 pk = make_uint4(pack2bf_valu(a[0], a[1]), pack2bf_valu(a[2], a[3]), pack2bf_valu(b[0], b[1]), pack2bf_valu(b[2], b[3]));
+                    if (yok && ((xm >> it) & 1)) {
+                        *reinterpret_cast<uint4*>(obase + A * o_row + (long)(4 * it) * p.out_cs) = pk;
+                        if (do_gn) {   // statistics of the values as stored (bf16-rounded)
+                            const f32x4 ar = {bflo(pk.x), bfhi(pk.x), bflo(pk.y), bfhi(pk.y)}, br = {bflo(pk.z), bfhi(pk.z), bflo(pk.w), bfhi(pk.w)};
+                            sA4 += ar; qA4 += ar * ar;
+                            sB4 += br; qB4 += br * br;
+                        }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }(), ...);
+        }(std::make_integer_sequence<int, 2>{});
+    };
+    if (do_passes) {
+        if (p.res) {
+            res_fetch(0);
+            pass(std::integral_constant<int, 0>{}, std::true_type{});
+            pass(std::integral_constant<int, 1>{}, std::true_type{});
+            pass(std::integral_constant<int, 2>{}, std::true_type{});
+            pass(std::integral_constant<int, 3>{}, std::true_type{});
+        } else {
+            pass(std::integral_constant<int, 0>{}, std::false_type{});
+            pass(std::integral_constant<int, 1>{}, std::false_type{});
+            pass(std::integral_constant<int, 2>{}, std::false_type{});
+            pass(std::integral_constant<int, 3>{}, std::false_type{});
+        }
+    }
+    if (mid_stamp) *mid_stamp = __builtin_amdgcn_s_memrealtime();
+    if (p.gn_part && do_stats) {
+        // Fixed-order workgroup reduction (no atomics, bit-identical run to run). Unit u = 4 channels; lane (L = lane & 15) holds units 2L and
+        // 2L+1 over the pixel columns xq, xq + 4, ...: first the four column classes of a wave (lanes L, L+16, L+32, L+48), then the four
+        // waves through LDS, then the units of a group.
+        const float sA = (sA4[0] + sA4[1]) + (sA4[2] + sA4[3]), qA = (qA4[0] + qA4[1]) + (qA4[2] + qA4[3]);
+        const float sB = (sB4[0] + sB4[1]) + (sB4[2] + sB4[3]), qB = (qB4[0] + qB4[1]) + (qB4[2] + qB4[3]);
+        f32x4 v = {sA, qA, sB, qB};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] += __shfl_xor(v[e], 16);
+            v[e] += __shfl_xor(v[e], 32);
+        }
+        float* red = reinterpret_cast<float*>(ebuf + RED_OFF);   // [wave][L][4]
+        if (lane < 16) *reinterpret_cast<f32x4*>(&red[(wid * 16 + lane) * 4]) = v;
+        __syncthreads();
+        if (tid < 32) {   // thread u: unit u of the 32 units of this channel tile
+            const int L = tid >> 1, hf = (tid & 1) * 2;
+            float a = (red[(0 * 16 + L) * 4 + hf] + red[(1 * 16 + L) * 4 + hf]) + (red[(2 * 16 + L) * 4 + hf] + red[(3 * 16 + L) * 4 + hf]);
+            float b = (red[(0 * 16 + L) * 4 + hf + 1] + red[(1 * 16 + L) * 4 + hf + 1]) + (red[(2 * 16 + L) * 4 + hf + 1] + red[(3 * 16 + L) * 4 + hf + 1]);
+            const int upg = p.gn_cpg >> 2;   // units per group: 1, 2, 4 or 8 (launcher)
+            for (int m = 1; m < upg; m <<= 1) {
+                a += __shfl_xor(a, m);
+                b += __shfl_xor(b, m);
+            }
+            if ((tid & (upg - 1)) == 0) {
+                const int G = p.Cout / p.gn_cpg, g = n0 / p.gn_cpg + tid / upg;
+                float* dst = p.gn_part + ((long)img * p.gn_chunks + t_trem) * 2 * G;
+                dst[g] = a;
+                dst[G + g] = b;
+            }
+        }
+    }
+}

@@ -1478,7 +1478,7 @@ static bool takes_halo_pp(const IGemmParams& p) {  // the 8-wave ping-pong varia
 int ir_igemm_gn_chunks(const IGemmParams& p) {
     if (p.gn_cpg < 4 || (p.gn_cpg & 3) || p.Cout % p.gn_cpg || p.Cout_pad % 64 || (p.Cout & 3) || p.NB <= 0) return 0;
     if ((p.Cout_pad % 128 == 0 ? 128 : 64) % p.gn_cpg) return 0;
-    if (ir_conv_s1_takes(p)) return (p.gn_cpg <= 32 && !(p.gn_cpg & (p.gn_cpg - 1))) ? ir_conv_s1_tiles(p) : 0;   // its reduction wants 4, 8, 16 or 32 channels per group
+    if (ir_conv_s1_takes(p) || ir_conv_s1_fp8_takes(p)) return (p.gn_cpg <= 32 && !(p.gn_cpg & (p.gn_cpg - 1))) ? ir_conv_s1_tiles(p) : 0;   // its reduction wants 4, 8, 16 or 32 channels per group
     if (takes_halo_pp(p)) return ((p.Ho + 15) / 16) * ((p.Wo + 15) / 16);
     if (takes_halo(p)) return ((p.Ho + 7) / 8) * ((p.Wo + 15) / 16);
     if (p.M % p.NB) return 0;
@@ -1494,7 +1494,7 @@ static bool igemm_vec(const IGemmParams& p) {
 int ir_igemm_kernel_id(const IGemmParams& pin) {
     IGemmParams p = pin;
     p.vec = igemm_vec(p);
-    if (ir_conv_s1_takes(p)) return 0;
+    if (ir_conv_s1_takes(p) || ir_conv_s1_fp8_takes(p)) return 0;
     if (takes_halo_pp(p)) return 1;
     if (takes_gemm_pp(p)) return 2;
     if (takes_halo(p)) return 3;
@@ -1524,6 +1524,7 @@ int ir_launch_igemm(const IGemmParams& pin, hipStream_t s) {
     if (p.gn_part && (!p.vec || p.gn_chunks <= 0 || p.gn_chunks != ir_igemm_gn_chunks(p))) return -13;
     if (p.fp8 && (!takes_halo(p) || !p.gate || p.act != IR_ACT_NONE)) return -14;  // fp8 operands: stride-1 3x3 halo kernel only
     if (ir_conv_s1_takes(p)) return ir_launch_conv_s1(p, s);
+    if (ir_conv_s1_fp8_takes(p)) return ir_launch_conv_s1_fp8(p, s);
     if (takes_halo_pp(p)) return launch_halo_pp(p, s);
     if (takes_gemm_pp(p)) return launch_gemm_pp(p, s);
     if (takes_halo(p)) {

@@ -57,6 +57,9 @@ int ir_igemm_gn_chunks(const IGemmParams& p);
 bool ir_conv_s1_takes(const IGemmParams& p);
 int ir_conv_s1_tiles(const IGemmParams& p);   // pixel tiles per image (fused GroupNorm statistics: one partial per tile)
 int ir_launch_conv_s1(const IGemmParams& p, hipStream_t s);
+// conv_s1_fp8.hip: the same structure on e4m3 operands (p.fp8 launches with Cin a multiple of 128 channels)
+bool ir_conv_s1_fp8_takes(const IGemmParams& p);
+int ir_launch_conv_s1_fp8(const IGemmParams& p, hipStream_t s);
 
 // ---- norms (norm.hip)
 static inline int ir_gn_chunks(long HW) {

@@ -159,11 +159,17 @@ def test_conv3x3(ctx, case):
     close(out.cpu().permute(0, 3, 1, 2), ref, 1e-4, 1e-3, f"conv {case}")
 
 
-@pytest.mark.parametrize("n,h,w,cin,cout,res", [(1, 16, 16, 128, 128, False), (2, 24, 40, 256, 128, True), (1, 20, 28, 512, 64, False)])
-def test_conv3x3_fp8(ctx, n, h, w, cin, cout, res):
-    """3x3 conv on OCP e4m3 operands through the MX-scaled MFMA (conv_halo_kernel<.., FP8>; BASELINE.json configs[4]). Products of
-    two e4m3 values are exact in fp32, so against a float64 convolution of the DEQUANTISED operands only the fp32 accumulation order
-    and the bf16 rounding of the output remain (2^-7 relative + 2e-3)."""
+@pytest.mark.parametrize("n,h,w,cin,cout,res,s1", [
+    (1, 16, 16, 128, 128, False, False), (2, 24, 40, 256, 128, True, False), (1, 20, 28, 512, 64, False, False),   # conv_halo_kernel<.., FP8>
+    (1, 128, 256, 128, 128, True, True),     # conv_halo_s1_fp8_kernel: one period of 9 MFMA steps, whole patches, residual
+    (2, 200, 488, 128, 128, True, True),     # ragged 16 x 32 patches, two images
+    (1, 100, 120, 256, 256, False, True),    # two periods, two channel tiles
+    (1, 128, 128, 512, 128, True, True)])    # four periods
+def test_conv3x3_fp8(ctx, n, h, w, cin, cout, res, s1):
+    """3x3 conv on OCP e4m3 operands through the MX-scaled MFMAs (conv_halo_kernel<.., FP8> and, from 32 patch tiles per image up,
+    conv_halo_s1_fp8_kernel; BASELINE.json configs[4]). Products of two e4m3 values are exact in fp32, so against a float64 convolution
+    of the DEQUANTISED operands only the fp32 accumulation order and the bf16 rounding of the output remain (2^-7 relative + 2e-3)."""
+    assert (ctx.lib.ir_op_conv_fp8_route(ctx.h, n, h, w, cin, cout, 1 if res else 0) == 0) == s1
     g = torch.Generator().manual_seed(n + h + w + cin + cout)
     x8 = (torch.randn(n, cin, h, w, generator=g) * 4).clamp(-448, 448).to(torch.float8_e4m3fn)
     w8 = (torch.randn(cout, cin, 3, 3, generator=g) * 64).clamp(-448, 448).to(torch.float8_e4m3fn)

@@ -34,6 +34,18 @@ def conv(n, h, w, cin, cout, up=0, stride=1):
     print(f"conv {n}x{h}x{w} {cin}->{cout} up={up} s={stride}: {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s")
 
 
+def conv8(n, h, w, cin, cout):
+    """3x3 conv on e4m3 operands (conv_halo_s1_fp8_kernel when it takes the shape; IR_NO_CONV_S1_FP8=1 forces conv_halo_kernel<.., FP8>)"""
+    x = torch.randint(0, 120, (n, h, w, cin), device="cuda", dtype=torch.uint8)
+    wt = torch.randint(0, 120, (cout, 9 * cin), device="cuda", dtype=torch.uint8)
+    g, b = torch.full((cout,), 1e-3, device="cuda"), torch.zeros(cout, device="cuda")
+    out = torch.empty(n, h, w, cout, dtype=torch.int16, device="cuda")
+    fn = lambda: ctx.check(ctx.lib.ir_op_conv_fp8(ctx.h, ctx.stream(), L.ptr(x), L.ptr(wt), L.ptr(g), L.ptr(b), L.ptr(out), n, h, w, cin, cout, None), "conv8")
+    ms = timeit(fn)
+    fl = 2.0 * n * h * w * cout * 9 * cin
+    print(f"conv fp8 {n}x{h}x{w} {cin}->{cout} (route {ctx.lib.ir_op_conv_fp8_route(ctx.h, n, h, w, cin, cout, 0)}): {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s")
+
+
 def linear(m, k, n, out_f32=0, act=0, res=0):
     """res: 0 none, 1 bf16 residual, 2 fp32 residual + gate (the DiT residual stream)"""
     x = torch.randn(m, k, device="cuda").to(torch.bfloat16).view(torch.int16)
@@ -139,6 +151,13 @@ if __name__ == "__main__":
         gn(1, 1024 * 1024, 256)
         gn(1, 1024 * 1024, 512)
         gn(1, 512 * 512, 512)
+    if "conv8" in which:
+        conv8(1, 2048, 2048, 128, 128)
+        conv8(1, 2048, 2048, 256, 128)
+        conv8(1, 1024, 1024, 256, 256)
+        conv8(1, 1024, 1024, 512, 512)
+        conv8(1, 512, 512, 512, 512)
+        conv8(1, 256, 256, 512, 512)
     if "attn8" in which:
         attn8(1, 16, 16384)
         attn8(1, 16, 1024)
