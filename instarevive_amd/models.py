@@ -166,15 +166,29 @@ class SwinIR(_DeviceModule):
 
 # ====================================================================================================== VAE
 def _load_weights_file(folder):
-    st = os.path.join(folder, "diffusion_pytorch_model.safetensors")
-    if os.path.exists(st):
-        from safetensors.torch import load_file
-        return load_file(st)
-    for name in ("diffusion_pytorch_model.bin", "diffusion_pytorch_model.pt"):
-        p = os.path.join(folder, name)
-        if os.path.exists(p):
-            return torch.load(p, map_location="cpu")
-    raise FileNotFoundError(f"no diffusion_pytorch_model.(safetensors|bin) under {folder}")
+    """The state dict of a diffusers (diffusion_pytorch_model.*) or transformers (model.safetensors / pytorch_model.bin, single file or
+    sharded behind an *.index.json as DeepFloyd/t5-v1_1-xxl ships it) weight folder."""
+    def load_one(path):
+        if path.endswith(".safetensors"):
+            from safetensors.torch import load_file
+            return load_file(path)
+        return torch.load(path, map_location="cpu")
+
+    for name in ("diffusion_pytorch_model.safetensors", "diffusion_pytorch_model.bin", "diffusion_pytorch_model.pt", "model.safetensors",
+                 "pytorch_model.bin"):
+        path = os.path.join(folder, name)
+        if os.path.exists(path):
+            return load_one(path)
+    for index in ("model.safetensors.index.json", "pytorch_model.bin.index.json", "diffusion_pytorch_model.safetensors.index.json"):
+        path = os.path.join(folder, index)
+        if os.path.exists(path):
+            with open(path) as f:
+                shards = sorted(set(json.load(f)["weight_map"].values()))
+            sd = {}
+            for shard in shards:
+                sd.update(load_one(os.path.join(folder, shard)))
+            return sd
+    raise FileNotFoundError(f"no diffusion_pytorch_model.* / model.safetensors / pytorch_model.bin (or a sharded index) under {folder}")
 
 
 def _resolve_pretrained(name_or_path, subfolder=None):
