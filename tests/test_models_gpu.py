@@ -543,3 +543,26 @@ def test_fp8_whole_path_psnr_guard(full_models):
     assert not np.array_equal(f8[0], bf[0]), "the fp8 path must actually run"
     assert p8 >= 40.0 and d8 <= 0.1   # measured 42.9 dB
 
+
+
+def test_fp8_tiled_and_hipgraph(full_models):
+    """cfg-5 under --tiled: the fp8 attention then runs per batch of 1024-token tiles and the fp8 convs on 512 x 512 tiles (the small levels
+    stay with the 4-wave fp8 kernel); tiled fp8 against tiled bf16 on a 1024 x 1024 image, and the hipGraph replay of the fp8 path against
+    its plain launches (the prep kernel, the flagged fallback launches and the fp8 convs must all be capturable and re-playable)."""
+    import bench
+    from instarevive_amd.pipeline import process
+    swin, vae, dit, sds, y, mask = full_models
+    img = bench.synthetic_lq(1, 1024, 1024, 61)[0].numpy()
+    kw = dict(preprocess_model=swin, vae=vae, y=full_models.y_cuda, y_mask=full_models.mask_cuda)
+    bf, _ = process(dit, [img], 1, "wavelet", False, True, 512, 448, **kw)
+    vae.enable_fp8(True)
+    try:
+        f8, _ = process(dit, [img], 1, "wavelet", False, True, 512, 448, fp8=True, **kw)
+        g1, _ = process(dit, [img], 1, "wavelet", False, True, 512, 448, fp8=True, graph=True, **kw)   # records
+        g2, _ = process(dit, [img], 1, "wavelet", False, True, 512, 448, fp8=True, graph=True, **kw)   # replays
+    finally:
+        vae.enable_fp8(False)
+    p = _psnr_u8(f8, bf)
+    print(f"fp8 tiled 1024x1024 vs bf16 tiled: {p:.2f} dB")
+    assert not np.array_equal(f8[0], bf[0]) and p >= 38.0
+    assert np.array_equal(g1[0], f8[0]) and np.array_equal(g2[0], f8[0]), "hipGraph record / replay of the fp8 path must equal its plain launches"

@@ -354,6 +354,38 @@ def test_flash_attention_spike(ctx, t, gain):
     close(L.from_bf16_bits(o).cpu(), ref, rtol, atol, "flash attention spike")
 
 
+@pytest.mark.parametrize("t,gain", [(512, 4.0), (512, 12.0)])
+def test_flash_attention_fp8_spike(ctx, t, gain):
+    """flash_attn_fp8_kernel with its fixed softmax reference: a late key dominates one query. gain 4: the spike is about 2^40 above the first
+    tile's maximum - inside the range the exponent bytes carry (probabilities relative to the fixed reference up to ~2^100); gain 12: beyond
+    it -> overflow flag -> the bf16 V^T is built (transpose_v with only_if) and the rescaling bf16 kernel recomputes everything. Either way
+    the spiked query must return the spiked key's value row (e4m3 rounding of V: 2^-4 relative in the first case)."""
+    g = torch.Generator().manual_seed(3)
+    b, heads, d = 1, 1, 72
+    q = rb(torch.randn(b, t, heads, d, generator=g))
+    k = rb(torch.randn(b, t, heads, d, generator=g))
+    v = rb(torch.randn(b, t, heads, d, generator=g))
+    k[0, t - 6, 0] = q[0, 7, 0] * gain
+    k = rb(k)
+    scale = d ** -0.5
+    qd64, kd64, vd64 = (x_.transpose(1, 2).double() for x_ in (q, k, v))
+    ref = (torch.softmax(qd64 @ kd64.transpose(-1, -2) * scale, dim=-1) @ vd64).transpose(1, 2).float()
+    o = torch.empty(b, t, heads, d, dtype=torch.int16, device="cuda")
+    ws = torch.zeros(16 << 20, dtype=torch.uint8, device="cuda")
+    ctx.check(ctx.lib.ir_op_attention_fp8(ctx.h, ctx.stream(), P(dev_bf16(q)), P(dev_bf16(k)), P(dev_bf16(v)), P(o), b, heads, t, scale, P(ws), ws.numel()),
+              "attention_fp8")
+    torch.cuda.synchronize()
+    got = L.from_bf16_bits(o).cpu()
+    tiles = heads * (t // 64) * 10240
+    flag = int(ws[((tiles + 255) & ~255) + ((heads * 96 * (t + 64) * 2 + 255) & ~255):][:4].view(torch.int32)[0])   # layout of ir_op_attention_fp8: tiles | V^T [heads][96][t + 64] | flag
+    assert (flag != 0) == (gain > 8), f"overflow flag {flag} at gain {gain}"
+    spike_err = float((got[0, 7, 0] - v[0, t - 6, 0]).abs().max())
+    assert spike_err < (2 ** -6 if flag else 2 ** -3), f"the spiked query must return the spiked key's value row (max error {spike_err:.4f})"
+    r = float((got - ref).norm() / ref.norm())
+    print(f"fp8 attention spike gain {gain}: flag {flag}, rel-L2 {r:.4f}, spiked row error {spike_err:.4f}")
+    assert r <= (0.02 if flag else 0.12)
+
+
 @pytest.mark.parametrize("t,gain", [(512, 2.0), (512, 4.0)])
 def test_flash_attention_d512_spike(ctx, t, gain):
     """d = 512 kernel with the fixed softmax reference (attn_d512.hip): a late key dominates one query. gain 2: the spike is 2^65 above
