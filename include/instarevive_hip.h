@@ -23,7 +23,8 @@ typedef struct ir_ctx ir_ctx;
 
 /* stages for ir_workspace_bytes */
 enum { IR_STAGE_SWINIR = 0, IR_STAGE_VAE_ENCODE = 1, IR_STAGE_DIT = 2, IR_STAGE_VAE_DECODE = 3, IR_STAGE_PIPELINE = 4,
-       IR_STAGE_COLORFIX = 5, IR_STAGE_T5 = 6 /* ir_workspace_bytes(ctx, IR_STAGE_T5, batch, tokens, 0, ...) */ };
+       IR_STAGE_COLORFIX = 5, IR_STAGE_T5 = 6 /* ir_workspace_bytes(ctx, IR_STAGE_T5, batch, tokens, 0, ...) */,
+       IR_STAGE_CLDM = 7 /* ir_cldm_sample: n, h, w = the LATENT size */ };
 /* ir_pipeline flags */
 enum { IR_FLAG_NO_PREPROCESS = 1, IR_FLAG_TILED = 2, IR_FLAG_FIX_WAVELET = 4, IR_FLAG_FIX_ADAIN = 8,
        /* ir_pipeline only, needs ir_dit_control_configure: run the DiT step with the ControlNet-Half branch, condition latent
@@ -68,6 +69,26 @@ int ir_dit_control_configure(ir_ctx* ctx, int copy_blocks_num);
 /* encoder_hidden_states / encoder_attention_mask of the fixed prompt (inference.py:256-259,273-277): host fp32
  * [n_tok][caption_dim] and [n_tok]; projects the caption and caches K/V of all layers on the device. */
 int ir_dit_set_prompt(ir_ctx* ctx, void* stream, const float* embeds_host, const float* mask_host, int n_tok);
+
+/* ---- ControlLDM one-step: Reflow_ControlLDM of diffusion/cldm.py:425-588, configs/cldm.yaml.
+ * ir_unet_configure binds the SD-2.1 UNet (`which` 0: ControlledUnetModel, cldm.py:32-55 = UNetModel of openaimodel.py:411-786; tensors
+ * `unet.*`) or the ControlNet (`which` 1: cldm.py:58-292, input_blocks.0 takes cat(x, hint) = 8 channels; tensors `cnet.*`). Options as
+ * in the yaml: use_spatial_transformer, transformer_depth 1, use_linear_in_transformer, legacy False, one num_head_channels (64 or 32),
+ * no scale-shift norm, conv_resample. attention_levels: bit l set = attention at level l (ds = 2^l in attention_resolutions). Level
+ * widths model_channels * channel_mult[l] must be multiples of head_dim and <= 1280 (cldm.yaml: 320 x [1, 2, 4, 4]).
+ * Tensor names per block i of input_blocks / output_blocks (`in{i}` / `out{i}`; `mid0`, `mid1`, `mid2`): `.res.{n1,c1,emb,n2,c2,sc}`,
+ * `.xf.{gn,pin,ln1,qkv,ao,ln2,cq,ckv,co,ln3,ff1,ff2,pout}`, `.down`, `.up`, `in0.conv`; `temb1`, `temb2`; `out.norm`, `out.conv`;
+ * ControlNet: `zero{i}`, `midzero`. (`emb.b` holds emb_layers.1.bias + in_layers.2.bias.) */
+int ir_unet_configure(ir_ctx* ctx, int which, int model_channels, int n_levels, const int* channel_mult, int num_res_blocks, int attention_levels,
+                      int head_dim, int context_dim, int in_channels);
+/* c_crossattn: the frozen text encoder's embedding of the prompt (cldm.py:351,574), host fp32 [n_tok][context_dim], shared by the batch.
+ * Builds the K / V caches of every attn2 of the configured UNet and ControlNet; call after both ir_unet_configure calls. Synchronises. */
+int ir_unet_set_context(ir_ctx* ctx, void* stream, const float* context_host, int n_tok);
+/* sample_log (cldm.py:568-588): out = zT + diffusion_model(zT, t, context, control = control_model(zT, hint = c_latent, t, context)).
+ * zT, c_latent, out: device fp32 NCHW [n][4][h][w] at LATENT resolution (h, w multiples of 2^(n_levels-1)); c_latent NULL = the UNet
+ * alone (cond['c_latent'] is None). timestep: num_timesteps - 1 = 999 in the reference. ws: ir_workspace_bytes(ctx, IR_STAGE_CLDM, n, h, w, ...). */
+int ir_cldm_sample(ir_ctx* ctx, void* stream, const float* zT, const float* c_latent, float* out, int n, int h, int w, float timestep, void* ws,
+                   size_t ws_bytes);
 
 /* The prompt producer's text encoder: T5EncoderModel.from_pretrained(...) — diffusion/model/t5.py:80 (T5 v1.1: gated-GELU, relative
  * position bias, no biases). Tensors `t5.embed`, `t5.final_ln`, `t5.l{i}.{ln1,ln2,qkv,o,wi,wo}`; the additive position bias of a
@@ -177,6 +198,13 @@ int ir_op_layernorm(ir_ctx* ctx, void* stream, const float* x, uint16_t* y, cons
                     int ldy, float eps);
 int ir_op_attention(ir_ctx* ctx, void* stream, const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* o, int b, int heads,
                     int tq, int tk, int d, float scale, const float* key_bias, void* ws, size_t ws_bytes);
+/* GroupNorm(groups) over NHWC bf16 rows for ANY channel count with ch % groups == 0, ch % 8 == 0 and an even group width (the UNet's
+ * 320 ... 2560 channels; ir_op_groupnorm needs ch = 8 * 2^k <= 512). ws: (n * 32 * 64 * 2 + 2 * n * ch) floats at most. */
+int ir_op_groupnorm_any(ir_ctx* ctx, void* stream, const uint16_t* x, uint16_t* y, const float* gamma, const float* beta, int n, long hw, int ch,
+                        int groups, float eps, int silu, void* ws, size_t ws_bytes);
+/* GEGLU (ldm/modules/attention.py:48-56): out[r][c] = ag[r][c] * gelu(ag[r][f + c]); ag [rows][2f] bf16, out [rows][f], f % 8 == 0. */
+int ir_op_geglu(ir_ctx* ctx, void* stream, const uint16_t* ag, uint16_t* out, long rows, int f);
+
 /* DiT self-attention with both products on fp8 (e4m3) MFMA operands (IR_FP8_DIT_SELF_ATTENTION; attn_fp8.hip): q / k / v / o
  * [b][t][heads * 72] bf16, t a multiple of 64 (>= 256). ws receives, at its start, the quantised tile images
  * [b][heads][t / 64][10240 B] (K8 rows of 80 B, then V8^T rows of 64 B in the kernel's key order; row 79 of the V part starts with the

@@ -130,6 +130,45 @@ struct T5Model {
     int* bad = nullptr;   // device flag: an input id was outside the vocabulary
 };
 
+
+// SD-2.1 UNet / ControlNet of the ControlLDM one-step path (ldm/modules/diffusionmodules/openaimodel.py:411-786,
+// diffusion/cldm.py:58-292)
+struct UResW {        // ResBlock (openaimodel.py:163-272, use_scale_shift_norm = False)
+    Norm n1, n2;
+    Conv c1, c2, sc;
+    bool has_sc = false;
+    const float *ew = nullptr, *eb = nullptr;  // emb_layers.1 [cout][temb] fp32; eb already holds in_layers.2's bias + emb_layers.1's bias
+    float* bias1 = nullptr;                    // device [cout_pad]: the bias conv1 runs with = eb + ew . silu(emb) for the cached timestep
+};
+struct UXfW {         // SpatialTransformer with one BasicTransformerBlock (attention.py:205-350, use_linear = True)
+    Norm gn, l1, l2, l3;
+    Conv pin, pout, qkv, ao, cq, ckv, co, ff1, ff2;
+    int heads = 0;
+    bf16_t* kc = nullptr;    // [tok_pad][2C]: K | V of the context (set by ir_unet_set_context)
+    bf16_t* vtc = nullptr;   // [heads][DV][tok_pad]
+};
+struct UBlock {
+    bool has_res = false, has_xf = false;
+    int resample = 0;   // 1: Downsample (stride-2 conv), 2: Upsample (nearest x2 + conv), 3: input_blocks.0 (the first conv)
+    UResW res;
+    UXfW xf;
+    Conv rs;
+    int cin = 0, cout = 0;   // channels entering / leaving the block (decoder: cin = h + skip)
+    int skip = 0;            // decoder: channels of the skip it pops
+};
+struct UNetW {
+    bool ok = false, ctx_ok = false, control = false;
+    int mc = 0, temb = 0, ctx_dim = 0, hd = 0, in_ch = 0, n_levels = 0;
+    std::vector<UBlock> in, mid, out;
+    std::vector<Conv> zero;   // ControlNet: zero_convs[i] per input block, then middle_block_out
+    Norm out_norm;
+    Conv out_conv;
+    const float *t1w = nullptr, *t1b = nullptr, *t2w = nullptr, *t2b = nullptr;
+    float *tsin = nullptr, *th = nullptr, *emb = nullptr, *semb = nullptr;
+    float cached_t = -1e30f;
+    int n_tok = 0, tok_pad = 0;
+};
+
 }  // namespace
 
 // optional per-launch timing with HIP events on the launch stream (bench.py's roofline numbers come from here)
@@ -187,6 +226,8 @@ struct ir_ctx {
     VaeModel vae;
     DitModel dit;
     T5Model t5;
+    UNetW unet[2];                                  // [0] the diffusion UNet, [1] the ControlNet
+    std::vector<void*> unet_tabs[2], unet_ctx[2];   // their timestep tables / context K-V caches
     // hipGraph cache of ir_pipeline (IR_FLAG_GRAPH): one instantiated graph per exact call signature. `generation` changes whenever
     // device allocations or bindings may have moved (upload with a new size, *_configure, set_prompt), which drops every graph.
     struct GraphKey {
@@ -839,6 +880,257 @@ float* dit_tokens_run(Run& r, const float* lat, int n, int h, int w, float times
     return tok;
 }
 
+// ================================================================ ControlLDM one-step
+// Reflow_ControlLDM.sample_log (diffusion/cldm.py:568-588): control = ControlNet(zT, hint = c_latent, t, context); v = UNet(zT, t,
+// context, control); return zT + v. Activations are NHWC bf16 rows at latent resolution; inside a SpatialTransformer the token stream is
+// fp32 (like the DiT's). The concatenations of the decoder (openaimodel.py:779, cldm.py:49-52) are never materialised by a copy on the
+// controlled path: every producer writes its channel slice of the consumer's buffer (zero_conv_i(g_i) + hs_i is one linear with a
+// residual; the previous decoder block writes the h part).
+int unet_update_timestep(Run& r, UNetW& m, float t) {
+    if (!r.live() || m.cached_t == t) return 0;
+    r.chk(ir_launch_timestep_embed(m.tsin, t, m.mc, r.s), "timestep_embed");            // util.py:151-171 (cos | sin)
+    r.chk(ir_launch_gemv_f32(m.t1w, m.tsin, m.t1b, m.th, m.temb, m.mc, ACT_SILU, r.s), "time_embed.0");
+    r.chk(ir_launch_gemv_f32(m.t2w, m.th, m.t2b, m.emb, m.temb, m.temb, ACT_NONE, r.s), "time_embed.2");
+    r.chk(ir_launch_silu_f32(m.emb, m.semb, m.temb, r.s), "silu");
+    for (std::vector<UBlock>* set : {&m.in, &m.mid, &m.out})
+        for (UBlock& b : *set)
+            if (b.has_res) r.chk(ir_launch_gemv_f32(b.res.ew, m.semb, b.res.eb, b.res.bias1, b.res.c1.cout_pad, m.temb, ACT_NONE, r.s), "emb_layers");
+    r.chain = nullptr;
+    if (r.rc == 0) m.cached_t = t;
+    return r.rc;
+}
+
+struct UBufs {
+    bf16_t *t1, *t2, *ta, *tb;   // conv-side temporaries [max T*C]
+    float* gws;
+    float* x;                    // SpatialTransformer scratch
+    bf16_t *xn, *xb, *qkv, *vt, *att, *cq, *ff, *hid;
+};
+
+void gn_any(Run& r, const Norm& n, const bf16_t* x, bf16_t* y, float* ws, int N, long HW, int silu_, float eps) {
+    LAUNCH(r, PC_GROUPNORM, 0.0, 6.0 * N * (double)HW * n.c, ir_launch_groupnorm_any(x, y, n.g, n.b, ws, N, HW, n.c, 32, eps, silu_, r.s), "groupnorm_any");
+}
+
+// ResBlock._forward (openaimodel.py:252-272): x [N*H*W][cin] contiguous -> out rows of out_cs elements
+void ures(Run& r, const UResW& w, const bf16_t* x, int N, int H, int W, bf16_t* out, int out_cs, const UBufs& b) {
+    const int cin = w.c1.cin, cout = w.c1.cout;
+    const long HW = (long)H * W;
+    gn_any(r, w.n1, x, b.t1, b.gws, N, HW, 1, 1e-5f);
+    Conv c1 = w.c1;
+    c1.b = w.bias1;   // h + emb_out: the time embedding is one value per channel at a fixed timestep
+    conv(r, c1, b.t1, N, H, W, cin, b.t2, cout, 0, 1, 1, 0, ACT_NONE, 0.f, nullptr, 0, 0);
+    gn_any(r, w.n2, b.t2, b.t2, b.gws, N, HW, 1, 1e-5f);
+    const bf16_t* res = x;
+    if (w.has_sc) {
+        linear(r, w.sc, x, (int)(N * HW), cin, b.t1, cout, 0, ACT_NONE, nullptr, 0, 0);
+        res = b.t1;
+    }
+    conv(r, w.c2, b.t2, N, H, W, cout, out, out_cs, 0, 1, 1, 0, ACT_NONE, 0.f, res, 0, cout);
+}
+
+// SpatialTransformer.forward (attention.py:323-350) around BasicTransformerBlock._forward (:289-293): h [N*HW][C] contiguous
+void uxf(Run& r, const UNetW& m, const UXfW& w, const bf16_t* h, int N, long HW, bf16_t* out, int out_cs, const UBufs& b) {
+    const int C = w.gn.c, Hh = w.heads, hd = m.hd, DV = ir_attn_dv(hd);
+    const long BT = N * HW;
+    const int Tpad = (int)((HW + 63) & ~63L) + 64;
+    const float sl2 = (1.0f / sqrtf((float)hd)) * 1.44269504088896340736f;
+    gn_any(r, w.gn, h, b.t1, b.gws, N, HW, 0, 1e-6f);
+    linear(r, w.pin, b.t1, (int)BT, C, b.x, C, 1, ACT_NONE, nullptr, 0, 0);
+    // attn1: self-attention
+    layernorm(r, b.x, b.xn, nullptr, w.l1.g, w.l1.b, BT, C, C, C, 1e-5f);
+    linear(r, w.qkv, b.xn, (int)BT, C, b.qkv, 3 * C, 0, ACT_NONE, nullptr, 0, 0);
+    LAUNCH(r, PC_TRANSPOSE, 0.0, 0.0, ir_launch_transpose_v(b.qkv + 2 * C, b.vt, HW * 3 * C, 3 * C, hd, N, Hh, (int)HW, Tpad, hd, DV, r.s), "transpose_v");
+    if (r.live()) {
+        AttnParams p;
+        memset(&p, 0, sizeof p);
+        p.q = b.qkv; p.k = b.qkv + C; p.vt = b.vt; p.o = b.att;
+        p.q_bs = p.k_bs = HW * 3 * C; p.o_bs = HW * C; p.vt_bs = (long)Hh * DV * Tpad;
+        p.q_rs = p.k_rs = 3 * C; p.o_rs = C; p.q_hs = p.k_hs = p.o_hs = hd;
+        p.B = N; p.Hh = Hh; p.Tq = (int)HW; p.Tk = (int)HW; p.Tk_pad = Tpad; p.D = hd; p.scale_log2 = sl2;
+        LAUNCHK(r, PK_ATTN_OTHER, 4.0 * N * Hh * (double)HW * HW * hd, 0.0, ir_launch_flash_attn(p, r.s), "unet_self_attn");
+    }
+    linear(r, w.ao, b.att, (int)BT, C, b.x, C, 1, ACT_NONE, b.x, 1, C);
+    // attn2: cross-attention to the context (K / V cached per layer)
+    layernorm(r, b.x, b.xn, nullptr, w.l2.g, w.l2.b, BT, C, C, C, 1e-5f);
+    linear(r, w.cq, b.xn, (int)BT, C, b.cq, C, 0, ACT_NONE, nullptr, 0, 0);
+    if (r.live()) {
+        AttnParams p;
+        memset(&p, 0, sizeof p);
+        p.q = b.cq; p.k = w.kc; p.vt = w.vtc; p.o = b.att;
+        p.q_bs = HW * C; p.k_bs = 0; p.o_bs = HW * C; p.vt_bs = 0;
+        p.q_rs = C; p.k_rs = 2 * C; p.o_rs = C; p.q_hs = p.k_hs = p.o_hs = hd;
+        p.B = N; p.Hh = Hh; p.Tq = (int)HW; p.Tk = m.n_tok; p.Tk_pad = m.tok_pad; p.D = hd; p.scale_log2 = sl2;
+        LAUNCHK(r, PK_ATTN_OTHER, 4.0 * N * Hh * (double)HW * m.n_tok * hd, 0.0, ir_launch_flash_attn(p, r.s), "unet_cross_attn");
+    }
+    linear(r, w.co, b.att, (int)BT, C, b.x, C, 1, ACT_NONE, b.x, 1, C);
+    // GEGLU feed-forward (attention.py:48-56,59-77)
+    layernorm(r, b.x, b.xn, nullptr, w.l3.g, w.l3.b, BT, C, C, C, 1e-5f);
+    linear(r, w.ff1, b.xn, (int)BT, C, b.ff, 8 * C, 0, ACT_NONE, nullptr, 0, 0);
+    LAUNCH(r, PC_OTHER, 0.0, 24.0 * BT * C, ir_launch_geglu(b.ff, b.hid, BT, 4 * C, r.s), "geglu");
+    linear(r, w.ff2, b.hid, (int)BT, 4 * C, b.x, C, 1, ACT_NONE, b.x, 1, C, b.xb, C);
+    linear(r, w.pout, b.xb, (int)BT, C, out, out_cs, 0, ACT_NONE, h, 0, C);
+}
+
+// one input / middle / output block: x contiguous [N*H*W][blk.cin] -> out (row stride out_cs); H, W updated by a resample
+void ublock(Run& r, const UNetW& m, const UBlock& blk, const bf16_t* x, int N, int& H, int& W, bf16_t* out, int out_cs, const UBufs& b) {
+    if (blk.resample == 3) {   // input_blocks.0
+        conv(r, blk.rs, x, N, H, W, 32, out, out_cs, 0, 1, 1, 0, ACT_NONE, 0.f, nullptr, 0, 0);
+        return;
+    }
+    if (blk.resample == 1 && !blk.has_res) {   // Downsample (openaimodel.py:137-160): 3x3, stride 2, padding 1
+        conv(r, blk.rs, x, N, H, W, blk.cin, out, out_cs, 0, 2, 1, 0, ACT_NONE, 0.f, nullptr, 0, 0);
+        H /= 2; W /= 2;
+        return;
+    }
+    const bool up = blk.resample == 2;
+    const bf16_t* cur = x;
+    if (blk.has_res) {
+        const bool last = !blk.has_xf && !up;
+        ures(r, blk.res, cur, N, H, W, last ? out : b.ta, last ? out_cs : blk.cout, b);
+        cur = b.ta;
+    }
+    if (blk.has_xf) {
+        uxf(r, m, blk.xf, cur, N, (long)H * W, up ? b.tb : out, up ? blk.cout : out_cs, b);
+        cur = b.tb;
+    }
+    if (up) {   // Upsample (openaimodel.py:90-120): nearest x2 folded into the conv's addressing
+        conv(r, blk.rs, cur, N, H, W, blk.cout, out, out_cs, 0, 1, 1, 1, ACT_NONE, 0.f, nullptr, 0, 0);
+        H *= 2; W *= 2;
+    }
+}
+
+struct USizes { long tc = 0, xc = 0, vt = 0; int cmax = 0; };
+void usizes_block(const UNetW& m, const UBlock& blk, int N, int H, int W, USizes& z) {
+    const long T = (long)N * H * W;
+    const int c = std::max(blk.cin, blk.cout);
+    z.tc = std::max(z.tc, T * c);
+    z.cmax = std::max(z.cmax, c);
+    if (blk.has_xf) {
+        z.xc = std::max(z.xc, T * blk.cout);
+        const int Tpad = (int)(((long)H * W + 63) & ~63L) + 64;
+        z.vt = std::max(z.vt, (long)N * blk.xf.heads * ir_attn_dv(m.hd) * Tpad);
+    }
+}
+
+// zT, c_latent (null: the UNet alone, control = None), out: fp32 NCHW [n][4][h][w]
+void cldm_run(Run& r, const float* zT, const float* c_latent, float* out, int n, int h, int w, float timestep) {
+    UNetW& U = r.c->unet[0];
+    UNetW& Cn = r.c->unet[1];
+    const bool ctl = c_latent != nullptr;
+    unet_update_timestep(r, U, timestep);
+    if (ctl) unet_update_timestep(r, Cn, timestep);
+    const size_t mk = r.a.mark();
+    const int nin = (int)U.in.size(), nout = (int)U.out.size();
+    // geometry of every block
+    std::vector<int> Hi(nin + 1), Wi(nin + 1);   // resolution entering input block i (index nin: the middle block)
+    USizes z;
+    {
+        int H = h, W = w;
+        for (int i = 0; i < nin; ++i) {
+            Hi[i] = H; Wi[i] = W;
+            usizes_block(U, U.in[i], n, H, W, z);
+            if (U.in[i].resample == 1) { H /= 2; W /= 2; }
+        }
+        Hi[nin] = H; Wi[nin] = W;
+        for (const UBlock& b : U.mid) usizes_block(U, b, n, H, W, z);
+        for (int j = 0; j < nout; ++j) {
+            usizes_block(U, U.out[j], n, H, W, z);
+            if (U.out[j].resample == 2) { H *= 2; W *= 2; }
+        }
+    }
+    const long T0 = (long)n * h * w;
+    UBufs b;
+    b.t1 = r.a.alloc<bf16_t>(z.tc); b.t2 = r.a.alloc<bf16_t>(z.tc); b.ta = r.a.alloc<bf16_t>(z.tc); b.tb = r.a.alloc<bf16_t>(z.tc);
+    b.gws = r.a.alloc<float>(ir_gn_any_ws_floats(n, (long)h * w, z.cmax));
+    b.x = r.a.alloc<float>(z.xc); b.xn = r.a.alloc<bf16_t>(z.xc); b.xb = r.a.alloc<bf16_t>(z.xc); b.att = r.a.alloc<bf16_t>(z.xc);
+    b.cq = r.a.alloc<bf16_t>(z.xc); b.qkv = r.a.alloc<bf16_t>(3 * z.xc); b.ff = r.a.alloc<bf16_t>(8 * z.xc); b.hid = r.a.alloc<bf16_t>(4 * z.xc);
+    b.vt = r.a.alloc<bf16_t>(z.vt);
+    bf16_t* in32 = r.a.alloc<bf16_t>(T0 * 32);
+    // encoder of the UNet: hs[i] kept for the decoder
+    std::vector<bf16_t*> hs(nin);
+    LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_cldm_in(zT, nullptr, in32, n, (long)h * w, r.s), "cldm_in");
+    {
+        int H = h, W = w;
+        const bf16_t* cur = in32;
+        for (int i = 0; i < nin; ++i) {
+            const UBlock& blk = U.in[i];
+            const int Ho = blk.resample == 1 ? H / 2 : H, Wo = blk.resample == 1 ? W / 2 : W;
+            hs[i] = r.a.alloc<bf16_t>((long)n * Ho * Wo * blk.cout);
+            ublock(r, U, blk, cur, n, H, W, hs[i], blk.cout, b);
+            cur = hs[i];
+        }
+    }
+    // middle block
+    const int Hm = Hi[nin], Wm = Wi[nin], Cm = U.mid.back().cout;
+    const long Tm = (long)n * Hm * Wm;
+    bf16_t* hm[2] = {r.a.alloc<bf16_t>(Tm * Cm), r.a.alloc<bf16_t>(Tm * Cm)};
+    {
+        int H = Hm, W = Wm;
+        const bf16_t* cur = hs[nin - 1];
+        for (size_t k = 0; k < U.mid.size(); ++k) {
+            ublock(r, U, U.mid[k], cur, n, H, W, hm[k & 1], Cm, b);
+            cur = hm[k & 1];
+        }
+    }
+    bf16_t* hmid = hm[(U.mid.size() - 1) & 1];
+    // the decoder's concatenation buffers: block j reads [h (ch_j) | skip (U.out[j].skip)]
+    std::vector<bf16_t*> cat(nout);
+    std::vector<int> Ho(nout), Wo(nout);
+    {
+        int H = Hm, W = Wm;
+        for (int j = 0; j < nout; ++j) {
+            Ho[j] = H; Wo[j] = W;
+            cat[j] = r.a.alloc<bf16_t>((long)n * H * W * U.out[j].cin);
+            if (U.out[j].resample == 2) { H *= 2; W *= 2; }
+        }
+    }
+    bf16_t* fin = r.a.alloc<bf16_t>(T0 * U.out.back().cout);
+    if (ctl) {
+        // ControlNet (cldm.py:276-292): same input + middle blocks on cat(zT, hint); outs[i] = zero_conv_i(h_i), scaled by control_scales = 1
+        LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_cldm_in(zT, c_latent, in32, n, (long)h * w, r.s), "cldm_in_hint");
+        bf16_t* g[2] = {r.a.alloc<bf16_t>(z.tc), r.a.alloc<bf16_t>(z.tc)};
+        int H = h, W = w;
+        const bf16_t* cur = in32;
+        for (int i = 0; i < nin; ++i) {
+            const UBlock& blk = Cn.in[i];
+            ublock(r, Cn, blk, cur, n, H, W, g[i & 1], blk.cout, b);
+            cur = g[i & 1];
+            // hs.pop() + control.pop() -> the skip slice of decoder block j = nin - 1 - i
+            const int j = nin - 1 - i, hch = U.out[j].cin - U.out[j].skip;
+            linear(r, Cn.zero[i], cur, (int)((long)n * H * W), blk.cout, cat[j] + hch, U.out[j].cin, 0, ACT_NONE, hs[i], 0, blk.cout);
+        }
+        for (size_t k = 0; k < Cn.mid.size(); ++k) {
+            ublock(r, Cn, Cn.mid[k], cur, n, H, W, g[(nin + k) & 1], Cm, b);
+            cur = g[(nin + k) & 1];
+        }
+        // h += control.pop()  (cldm.py:46-47): written as the h slice of the first decoder block
+        linear(r, Cn.zero[nin], cur, (int)Tm, Cm, cat[0], U.out[0].cin, 0, ACT_NONE, hmid, 0, Cm);
+    } else {
+        for (int i = 0; i < nin; ++i) {
+            const int j = nin - 1 - i, hch = U.out[j].cin - U.out[j].skip;
+            const long rows = (long)n * Ho[j] * Wo[j];
+            LAUNCH(r, PC_OTHER, 0.0, 4.0 * rows * U.in[i].cout,
+                   ir_launch_copy_rows(hs[i], U.in[i].cout, nullptr, 0, cat[j] + hch, U.out[j].cin, rows, U.in[i].cout, r.s), "skip_copy");
+        }
+        LAUNCH(r, PC_OTHER, 0.0, 4.0 * Tm * Cm, ir_launch_copy_rows(hmid, Cm, nullptr, 0, cat[0], U.out[0].cin, Tm, Cm, r.s), "mid_copy");
+    }
+    // decoder
+    {
+        int H = Hm, W = Wm;
+        for (int j = 0; j < nout; ++j) {
+            bf16_t* dst = j + 1 < nout ? cat[j + 1] : fin;
+            const int dcs = j + 1 < nout ? U.out[j + 1].cin : U.out[j].cout;
+            ublock(r, U, U.out[j], cat[j], n, H, W, dst, dcs, b);
+        }
+    }
+    // out: GroupNorm32 -> SiLU -> conv (openaimodel.py:706-710), then zT + v
+    gn_any(r, U.out_norm, fin, b.t1, b.gws, n, (long)h * w, 1, 1e-5f);
+    float* v4 = r.a.alloc<float>(T0 * 4);
+    conv(r, U.out_conv, b.t1, n, h, w, U.out_conv.cin, v4, 4, 1, 1, 1, 0, ACT_NONE, 0.f, nullptr, 0, 0);
+    LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_cldm_out(zT, v4, 4, out, n, (long)h * w, r.s), "cldm_out");
+    r.a.release(mk);
+}
+
 const float* dit_pos(ir_ctx* c, int gh, int gw, bool dry) {
     if (dry) return reinterpret_cast<const float*>((uintptr_t)0x1000);
     auto it = c->t.find(fmt("dit.pos.%dx%d", gh, gw));
@@ -1380,6 +1672,180 @@ int ir_dit_set_prompt(ir_ctx* c, void* stream, const float* embeds_host, const f
     return 0;
 }
 
+// ---------------------------------------------------------------- ControlLDM (N4)
+static UResW bind_ures(Binder& b, const std::string& p, int cin, int cout, int temb) {
+    UResW w;
+    w.n1 = b.norm(p + ".n1", cin);
+    w.c1 = b.conv(p + ".c1", cin, cout, cout, 9);
+    w.ew = b.f32(p + ".emb.w", (size_t)cout * temb);
+    w.eb = b.f32(p + ".emb.b", cout);
+    w.n2 = b.norm(p + ".n2", cout);
+    w.c2 = b.conv(p + ".c2", cout, cout, cout, 9);
+    w.has_sc = cin != cout;
+    if (w.has_sc) w.sc = b.conv(p + ".sc", cin, cout, cout, 1);
+    return w;
+}
+static UXfW bind_uxf(Binder& b, const std::string& p, int C, int heads, int ctx_dim) {
+    UXfW w;
+    w.heads = heads;
+    w.gn = b.norm(p + ".gn", C);
+    w.l1 = b.norm(p + ".ln1", C); w.l2 = b.norm(p + ".ln2", C); w.l3 = b.norm(p + ".ln3", C);
+    w.pin = b.conv(p + ".pin", C, C, C, 1);
+    w.qkv = b.conv(p + ".qkv", C, 3 * C, 3 * C, 1);
+    w.ao = b.conv(p + ".ao", C, C, C, 1);
+    w.cq = b.conv(p + ".cq", C, C, C, 1);
+    w.ckv = b.conv(p + ".ckv", ctx_dim, 2 * C, 2 * C, 1);
+    w.co = b.conv(p + ".co", C, C, C, 1);
+    w.ff1 = b.conv(p + ".ff1", C, 8 * C, 8 * C, 1);
+    w.ff2 = b.conv(p + ".ff2", 4 * C, C, C, 1);
+    w.pout = b.conv(p + ".pout", C, C, C, 1);
+    return w;
+}
+
+int ir_unet_configure(ir_ctx* c, int which, int model_channels, int n_levels, const int* channel_mult, int num_res_blocks, int attention_levels,
+                      int head_dim, int context_dim, int in_channels) {
+    if (!c || (which != 0 && which != 1) || n_levels < 1 || n_levels > 8 || !channel_mult || num_res_blocks < 1)
+        return fail(c, -1, "ir_unet_configure: bad argument");
+    const int mc = model_channels, temb = 4 * mc;
+    if ((mc & 31) || (head_dim != 64 && head_dim != 32) || (context_dim & 31) || (in_channels != 4 && in_channels != 8) || (which == 1) != (in_channels == 8))
+        return fail(c, -1, "ir_unet_configure: unsupported dims (model_channels %d, head_dim %d, context_dim %d, in_channels %d)", mc, head_dim, context_dim, in_channels);
+    for (int l = 0; l < n_levels; ++l)
+        if (channel_mult[l] < 1 || (mc * channel_mult[l]) % head_dim || mc * channel_mult[l] > 1280)
+            return fail(c, -1, "ir_unet_configure: level %d width %d unsupported (multiple of head_dim, <= 1280)", l, mc * channel_mult[l]);
+    HIPOK(c, hipSetDevice(c->device));
+    Binder b{c};
+    const std::string P = which ? "cnet" : "unet";
+    UNetW m;
+    m.control = which == 1; m.mc = mc; m.temb = temb; m.ctx_dim = context_dim; m.hd = head_dim; m.in_ch = in_channels; m.n_levels = n_levels;
+    m.t1w = b.f32(P + ".temb1.w", (size_t)temb * mc); m.t1b = b.f32(P + ".temb1.b", temb);
+    m.t2w = b.f32(P + ".temb2.w", (size_t)temb * temb); m.t2b = b.f32(P + ".temb2.b", temb);
+    std::vector<int> chans;
+    int ch = mc;
+    {   // input_blocks (openaimodel.py:520-590 / cldm.py:152-230)
+        UBlock b0;
+        b0.resample = 3; b0.cin = 32; b0.cout = mc;
+        b0.rs = b.conv(P + ".in0.conv", 32, mc, mc, 9, in_channels, mc);
+        m.in.push_back(b0);
+        chans.push_back(mc);
+        for (int l = 0; l < n_levels; ++l) {
+            for (int k = 0; k < num_res_blocks; ++k) {
+                UBlock blk;
+                const int co = mc * channel_mult[l];
+                const std::string p = fmt("%s.in%d", P.c_str(), (int)m.in.size());
+                blk.has_res = true; blk.cin = ch; blk.cout = co;
+                blk.res = bind_ures(b, p + ".res", ch, co, temb);
+                ch = co;
+                if ((attention_levels >> l) & 1) {
+                    blk.has_xf = true;
+                    blk.xf = bind_uxf(b, p + ".xf", ch, ch / head_dim, context_dim);
+                }
+                m.in.push_back(blk);
+                chans.push_back(ch);
+            }
+            if (l != n_levels - 1) {
+                UBlock blk;
+                blk.resample = 1; blk.cin = blk.cout = ch;
+                blk.rs = b.conv(fmt("%s.in%d.down", P.c_str(), (int)m.in.size()), ch, ch, ch, 9);
+                m.in.push_back(blk);
+                chans.push_back(ch);
+            }
+        }
+    }
+    {   // middle_block: ResBlock, SpatialTransformer, ResBlock
+        UBlock r0, x1, r2;
+        r0.has_res = true; r0.cin = r0.cout = ch; r0.res = bind_ures(b, P + ".mid0.res", ch, ch, temb);
+        x1.has_xf = true; x1.cin = x1.cout = ch; x1.xf = bind_uxf(b, P + ".mid1.xf", ch, ch / head_dim, context_dim);
+        r2.has_res = true; r2.cin = r2.cout = ch; r2.res = bind_ures(b, P + ".mid2.res", ch, ch, temb);
+        m.mid = {r0, x1, r2};
+    }
+    if (m.control) {   // zero_convs + middle_block_out (cldm.py:150,231,273-274)
+        for (size_t i = 0; i < chans.size(); ++i) m.zero.push_back(b.conv(fmt("%s.zero%d", P.c_str(), (int)i), chans[i], chans[i], chans[i], 1));
+        m.zero.push_back(b.conv(P + ".midzero", ch, ch, ch, 1));
+    } else {           // output_blocks (openaimodel.py:640-700) and out (:706-710)
+        for (int l = n_levels - 1; l >= 0; --l)
+            for (int k = 0; k <= num_res_blocks; ++k) {
+                UBlock blk;
+                const int ich = chans.back(), co = mc * channel_mult[l];
+                chans.pop_back();
+                const std::string p = fmt("%s.out%d", P.c_str(), (int)m.out.size());
+                blk.has_res = true; blk.cin = ch + ich; blk.skip = ich; blk.cout = co;
+                blk.res = bind_ures(b, p + ".res", ch + ich, co, temb);
+                ch = co;
+                if ((attention_levels >> l) & 1) {
+                    blk.has_xf = true;
+                    blk.xf = bind_uxf(b, p + ".xf", ch, ch / head_dim, context_dim);
+                }
+                if (l && k == num_res_blocks) {
+                    blk.resample = 2;
+                    blk.rs = b.conv(p + ".up", ch, ch, ch, 9);
+                }
+                m.out.push_back(blk);
+            }
+        m.out_norm = b.norm(P + ".out.norm", mc);
+        m.out_conv = b.conv(P + ".out.conv", mc, 4, 32, 9);
+    }
+    if (!b.ok) return fail(c, -2, "ir_unet_configure: tensor %s", b.missing.c_str());
+    release_list(c->unet_tabs[which]);
+    release_list(c->unet_ctx[which]);
+    c->unet[which] = UNetW();
+    int rc = 0;
+    rc |= dev_alloc(c, c->unet_tabs[which], (void**)&m.tsin, (size_t)mc * 4);
+    rc |= dev_alloc(c, c->unet_tabs[which], (void**)&m.th, (size_t)temb * 4);
+    rc |= dev_alloc(c, c->unet_tabs[which], (void**)&m.emb, (size_t)temb * 4);
+    rc |= dev_alloc(c, c->unet_tabs[which], (void**)&m.semb, (size_t)temb * 4);
+    for (std::vector<UBlock>* set : {&m.in, &m.mid, &m.out})
+        for (UBlock& blk : *set)
+            if (blk.has_res) rc |= dev_alloc(c, c->unet_tabs[which], (void**)&blk.res.bias1, (size_t)blk.res.c1.cout_pad * 4);
+    if (rc) return rc;
+    m.ok = true;
+    c->unet[which] = m;
+    ++c->generation;
+    return 0;
+}
+
+// context: the text conditioning c_crossattn [n_tok][context_dim] (host fp32; the frozen OpenCLIP embedding of the prompt, cldm.yaml:86-91),
+// shared by every image of a batch. Builds the K / V caches of every cross-attention of the configured UNet and ControlNet.
+int ir_unet_set_context(ir_ctx* c, void* stream, const float* context_host, int n_tok) {
+    if (!c || !context_host || n_tok <= 0 || (!c->unet[0].ok && !c->unet[1].ok)) return fail(c, -1, "ir_unet_set_context: bad argument / no UNet configured");
+    HIPOK(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int tok_pad = ((n_tok + 63) & ~63) + 64;
+    const int ctx_dim = c->unet[0].ok ? c->unet[0].ctx_dim : c->unet[1].ctx_dim;
+    struct Temps {
+        void* p[2] = {nullptr, nullptr};
+        ~Temps() { for (void* q : p) if (q) (void)hipFree(q); }
+    } tmp;
+    HIPOK(c, hipMalloc(&tmp.p[0], (size_t)n_tok * ctx_dim * 4));
+    HIPOK(c, hipMalloc(&tmp.p[1], (size_t)n_tok * ctx_dim * 2));
+    float* e32 = (float*)tmp.p[0];
+    bf16_t* e16 = (bf16_t*)tmp.p[1];
+    HIPOK(c, hipMemcpyAsync(e32, context_host, (size_t)n_tok * ctx_dim * 4, hipMemcpyHostToDevice, s));
+    Run r = make_run(c, stream, nullptr, 0, false);
+    r.chk(ir_launch_f32_to_bf16(e32, e16, (long)n_tok * ctx_dim, s), "f32_to_bf16");
+    for (int which = 0; which < 2; ++which) {
+        UNetW& m = c->unet[which];
+        if (!m.ok) continue;
+        if (m.ctx_dim != ctx_dim) return fail(c, -1, "ir_unet_set_context: UNet and ControlNet disagree on context_dim");
+        release_list(c->unet_ctx[which]);
+        const int DV = ir_attn_dv(m.hd);
+        for (std::vector<UBlock>* set : {&m.in, &m.mid, &m.out})
+            for (UBlock& blk : *set) {
+                if (!blk.has_xf) continue;
+                UXfW& w = blk.xf;
+                const int C = w.gn.c;
+                if (dev_alloc(c, c->unet_ctx[which], (void**)&w.kc, (size_t)tok_pad * 2 * C * 2)) return -100;
+                if (dev_alloc(c, c->unet_ctx[which], (void**)&w.vtc, (size_t)w.heads * DV * tok_pad * 2)) return -100;
+                linear(r, w.ckv, e16, n_tok, ctx_dim, w.kc, 2 * C, 0, ACT_NONE, nullptr, 0, 0);
+                LAUNCH(r, PC_TRANSPOSE, 0.0, 0.0, ir_launch_transpose_v(w.kc + C, w.vtc, 0, 2 * C, m.hd, 1, w.heads, n_tok, tok_pad, m.hd, DV, s), "transpose_v");
+            }
+        m.n_tok = n_tok; m.tok_pad = tok_pad; m.ctx_ok = true;
+    }
+    HIPOK(c, hipStreamSynchronize(s));
+    if (r.rc) return fail(c, r.rc, "ir_unet_set_context: %s failed", r.where);
+    ++c->generation;
+    return 0;
+}
+
 #define REQUIRE(cond, msg) \
     if (!(cond)) return fail(c, -11, msg)
 
@@ -1407,6 +1873,10 @@ static int stage_dispatch(ir_ctx* c, Run& r, int stage, int n, int h, int w, int
             break;
         case IR_STAGE_COLORFIX: colorfix_run(r, IR_FLAG_FIX_WAVELET, fin, fin, fout, n, h, w); break;
         case IR_STAGE_T5: t5_run(r, (const int*)fin, nullptr, fin, fout, n, h); break;  // n = batch, h = tokens
+        case IR_STAGE_CLDM:
+            if (!c->unet[0].ok) return fail(c, -11, "UNet not configured");
+            cldm_run(r, fin, c->unet[1].ok ? fin : nullptr, fout, n, h, w, 0.f);
+            break;
         default: return fail(c, -1, "unknown stage %d", stage);
     }
     return 0;
@@ -1493,6 +1963,25 @@ int ir_vae_decode(ir_ctx* c, void* stream, const float* lat, float* out, int n, 
     float* o4 = r.a.alloc<float>((long)n * h * 8 * w * 8 * 4);
     vae_decode_run(r, lat, 1.f, o4, n, h, w);
     LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_nhwc_to_nchw(o4, 4, out, n, 3, (long)h * 8 * w * 8, 1.f, 0.f, 0, r.s), "dec_out");
+    return finish(r, c, ws_bytes);
+}
+
+// Reflow_ControlLDM.sample_log (diffusion/cldm.py:568-588): out = zT + UNet(zT, t, context, control = ControlNet(zT, c_latent, t, context)).
+// zT, c_latent, out: fp32 NCHW [n][4][h][w] (latent resolution); c_latent null: the UNet alone (cond['c_latent'] is None, cldm.py:577-578).
+int ir_cldm_sample(ir_ctx* c, void* stream, const float* zT, const float* c_latent, float* out, int n, int h, int w, float timestep, void* ws,
+                   size_t ws_bytes) {
+    REQUIRE(c && c->unet[0].ok, "UNet not configured");
+    REQUIRE(c->unet[0].ctx_ok, "ir_unet_set_context has not run since the UNet was configured");
+    if (c_latent) {
+        REQUIRE(c->unet[1].ok && c->unet[1].ctx_ok, "ControlNet not configured (or no context set) but c_latent given");
+        REQUIRE(c->unet[1].in.size() == c->unet[0].in.size() && c->unet[1].mc == c->unet[0].mc, "ControlNet and UNet layouts differ");
+    }
+    const int div = 1 << (c->unet[0].n_levels - 1);
+    if (!zT || !out || n < 1 || h < div || w < div || h % div || w % div)
+        return fail(c, -1, "ir_cldm_sample: latent %dx%d must be a positive multiple of %d", h, w, div);
+    use_ctx(c);
+    Run r = make_run(c, stream, ws, ws_bytes, false);
+    cldm_run(r, zT, c_latent, out, n, h, w, timestep);
     return finish(r, c, ws_bytes);
 }
 
@@ -1937,6 +2426,20 @@ int ir_op_nhwc_to_nchw(ir_ctx* c, void* stream, const float* in, int in_cs, floa
     use_ctx(c);
     int rc = ir_launch_nhwc_to_nchw(in, in_cs, out, n, ch, hw, scale, shift, clamp01, (hipStream_t)stream);
     return rc ? fail(c, rc, "nhwc_to_nchw failed (%d)", rc) : 0;
+}
+int ir_op_groupnorm_any(ir_ctx* c, void* stream, const uint16_t* x, uint16_t* y, const float* gamma, const float* beta, int n, long hw, int ch,
+                        int groups, float eps, int silu, void* ws, size_t ws_bytes) {
+    if (!c || !x || !y || !ws) return fail(c, -1, "ir_op_groupnorm_any: null argument");
+    if (ws_bytes < (size_t)ir_gn_any_ws_floats(n, hw, ch) * 4) return fail(c, -20, "ir_op_groupnorm_any: workspace too small");
+    use_ctx(c);
+    const int rc = ir_launch_groupnorm_any(x, y, gamma, beta, (float*)ws, n, hw, ch, groups, eps, silu, (hipStream_t)stream);
+    return rc ? fail(c, rc, "ir_op_groupnorm_any failed (code %d)", rc) : 0;
+}
+int ir_op_geglu(ir_ctx* c, void* stream, const uint16_t* ag, uint16_t* out, long rows, int f) {
+    if (!c || !ag || !out) return fail(c, -1, "ir_op_geglu: null argument");
+    use_ctx(c);
+    const int rc = ir_launch_geglu(ag, out, rows, f, (hipStream_t)stream);
+    return rc ? fail(c, rc, "ir_op_geglu failed (code %d)", rc) : 0;
 }
 int ir_op_softmax_rows(ir_ctx* c, void* stream, const float* x, uint16_t* y, int rows, int cols) {
     use_ctx(c);

@@ -170,3 +170,13 @@ int ir_launch_timestep_embed(float* out, float t, int dim, hipStream_t s);
 int ir_launch_f32_to_bf16(const float* in, bf16_t* out, long n, hipStream_t s);
 int ir_launch_modtab(const float* t, const float* sst, float* out, int L, int R, int C, int t_stride, int scale_mask, hipStream_t s);
 int ir_launch_add_bias_rows(float* x, const float* b, long n, int C, hipStream_t s);
+
+// unet.hip: memory-bound kernels of the ControlLDM path (GroupNorm over any channel count, GEGLU, latent ends, skip rows)
+int ir_gn_any_chunks(long HW);
+long ir_gn_any_ws_floats(int N, long HW, int C);
+int ir_launch_groupnorm_any(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, float* ws, int N, long HW, int C, int G, float eps,
+                            int do_silu, hipStream_t s);
+int ir_launch_geglu(const bf16_t* ag, bf16_t* out, long rows, int F, hipStream_t s);
+int ir_launch_cldm_in(const float* x, const float* hint, bf16_t* out, int N, long HW, hipStream_t s);
+int ir_launch_cldm_out(const float* zT, const float* v, int v_cs, float* out, int N, long HW, hipStream_t s);
+int ir_launch_copy_rows(const bf16_t* src, int src_cs, const bf16_t* add, int add_cs, bf16_t* dst, int dst_cs, long rows, int C, hipStream_t s);

@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256) void layernorm_r16_kernel(const float* __restr
 int ir_launch_layernorm(const float* x, bf16_t* y, float* yf, const float* a, const float* b, long rows, int C, int ldx, int ldy,
                         float eps, long rows_per_batch, int ab_stride, hipStream_t s) {
     if (rows <= 0) return 0;
-    if (C > ldx || C > ldy || ldy > 1152) return -2;
+    if (C > ldx || C > ldy || ldy > 1280) return -2;
     if (rows_per_batch <= 0) return -3;
     const unsigned grid = (unsigned)((rows + 3) / 4);
     const bool v4 = !((C | ldx | ldy | ab_stride) & 3) && !(reinterpret_cast<uintptr_t>(x) & 15) && !(reinterpret_cast<uintptr_t>(y) & 7) &&

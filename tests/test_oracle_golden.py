@@ -293,3 +293,43 @@ def test_center_crop_and_assets_match_reference():
             ar = utils.pad(np.array(utils.auto_resize(im, 512)), 64)
             want = fx["asset_" + name.split(".")[0]]
             assert [im.size[0], im.size[1], ar.shape[0], ar.shape[1], int(ar.astype(np.int64).sum() % (1 << 31))] == want.tolist(), name
+
+
+CLDM_SMALL = dict(model_channels=64, channel_mult=(1, 2, 4, 4), num_res_blocks=2, attention_resolutions=(4, 2, 1), num_head_channels=32,
+                  context_dim=64, in_channels=4, hint_channels=4, out_channels=4)
+
+
+def cldm_small_weights():
+    from oracle import cldm as ocldm
+    sd_u = det_state_dict(ocldm.state_dict_shapes(CLDM_SMALL), seed=707)
+    sd_c = det_state_dict(ocldm.state_dict_shapes(CLDM_SMALL, control=True), seed=708)
+    return sd_u, sd_c
+
+
+def test_cldm_matches_reference():
+    """N4: ControlledUnetModel / ControlNet forward and Reflow_ControlLDM.sample_log / apply_condition_encoder of the reference
+    (diffusion/cldm.py:32-292,486-490,568-588) against oracle/cldm.py on the same deterministic weights."""
+    from oracle import cldm as ocldm
+    fx = load("cldm_small.npz")
+    sd_u, sd_c = cldm_small_weights()
+    assert abs(checksum(sd_u) - float(fx["wsum_unet"])) < 1e-6 * float(fx["wsum_unet"])
+    assert abs(checksum(sd_c) - float(fx["wsum_cnet"])) < 1e-6 * float(fx["wsum_cnet"])
+    B = fx["x"].shape[0]
+    ctx = fx["context"].expand(B, -1, -1)
+    t = torch.full((B,), 999.0)
+    torch.testing.assert_close(ocldm.unet_forward(sd_u, fx["x"], t, ctx, None, CLDM_SMALL), fx["unet_alone"], rtol=2e-4, atol=2e-4)
+    ctrl = ocldm.controlnet_forward(sd_c, fx["x"], fx["c_latent"], t, ctx, CLDM_SMALL)
+    assert len(ctrl) == 13
+    stats = torch.stack([torch.stack([c.mean(), c.abs().mean(), c.std()]) for c in ctrl])
+    torch.testing.assert_close(stats, fx["control_stats"], rtol=2e-4, atol=2e-5)
+    torch.testing.assert_close(ctrl[0], fx["control_0"], rtol=2e-4, atol=2e-4)
+    torch.testing.assert_close(ctrl[12], fx["control_12"], rtol=2e-4, atol=2e-4)
+    torch.testing.assert_close(ocldm.unet_forward(sd_u, fx["x"], t, ctx, ctrl, CLDM_SMALL), fx["unet_controlled"], rtol=2e-4, atol=2e-4)
+    sd = {**{"model.diffusion_model." + k: v for k, v in sd_u.items()}, **{"control_model." + k: v for k, v in sd_c.items()}}
+    torch.testing.assert_close(ocldm.reflow_sample(sd, fx["zT"], fx["c_latent"], ctx, CLDM_SMALL), fx["sample"], rtol=2e-4, atol=2e-4)
+    torch.testing.assert_close(ocldm.reflow_sample(sd, fx["zT"], None, ctx, CLDM_SMALL), fx["sample_no_control"], rtol=2e-4, atol=2e-4)
+    # apply_condition_encoder: mode of the posterior of the encoder copy on control * 2 - 1, times scale_factor
+    sd_v = det_state_dict(ovae.state_dict_shapes(dict(ch=32)), seed=202)
+    assert abs(checksum(sd_v) - float(fx["wsum_vae"])) < 1e-6 * float(fx["wsum_vae"])
+    lat = ovae.vae_encode_mean(sd_v, fx["cond_control"] * 2 - 1, dict(ch=32)) * 0.18215
+    torch.testing.assert_close(lat, fx["cond_latent"], rtol=1e-4, atol=2e-5)
