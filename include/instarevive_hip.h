@@ -24,7 +24,7 @@ typedef struct ir_ctx ir_ctx;
 /* stages for ir_workspace_bytes */
 enum { IR_STAGE_SWINIR = 0, IR_STAGE_VAE_ENCODE = 1, IR_STAGE_DIT = 2, IR_STAGE_VAE_DECODE = 3, IR_STAGE_PIPELINE = 4,
        IR_STAGE_COLORFIX = 5, IR_STAGE_T5 = 6 /* ir_workspace_bytes(ctx, IR_STAGE_T5, batch, tokens, 0, ...) */,
-       IR_STAGE_CLDM = 7 /* ir_cldm_sample: n, h, w = the LATENT size */ };
+       IR_STAGE_CLDM = 7 /* ir_cldm_sample: n, h, w = the LATENT size */, IR_STAGE_CLDM_PIPELINE = 8 /* ir_cldm_pipeline: image size */ };
 /* ir_pipeline flags */
 enum { IR_FLAG_NO_PREPROCESS = 1, IR_FLAG_TILED = 2, IR_FLAG_FIX_WAVELET = 4, IR_FLAG_FIX_ADAIN = 8,
        /* ir_pipeline only, needs ir_dit_control_configure: run the DiT step with the ControlNet-Half branch, condition latent
@@ -86,9 +86,18 @@ int ir_unet_configure(ir_ctx* ctx, int which, int model_channels, int n_levels, 
 int ir_unet_set_context(ir_ctx* ctx, void* stream, const float* context_host, int n_tok);
 /* sample_log (cldm.py:568-588): out = zT + diffusion_model(zT, t, context, control = control_model(zT, hint = c_latent, t, context)).
  * zT, c_latent, out: device fp32 NCHW [n][4][h][w] at LATENT resolution (h, w multiples of 2^(n_levels-1)); c_latent NULL = the UNet
- * alone (cond['c_latent'] is None). timestep: num_timesteps - 1 = 999 in the reference. ws: ir_workspace_bytes(ctx, IR_STAGE_CLDM, n, h, w, ...). */
-int ir_cldm_sample(ir_ctx* ctx, void* stream, const float* zT, const float* c_latent, float* out, int n, int h, int w, float timestep, void* ws,
-                   size_t ws_bytes);
+ * alone (cond['c_latent'] is None). timestep: num_timesteps - 1 = 999 in the reference. return_v != 0: out = v alone (apply_model's eps,
+ * cldm.py:511-527). ws: ir_workspace_bytes(ctx, IR_STAGE_CLDM, n, h, w, ...). */
+int ir_cldm_sample(ir_ctx* ctx, void* stream, const float* zT, const float* c_latent, float* out, int n, int h, int w, float timestep, int return_v,
+                   void* ws, size_t ws_bytes);
+
+/* get_input + sample_log + decode_first_stage of Reflow_ControlLDM as one launch sequence (cldm.py:494-509,568-588,548-549):
+ * control = SwinIR(lq) (skipped under IR_FLAG_NO_PREPROCESS); c_latent = mode(cond_encoder(control * 2 - 1)) * scale_factor (the encoder half
+ * of the bound VAE: upload the checkpoint's cond_encoder.* there); z = zT + v; samples = (decoder(z / scale_factor) + 1) / 2.
+ * lq, samples, control_out (NULL: not returned): device fp32 NCHW [n][3][h][w], h, w multiples of 64; zT: device fp32 [n][4][h/8][w/8].
+ * ws: ir_workspace_bytes(ctx, IR_STAGE_CLDM_PIPELINE, n, h, w, flags, 0, 0). */
+int ir_cldm_pipeline(ir_ctx* ctx, void* stream, const float* lq, const float* zT, float* samples, float* control_out, int n, int h, int w, int flags,
+                     float timestep, float scale_factor, void* ws, size_t ws_bytes);
 
 /* The prompt producer's text encoder: T5EncoderModel.from_pretrained(...) — diffusion/model/t5.py:80 (T5 v1.1: gated-GELU, relative
  * position bias, no biases). Tensors `t5.embed`, `t5.final_ln`, `t5.l{i}.{ln1,ln2,qkv,o,wi,wo}`; the additive position bias of a

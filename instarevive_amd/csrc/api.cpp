@@ -1013,7 +1013,7 @@ void usizes_block(const UNetW& m, const UBlock& blk, int N, int H, int W, USizes
 }
 
 // zT, c_latent (null: the UNet alone, control = None), out: fp32 NCHW [n][4][h][w]
-void cldm_run(Run& r, const float* zT, const float* c_latent, float* out, int n, int h, int w, float timestep) {
+void cldm_run(Run& r, const float* zT, const float* c_latent, float* out, int n, int h, int w, float timestep, bool add_zT = true) {
     UNetW& U = r.c->unet[0];
     UNetW& Cn = r.c->unet[1];
     const bool ctl = c_latent != nullptr;
@@ -1127,7 +1127,30 @@ void cldm_run(Run& r, const float* zT, const float* c_latent, float* out, int n,
     gn_any(r, U.out_norm, fin, b.t1, b.gws, n, (long)h * w, 1, 1e-5f);
     float* v4 = r.a.alloc<float>(T0 * 4);
     conv(r, U.out_conv, b.t1, n, h, w, U.out_conv.cin, v4, 4, 1, 1, 1, 0, ACT_NONE, 0.f, nullptr, 0, 0);
-    LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_cldm_out(zT, v4, 4, out, n, (long)h * w, r.s), "cldm_out");
+    LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_cldm_out(add_zT ? zT : nullptr, v4, 4, out, n, (long)h * w, r.s), "cldm_out");
+    r.a.release(mk);
+}
+
+// The whole ControlLDM restoration of one batch, as Reflow_ControlLDM.get_input + sample_log + decode_first_stage chain it (cldm.py:494-509,
+// 568-588, 548-549): control = SwinIR(lq); c_latent = mode(cond_encoder(control * 2 - 1)) * scale_factor; z = zT + v;
+// x = decode(z / scale_factor); samples = (x + 1) / 2. lq, control_out (optional), samples: fp32 NCHW [n][3][h][w]; zT: [n][4][h/8][w/8].
+void cldm_pipeline_run(Run& r, const float* lq, const float* zT, float* samples, float* control_out, int n, int h, int w, int flags, float timestep,
+                       float sf) {
+    const size_t mk = r.a.mark();
+    const int lh = h / 8, lw = w / 8;
+    float* control = control_out ? control_out : r.a.alloc<float>((long)n * 3 * h * w);
+    const float* cimg = lq;
+    if (!(flags & IR_FLAG_NO_PREPROCESS)) {
+        swinir_run(r, lq, control, n, h, w);
+        cimg = control;
+    }
+    float* c_latent = r.a.alloc<float>((long)n * 4 * lh * lw);
+    float* z = r.a.alloc<float>((long)n * 4 * lh * lw);
+    vae_encode_run(r, cimg, c_latent, n, h, w, 2.f, -1.f, sf);
+    cldm_run(r, zT, c_latent, z, n, lh, lw, timestep);
+    float* px = r.a.alloc<float>((long)n * h * w * 4);
+    vae_decode_run(r, z, 1.f / sf, px, n, lh, lw);
+    LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_nhwc_to_nchw(px, 4, samples, n, 3, (long)h * w, 0.5f, 0.5f, 0, r.s), "nhwc_to_nchw");
     r.a.release(mk);
 }
 
@@ -1877,6 +1900,11 @@ static int stage_dispatch(ir_ctx* c, Run& r, int stage, int n, int h, int w, int
             if (!c->unet[0].ok) return fail(c, -11, "UNet not configured");
             cldm_run(r, fin, c->unet[1].ok ? fin : nullptr, fout, n, h, w, 0.f);
             break;
+        case IR_STAGE_CLDM_PIPELINE:
+            if (!c->unet[0].ok || !c->unet[1].ok || !c->vae.enc.ok || !c->vae.dec.ok || (!c->swin.ok && !(flags & IR_FLAG_NO_PREPROCESS)))
+                return fail(c, -11, "ControlLDM pipeline: a model is not configured");
+            cldm_pipeline_run(r, fin, fin, fout, nullptr, n, h, w, flags, 0.f, 1.f);
+            break;
         default: return fail(c, -1, "unknown stage %d", stage);
     }
     return 0;
@@ -1968,8 +1996,8 @@ int ir_vae_decode(ir_ctx* c, void* stream, const float* lat, float* out, int n, 
 
 // Reflow_ControlLDM.sample_log (diffusion/cldm.py:568-588): out = zT + UNet(zT, t, context, control = ControlNet(zT, c_latent, t, context)).
 // zT, c_latent, out: fp32 NCHW [n][4][h][w] (latent resolution); c_latent null: the UNet alone (cond['c_latent'] is None, cldm.py:577-578).
-int ir_cldm_sample(ir_ctx* c, void* stream, const float* zT, const float* c_latent, float* out, int n, int h, int w, float timestep, void* ws,
-                   size_t ws_bytes) {
+int ir_cldm_sample(ir_ctx* c, void* stream, const float* zT, const float* c_latent, float* out, int n, int h, int w, float timestep, int return_v,
+                   void* ws, size_t ws_bytes) {
     REQUIRE(c && c->unet[0].ok, "UNet not configured");
     REQUIRE(c->unet[0].ctx_ok, "ir_unet_set_context has not run since the UNet was configured");
     if (c_latent) {
@@ -1979,9 +2007,24 @@ int ir_cldm_sample(ir_ctx* c, void* stream, const float* zT, const float* c_late
     const int div = 1 << (c->unet[0].n_levels - 1);
     if (!zT || !out || n < 1 || h < div || w < div || h % div || w % div)
         return fail(c, -1, "ir_cldm_sample: latent %dx%d must be a positive multiple of %d", h, w, div);
-    use_ctx(c);
     Run r = make_run(c, stream, ws, ws_bytes, false);
-    cldm_run(r, zT, c_latent, out, n, h, w, timestep);
+    cldm_run(r, zT, c_latent, out, n, h, w, timestep, !return_v);
+    return finish(r, c, ws_bytes);
+}
+
+// log_images / test_step of Reflow_ControlLDM in one call (cldm.py:494-509,548-588): samples = (decode((zT + v) / scale_factor) + 1) / 2 with
+// the control image from the SwinIR preprocess model (skipped under IR_FLAG_NO_PREPROCESS: lq IS the control image) and c_latent from the
+// condition encoder. lq, samples, control_out (NULL: not returned): device fp32 NCHW [n][3][h][w], h and w multiples of 64; zT: [n][4][h/8][w/8].
+int ir_cldm_pipeline(ir_ctx* c, void* stream, const float* lq, const float* zT, float* samples, float* control_out, int n, int h, int w, int flags,
+                     float timestep, float scale_factor, void* ws, size_t ws_bytes) {
+    REQUIRE(c && c->unet[0].ok && c->unet[1].ok, "UNet / ControlNet not configured");
+    REQUIRE(c->unet[0].ctx_ok && c->unet[1].ctx_ok, "ir_unet_set_context has not run since the UNet / ControlNet were configured");
+    REQUIRE(c->vae.enc.ok && c->vae.dec.ok, "VAE (condition encoder + first-stage decoder) not configured");
+    REQUIRE(c->swin.ok || (flags & IR_FLAG_NO_PREPROCESS), "SwinIR not configured");
+    if (!lq || !zT || !samples || scale_factor <= 0.f) return fail(c, -1, "ir_cldm_pipeline: bad argument");
+    if (int e = check_size(c, n, h, w, 64)) return e;
+    Run r = make_run(c, stream, ws, ws_bytes, false);
+    cldm_pipeline_run(r, lq, zT, samples, control_out, n, h, w, flags, timestep, scale_factor);
     return finish(r, c, ws_bytes);
 }
 

@@ -127,14 +127,14 @@ __global__ __launch_bounds__(256) void cldm_in_kernel(const float* __restrict__ 
         o[1] = o[2] = o[3] = make_uint4(0, 0, 0, 0);
     }
 }
-// ---- out[n][c][p] = zT[n][c][p] + v[n*HW + p][c]  (cldm.py:588; v: the fp32 NHWC rows of the UNet's last conv, 4 of v_cs columns)
+// ---- out[n][c][p] = zT[n][c][p] + v[n*HW + p][c]  (cldm.py:588; zT null: v alone = apply_model's eps; v: the fp32 NHWC rows of the UNet's last conv, 4 of v_cs columns)
 __global__ __launch_bounds__(256) void cldm_out_kernel(const float* __restrict__ zT, const float* __restrict__ v, int v_cs, float* __restrict__ out, long HW,
                                                        long total) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const long n = i / HW, p = i - n * HW;
         const float* vp = v + i * v_cs;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) out[(n * 4 + c) * HW + p] = zT[(n * 4 + c) * HW + p] + vp[c];
+        for (int c = 0; c < 4; ++c) out[(n * 4 + c) * HW + p] = (zT ? zT[(n * 4 + c) * HW + p] : 0.f) + vp[c];
     }
 }
 // ---- rows of C bf16 channels from src (row stride src_cs) into dst (row stride dst_cs), optionally dst = src + add (add row stride add_cs)

@@ -487,3 +487,176 @@ def dit_shapes(cfg):
         s[p + "ff.net.0.proj.weight"], s[p + "ff.net.0.proj.bias"] = (mlp, C), (mlp,)
         s[p + "ff.net.2.weight"], s[p + "ff.net.2.bias"] = (C, mlp), (C,)
     return s
+
+
+# ------------------------------------------------------------------------------------------------ SD-UNet / ControlNet (ControlLDM, N4)
+def unet_layout(cfg, control=False):
+    """Block structure UNetModel.__init__ / ControlNet.__init__ build (openaimodel.py:520-700, cldm.py:143-274) for the options of
+    configs/cldm.yaml: per input / output block the list of layers ('conv', cin, cout) | ('res', cin, cout) | ('xf', ch) | ('down', ch) |
+    ('up', ch); returns (input_blocks, middle channels, output_blocks, channels of the 12 skips)."""
+    mc, mult, nrb = cfg["model_channels"], list(cfg["channel_mult"]), cfg["num_res_blocks"]
+    att = set(cfg["attention_resolutions"])
+    inb = [[("conv", cfg["in_channels"] + (cfg["hint_channels"] if control else 0), mc)]]
+    chans, ch, ds = [mc], mc, 1
+    for level, m in enumerate(mult):
+        for _ in range(nrb):
+            inb.append([("res", ch, m * mc)] + ([("xf", m * mc)] if ds in att else []))
+            ch = m * mc
+            chans.append(ch)
+        if level != len(mult) - 1:
+            inb.append([("down", ch)])
+            chans.append(ch)
+            ds *= 2
+    mid, skips, outb = ch, list(chans), []
+    if not control:
+        for level in range(len(mult) - 1, -1, -1):
+            for i in range(nrb + 1):
+                layers = [("res", ch + chans.pop(), mc * mult[level])]
+                ch = mc * mult[level]
+                if ds in att:
+                    layers.append(("xf", ch))
+                if level and i == nrb:
+                    layers.append(("up", ch))
+                    ds //= 2
+                outb.append(layers)
+    return inb, mid, outb, skips
+
+
+def _unet_walk(cfg, control):
+    """(reference parameter prefix, device tensor prefix, layer tuple) of every layer."""
+    inb, mid, outb, skips = unet_layout(cfg, control)
+    P = "cnet" if control else "unet"
+    leaf = {"conv": "conv", "res": "res", "xf": "xf", "down": "down", "up": "up"}
+    for i, layers in enumerate(inb):
+        for k, L in enumerate(layers):
+            yield f"input_blocks.{i}.{k}", f"{P}.in{i}.{leaf[L[0]]}", L
+    for k, L in enumerate([("res", mid, mid), ("xf", mid), ("res", mid, mid)]):
+        yield f"middle_block.{k}", f"{P}.mid{k}.{leaf[L[0]]}", L
+    for i, layers in enumerate(outb):
+        for k, L in enumerate(layers):
+            yield f"output_blocks.{i}.{k}", f"{P}.out{i}.{leaf[L[0]]}", L
+
+
+def unet_expected_keys(cfg, control=False):
+    keys = [f"time_embed.{i}.{t}" for i in (0, 2) for t in ("weight", "bias")]
+    wb = ("weight", "bias")
+    for src, _, L in _unet_walk(cfg, control):
+        if L[0] == "conv":
+            keys += [f"{src}.{t}" for t in wb]
+        elif L[0] == "res":
+            keys += [f"{src}.{n}.{t}" for n in ("in_layers.0", "in_layers.2", "emb_layers.1", "out_layers.0", "out_layers.3") for t in wb]
+            if L[1] != L[2]:
+                keys += [f"{src}.skip_connection.{t}" for t in wb]
+        elif L[0] == "xf":
+            keys += [f"{src}.{n}.{t}" for n in ("norm", "proj_in", "proj_out") for t in wb]
+            tb = f"{src}.transformer_blocks.0"
+            for a in ("attn1", "attn2"):
+                keys += [f"{tb}.{a}.{n}.weight" for n in ("to_q", "to_k", "to_v", "to_out.0")] + [f"{tb}.{a}.to_out.0.bias"]
+            keys += [f"{tb}.{n}.{t}" for n in ("ff.net.0.proj", "ff.net.2", "norm1", "norm2", "norm3") for t in wb]
+        elif L[0] == "down":
+            keys += [f"{src}.op.{t}" for t in wb]
+        elif L[0] == "up":
+            keys += [f"{src}.conv.{t}" for t in wb]
+    if control:
+        skips = unet_layout(cfg, True)[3]
+        keys += [f"zero_convs.{i}.0.{t}" for i in range(len(skips)) for t in wb] + [f"middle_block_out.0.{t}" for t in wb]
+    else:
+        keys += [f"out.{i}.{t}" for i in (0, 2) for t in wb]
+    return keys
+
+
+def pack_unet(sd, cfg, control=False):
+    """UNetModel / ControlNet state dict (reference names) -> the device tensors ir_unet_configure binds (include/instarevive_hip.h)."""
+    P = "cnet" if control else "unet"
+    out = {}
+    for dst, src in ((f"{P}.temb1", "time_embed.0"), (f"{P}.temb2", "time_embed.2")):
+        out[dst + ".w"], out[dst + ".b"] = sd[src + ".weight"].float().contiguous(), sd[src + ".bias"].float().contiguous()
+
+    def conv3(dst, src, cin_pad=None, cout_pad=None):
+        w, b = sd[src + ".weight"], sd[src + ".bias"]
+        out[dst + ".w"] = pack_conv3x3(w, cin_pad or w.shape[1], cout_pad or w.shape[0])
+        out[dst + ".b"] = pad_vec(b, cout_pad or w.shape[0])
+
+    def norm(dst, src):
+        out[dst + ".g"], out[dst + ".b"] = sd[src + ".weight"].float().contiguous(), sd[src + ".bias"].float().contiguous()
+
+    for src, dst, L in _unet_walk(cfg, control):
+        if L[0] == "conv":
+            conv3(dst, src, cin_pad=32)
+        elif L[0] == "res":
+            norm(dst + ".n1", src + ".in_layers.0")
+            conv3(dst + ".c1", src + ".in_layers.2")
+            out[dst + ".emb.w"] = sd[src + ".emb_layers.1.weight"].float().contiguous()
+            out[dst + ".emb.b"] = (sd[src + ".emb_layers.1.bias"].float() + sd[src + ".in_layers.2.bias"].float()).contiguous()
+            norm(dst + ".n2", src + ".out_layers.0")
+            conv3(dst + ".c2", src + ".out_layers.3")
+            if L[1] != L[2]:
+                _pack_lin(out, dst + ".sc", sd[src + ".skip_connection.weight"], sd[src + ".skip_connection.bias"])
+        elif L[0] == "xf":
+            c = L[1]
+            tb = src + ".transformer_blocks.0."
+            zeros = torch.zeros
+            norm(dst + ".gn", src + ".norm")
+            _pack_lin(out, dst + ".pin", sd[src + ".proj_in.weight"], sd[src + ".proj_in.bias"])
+            _pack_lin(out, dst + ".pout", sd[src + ".proj_out.weight"], sd[src + ".proj_out.bias"])
+            for i in (1, 2, 3):
+                norm(f"{dst}.ln{i}", f"{tb}norm{i}")
+            _pack_lin(out, dst + ".qkv", torch.cat([sd[tb + f"attn1.{n}.weight"] for n in ("to_q", "to_k", "to_v")], 0), zeros(3 * c))
+            _pack_lin(out, dst + ".ao", sd[tb + "attn1.to_out.0.weight"], sd[tb + "attn1.to_out.0.bias"])
+            _pack_lin(out, dst + ".cq", sd[tb + "attn2.to_q.weight"], zeros(c))
+            _pack_lin(out, dst + ".ckv", torch.cat([sd[tb + "attn2.to_k.weight"], sd[tb + "attn2.to_v.weight"]], 0), zeros(2 * c))
+            _pack_lin(out, dst + ".co", sd[tb + "attn2.to_out.0.weight"], sd[tb + "attn2.to_out.0.bias"])
+            _pack_lin(out, dst + ".ff1", sd[tb + "ff.net.0.proj.weight"], sd[tb + "ff.net.0.proj.bias"])
+            _pack_lin(out, dst + ".ff2", sd[tb + "ff.net.2.weight"], sd[tb + "ff.net.2.bias"])
+        elif L[0] == "down":
+            conv3(dst, src + ".op")
+        elif L[0] == "up":
+            conv3(dst, src + ".conv")
+    if control:
+        skips = unet_layout(cfg, True)[3]
+        for i in range(len(skips)):
+            _pack_lin(out, f"{P}.zero{i}", sd[f"zero_convs.{i}.0.weight"], sd[f"zero_convs.{i}.0.bias"])
+        _pack_lin(out, f"{P}.midzero", sd["middle_block_out.0.weight"], sd["middle_block_out.0.bias"])
+    else:
+        norm(f"{P}.out.norm", "out.0")
+        conv3(f"{P}.out.conv", "out.2", cout_pad=32)
+    return out
+
+
+def vae_ldm_to_diffusers(sd, n_levels=4, num_res_blocks=2):
+    """Parameter names of the LDM AutoencoderKL (ldm/models/autoencoder.py + ldm/modules/diffusionmodules/model.py: `encoder.down.0.block.0.
+    norm1.weight`, `decoder.up.3.upsample.conv.weight`, `encoder.mid.attn_1.q.weight` [C,C,1,1], ...) -> the diffusers names models.
+    AutoencoderKL loads. Both halves optional (the cond_encoder of cldm.py:476-480 has an encoder and quant_conv only)."""
+    out = {}
+    res_pairs = (("norm1", "norm1"), ("conv1", "conv1"), ("norm2", "norm2"), ("conv2", "conv2"), ("nin_shortcut", "conv_shortcut"))
+    attn_pairs = (("norm", "group_norm"), ("q", "to_q"), ("k", "to_k"), ("v", "to_v"), ("proj_out", "to_out.0"))
+
+    def mv(src, dst, flatten=False):
+        for t in ("weight", "bias"):
+            if f"{src}.{t}" in sd:
+                v = sd[f"{src}.{t}"]
+                out[f"{dst}.{t}"] = v.reshape(v.shape[0], -1) if flatten and t == "weight" else v
+
+    def res(src, dst):
+        for a, b in res_pairs:
+            mv(f"{src}.{a}", f"{dst}.{b}")
+
+    for half in ("encoder", "decoder"):
+        if f"{half}.conv_in.weight" not in sd:
+            continue
+        mv(f"{half}.conv_in", f"{half}.conv_in"); mv(f"{half}.conv_out", f"{half}.conv_out"); mv(f"{half}.norm_out", f"{half}.conv_norm_out")
+        res(f"{half}.mid.block_1", f"{half}.mid_block.resnets.0"); res(f"{half}.mid.block_2", f"{half}.mid_block.resnets.1")
+        for a, b in attn_pairs:
+            mv(f"{half}.mid.attn_1.{a}", f"{half}.mid_block.attentions.0.{b}", flatten=a != "norm")
+        for l in range(n_levels):
+            if half == "encoder":
+                for j in range(num_res_blocks):
+                    res(f"encoder.down.{l}.block.{j}", f"encoder.down_blocks.{l}.resnets.{j}")
+                mv(f"encoder.down.{l}.downsample.conv", f"encoder.down_blocks.{l}.downsamplers.0.conv")
+            else:
+                i = n_levels - 1 - l
+                for j in range(num_res_blocks + 1):
+                    res(f"decoder.up.{l}.block.{j}", f"decoder.up_blocks.{i}.resnets.{j}")
+                mv(f"decoder.up.{l}.upsample.conv", f"decoder.up_blocks.{i}.upsamplers.0.conv")
+    mv("quant_conv", "quant_conv"); mv("post_quant_conv", "post_quant_conv")
+    return out
