@@ -660,3 +660,42 @@ def vae_ldm_to_diffusers(sd, n_levels=4, num_res_blocks=2):
                 mv(f"decoder.up.{l}.upsample.conv", f"decoder.up_blocks.{i}.upsamplers.0.conv")
     mv("quant_conv", "quant_conv"); mv("post_quant_conv", "post_quant_conv")
     return out
+
+
+def unet_shapes(cfg, control=False):
+    """{parameter name: shape} of the reference's UNetModel / ControlNet for cfg (synthetic weights of bench tools)."""
+    mc, temb, ctx = cfg["model_channels"], 4 * cfg["model_channels"], cfg["context_dim"]
+    s = {"time_embed.0.weight": (temb, mc), "time_embed.0.bias": (temb,), "time_embed.2.weight": (temb, temb), "time_embed.2.bias": (temb,)}
+
+    def put(p, *shape):
+        s[p + ".weight"], s[p + ".bias"] = tuple(shape), (shape[0],)
+
+    for src, _, L in _unet_walk(cfg, control):
+        if L[0] == "conv":
+            put(src, L[2], L[1], 3, 3)
+        elif L[0] == "res":
+            put(src + ".in_layers.0", L[1]); put(src + ".in_layers.2", L[2], L[1], 3, 3); put(src + ".emb_layers.1", L[2], temb)
+            put(src + ".out_layers.0", L[2]); put(src + ".out_layers.3", L[2], L[2], 3, 3)
+            if L[1] != L[2]:
+                put(src + ".skip_connection", L[2], L[1], 1, 1)
+        elif L[0] == "xf":
+            c, tb = L[1], src + ".transformer_blocks.0"
+            put(src + ".norm", c); put(src + ".proj_in", c, c); put(src + ".proj_out", c, c)
+            for a, kd in (("attn1", c), ("attn2", ctx)):
+                s[f"{tb}.{a}.to_q.weight"], s[f"{tb}.{a}.to_k.weight"], s[f"{tb}.{a}.to_v.weight"] = (c, c), (c, kd), (c, kd)
+                put(f"{tb}.{a}.to_out.0", c, c)
+            put(tb + ".ff.net.0.proj", 8 * c, c); put(tb + ".ff.net.2", c, 4 * c)
+            for n in ("norm1", "norm2", "norm3"):
+                put(f"{tb}.{n}", c)
+        elif L[0] == "down":
+            put(src + ".op", L[1], L[1], 3, 3)
+        elif L[0] == "up":
+            put(src + ".conv", L[1], L[1], 3, 3)
+    if control:
+        skips = unet_layout(cfg, True)[3]
+        for i, c in enumerate(skips):
+            put(f"zero_convs.{i}.0", c, c, 1, 1)
+        put("middle_block_out.0", skips[-1], skips[-1], 1, 1)
+    else:
+        put("out.0", mc); put("out.2", cfg["out_channels"], mc, 3, 3)
+    return s

@@ -202,3 +202,57 @@ def test_clean_caption_matches_the_reference_fixture():
         assert clean_caption(c, fix=lambda t: t) == once            # the fixture's ftfy stand-in is the identity: these captions do not need repair
         assert text_preprocessing(c) == twice, (c, text_preprocessing(c), twice)
         assert text_preprocessing(c, use_text_preprocessing=False) == plain
+
+
+# ---------------------------------------------------------------------------------------------- ControlLDM (N4) host logic
+def test_unet_layout_keys_and_packing():
+    """weights.unet_expected_keys == the parameter names of the reference's UNetModel / ControlNet (via oracle.cldm.state_dict_shapes, which
+    the fixture generator loads into the reference modules with strict=True); pack_unet emits the tensors ir_unet_configure binds."""
+    import torch
+    from instarevive_amd import weights as W
+    from oracle import cldm as ocldm
+    from tests.golden._det import det_state_dict
+    for cfg, n_u, n_c in ((dict(ocldm.DEFAULT_CFG), 686, 324), (dict(ocldm.DEFAULT_CFG, model_channels=64, num_head_channels=32, context_dim=64), 686, 324)):
+        for control, n in ((False, n_u), (True, n_c)):
+            shapes = ocldm.state_dict_shapes(cfg, control)
+            assert set(W.unet_expected_keys(cfg, control)) == set(shapes) and len(shapes) == n
+    cfg = dict(ocldm.DEFAULT_CFG, model_channels=64, num_head_channels=32, context_dim=64)
+    inb, mid, outb, skips = W.unet_layout(cfg)
+    assert len(inb) == 12 and len(outb) == 12 and len(skips) == 12 and mid == 256
+    assert [L[0][1] for L in outb] == [512, 512, 512, 512, 512, 384, 384, 256, 192, 192, 128, 128]   # h + skip channels of each decoder block
+    assert [len(L) for L in outb] == [1, 1, 2, 2, 2, 3, 2, 2, 3, 2, 2, 2]                              # res [+ xf] [+ up]
+    sd = det_state_dict(ocldm.state_dict_shapes(cfg), seed=5)
+    p = W.pack_unet(sd, cfg)
+    assert p["unet.in0.conv.w"].shape == (64, 9 * 32) and p["unet.out.conv.w"].shape == (32, 9 * 64)
+    assert p["unet.in1.res.emb.w"].shape == (64, 256) and p["unet.in1.xf.qkv.w"].shape == (192, 64) and p["unet.in1.xf.ff1.w"].shape == (512, 64)
+    assert p["unet.in1.xf.ckv.w"].shape == (128, 64) and p["unet.out2.up.w"].shape == (256, 9 * 256) and p["unet.in3.down.w"].shape == (64, 9 * 64)
+    torch.testing.assert_close(p["unet.in1.res.emb.b"], sd["input_blocks.1.0.emb_layers.1.bias"] + sd["input_blocks.1.0.in_layers.2.bias"])
+    assert float(p["unet.in1.xf.qkv.b"].abs().max()) == 0.0   # to_q / to_k / to_v have no bias
+    pc = W.pack_unet(det_state_dict(ocldm.state_dict_shapes(cfg, True), seed=6), cfg, control=True)
+    assert pc["cnet.in0.conv.w"].shape == (64, 9 * 32) and "cnet.zero11.w" in pc and "cnet.midzero.w" in pc and "cnet.out.conv.w" not in pc
+
+
+def test_vae_ldm_names_round_trip():
+    """weights.vae_ldm_to_diffusers inverts the diffusers -> LDM renaming the fixtures use (ldm/modules/diffusionmodules/model.py names)."""
+    import torch
+    from instarevive_amd import weights as W
+    from oracle import vae as ovae
+    from tests.golden._det import det_state_dict
+    from tests.test_cldm_gpu import diffusers_to_ldm
+    sd = det_state_dict(ovae.state_dict_shapes(dict(ch=32)), seed=9)
+    ldm = diffusers_to_ldm(sd)
+    assert "encoder.down.0.block.0.norm1.weight" in ldm and "decoder.up.3.upsample.conv.weight" in ldm and ldm["encoder.mid.attn_1.q.weight"].dim() == 4
+    back = W.vae_ldm_to_diffusers(ldm)
+    assert set(back) == set(sd)
+    for k in sd:
+        torch.testing.assert_close(back[k].reshape(sd[k].shape), sd[k], rtol=0, atol=0)
+    enc_only = W.vae_ldm_to_diffusers({k: v for k, v in ldm.items() if k.startswith(("encoder.", "quant_conv."))})
+    assert all(k.startswith(("encoder.", "quant_conv.")) for k in enc_only) and len(enc_only) == sum(k.startswith(("encoder.", "quant_conv.")) for k in sd)
+
+
+def test_unet_shapes_match_the_reference_parameter_table():
+    from instarevive_amd import weights as W
+    from oracle import cldm as ocldm
+    for cfg in (dict(ocldm.DEFAULT_CFG), dict(ocldm.DEFAULT_CFG, model_channels=64, num_head_channels=32, context_dim=64)):
+        for control in (False, True):
+            assert {k: tuple(v) for k, v in W.unet_shapes(cfg, control).items()} == {k: tuple(v) for k, v in ocldm.state_dict_shapes(cfg, control).items()}
