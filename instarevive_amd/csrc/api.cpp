@@ -295,6 +295,7 @@ struct Run {
     const void* gn_x = nullptr;
     int gn_chunks = 0;
     hipEvent_t chain = nullptr;  // profiling: the event recorded right after the previous profiled launch of this run (see ProfScope)
+    bool splitk = false;         // conv() / linear() may split K over extra workgroups (IGemmParams::allow_splitk): set by the UNet path
     bool live() const { return !a.dry && rc == 0 && !a.overflow; }
     void chk(int r, const char* w) {
         if (r != 0 && rc == 0) { rc = r; where = w; }
@@ -339,7 +340,7 @@ struct ProfScope {
 void conv(Run& r, const Conv& cw, const bf16_t* in, int N, int H, int W, int in_cs, void* out, int out_cs, int out_f32, int stride,
           int pad, int up, int act, float slope, const void* res, int res_f32, int res_cs, bf16_t* out2 = nullptr, int out2_cs = 0,
           const float* gate = nullptr, int res_mod = 0, float out_scale = 1.f) {
-    if (!r.live()) return;
+    if (!r.live() && !(r.a.dry && r.splitk)) return;
     IGemmParams p;
     memset(&p, 0, sizeof p);
     p.in = in; p.NB = N; p.H = H; p.W = W; p.Cin = cw.cin; p.in_cs = in_cs;
@@ -357,6 +358,19 @@ void conv(Run& r, const Conv& cw, const bf16_t* in, int N, int H, int W, int in_
     p.gate = gate; p.gate_stride = 0; p.rows_per_batch = 1 << 30;
     p.res = res; p.res_f32 = res_f32; p.res_cs = res_cs; p.res_mod = res_mod;
     p.out = out; p.out_f32 = out_f32; p.out_cs = out_cs; p.out2 = out2; p.out2_cs = out2_cs;
+    size_t ks_mark = 0;
+    if (r.splitk) {   // small-M launches of the UNet path: K split over extra workgroups, partial sums in arena scratch (sized in dry runs too)
+        p.allow_splitk = 1;
+        if (const int ks = ir_igemm_splitk(p); ks > 1) {
+            ks_mark = r.a.mark() + 1;
+            p.ks_ws = r.a.alloc<float>((size_t)ks * p.M * p.Cout_pad);
+        }
+    }
+    struct Release {   // the scratch is dead once the launch is queued (stream order)
+        Run& r; size_t m;
+        ~Release() { if (m) r.a.release(m - 1); }
+    } rel{r, ks_mark};
+    if (!r.live()) return;
     static const bool no_gn_fuse = getenv("IR_NO_GN_FUSE") != nullptr;  // experiment knob
     if (r.gn_want && r.gn_buf && !out_f32 && cw.cout % 32 == 0 && !no_gn_fuse) {
         p.gn_cpg = cw.cout / 32;
@@ -1017,6 +1031,8 @@ void cldm_run(Run& r, const float* zT, const float* c_latent, float* out, int n,
     UNetW& U = r.c->unet[0];
     UNetW& Cn = r.c->unet[1];
     const bool ctl = c_latent != nullptr;
+    const bool splitk_before = r.splitk;
+    r.splitk = true;   // latent-resolution launches: 64 ... 4096 pixels
     unet_update_timestep(r, U, timestep);
     if (ctl) unet_update_timestep(r, Cn, timestep);
     const size_t mk = r.a.mark();
@@ -1129,6 +1145,7 @@ void cldm_run(Run& r, const float* zT, const float* c_latent, float* out, int n,
     conv(r, U.out_conv, b.t1, n, h, w, U.out_conv.cin, v4, 4, 1, 1, 1, 0, ACT_NONE, 0.f, nullptr, 0, 0);
     LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_cldm_out(add_zT ? zT : nullptr, v4, 4, out, n, (long)h * w, r.s), "cldm_out");
     r.a.release(mk);
+    r.splitk = splitk_before;
 }
 
 // The whole ControlLDM restoration of one batch, as Reflow_ControlLDM.get_input + sample_log + decode_first_stage chain it (cldm.py:494-509,

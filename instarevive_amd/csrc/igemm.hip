@@ -272,7 +272,16 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IGemmParams p) {
     const int m0 = mt * BM, n0 = nt * BN;
 
     const int cchunks = p.Cin / BK;
-    const int KT = TAPS * cchunks;
+    // split-K (p.ksplit > 1, blockIdx.y = split): this workgroup reduces k-tiles [kbeg, kbeg + KT) and stores its partial tile into slice
+    // blockIdx.y of the fp32 workspace p.out ([ksplit][M][Cout_pad]; splitk_finish_kernel adds the slices in order: deterministic). Small-M
+    // launches (the UNet's 8 x 8 and 16 x 16 levels) otherwise leave most CUs idle behind 10-40 workgroups that stream 30-60 MB of weights
+    int kbeg = 0, KT = TAPS * cchunks;
+    if (p.ksplit > 1) {
+        const int per = (KT + p.ksplit - 1) / p.ksplit;   // the launcher chose ksplit so that no split is empty
+        kbeg = (int)blockIdx.y * per;
+        KT = min(per, KT - kbeg);
+        p.out = reinterpret_cast<float*>(p.out) + (long)blockIdx.y * p.M * p.Cout_pad;
+    }
 
     // ---- per-lane DMA sources. Every lane always issues its loads on a valid address: rows beyond M re-read row M-1 (never
     // stored) and zero-padding taps read the zero page.
@@ -286,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IGemmParams p) {
         a_sw[i] = (lslot ^ ((row / RB) % SP)) * 8;
         if (TAPS == 1) {
             a_n[i] = a_oy[i] = a_ox[i] = 0;
-            a_ptr[i] = p.in + (long)m * p.in_cs + a_sw[i];
+            a_ptr[i] = p.in + (long)m * p.in_cs + a_sw[i] + (long)kbeg * BK;
         } else {
             const int hw = p.Ho * p.Wo;
             const int n = m / hw, rem = m - n * hw;
@@ -311,9 +320,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IGemmParams p) {
 #pragma unroll
     for (int i = 0; i < B_I; ++i) {
         const int row = min((wid + 4 * i) * RPI + lrow, BN - 1);
-        b_ptr[i] = p.wgt + (long)(n0 + row) * p.wgt_rs + (lslot ^ ((row / RB) % SP)) * 8;
+        b_ptr[i] = p.wgt + (long)(n0 + row) * p.wgt_rs + (lslot ^ ((row / RB) % SP)) * 8 + (long)kbeg * BK;
     }
-    int cc = 0, tap = 0;
+    int cc = TAPS > 1 ? kbeg % cchunks : 0, tap = TAPS > 1 ? kbeg / cchunks : 0;
     auto stage = [&](int buf) {  // asynchronous global -> LDS copy of the k-tile the pointers address; then advance them
 #pragma unroll
         for (int i = 0; i < A_I; ++i) {
@@ -360,7 +369,11 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IGemmParams p) {
     // while the last MFMAs of tile kt still issue.
     constexpr int NK = BK / 16;
     auto advance = [&]() { if (TAPS > 1 && ++cc == cchunks) { cc = 0; set_tap(++tap); } };
-    if (TAPS > 1) set_tap(0);
+    if (TAPS > 1) {
+        set_tap(tap);
+#pragma unroll
+        for (int i = 0; i < A_I; ++i) a_ptr[i] += cc * BK;
+    }
     stage(0);
     if (KT > 1) { advance(); stage(1); }
     wait_dma();
@@ -1445,10 +1458,67 @@ static int launch_halo(const IGemmParams& p, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// Second half of a split-K launch: out = act(sum_k ws[k] + bias) * out_scale * gate + res, the epilogue order of igemm_epilogue, slices added in
+// a fixed order. ws: [nsplit][M][Cout_pad] fp32.
+__global__ __launch_bounds__(256) void splitk_finish_kernel(IGemmParams p, const float* __restrict__ ws, int nsplit) {
+    const int vpr = p.Cout_pad >> 2;
+    const long nv = (long)p.M * vpr;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
+        const long m = i / vpr;
+        const int n0 = (int)(i - m * vpr) * 4;
+        f32x4 a = *reinterpret_cast<const f32x4*>(ws + m * p.Cout_pad + n0);
+        for (int k = 1; k < nsplit; ++k) a += *reinterpret_cast<const f32x4*>(ws + ((long)k * p.M + m) * p.Cout_pad + n0);
+        const long rm = p.res_mod > 0 ? m % p.res_mod : m;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int n = n0 + e;
+            if (n >= p.Cout) break;
+            float x = a[e] + (p.bias ? p.bias[n] : 0.f);
+            switch (p.act) {
+                case IR_ACT_GELU_ERF: x = gelu_erf(x); break;
+                case IR_ACT_GELU_TANH: x = gelu_tanh(x); break;
+                case IR_ACT_LRELU: x = x > 0.f ? x : x * p.slope; break;
+                case IR_ACT_SILU: x = silu(x); break;
+                default: break;
+            }
+            x *= p.out_scale * (p.gate ? p.gate[n] : 1.f);
+            if (p.res) x += p.res_f32 ? reinterpret_cast<const float*>(p.res)[rm * p.res_cs + n] : bf2f(reinterpret_cast<const bf16_t*>(p.res)[rm * p.res_cs + n]);
+            if (p.out_f32) reinterpret_cast<float*>(p.out)[m * p.out_cs + n] = x;
+            else reinterpret_cast<bf16_t*>(p.out)[m * p.out_cs + n] = f2bf(x);
+            if (p.out2) p.out2[m * p.out2_cs + n] = f2bf(x);
+        }
+    }
+}
+
+// Split count ir_launch_igemm uses for p (0: no split): only launches whose caller allows it (p.allow_splitk) and provides the workspace
+// (p.ks_ws, ir_igemm_splitk(p) * p.M * p.Cout_pad floats), with at most 48 output tiles and at least 24 k-tiles.
+int ir_igemm_splitk(const IGemmParams& p) {
+    static const bool off = getenv("IR_NO_SPLITK") != nullptr;   // experiment knob
+    if (!p.allow_splitk || off || p.fp8 || p.gn_part || (p.Cin & 63) || (p.Cout_pad & 3)) return 0;
+    const int BN = p.Cout_pad % 128 == 0 ? 128 : (p.Cout_pad % 64 == 0 ? 64 : 32);
+    const int tiles = ((p.M + 127) / 128) * (p.Cout_pad / BN), KT = p.taps * (p.Cin / 64);
+    if (tiles > 48 || KT < 24) return 0;
+    int ks = std::min(384 / tiles, KT / 6);
+    if (ks < 2) return 0;
+    const int per = (KT + ks - 1) / ks;
+    return (KT + per - 1) / per;   // no empty split
+}
+
 template <int BM, int BN, int WM, int WN>
-static int launch_cfg(const IGemmParams& p, hipStream_t s) {
+static int launch_cfg(const IGemmParams& pin, hipStream_t s) {
+    IGemmParams p = pin;
     const int MT = (p.M + BM - 1) / BM, NT = p.Cout_pad / BN;
-    const int grid = ((MT + 7) / 8) * 8 * NT;
+    const int tiles = ((MT + 7) / 8) * 8 * NT;
+    const int ks = p.ks_ws ? ir_igemm_splitk(pin) : 0;
+    const dim3 grid(tiles, ks > 1 ? ks : 1);
+    if (ks > 1) {   // partial tiles into the workspace; bias / activation / residual in splitk_finish_kernel
+        p.ksplit = ks;
+        p.bias = nullptr; p.act = IR_ACT_NONE; p.out_scale = 1.f; p.gate = nullptr; p.res = nullptr; p.out2 = nullptr; p.gn_part = nullptr;
+        p.out = p.ks_ws; p.out_f32 = 1; p.out_cs = p.Cout_pad;
+        p.vec = 1;
+    } else {
+        p.ksplit = 0;
+    }
     static const bool force32 = getenv("IR_IGEMM_BK32") != nullptr;  // experiment knob
     const bool k64 = (p.Cin & 63) == 0 && !force32;
     if (p.taps == 9) {
@@ -1461,6 +1531,11 @@ static int launch_cfg(const IGemmParams& p, hipStream_t s) {
         if (k64 && m16) hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, 1, 64, true>), dim3(grid), dim3(256), 0, s, p);
         else if (k64) hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, 1, 64>), dim3(grid), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, 1, 32>), dim3(grid), dim3(256), 0, s, p);
+    }
+    if (ks > 1) {
+        const long nv = (long)pin.M * (pin.Cout_pad / 4);
+        const unsigned fg = (unsigned)std::min<long>((nv + 255) / 256, 4096);
+        hipLaunchKernelGGL(splitk_finish_kernel, dim3(fg), dim3(256), 0, s, pin, pin.ks_ws, ks);
     }
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -1494,6 +1569,7 @@ static bool igemm_vec(const IGemmParams& p) {
 int ir_igemm_kernel_id(const IGemmParams& pin) {
     IGemmParams p = pin;
     p.vec = igemm_vec(p);
+    if (p.ks_ws && ir_igemm_splitk(p) > 1) return 4;
     if (ir_conv_s1_takes(p) || ir_conv_s1_fp8_takes(p)) return 0;
     if (takes_halo_pp(p)) return 1;
     if (takes_gemm_pp(p)) return 2;
@@ -1523,6 +1599,11 @@ int ir_launch_igemm(const IGemmParams& pin, hipStream_t s) {
     }
     if (p.gn_part && (!p.vec || p.gn_chunks <= 0 || p.gn_chunks != ir_igemm_gn_chunks(p))) return -13;
     if (p.fp8 && (!takes_halo(p) || !p.gate || p.act != IR_ACT_NONE)) return -14;  // fp8 operands: stride-1 3x3 halo kernel only
+    if (p.ks_ws && ir_igemm_splitk(p) > 1) {   // small-M launch of a caller that allows split-K: generic kernel, K split over blockIdx.y
+        if (p.Cout_pad % 128 == 0) return launch_cfg<128, 128, 2, 2>(p, s);
+        if (p.Cout_pad % 64 == 0) return launch_cfg<128, 64, 2, 2>(p, s);
+        return launch_cfg<128, 32, 4, 1>(p, s);
+    }
     if (ir_conv_s1_takes(p)) return ir_launch_conv_s1(p, s);
     if (ir_conv_s1_fp8_takes(p)) return ir_launch_conv_s1_fp8(p, s);
     if (takes_halo_pp(p)) return launch_halo_pp(p, s);

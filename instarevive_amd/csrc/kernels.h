@@ -46,12 +46,19 @@ struct IGemmParams {
     // G = Cout / gn_cpg, chunk = the workgroup's pixel tile within the image. Set gn_chunks from ir_igemm_gn_chunks().
     float* gn_part;
     int gn_cpg, gn_chunks;
+    // Split-K for small-M launches: the caller sets allow_splitk and, when ir_igemm_splitk(p) > 1, ks_ws (that many slices of p.M * Cout_pad
+    // floats of scratch); ksplit is set by the launcher. Each split stores its partial tile in its own slice; a second kernel adds the
+    // slices in order and applies the epilogue (deterministic).
+    int allow_splitk, ksplit;
+    float* ks_ws;
 };
 int ir_launch_igemm(const IGemmParams& p, hipStream_t s);
 // which kernel ir_launch_igemm picks for p: 0 conv_halo_s1, 1 conv_halo_pp, 2 gemm_pp, 3 conv_halo, 4 igemm_kernel (profiler rows)
 int ir_igemm_kernel_id(const IGemmParams& p);
 // Pixel tiles per image the kernel ir_launch_igemm would pick for p writes statistics for, or 0 if this launch cannot fuse them.
 int ir_igemm_gn_chunks(const IGemmParams& p);
+// Split count ir_launch_igemm would use for p given a workspace (0: none); see IGemmParams::allow_splitk.
+int ir_igemm_splitk(const IGemmParams& p);
 
 // conv_s1.hip: the one-wave-per-SIMD 3x3 convolution (16 x 32 patches x 128 channels); ir_launch_igemm routes eligible launches to it
 bool ir_conv_s1_takes(const IGemmParams& p);

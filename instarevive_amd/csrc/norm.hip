@@ -8,6 +8,8 @@
 //   gn_apply    : y = silu(x * scale + shift), 16-byte vectors                      (1 read, 1 write)
 // LayerNorm follows swinir.py:210,216,256,288,769 (affine, eps 1e-5) and PixArtMS.py:58,64,74-77 +
 // PixArt_blocks.py:24-25 (no affine, eps 1e-6, then x*(1+scale)+shift).
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -249,21 +251,61 @@ __global__ __launch_bounds__(256) void gn_reduce_groups_kernel(const float* __re
     if (tid < 2 * G) part2[((long)n * R + r) * 2 * G + tid] = ((s_red[0][tid] + s_red[1][tid]) + s_red[2][tid]) + s_red[3][tid];
 }
 
+// One workgroup per (group, image): thread t adds the partials of chunks t, t + 256, ... in fp64, then a fixed-order tree over the 256
+// threads (bit-identical run to run), then the group's channels get their scale / shift. Replaces the single-block finalise (12-14 us of
+// dependent loads per call) and, for images with more than 512 tiles, the extra reduction launch in front of it. grid = (G, N).
+__global__ __launch_bounds__(256) void gn_finalize_group_kernel(const float* __restrict__ part, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float* __restrict__ scale,
+                                                                float* __restrict__ shift, long HW, int C, int G, int chunks, float eps) {
+    __shared__ double s_s[256], s_q[256];
+    const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
+    const int cpg = C / G;
+    double s = 0.0, q = 0.0;
+    const float* pp = part + (long)n * chunks * 2 * G + g;
+    for (int ch = tid; ch < chunks; ch += 256) {
+        s += (double)pp[(long)ch * 2 * G];
+        q += (double)pp[(long)ch * 2 * G + G];
+    }
+    s_s[tid] = s;
+    s_q[tid] = q;
+    __syncthreads();
+#pragma unroll
+    for (int st = 128; st > 0; st >>= 1) {
+        if (tid < st) { s_s[tid] += s_s[tid + st]; s_q[tid] += s_q[tid + st]; }
+        __syncthreads();
+    }
+    if (tid < cpg) {
+        const double cnt = (double)HW * cpg;
+        const double mean = s_s[0] / cnt;
+        double var = s_q[0] / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const int c = g * cpg + tid;
+        const double a = (1.0 / sqrt(var + (double)eps)) * (double)gamma[c];
+        scale[(long)n * C + c] = (float)a;
+        shift[(long)n * C + c] = (float)((double)beta[c] - mean * a);
+    }
+}
+
 int ir_launch_groupnorm_fused(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, const float* part, float* ws, int N,
                               long HW, int C, int G, int chunks, float eps, int do_silu, hipStream_t s, int out_fp8, float out_mul) {
     if (C % 8 || C > 512 || G > 64 || C % G || 256 % (C / 8) || 256 % G || chunks <= 0) return -2;
     if (HW >= (1L << 31)) return -3;
     float* scale = ws;                 // [N][C]
     float* shift = ws + (long)N * C;   // [N][C]
-    if (chunks > 512) {                // two-stage: a single finalise block per image would crawl through megabytes of partials
-        if (2 * G > 64) return -2;
-        const int R = 256;
-        float* part2 = shift + (long)N * C;  // [N][R][2][G]: fits the stand-alone path's partial area of ws (R*2*G <= chunks*2*C)
-        hipLaunchKernelGGL(gn_reduce_groups_kernel, dim3(R, N), dim3(256), 0, s, part, part2, G, chunks, R);
-        part = part2;
-        chunks = R;
+    static const bool old_finalize = getenv("IR_GN_FINALIZE_V1") != nullptr;   // experiment knob: round 2's single-block finalise
+    if (old_finalize) {
+        if (chunks > 512) {                // two-stage: a single finalise block per image would crawl through megabytes of partials
+            if (2 * G > 64) return -2;
+            const int R = 256;
+            float* part2 = shift + (long)N * C;  // [N][R][2][G]: fits the stand-alone path's partial area of ws (R*2*G <= chunks*2*C)
+            hipLaunchKernelGGL(gn_reduce_groups_kernel, dim3(R, N), dim3(256), 0, s, part, part2, G, chunks, R);
+            part = part2;
+            chunks = R;
+        }
+        hipLaunchKernelGGL(gn_finalize_groups_kernel, dim3(N), dim3(256), 0, s, part, gamma, beta, scale, shift, (int)HW, C, G, chunks, eps);
+    } else {
+        hipLaunchKernelGGL(gn_finalize_group_kernel, dim3(G, N), dim3(256), 0, s, part, gamma, beta, scale, shift, HW, C, G, chunks, eps);
     }
-    hipLaunchKernelGGL(gn_finalize_groups_kernel, dim3(N), dim3(256), 0, s, part, gamma, beta, scale, shift, (int)HW, C, G, chunks, eps);
     launch_gn_apply(x, y, scale, shift, N, HW, C, do_silu, s, out_fp8, out_mul);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
