@@ -95,6 +95,7 @@ int ir_cldm_sample(ir_ctx* ctx, void* stream, const float* zT, const float* c_la
  * control = SwinIR(lq) (skipped under IR_FLAG_NO_PREPROCESS); c_latent = mode(cond_encoder(control * 2 - 1)) * scale_factor (the encoder half
  * of the bound VAE: upload the checkpoint's cond_encoder.* there); z = zT + v; samples = (decoder(z / scale_factor) + 1) / 2.
  * lq, samples, control_out (NULL: not returned): device fp32 NCHW [n][3][h][w], h, w multiples of 64; zT: device fp32 [n][4][h/8][w/8].
+ * IR_FLAG_GRAPH: record the launch sequence once per exact signature and replay it (as ir_pipeline does).
  * ws: ir_workspace_bytes(ctx, IR_STAGE_CLDM_PIPELINE, n, h, w, flags, 0, 0). */
 int ir_cldm_pipeline(ir_ctx* ctx, void* stream, const float* lq, const float* zT, float* samples, float* control_out, int n, int h, int w, int flags,
                      float timestep, float scale_factor, void* ws, size_t ws_bytes);

@@ -231,7 +231,8 @@ struct ir_ctx {
     // hipGraph cache of ir_pipeline (IR_FLAG_GRAPH): one instantiated graph per exact call signature. `generation` changes whenever
     // device allocations or bindings may have moved (upload with a new size, *_configure, set_prompt), which drops every graph.
     struct GraphKey {
-        const void *in, *out, *stage1, *ws;
+        const void *in, *out, *stage1, *ws, *extra;   // extra + kind: which entry point recorded it (0 ir_pipeline, 1 ir_cldm_pipeline)
+        int kind;
         size_t ws_bytes;
         int n, h, w, flags, tile_size, tile_stride;
         float timestep, acp, sf;
@@ -2040,9 +2041,59 @@ int ir_cldm_pipeline(ir_ctx* c, void* stream, const float* lq, const float* zT, 
     REQUIRE(c->swin.ok || (flags & IR_FLAG_NO_PREPROCESS), "SwinIR not configured");
     if (!lq || !zT || !samples || scale_factor <= 0.f) return fail(c, -1, "ir_cldm_pipeline: bad argument");
     if (int e = check_size(c, n, h, w, 64)) return e;
-    Run r = make_run(c, stream, ws, ws_bytes, false);
+    if (!(flags & IR_FLAG_GRAPH) || c->prof.on) {
+        Run r = make_run(c, stream, ws, ws_bytes, false);
+        cldm_pipeline_run(r, lq, zT, samples, control_out, n, h, w, flags, timestep, scale_factor);
+        return finish(r, c, ws_bytes);
+    }
+    // ---- hipGraph form (as in ir_pipeline): ~1100 mostly short launches at 512 x 512 recorded once per exact signature, then replayed
+    hipStream_t s = (hipStream_t)stream;
+    HIPOK(c, hipSetDevice(c->device));
+    if (c->graphs_generation != c->generation) {
+        for (auto& g : c->graphs) (void)hipGraphExecDestroy(g.exec);
+        c->graphs.clear();
+        c->graphs_generation = c->generation;
+    }
+    ir_ctx::GraphKey key;
+    memset(&key, 0, sizeof key);
+    key.kind = 1; key.in = lq; key.out = samples; key.stage1 = zT; key.extra = control_out; key.ws = ws; key.ws_bytes = ws_bytes;
+    key.n = n; key.h = h; key.w = w; key.flags = flags; key.timestep = timestep; key.sf = scale_factor;
+    auto stale = [&]() { c->unet[0].cached_t = c->unet[1].cached_t = -1e30f; };   // a replay rewrites the timestep tables for ITS timestep
+    for (auto& g : c->graphs)
+        if (g.key == key) {
+            stale();
+            HIPOK(c, hipGraphLaunch(g.exec, s));
+            return 0;
+        }
+    {
+        Run dry = make_run(c, nullptr, nullptr, 0, true);
+        cldm_pipeline_run(dry, lq, zT, samples, control_out, n, h, w, flags, timestep, scale_factor);
+        if (dry.a.peak > ws_bytes) return fail(c, -20, "workspace too small: need %zu bytes, got %zu", dry.a.peak, ws_bytes);
+    }
+    stale();   // the graph must contain the timestep-table kernels
+    if (!c->cap_stream) HIPOK(c, hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking));
+    HIPOK(c, hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
+    Run r = make_run(c, c->cap_stream, ws, ws_bytes, false);
     cldm_pipeline_run(r, lq, zT, samples, control_out, n, h, w, flags, timestep, scale_factor);
-    return finish(r, c, ws_bytes);
+    hipGraph_t graph = nullptr;
+    const hipError_t ee = hipStreamEndCapture(c->cap_stream, &graph);
+    stale();   // nothing ran yet
+    if (int rc = finish(r, c, ws_bytes)) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return rc;
+    }
+    if (ee != hipSuccess || !graph) return fail(c, -101, "hipStreamEndCapture: %s", hipGetErrorString(ee));
+    hipGraphExec_t exec = nullptr;
+    const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ei != hipSuccess) return fail(c, -101, "hipGraphInstantiate: %s", hipGetErrorString(ei));
+    if (c->graphs.size() >= 16) {
+        (void)hipGraphExecDestroy(c->graphs.front().exec);
+        c->graphs.erase(c->graphs.begin());
+    }
+    c->graphs.push_back({key, exec});
+    HIPOK(c, hipGraphLaunch(exec, s));
+    return 0;
 }
 
 int ir_color_fix(ir_ctx* c, void* stream, int kind, const float* content, const float* style, float* out, int n, int h, int w, void* ws,

@@ -241,3 +241,51 @@ def test_errors_are_loud(small):
     with pytest.raises(RuntimeError):  # latent not a multiple of 8 (three stride-2 levels)
         ctxt = torch.zeros(1, 77, CLDM_SMALL["context_dim"])
         m.sample_log({"c_concat": [torch.zeros(1, 3, 96, 96)], "c_crossattn": [ctxt], "c_latent": None}, zT=torch.zeros(1, 4, 12, 12))
+
+
+def test_nonsquare_timestep_and_context_changes(small):
+    """A non-square latent against the oracle; the per-timestep tables (emb_layers folded into the conv biases) and the per-context K / V caches
+    are rebuilt when the timestep / context changes and give the first result again when it changes back."""
+    m, sds = small
+    B, h, w = 1, 16, 24
+    zT, c_latent = det_input(61, (B, 4, h, w), -2.0, 2.0), det_input(62, (B, 4, h, w), -2.0, 2.0)
+    ctx_a = det_input(63, (1, 77, CLDM_SMALL["context_dim"]), -1.0, 1.0)
+    ctx_b = det_input(64, (1, 50, CLDM_SMALL["context_dim"]), -1.0, 1.0)   # another prompt length (50 tokens)
+    sd = {**{"model.diffusion_model." + k: v for k, v in sds["unet"].items()}, **{"control_model." + k: v for k, v in sds["cnet"].items()}}
+    cond = lambda c: {"c_concat": [torch.zeros(B, 3, 8 * h, 8 * w)], "c_crossattn": [c], "c_latent": [c_latent]}
+    first = m.sample_log(cond(ctx_a), zT=zT)
+    check(first, ocldm.reflow_sample(sd, zT, c_latent, ctx_a, CLDM_SMALL), "16 x 24 latent vs oracle")
+    t = torch.full((B,), 500.0)
+    eps500 = m.apply_model(zT, t, cond(ctx_a))
+    ref500 = ocldm.unet_forward(sds["unet"], zT, t, ctx_a, ocldm.controlnet_forward(sds["cnet"], zT, c_latent, t, ctx_a, CLDM_SMALL), CLDM_SMALL)
+    check(eps500, ref500, "apply_model at t = 500 vs oracle")
+    other = m.sample_log(cond(ctx_b), zT=zT)
+    check(other, ocldm.reflow_sample(sd, zT, c_latent, ctx_b, CLDM_SMALL), "50-token context vs oracle")
+    assert float((other.cpu() - first.cpu()).abs().max()) > 1e-3
+    again = m.sample_log(cond(ctx_a), zT=zT)
+    assert torch.equal(again.cpu(), first.cpu())
+
+
+def test_pipeline_hipgraph_replay_is_identical(small):
+    from instarevive_amd import _lib as L
+    from instarevive_amd.cldm import _set_context
+    m, _ = small
+    ctx = m.ctx
+    n, h, w = 1, 128, 128
+    lq = det_input(51, (n, 3, h, w)).cuda()
+    zT = det_input(52, (n, 4, h // 8, w // 8), -2.0, 2.0).cuda()
+    _set_context(ctx, det_input(71, (1, 77, CLDM_SMALL["context_dim"]), -1.0, 1.0))
+    m._ready(); m.preprocess_model._ready()
+    ws = ctx.workspace(ctx.ws_bytes(L.STAGE_CLDM_PIPELINE, n, h, w))
+    outs = []
+    for flags in (0, L.FLAG_GRAPH, L.FLAG_GRAPH, 0):   # plain, record + first replay, replay, plain
+        out = torch.zeros_like(lq)
+        if flags:
+            out = outs[1] if len(outs) > 1 else out   # a graph is keyed by its pointers: replay into the same buffer
+        ctx.check(ctx.lib.ir_cldm_pipeline(ctx.h, ctx.stream(), L.ptr(lq), L.ptr(zT), L.ptr(out), None, n, h, w, flags, 999.0, 0.18215, L.ptr(ws), ws.numel()),
+                  "ir_cldm_pipeline")
+        torch.cuda.synchronize()
+        outs.append(out.clone() if flags else out)
+    assert float(outs[0].std()) > 1e-3
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])

@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--verify", action="store_true", help="compare the last output with the fp32 CPU oracle")
+    ap.add_argument("--graph", action="store_true", help="replay the step as one hipGraph (IR_FLAG_GRAPH); no per-kernel rows")
     args = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("bench_cldm.py needs an MI355X GPU; the product path has no CPU fallback")
@@ -85,19 +86,20 @@ def main():
     log(f"workspace {ws.numel() / 2 ** 20:.0f} MiB")
 
     def step():
-        ctx.check(ctx.lib.ir_cldm_pipeline(ctx.h, ctx.stream(), L.ptr(lq), L.ptr(zT), L.ptr(samples), L.ptr(control), n, h, w, 0, 999.0, 0.18215,
+        ctx.check(ctx.lib.ir_cldm_pipeline(ctx.h, ctx.stream(), L.ptr(lq), L.ptr(zT), L.ptr(samples), L.ptr(control), n, h, w, L.FLAG_GRAPH if args.graph else 0, 999.0, 0.18215,
                                            L.ptr(ws), ws.numel()), "ir_cldm_pipeline")
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    ctx.profile_begin()
+    if not args.graph:
+        ctx.profile_begin()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
-    kprof = ctx.profile_end_kernels()
+    kprof = ctx.profile_end_kernels() if not args.graph else {}
     total_ms = sum(v["ms"] for v in kprof.values())
     flops = sum(v["flops"] for v in kprof.values()) / args.steps
     per_kernel = {}
@@ -135,13 +137,13 @@ def main():
         verify = dict(verified=bool(psnr >= 35.0 and float(got.std()) > 1e-3), psnr_vs_fp32_oracle_db=round(psnr, 2), rel_l2_vs_fp32_oracle=round(rel, 5),
                       oracle_seconds=round(time.time() - t1, 1), oracle_images_per_sec=round(n / (time.time() - t1), 4), oracle_threads=torch.get_num_threads())
         log(f"verify: {psnr:.2f} dB, rel-L2 {rel:.4f} against the fp32 oracle ({time.time() - t1:.1f} s on {torch.get_num_threads()} threads)")
-    dom = max(per_kernel, key=lambda k: per_kernel[k]["ms_per_step"])
+    dom = max(per_kernel, key=lambda k: per_kernel[k]["ms_per_step"]) if per_kernel else None
     line = {"metric": "ControlLDM one-step restoration images/sec", "value": round(n / dt, 3), "unit": "images/sec", "n_gpus": 1, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 3), "higher_is_better": True, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{h}x{w} LQ -> SwinIR -> condition encoder -> ControlNet + SD-2.1 UNet (t=999, 77x1024 context) -> decoder, batch {n}",
                        "weights": "seeded random, configs/cldm.yaml widths"},
             "algorithmic_tflop_per_step": round(flops / 1e12, 3), "path_tflops": round(flops / dt / 1e12, 1),
-            "roofline": dict(per_kernel[dom], kernel=dom, per_kernel=per_kernel)}
+            "roofline": dict(per_kernel[dom], kernel=dom, per_kernel=per_kernel) if dom else None, "graph": bool(args.graph)}
     if verify:
         line.update(verify)
     print(json.dumps(line), flush=True)
