@@ -513,10 +513,13 @@ void swinir_run(Run& r, const float* in, float* out, int n, int h, int w) {
     const float scale = 1.0f / sqrtf((float)m.C / (float)m.heads);
     for (const SwinLayer& L : m.layers) {
         const float* cur = xa;
+        bool have_ln1 = false;   // xn already holds norm1 of this block: written by the previous block's fused MLP kernel
+        static const bool no_ln_fuse = getenv("IR_NO_SWIN_LN_FUSE") != nullptr;   // experiment knob
         for (size_t j = 0; j < L.blocks.size(); ++j) {
             const SwinBlock& b = L.blocks[j];
             const bool last = j + 1 == L.blocks.size();
-            layernorm(r, cur, xn, nullptr, b.n1.g, b.n1.b, T, m.C, Cp, Cp, 1e-5f);
+            if (!have_ln1) layernorm(r, cur, xn, nullptr, b.n1.g, b.n1.b, T, m.C, Cp, Cp, 1e-5f);
+            have_ln1 = false;
             linear(r, b.qkv, xn, (int)T, Cp, qkv, 3 * m.heads * 32, 0, ACT_NONE, nullptr, 0, 0);
             if (b.proj_t && !g_ir_plain_kernels) {  // window attention of all heads -> proj -> + x in one launch, no LDS (swin_fused.hip)
                 LAUNCHK(r, PK_SWIN_ATTN_PROJ, 4.0 * (double)T * 64 * m.C + 2.0 * (double)T * m.C * m.C, 0.0,
@@ -527,8 +530,13 @@ void swinir_run(Run& r, const float* in, float* out, int n, int h, int w) {
                 linear(r, b.proj, att, (int)T, Cp, xb, Cp, 1, ACT_NONE, cur, 1, Cp);
             }
             if (b.mlp_t && !g_ir_plain_kernels) {  // LN2 -> fc1 -> GELU -> fc2 -> + x in one kernel, the token's state in registers throughout
+                // not the last block of the RSTB: the kernel also writes norm1 of the NEXT block (its qkv GEMM's input) into xn
+                const bool fuse_ln = !last && !no_ln_fuse && (m.C & 3) == 0;
+                const SwinBlock* nb = fuse_ln ? &L.blocks[j + 1] : nullptr;
                 LAUNCHK(r, PK_SWIN_MLP, 4.0 * (double)T * m.C * m.hid, 4.0 * (double)T * m.C * 2,
-                       ir_launch_swin_mlp(xb, xb, last ? xc : nullptr, b.mlp_t, b.mlp_v, T, m.C, m.hid_p, 1e-5f, r.s), "swin_mlp");
+                       ir_launch_swin_mlp(xb, xb, last ? xc : (fuse_ln ? xn : nullptr), b.mlp_t, b.mlp_v, T, m.C, m.hid_p, 1e-5f, r.s,
+                                          nb ? nb->n1.g : nullptr, nb ? nb->n1.b : nullptr), "swin_mlp");
+                have_ln1 = fuse_ln;
             } else {
                 layernorm(r, xb, xn, nullptr, b.n2.g, b.n2.b, T, m.C, Cp, Cp, 1e-5f);
                 linear(r, b.fc1, xn, (int)T, Cp, hid, m.hid_p, 0, ACT_GELU_ERF, nullptr, 0, 0);

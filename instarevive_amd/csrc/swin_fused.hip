@@ -27,10 +27,11 @@ constexpr int W1_ROW = 400, W1_TILE = 13312; // 32 rows x (384 + 16) B, padded t
 constexpr int W2_ROW = 80, W2_TILE = 15360;  // 192 rows x (64 + 16) B = 15 DMA pieces
 constexpr int SLOT = W1_TILE + W2_TILE;      // 28 672 B
 constexpr int PIECES = SLOT / 1024;          // 28
-constexpr int VEC_OFF = 2 * SLOT;            // fp32 vectors behind the ring: g[192] b[192] b1[hid_p <= 512] b2[192]
-constexpr int STG_OFF = VEC_OFF + 4608;      // wave-private staging of token rows: 8 waves x 3 slices x 4 KB
+constexpr int VEC_OFF = 2 * SLOT;            // fp32 vectors behind the ring: g[192] b[192] b1[hid_p <= 512] b2[192] | next block's LN1 g[192] b[192]
+constexpr int NEXT_OFF = 1152;               // float offset of the next block's LayerNorm vectors inside the vector area
+constexpr int STG_OFF = VEC_OFF + 6144;      // wave-private staging of token rows: 8 waves x 3 slices x 4 KB
 constexpr int STG_WAVE = 3 * 4096;
-constexpr int LDS_TOTAL = STG_OFF + 8 * STG_WAVE;   // 160 256 B
+constexpr int LDS_TOTAL = STG_OFF + 8 * STG_WAVE;   // 161 792 B
 }  // namespace swf
 
 // x, out: [T][192] fp32 (out may alias x); out2 (optional): [T][192] bf16 copy of the result; w: [NJ] tiles {W1 tile | W2 tile};
@@ -40,9 +41,14 @@ constexpr int LDS_TOTAL = STG_OFF + 8 * STG_WAVE;   // 160 256 B
 // the memory path), so each 32-channel slice t of the wave's 32 tokens (one 128-byte line per token) is brought in by LDS-DMA
 // pieces of 8 tokens x 128 B, chunk-swizzled on the source side, and read back as the lane's groups 32t + 8i + 4h; results leave
 // the same way (LDS image -> coalesced 16-byte stores). Three slices (12 KB per wave) at a time.
+// next_g / next_b (optional, C fp32 each): out2 then receives LayerNorm(result; next_g, next_b) instead of the plain bf16 copy - the norm1
+// of the NEXT SwinTransformerBlock (swinir.py:263), whose qkv GEMM reads out2 directly; the stand-alone LayerNorm launch between two
+// blocks of an RSTB disappears. The new token row is still in registers when the last product ends, so this costs one more pass through
+// the wave-private staging area.
+template <bool LN_NEXT>
 __global__ __launch_bounds__(512, 1) void swin_mlp_kernel(const float* __restrict__ x, float* __restrict__ out, bf16_t* __restrict__ out2,
                                                           const unsigned char* __restrict__ w, const float* __restrict__ vec, long T, int C,
-                                                          int NJ, float eps) {
+                                                          int NJ, float eps, const float* __restrict__ next_g, const float* __restrict__ next_b) {
     using namespace swf;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -61,6 +67,12 @@ __global__ __launch_bounds__(512, 1) void swin_mlp_kernel(const float* __restric
     float* vs = reinterpret_cast<float*>(smem + VEC_OFF);
     const int nvec = 3 * CP + 32 * NJ;
     for (int i = tid; i < nvec; i += 512) vs[i] = vec[i];
+    constexpr bool ln_next = LN_NEXT;
+    if (ln_next)
+        for (int i = tid; i < 2 * CP; i += 512) {
+            const int c = i < CP ? i : i - CP;
+            vs[NEXT_OFF + i] = c < C ? (i < CP ? next_g[c] : next_b[c]) : 0.f;   // padded channels normalise to exactly 0
+        }
 
     // wave-private staging: 3 slices x [32 tokens][128 B]; piece p of a slice = tokens 8p .. 8p+7, lane L -> token 8p + (L >> 3), slot L & 7
     unsigned char* stg = smem + STG_OFF + wu * STG_WAVE;
@@ -184,7 +196,9 @@ __global__ __launch_bounds__(512, 1) void swin_mlp_kernel(const float* __restric
                 const int t = 3 * hf + ts;
                 const f32x4 b2 = *reinterpret_cast<const f32x4*>(vs + 2 * CP + 32 * NJ + 32 * t + 8 * i + 4 * h);
                 f32x4* pa = reinterpret_cast<f32x4*>(frag_addr(ts, i));
-                *pa = f32x4{y[t][4 * i], y[t][4 * i + 1], y[t][4 * i + 2], y[t][4 * i + 3]} + b2 + *pa;
+                const f32x4 nx = f32x4{y[t][4 * i], y[t][4 * i + 1], y[t][4 * i + 2], y[t][4 * i + 3]} + b2 + *pa;
+                *pa = nx;
+                if (ln_next) xr[t][i] = nx;   // the new row, kept for the next block's LayerNorm
             }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -199,25 +213,67 @@ __global__ __launch_bounds__(512, 1) void swin_mlp_kernel(const float* __restric
                 const int ch = 32 * (3 * hf + ts) + 4 * (pslot ^ ((tk >> 1) & 7));
                 if (gt < T) {
                     *reinterpret_cast<f32x4*>(out + gt * CP + ch) = v;
-                    if (out2) *reinterpret_cast<uint2*>(out2 + gt * CP + ch) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+                    if (out2 && !ln_next) *reinterpret_cast<uint2*>(out2 + gt * CP + ch) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
                 }
             }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the image has been read before the next half's DMA lands on it
     }
+    if (!ln_next || !out2) return;
+    // ---- out2 = LayerNorm(new row) with the next block's norm1 parameters, same two-pass arithmetic as above
+    float t1 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t1 += (xr[t][i][0] + xr[t][i][1]) + (xr[t][i][2] + xr[t][i][3]);   // padded channels are zero
+    t1 += __shfl_xor(t1, 32);
+    const float mean2 = t1 / (float)C;
+    float t2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = xr[t][i][e] - mean2;
+                t2 += (32 * t + 8 * i + 4 * h + e < C) ? d * d : 0.f;
+            }
+    t2 += __shfl_xor(t2, 32);
+    const float rstd2 = rsqrtf(t2 / (float)C + eps);
+    // straight from the accumulator layout: lanes r and r + 32 hold adjacent 8-byte pieces of token r's row (16 B per token and
+    // instruction; a write needs no staging - nothing waits for it)
+    const long gtok = tok0 + r;
+    if (gtok < T) {
+        bf16_t* orow = out2 + gtok * CP + 4 * h;
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c0 = 32 * t + 8 * i + 4 * h;
+                const f32x4 g = *reinterpret_cast<const f32x4*>(vs + NEXT_OFF + c0), b = *reinterpret_cast<const f32x4*>(vs + NEXT_OFF + CP + c0);
+                const f32x4 v = (xr[t][i] - mean2) * rstd2 * g + b;
+                *reinterpret_cast<uint2*>(orow + 32 * t + 8 * i) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+            }
+    }
 }
 
 int ir_launch_swin_mlp(const float* x, float* out, bf16_t* out2, const void* w_tiles, const float* vec, long T, int C, int hid_p, float eps,
-                       hipStream_t s) {
+                       hipStream_t s, const float* next_g, const float* next_b) {
     if (T <= 0 || C <= 0 || C > swf::CP || hid_p <= 0 || (hid_p & 31) || hid_p > 512) return -2;
+    if ((next_g != nullptr) != (next_b != nullptr) || (next_g && (!out2 || (C & 3)))) return -2;
     const int NJ = hid_p / 32;
     const size_t lds = swf::LDS_TOTAL;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(swin_mlp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(swin_mlp_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(swin_mlp_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
         attr_set = true;
     }
-    hipLaunchKernelGGL(swin_mlp_kernel, dim3((unsigned)((T + 255) / 256)), dim3(512), lds, s, x, out, out2, reinterpret_cast<const unsigned char*>(w_tiles),
-                       vec, T, C, NJ, eps);
+    if (next_g)
+        hipLaunchKernelGGL(swin_mlp_kernel<true>, dim3((unsigned)((T + 255) / 256)), dim3(512), lds, s, x, out, out2, reinterpret_cast<const unsigned char*>(w_tiles),
+                           vec, T, C, NJ, eps, next_g, next_b);
+    else
+        hipLaunchKernelGGL(swin_mlp_kernel<false>, dim3((unsigned)((T + 255) / 256)), dim3(512), lds, s, x, out, out2, reinterpret_cast<const unsigned char*>(w_tiles),
+                           vec, T, C, NJ, eps, next_g, next_b);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
