@@ -252,7 +252,7 @@ def main():
     if args.fp8:
         feats = ctx.lib.ir_fp8_features()   # what THIS build moves to fp8 operands: the workload string says exactly that
         fp8_words = ", fp8 MFMA operands (MX-scaled e4m3) in " + " and ".join(
-            w for bit, w in ((1, "the VAE ResnetBlock 3x3 convs"), (2, "the DiT self-attention products")) if feats & bit)
+            w for bit, w in ((1, "the VAE ResnetBlock 3x3 convs"), (2, "the DiT self-attention products"), (4, "the VAE mid-block attention products")) if feats & bit)
         vae.enable_fp8(True)                                # packs + uploads the fp8 weight forms of the VAE resnet convs
         ctx.check(ctx.lib.ir_set_fp8(ctx.h, 0), "ir_set_fp8")  # ... the mode itself is switched per call by IR_FLAG_FP8
     if args.graph:

@@ -42,7 +42,7 @@ enum { IR_FLAG_NO_PREPROCESS = 1, IR_FLAG_TILED = 2, IR_FLAG_FIX_WAVELET = 4, IR
         * quantised per 64-key tile and head on the fly, probabilities per query and 32-key block through the MFMA's E8M0 block scales). */
        IR_FLAG_FP8 = 64 };
 /* which parts of the path IR_FLAG_FP8 / ir_set_fp8 move to fp8 operands in THIS build (bench.py words its workload string from it) */
-enum { IR_FP8_VAE_RESNET_CONVS = 1, IR_FP8_DIT_SELF_ATTENTION = 2 };
+enum { IR_FP8_VAE_RESNET_CONVS = 1, IR_FP8_DIT_SELF_ATTENTION = 2, IR_FP8_VAE_MID_ATTENTION = 4 };
 int ir_fp8_features(void);
 
 int ir_abi_version(void);
@@ -215,6 +215,12 @@ int ir_op_groupnorm_any(ir_ctx* ctx, void* stream, const uint16_t* x, uint16_t* 
 /* GEGLU (ldm/modules/attention.py:48-56): out[r][c] = ag[r][c] * gelu(ag[r][f + c]); ag [rows][2f] bf16, out [rows][f], f % 8 == 0. */
 int ir_op_geglu(ir_ctx* ctx, void* stream, const uint16_t* ag, uint16_t* out, long rows, int f);
 
+/* VAE mid-block attention (one head, d = 512; ldm/modules/diffusionmodules/model.py:181-205) with both products on fp8 (e4m3) MFMA operands
+ * (IR_FP8_VAE_MID_ATTENTION; attn_d512_fp8.hip): q / k / v / o [b][t][512] bf16, t a multiple of 128 (>= 256). ws receives, at its start, the
+ * quantised tile images [b][t / 64][66560 B] (K8 rows of 528 B - the first dword of row 0's padding (offset 512) holds the K | V E8M0
+ * exponent bytes - then V8^T rows of 64 B in the kernel's key order), then the flag and the V^T of the bf16 fallback. */
+int ir_op_attention_d512_fp8(ir_ctx* ctx, void* stream, const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* o, int b, int t, float scale,
+                             void* ws, size_t ws_bytes);
 /* DiT self-attention with both products on fp8 (e4m3) MFMA operands (IR_FP8_DIT_SELF_ATTENTION; attn_fp8.hip): q / k / v / o
  * [b][t][heads * 72] bf16, t a multiple of 64 (>= 256). ws receives, at its start, the quantised tile images
  * [b][heads][t / 64][10240 B] (K8 rows of 80 B, then V8^T rows of 64 B in the kernel's key order; row 79 of the V part starts with the

@@ -175,19 +175,20 @@ struct UNetW {
 enum { PC_CONV3X3 = 0, PC_LINEAR, PC_FLASH_ATTN, PC_SWIN_ATTN, PC_GROUPNORM, PC_LAYERNORM, PC_SOFTMAX, PC_TRANSPOSE, PC_OTHER, PC_COUNT };
 // kernel-level rows of the same measurement (ir_profile_end_kernels): one id per kernel (family) that matters on the 2048 x 2048 path,
 // each with the algorithmic FLOPs (un-padded dims) / bytes of its launches. Keep KERNEL_NAMES and KERNEL_CLASS in step.
-enum { PK_CONV_S1 = 0, PK_CONV_HALO_PP, PK_CONV_HALO, PK_CONV_S1_FP8, PK_CONV_FP8, PK_CONV_IGEMM, PK_GEMM_PP, PK_LINEAR_IGEMM, PK_SWIN_MLP, PK_ATTN_SELF, PK_ATTN_SELF_FP8,
+enum { PK_CONV_S1 = 0, PK_CONV_HALO_PP, PK_CONV_HALO, PK_CONV_S1_FP8, PK_CONV_FP8, PK_CONV_IGEMM, PK_GEMM_PP, PK_LINEAR_IGEMM, PK_SWIN_MLP, PK_ATTN_SELF, PK_ATTN_SELF_FP8, PK_ATTN_D512_FP8,
        PK_ATTN_D512, PK_ATTN_CROSS, PK_ATTN_OTHER, PK_SWIN_ATTN_PROJ, PK_SWIN_ATTN, PK_GN_APPLY, PK_GN_FULL, PK_LAYERNORM, PK_SOFTMAX, PK_TRANSPOSE, PK_OTHER,
        PK_COUNT };
 static const char* const KERNEL_NAMES[PK_COUNT] = {
     "conv3x3/conv_halo_s1_kernel", "conv3x3/conv_halo_pp_kernel", "conv3x3/conv_halo_kernel", "conv3x3/conv_halo_s1_fp8_kernel",
     "conv3x3/conv_halo_kernel<.., fp8>", "conv3x3/igemm_kernel<taps=9>",
     "linear/gemm_pp_kernel", "linear/igemm_kernel<taps=1>", "linear/swin_mlp_kernel", "flash_attn/flash_attn_pp2_kernel (DiT self-attention)",
-    "flash_attn/flash_attn_fp8_kernel (DiT self-attention, fp8 operands)", "flash_attn/flash_attn_d512_v2_kernel (VAE mid-block)",
+    "flash_attn/flash_attn_fp8_kernel (DiT self-attention, fp8 operands)", "flash_attn/flash_attn_d512_fp8_kernel (VAE mid-block, fp8 operands)",
+    "flash_attn/flash_attn_d512_v2_kernel (VAE mid-block)",
     "flash_attn/flash_attn_kernel<72,true> (DiT cross-attention)", "flash_attn/other", "swin_attn/swin_attn_proj_kernel", "swin_attn/swin_window_attn_kernel",
     "groupnorm/gn_finalize_groups+gn_apply (statistics from the conv epilogue)", "groupnorm/gn_partial+gn_finalize+gn_apply", "layernorm/layernorm_*_kernel",
     "softmax_rows/softmax_rows_kernel", "transpose/transpose_v*", "other/layout+glue"};
 static const int KERNEL_CLASS[PK_COUNT] = {PC_CONV3X3, PC_CONV3X3, PC_CONV3X3, PC_CONV3X3, PC_CONV3X3, PC_CONV3X3, PC_LINEAR, PC_LINEAR, PC_LINEAR, PC_FLASH_ATTN, PC_FLASH_ATTN,
-                                           PC_FLASH_ATTN, PC_FLASH_ATTN, PC_FLASH_ATTN, PC_SWIN_ATTN, PC_SWIN_ATTN, PC_GROUPNORM, PC_GROUPNORM, PC_LAYERNORM,
+                                           PC_FLASH_ATTN, PC_FLASH_ATTN, PC_FLASH_ATTN, PC_FLASH_ATTN, PC_SWIN_ATTN, PC_SWIN_ATTN, PC_GROUPNORM, PC_GROUPNORM, PC_LAYERNORM,
                                            PC_SOFTMAX, PC_TRANSPOSE, PC_OTHER};
 static const int CLASS_DEFAULT_KERNEL[PC_COUNT] = {PK_CONV_IGEMM, PK_LINEAR_IGEMM, PK_ATTN_OTHER, PK_SWIN_ATTN, PK_GN_FULL, PK_LAYERNORM, PK_SOFTMAX, PK_TRANSPOSE, PK_OTHER};
 struct ProfRec {
@@ -621,6 +622,10 @@ int attnblock(Run& r, const AttnW& w, bf16_t* B[3], int ci, float* gws, int N, i
     const bool flash = (C == 512 && (T & 63) == 0);
     // d = 512 without the redundant score product (attn_d512.hip): the whole batch in one launch, V^T in 32-key tiles
     const bool v2 = flash && !g_ir_plain_kernels;
+    // BASELINE.json configs[4]: both products on e4m3 operands (attn_d512_fp8.hip); the bf16 rescaling kernel stays behind it as the fallback
+    const bool f8 = v2 && r.c->fp8 && ir_attn_d512_fp8_takes((int)T);
+    // (sized whenever the shape allows it, so that ir_workspace_bytes - which does not know the per-call IR_FLAG_FP8 - covers the fp8 call)
+    uint8_t* f8tiles = (v2 && ir_attn_d512_fp8_takes((int)T)) ? r.a.alloc<uint8_t>(ir_attn_d512_fp8_tile_bytes(N, (int)T)) : nullptr;
     bf16_t* vtt = v2 ? r.a.alloc<bf16_t>((long)N * T * C) : nullptr;
     int* flag = v2 ? r.a.alloc<int>(16) : nullptr;
     float* S = flash ? nullptr : r.a.alloc<float>(T * ld);
@@ -631,7 +636,11 @@ int attnblock(Run& r, const AttnW& w, bf16_t* B[3], int ci, float* gws, int N, i
     linear(r, w.v, B[t1], (int)(N * T), C, v, C, 0, ACT_NONE, nullptr, 0, 0);
     const int dsub = (C % 128 == 0) ? 128 : (C % 64 == 0 ? 64 : 32);
     const float sc = 1.0f / sqrtf((float)C);
-    if (v2) {
+    if (f8) {
+        LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_zero_f32(reinterpret_cast<float*>(flag), 1, r.s), "zero");
+        LAUNCHK(r, PK_ATTN_D512_FP8, 4.0 * (double)N * T * T * C, 0.0,
+               ir_launch_flash_attn_d512_fp8(q, k, v, o, f8tiles, N, (int)T, C, C, T * C, T * C, sc, flag, r.s), "vae_flash_attn_fp8");
+    } else if (v2) {
         LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_zero_f32(reinterpret_cast<float*>(flag), 1, r.s), "zero");
         LAUNCH(r, PC_TRANSPOSE, 0.0, 4.0 * (double)N * T * C, ir_launch_transpose_v_tiles(v, vtt, N, (int)T, C, T * C, T * C, r.s), "transpose_v_tiles");
         LAUNCHK(r, PK_ATTN_D512, 4.0 * (double)N * T * T * C, 0.0,
@@ -2251,7 +2260,7 @@ int ir_tiled_blend_pixels(ir_ctx* c, void* stream, const float* px_tiles, uint8_
 // d = 512 attention), the independent second implementation of the same arithmetic that bench.py and the tests cross-check the
 // fast kernels against. Process-wide.
 // fp8 mode of the stage entry points (ir_pipeline: IR_FLAG_FP8): VAE resnet convs whose fp8 weights were uploaded run on fp8 operands
-int ir_fp8_features(void) { return IR_FP8_VAE_RESNET_CONVS | IR_FP8_DIT_SELF_ATTENTION; }
+int ir_fp8_features(void) { return IR_FP8_VAE_RESNET_CONVS | IR_FP8_DIT_SELF_ATTENTION | IR_FP8_VAE_MID_ATTENTION; }
 int ir_set_fp8(ir_ctx* c, int on) {
     if (!c) return -1;
     if (c->fp8 != (on != 0)) ++c->generation;   // recorded hipGraphs hold the launches of the mode they were captured in
@@ -2529,6 +2538,29 @@ int ir_op_attention_fp8(ir_ctx* c, void* stream, const uint16_t* q, const uint16
     if (!rc) rc = ir_launch_transpose_v(v, const_cast<bf16_t*>(p.vt), (long)t * heads * d, heads * d, d, b, heads, t, tkp, d, DV, s, p.ovf_flag);
     if (!rc) rc = ir_launch_flash_attn_fallback(p, s);
     return rc ? fail(c, rc, "flash_attn_fp8 failed (%d)", rc) : 0;
+}
+// q, k, v, o: [b][t][512] bf16 contiguous; single head, softmax scale `scale`. ws: tile images | flag | V^T of the bf16 fallback.
+int ir_op_attention_d512_fp8(ir_ctx* c, void* stream, const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* o, int b, int t, float scale,
+                             void* ws, size_t ws_bytes) {
+    if (!c || !q || !k || !v || !o || !ws) return fail(c, -1, "ir_op_attention_d512_fp8: null argument");
+    if (b < 1 || !ir_attn_d512_fp8_takes(t)) return fail(c, -1, "ir_op_attention_d512_fp8: t must be a multiple of 128, >= 256");
+    use_ctx(c);
+    hipStream_t s = (hipStream_t)stream;
+    const long ld = t + 64;
+    const size_t tb = (ir_attn_d512_fp8_tile_bytes(b, t) + 255) & ~(size_t)255;
+    if (ws_bytes < tb + 256 + (size_t)ld * 512 * 2) return fail(c, -20, "ir_op_attention_d512_fp8: workspace too small");
+    uint8_t* tiles = (uint8_t*)ws;
+    int* flag = (int*)((char*)ws + tb);
+    bf16_t* vt = (bf16_t*)((char*)ws + tb + 256);
+    if (ir_launch_zero_f32((float*)flag, 1, s)) return fail(c, -1, "zero failed");
+    int rc = ir_launch_flash_attn_d512_fp8(q, k, v, o, tiles, b, t, 512, 512, (long)t * 512, (long)t * 512, scale, flag, s);
+    if (rc) return fail(c, rc, "ir_launch_flash_attn_d512_fp8 failed (code %d)", rc);
+    for (int i = 0; i < b; ++i) {   // rescaling fallback: both launches return at once unless the kernel above raised the flag
+        rc = ir_launch_transpose_v(v + (long)i * t * 512, vt, 0, 512, 128, 1, 4, t, (int)ld, 128, 128, s, flag);
+        if (!rc) rc = ir_launch_flash_attn_d512(q + (long)i * t * 512, k + (long)i * t * 512, vt, o + (long)i * t * 512, t, 512, 512, ld, scale, s, flag);
+        if (rc) return fail(c, rc, "fallback launch failed (code %d)", rc);
+    }
+    return 0;
 }
 int ir_op_swin_attention(ir_ctx* c, void* stream, const uint16_t* qkv, uint16_t* out, const float* bias_t, int b, int h, int w,
                          int heads, int shift, float scale) {

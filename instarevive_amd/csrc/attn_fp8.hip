@@ -24,13 +24,9 @@
 // its own LDS image (LDS-DMA, lane-linear), ring of PF + 1 slots, fixed softmax reference with overflow flag + rescaling fallback.
 #include "common.h"
 #include "kernels.h"
+#include "attn_fp8_common.h"
 #include <type_traits>
 #include <utility>
-
-typedef __attribute__((address_space(3))) void* f8_lds_t;
-typedef __attribute__((ext_vector_type(8))) int i32x8;
-typedef __attribute__((ext_vector_type(2))) short s16x2;
-IR_DEVINL void f8_glds16(const void* g, f8_lds_t l) { __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0); }
 
 namespace f8a {
 constexpr int D = 72;
@@ -47,32 +43,7 @@ constexpr int OS = 96 + 8;                     // O staging row stride (elements
 constexpr int LDS_O = 8 * 32 * OS * 2;         // 53 248 B
 constexpr int LDS_BYTES = LDS_MAIN > LDS_O ? LDS_MAIN : LDS_O;
 constexpr float MARGIN = 24.0f;                // headroom below the first tile's maximum
-constexpr int E_BIAS = 7;                      // block exponent = exponent of the block maximum - 7: the maximum lands in [128, 256) <= 448
 }  // namespace f8a
-
-// E8M0 byte of a block whose largest magnitude is mx (>= 0): 2^(byte - 127) = 2^(floor(log2 mx) - 7), clamped to a valid byte
-IR_DEVINL int f8_block_byte(float mx) {
-    const int b = (int)(__builtin_bit_cast(uint32_t, mx) >> 23) - f8a::E_BIAS;
-    return b < 1 ? 1 : (b > 254 ? 254 : b);
-}
-// The MFMA's two 32-k scale blocks are BYTE RANGES of the operand registers, not lane halves (tools/fp8_cvt_probe.hip): block b = bytes
-// 16b .. 16b+15 of BOTH lanes (l, l ^ 32) of a row / column, and its exponent is read from lane (l & 31) + 32 b. This kernel gives both
-// blocks of a row / column ONE exponent (e4m3 is a floating format: the shared exponent only has to keep the largest of the 64 values
-// in range, values 2^17 below it do not matter to any sum), so an operand's exponent is the maximum over the lane PAIR's 2 x 32 values.
-// mx: the lane's own maximum (>= 0). Returns 2^(byte - 127) as a float (the convert's scale operand) and the byte for the MFMA.
-IR_DEVINL float f8_pair_scale(float mx, int& byte) {
-    float a = mx, b = mx;
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));   // a = {lower half's mx} on both halves, b = {upper half's}
-    const int t = max((int)(__builtin_bit_cast(uint32_t, __builtin_fmaxf(a, b)) >> 23), f8a::E_BIAS + 1);   // biased exponent of the pair maximum, >= 8
-    byte = t - f8a::E_BIAS;
-    return __builtin_bit_cast(float, (uint32_t)byte << 23);
-}
-// two fp32 / 2^(byte - 127) -> two e4m3 bytes in the low or the high half of `old`
-template <bool HI>
-IR_DEVINL uint32_t f8_cvt2(uint32_t old, float a, float b, float scale_f) {
-    return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(__builtin_bit_cast(s16x2, old), a, b, scale_f, HI));
-}
-
 // ---------------------------------------------------------------------------------------------------------------------------------
 // K, V [B][T][..] bf16 (token stride rs, head stride hs) -> tile images [B][Hh][T/64][10240 B] (see the header of this file)
 __global__ __launch_bounds__(256) void attn_fp8_prep_kernel(const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, uint8_t* __restrict__ tiles,
@@ -203,12 +174,8 @@ IR_DEVINL void f8_mfma_o(i32x8 a, i32x8 b, int sa, int sb) {   // a[LO : LO + 15
     if constexpr (IR_F8_NOP & 4) asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 a[%c4:%c5], %0, %1, a[%c4:%c5], %2, %3 op_sel_hi:[0,0,0]\n\ts_nop 15" ::"v"(a), "v"(b), "v"(sa), "v"(sb), "n"(LO), "n"(LO + 15));
     else asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 a[%c4:%c5], %0, %1, a[%c4:%c5], %2, %3 op_sel_hi:[0,0,0]" ::"v"(a), "v"(b), "v"(sa), "v"(sb), "n"(LO), "n"(LO + 15));
 }
-// An MFMA reads its A / B registers for a while after it has issued (the 8-register e4m3 operands longest), and nothing stalls a VALU
-// instruction that overwrites them meanwhile: with the fragment registers handed back to hipcc right behind the MFMA, an exponential of the
-// softmax landed in them and the product came out wrong - intermittently. keep() pins a value's registers up to the point where it stands
-// (an empty asm that "reads" it), i.e. past the softmax items that follow the MFMA.
-template <class T>
-IR_DEVINL void keep(const T& x) { asm volatile("" ::"v"(x)); }
+// (keep(): attn_fp8_common.h - pins an MFMA's operand registers past the softmax items that follow it: with the fragment registers handed
+// back to hipcc right behind the MFMA, an exponential landed in them and the product came out wrong - intermittently.)
 template <int I>
 IR_DEVINL float f8_acc_read() {
     float x;
@@ -216,12 +183,6 @@ IR_DEVINL float f8_acc_read() {
     return x;
 }
 #define IR_AGPR96_CLOBBERS "a0","a1","a2","a3","a4","a5","a6","a7","a8","a9","a10","a11","a12","a13","a14","a15","a16","a17","a18","a19","a20","a21","a22","a23","a24","a25","a26","a27","a28","a29","a30","a31","a32","a33","a34","a35","a36","a37","a38","a39","a40","a41","a42","a43","a44","a45","a46","a47","a48","a49","a50","a51","a52","a53","a54","a55","a56","a57","a58","a59","a60","a61","a62","a63","a64","a65","a66","a67","a68","a69","a70","a71","a72","a73","a74","a75","a76","a77","a78","a79","a80","a81","a82","a83","a84","a85","a86","a87","a88","a89","a90","a91","a92","a93","a94","a95"
-IR_DEVINL i32x8 f8_join(bf16x8 lo, bf16x8 hi) {
-    const uint4 a = __builtin_bit_cast(uint4, lo), b = __builtin_bit_cast(uint4, hi);
-    i32x8 r;
-    r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = b.x; r[5] = b.y; r[6] = b.z; r[7] = b.w;
-    return r;
-}
 
 __global__ __launch_bounds__(256, 1) void flash_attn_fp8_kernel(AttnF8Params p) {
     using namespace f8a;

@@ -178,6 +178,12 @@ int ir_launch_f32_to_bf16(const float* in, bf16_t* out, long n, hipStream_t s);
 int ir_launch_modtab(const float* t, const float* sst, float* out, int L, int R, int C, int t_stride, int scale_mask, hipStream_t s);
 int ir_launch_add_bias_rows(float* x, const float* b, long n, int C, hipStream_t s);
 
+// attn_d512_fp8.hip: the VAE mid-block attention (d = 512) on fp8 (e4m3) MFMA operands (BASELINE.json configs[4]); T % 128 == 0, T >= 256
+size_t ir_attn_d512_fp8_tile_bytes(int B, int T);
+bool ir_attn_d512_fp8_takes(int T);
+int ir_launch_flash_attn_d512_fp8(const bf16_t* q, const bf16_t* k, const bf16_t* v, bf16_t* o, uint8_t* tiles, int B, int T, int rs, int o_rs,
+                                  long qk_bs, long o_bs, float scale, int* ovf_flag, hipStream_t s);
+
 // unet.hip: memory-bound kernels of the ControlLDM path (GroupNorm over any channel count, GEGLU, latent ends, skip rows)
 int ir_gn_any_chunks(long HW);
 long ir_gn_any_ws_floats(int N, long HW, int C);

@@ -55,3 +55,44 @@ def quantise_q(q_bf16, scale_log2):
     s = torch.pow(2.0, (byte - 127).float())
     q8 = (blocks / s).to(torch.float8_e4m3fn).float() * s
     return torch.cat([q8.reshape(*qs.shape[:-1], 64), qs[..., 64:].to(torch.bfloat16).float()], dim=-1)
+
+
+# ---- attn_d512_fp8.hip (VAE mid-block attention, d = 512): per batch and 64-key tile 66 560 bytes
+#    K8    64 rows x 528 B: bytes 0..511 = e4m3(K[key][d] / 2^(bk - 127)); bytes 512..515 of row 0 = {bk, bv, 0, 0}
+#    V8^T  512 rows x 64 B, logical byte / chunk swizzle as above, value e4m3(V[key][d] / 2^(bv - 127))
+D512_TILE_BYTES, D512_K_BYTES, D512_KROW = 66560, 33792, 528
+
+
+def decode_tiles_d512(ws_u8, b, t):
+    """-> (K, V) dequantised, float32 [b][t][512], on ws_u8's device."""
+    nt = t // 64
+    img = ws_u8[: b * nt * D512_TILE_BYTES].view(b, nt, D512_TILE_BYTES)
+    dev = img.device
+    kpart = img[..., :D512_K_BYTES].reshape(b, nt, 64, D512_KROW)
+    vpart = img[..., D512_K_BYTES:].reshape(b, nt, 512, 64)
+    bk = kpart[..., 0, 512].to(torch.int32)
+    bv = kpart[..., 0, 513].to(torch.int32)
+    sk = torch.pow(2.0, (bk - 127).float())[..., None, None]
+    sv = torch.pow(2.0, (bv - 127).float())[..., None, None]
+    K = kpart[..., :512].contiguous().view(torch.float8_e4m3fn).float() * sk        # [b][nt][64][512]
+    d = torch.arange(512, device=dev)
+    pc = torch.arange(4, device=dev)
+    lc = pc[None, :] ^ ((d[:, None] >> 2) & 3)
+    rows = vpart.reshape(b, nt, 512, 4, 16)
+    logical = torch.empty_like(rows)
+    logical.scatter_(3, lc[None, None, :, :, None].expand(b, nt, 512, 4, 16), rows)
+    v8 = logical.reshape(b, nt, 512, 64).contiguous().view(torch.float8_e4m3fn).float() * sv   # [..][d][logical byte]
+    key = _key_of_logical().to(dev)
+    Vt = torch.empty_like(v8)
+    Vt[..., key] = v8
+    return K.reshape(b, t, 512), Vt.transpose(-1, -2).reshape(b, t, 512)
+
+
+def quantise_q_d512(q_bf16, scale_log2):
+    """[..., 512] bfloat16 -> the kernel's Q operand: times scale * log2(e) in fp32, e4m3 with ONE exponent per query
+    (floor(log2 of the row maximum) - 7, at least 2^-126 * 2)."""
+    qs = q_bf16.float() * scale_log2
+    mx = qs.abs().amax(dim=-1, keepdim=True)
+    byte = ((mx.view(torch.int32) >> 23).clamp_min(8) - 7)
+    s = torch.pow(2.0, (byte - 127).float())
+    return (qs / s).to(torch.float8_e4m3fn).float() * s

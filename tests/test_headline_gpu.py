@@ -111,6 +111,48 @@ def test_attention_fp8(ctx, heads, t, gain):
     assert r <= 0.03 and r_bf <= 0.12   # measured 0.017 / 0.083 at gain 3 (peaked softmax: the e4m3 rounding of Q and K moves the logits by ~0.08 nat)
 
 
+@pytest.mark.parametrize("b,t,gain", [(1, 1024, 1.0), (2, 4096, 2.0), (1, 65536, 1.0)])
+def test_attention_d512_fp8(ctx, b, t, gain):
+    """BASELINE.json configs[4], the VAE mid-block attention (one head, d = 512) on e4m3 MFMA operands (flash_attn_d512_fp8_kernel): against
+    an fp64 softmax over the DEQUANTISED operands its MFMAs saw (K8 / V8^T tile images read back, Q quantised as the kernel does), where only
+    the e4m3 rounding of the probabilities and the bf16 output rounding remain, and against the fp64 softmax of the bf16 operands, which
+    prices the whole fp8 error. T = 65 536 is the headline size (2048 x 2048 image)."""
+    from tests.support.fp8_tiles import decode_tiles_d512, quantise_q_d512, D512_TILE_BYTES
+    d = 512
+    g = torch.Generator(device="cuda").manual_seed(t + b)
+    q = (torch.randn(b, t, d, generator=g, device="cuda") * gain).to(torch.bfloat16)
+    k = torch.randn(b, t, d, generator=g, device="cuda").to(torch.bfloat16)
+    v = torch.randn(b, t, d, generator=g, device="cuda").to(torch.bfloat16)
+    o = torch.empty(b, t, d, dtype=torch.int16, device="cuda")
+    ws = torch.zeros(b * (t // 64) * D512_TILE_BYTES + 4096 + (t + 64) * 512 * 2, dtype=torch.uint8, device="cuda")
+    scale = d ** -0.5
+    ctx.check(ctx.lib.ir_op_attention_d512_fp8(ctx.h, ctx.stream(), L.ptr(q.view(torch.int16)), L.ptr(k.view(torch.int16)), L.ptr(v.view(torch.int16)),
+                                               L.ptr(o), b, t, scale, L.ptr(ws), ws.numel()), "attention_d512_fp8")
+    torch.cuda.synchronize()
+    tb = (b * (t // 64) * D512_TILE_BYTES + 255) // 256 * 256
+    assert int(ws[tb:tb + 4].view(torch.int32)[0]) == 0, "the fixed softmax reference must hold on this input (no fallback)"
+    Kd, Vd = decode_tiles_d512(ws, b, t)
+    for name, deq, src in (("K", Kd, k), ("V", Vd, v)):
+        err = (deq - src.float()).abs().max() / src.float().abs().max()
+        assert float(err) <= 2 ** -4, f"{name} tile images: max error {float(err):.4f} of the maximum"
+    rows = sorted(set([0, 1, 31, 32, 127, 128, t // 2, t - 129, t - 1] + torch.randint(0, t, (120,), generator=torch.Generator().manual_seed(5)).tolist()))
+    idx = torch.tensor(rows, device="cuda")
+    num = num_bf = den = 0.0
+    worst = worst_bf = 0.0
+    for bi in range(b):
+        got = o.view(torch.bfloat16)[bi, idx].float()
+        qd = quantise_q_d512(q[bi, idx], scale * 1.4426950408889634)
+        s2 = qd.double() @ Kd[bi].double().t()
+        ref = (torch.softmax(s2 * 0.6931471805599453, dim=-1) @ Vd[bi].double()).float()
+        ref_bf = (torch.softmax((q[bi, idx].double() @ k[bi].double().t()) * scale, dim=-1) @ v[bi].double()).float()
+        err, err_bf = (got - ref).abs(), (got - ref_bf).abs()
+        worst, worst_bf = max(worst, float(err.max())), max(worst_bf, float(err_bf.max()))
+        num, num_bf, den = num + float((err ** 2).sum()), num_bf + float((err_bf ** 2).sum()), den + float((ref_bf ** 2).sum())
+    r, r_bf = (num / den) ** 0.5, (num_bf / den) ** 0.5
+    print(f"attention d512 fp8 b={b} T={t} gain {gain}: vs dequantised operands rel-L2 {r:.4f} max abs {worst:.4f}; vs bf16 operands rel-L2 {r_bf:.4f} max abs {worst_bf:.4f}")
+    assert r <= 0.03 and r_bf <= 0.12
+
+
 # ------------------------------------------------------------------------------------------------ 3x3 convs on 2048 x 2048 x 256
 @pytest.mark.parametrize("cin,cout,up", [(256, 256, 0), (256, 128, 0), (256, 256, 1)])
 def test_conv_at_headline_size(ctx, cin, cout, up):
