@@ -38,8 +38,9 @@ enum { IR_FLAG_NO_PREPROCESS = 1, IR_FLAG_TILED = 2, IR_FLAG_FIX_WAVELET = 4, IR
        IR_FLAG_GRAPH = 32,
        /* BASELINE.json configs[4]: fp8 (OCP e4m3) MFMA operands in the parts ir_fp8_features() reports: the VAE ResnetBlock 3x3
         * convolutions (weights quantised per output channel at load time, GroupNorm+SiLU outputs written as e4m3; needs the fp8 weight
-        * forms `*.w8`, `*.g8`, `*.b8` uploaded, layers without them run in bf16) and both products of the DiT self-attention (Q / K / V
-        * quantised per 64-key tile and head on the fly, probabilities per query and 32-key block through the MFMA's E8M0 block scales). */
+        * forms `*.w8`, `*.g8`, `*.b8` uploaded, layers without them run in bf16), both products of the DiT self-attention (Q / K / V
+        * quantised per 64-key tile and head on the fly, probabilities per query and 32-key block through the MFMA's E8M0 block scales)
+        * and both products of the VAE mid-block attention (d = 512; same scheme, token counts that are multiples of 128). */
        IR_FLAG_FP8 = 64 };
 /* which parts of the path IR_FLAG_FP8 / ir_set_fp8 move to fp8 operands in THIS build (bench.py words its workload string from it) */
 enum { IR_FP8_VAE_RESNET_CONVS = 1, IR_FP8_DIT_SELF_ATTENTION = 2, IR_FP8_VAE_MID_ATTENTION = 4 };
