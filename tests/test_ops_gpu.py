@@ -465,3 +465,34 @@ def test_softmax_rows(ctx, rows, cols):
     y = torch.empty(rows, cols, dtype=torch.int16, device="cuda")
     ctx.check(ctx.lib.ir_op_softmax_rows(ctx.h, ctx.stream(), P(x.cuda()), P(y), rows, cols), "softmax")
     close(L.from_bf16_bits(y).cpu(), x.softmax(-1), 2 ** -7, 1e-6, "softmax rows")
+
+
+@pytest.mark.parametrize("t,gain", [(512, 2.0), (512, 6.0)])
+def test_flash_attention_d512_fp8_spike(ctx, t, gain):
+    """flash_attn_d512_fp8_kernel with its fixed softmax reference: a late key dominates one query. gain 2: the spike is about 2^65 above the
+    first tile's maximum - inside what the per-tile exponent bytes and the fp32 row sum carry (up to ~2^100); gain 6: about 2^195 above ->
+    the overflow flag -> V^T is built and the bf16 rescaling kernel recomputes everything. Either way the spiked query returns the spiked
+    key's value row (e4m3 rounding of V, 2^-4 relative, in the first case)."""
+    g = torch.Generator().manual_seed(4)
+    d = 512
+    q = rb(torch.randn(1, t, d, generator=g))
+    k = rb(torch.randn(1, t, d, generator=g))
+    v = rb(torch.randn(1, t, d, generator=g))
+    k[0, t - 6] = q[0, 7] * gain
+    k = rb(k)
+    scale = d ** -0.5
+    ref = (torch.softmax(q[0].double() @ k[0].double().t() * scale, dim=-1) @ v[0].double()).float()
+    o = torch.empty(1, t, d, dtype=torch.int16, device="cuda")
+    tiles = (t // 64) * 66560
+    ws = torch.zeros(((tiles + 255) & ~255) + 256 + (t + 64) * 512 * 2, dtype=torch.uint8, device="cuda")
+    ctx.check(ctx.lib.ir_op_attention_d512_fp8(ctx.h, ctx.stream(), P(dev_bf16(q)), P(dev_bf16(k)), P(dev_bf16(v)), P(o), 1, t, scale, P(ws), ws.numel()),
+              "attention_d512_fp8")
+    torch.cuda.synchronize()
+    got = L.from_bf16_bits(o).cpu()[0]
+    flag = int(ws[(tiles + 255) & ~255:][:4].view(torch.int32)[0])   # layout of ir_op_attention_d512_fp8: tiles | flag | V^T
+    assert (flag != 0) == (gain > 4), f"overflow flag {flag} at gain {gain}"
+    spike_err = float((got[7] - v[0, t - 6]).abs().max())
+    assert spike_err < (2 ** -6 if flag else 2 ** -2), f"the spiked query must return the spiked key's value row (max error {spike_err:.4f})"
+    r = float((got - ref).norm() / ref.norm())
+    print(f"fp8 d512 attention spike gain {gain}: flag {flag}, rel-L2 {r:.4f}, spiked row error {spike_err:.4f}")
+    assert r <= (0.02 if flag else 0.12)
