@@ -118,14 +118,20 @@ struct AttnD512F8Params {
 // MFMA results are read by the VALU at least three MFMAs (about 200 cycles) behind their producer or behind explicit s_nops; VALU-written
 // operands (P8, exponent bytes) are half a tile old when an MFMA reads them; all MFMAs are of ONE opcode, whose back-to-back accumulation
 // the hardware interlocks; operand registers are pinned with keep() past the VALU work that follows their MFMA.
+// knock-out builds (diagnostic, results wrong by design): -DIR_KO_D8=1 no end-of-tile DMA wait, 2 no softmax items, 4 no LDS-DMA in the loop, 8 no MFMAs
+#ifndef IR_KO_D8
+#define IR_KO_D8 0
+#endif
 IR_DEVINL void d8_mfma_c(f32x16& s, i32x8 a, i32x8 b, const f32x16& c, int sa, int sb) {   // s = A8 B8 + c (fresh destination)
     asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %3, %4, %5 op_sel_hi:[0,0,0]" : "=&v"(s) : "v"(a), "v"(b), "v"(c), "v"(sa), "v"(sb));
 }
 IR_DEVINL void d8_mfma_acc(f32x16& s, i32x8 a, i32x8 b, int sa, int sb) {                  // s += A8 B8
+    if constexpr (IR_KO_D8 & 8) { asm volatile("" : "+v"(s) : "v"(a), "v"(b), "v"(sa), "v"(sb)); return; }
     asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel_hi:[0,0,0]" : "+v"(s) : "v"(a), "v"(b), "v"(sa), "v"(sb));
 }
 template <int LO>
 IR_DEVINL void d8_mfma_o(i32x8 a, i32x8 b, int sa, int sb) {                                // a[LO : LO + 15] += A8 B8
+    if constexpr (IR_KO_D8 & 8) { asm volatile("" ::"v"(a), "v"(b), "v"(sa), "v"(sb)); return; }
     asm volatile("v_mfma_scale_f32_32x32x64_f8f6f4 a[%c4:%c5], %0, %1, a[%c4:%c5], %2, %3 op_sel_hi:[0,0,0]" ::"v"(a), "v"(b), "v"(sa), "v"(sb), "n"(LO), "n"(LO + 15));
 }
 template <int I>
@@ -331,16 +337,18 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d512_fp8_kernel(AttnD512F8P
         }
         qk(SL ^ 1, [&](auto ic) {
             constexpr int I = decltype(ic)::value;
+            if constexpr (IR_KO_D8 & 4) return;
             if constexpr (I < 8) piece(t + 1, 33 + min(wu + 4 * I, 31), SL ^ 1);                  // V^T(t+1): pieces 33 + (wu + 4 i), i < 8
             else piece(t + 2, min(wu + 4 * (I - 8), 32), SL);                                  // K(t+2): pieces wu + 4 i, i < 9 (the ninth below)
             if constexpr (I == 15) piece(t + 2, min(wu + 32, 32), SL);
         });
         pv(SL, Pcur, epcur, ev, [&](auto ic) {
             constexpr int I = decltype(ic)::value;
+            if constexpr (IR_KO_D8 & 2) { asm volatile("" : "+v"(S[0]), "+v"(S[1]), "+v"(Pnext), "+v"(epnext)); return; }
             sm_range(std::integral_constant<int, SM_LO[I]>{}, std::integral_constant<int, SM_LO[I + 1]>{}, S, Pnext, epnext);
         });
         read_scale(esc, SL ^ 1);   // exponents of tile t + 1 (its K part has been there since the previous iteration)
-        wait_dma();
+        if constexpr (!(IR_KO_D8 & 1)) wait_dma();
         wait_lds<0>();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -371,7 +379,7 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d512_fp8_kernel(AttnD512F8P
                     make_uint2(pack2bf(x[4 * gg] * inv, x[4 * gg + 1] * inv), pack2bf(x[4 * gg + 2] * inv, x[4 * gg + 3] * inv));
         }(), ...);
     }(std::make_integer_sequence<int, NDT>{});
-    if (__any(bad) && lane == 0) atomicOr(p.ovf_flag, 1);
+    if (IR_KO_D8 == 0 && __any(bad) && lane == 0) atomicOr(p.ovf_flag, 1);   // (knock-out builds compute garbage: keep their timing free of the fallback)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
