@@ -199,6 +199,11 @@ int ir_op_conv_groupnorm(ir_ctx* ctx, void* stream, const uint16_t* in, const ui
 /* 3x3 stride-1 conv on fp8 operands: in8 [n][h][w][cin] e4m3, wgt8 [cout][9][cin] e4m3, out = (acc + bias_div[co]) * dequant[co] (+ res) in bf16 */
 int ir_op_conv_fp8(ir_ctx* ctx, void* stream, const uint8_t* in8, const uint8_t* wgt8, const float* dequant, const float* bias_div, uint16_t* out,
                    int n, int h, int w, int cin, int cout, const uint16_t* res);
+/* ir_op_conv_fp8 on the nearest-2x upsampled input (the VAE decoder's Upsample convs under IR_FLAG_FP8): in8 [n][h][w][cin] e4m3,
+ * out [n][2h][2w][cout] bf16. */
+int ir_op_conv_fp8_up(ir_ctx* ctx, void* stream, const uint8_t* in8, const uint8_t* wgt8, const float* dequant, const float* bias_div, uint16_t* out,
+                      int n, int h, int w, int cin, int cout);
+
 /* which kernel ir_op_conv_fp8 routes this shape to (tests: 0 = the one-wave-per-SIMD conv_halo_s1_fp8_kernel, 3 = conv_halo_kernel<.., FP8>) */
 int ir_op_conv_fp8_route(ir_ctx* ctx, int n, int h, int w, int cin, int cout, int has_res);
 int ir_op_linear(ir_ctx* ctx, void* stream, const uint16_t* in, const uint16_t* wgt, const float* bias, void* out, int m, int k, int n,

@@ -413,14 +413,14 @@ void groupnorm(Run& r, const Norm& n, const bf16_t* x, bf16_t* y, float* ws, int
            ir_launch_groupnorm(x, y, n.g, n.b, ws, N, HW, n.c, 32, 1e-6f, silu, r.s, out_fp8, FP8_ACT_SCALE), "groupnorm");
 }
 // 3x3 stride-1 conv on fp8 operands (conv_halo_kernel<.., FP8>): in8 holds e4m3(x * FP8_ACT_SCALE) NHWC, cw.w8 / g8 / b8 the weights
-void conv_fp8(Run& r, const Conv& cw, const bf16_t* in8, int N, int H, int W, void* out, int out_cs, const void* res, int res_cs) {
+void conv_fp8(Run& r, const Conv& cw, const bf16_t* in8, int N, int H, int W, void* out, int out_cs, const void* res, int res_cs, int up = 0) {
     if (!r.live()) return;
     IGemmParams p;
     memset(&p, 0, sizeof p);
     p.fp8 = 1;
     p.in = in8; p.NB = N; p.H = H; p.W = W; p.Cin = cw.cin / 2; p.in_cs = cw.cin / 2;
-    p.taps = 9; p.stride = 1; p.pad = 1; p.up = 0;
-    p.Ho = H; p.Wo = W; p.M = N * H * W;
+    p.taps = 9; p.stride = 1; p.pad = 1; p.up = up;
+    p.Ho = up ? 2 * H : H; p.Wo = up ? 2 * W : W; p.M = N * p.Ho * p.Wo;
     p.wgt = reinterpret_cast<const bf16_t*>(cw.w8); p.wgt_rs = 9L * (cw.cin / 2); p.Cout = cw.cout; p.Cout_pad = cw.cout_pad; p.bias = cw.b8;
     p.act = ACT_NONE; p.out_scale = 1.f;
     p.gate = cw.g8; p.gate_stride = 0; p.rows_per_batch = 1 << 30;
@@ -2436,6 +2436,16 @@ int ir_op_conv_fp8(ir_ctx* c, void* stream, const uint8_t* in8, const uint8_t* w
     Conv cw;
     cw.cin = cin; cw.cout = cout; cw.cout_pad = cout; cw.taps = 9; cw.w8 = wgt8; cw.g8 = dequant; cw.b8 = bias_div;
     conv_fp8(r, cw, reinterpret_cast<const bf16_t*>(in8), n, h, w, out, cout, res, cout);
+    return finish(r, c, 0);
+}
+// the same on the nearest-2x upsampled input: in8 [n][h][w][cin], out [n][2h][2w][cout] (the VAE decoder's Upsample convs under IR_FLAG_FP8)
+int ir_op_conv_fp8_up(ir_ctx* c, void* stream, const uint8_t* in8, const uint8_t* wgt8, const float* dequant, const float* bias_div, uint16_t* out,
+                      int n, int h, int w, int cin, int cout) {
+    if (!c || (cin % 128) || (cout % 64)) return fail(c, -1, "ir_op_conv_fp8_up: cin must be a multiple of 128, cout of 64");
+    Run r = make_run(c, stream, nullptr, 0, false);
+    Conv cw;
+    cw.cin = cin; cw.cout = cout; cw.cout_pad = cout; cw.taps = 9; cw.w8 = wgt8; cw.g8 = dequant; cw.b8 = bias_div;
+    conv_fp8(r, cw, reinterpret_cast<const bf16_t*>(in8), n, h, w, out, cout, nullptr, 0, 1);
     return finish(r, c, 0);
 }
 int ir_op_conv_fp8_route(ir_ctx* c, int n, int h, int w, int cin, int cout, int has_res) {

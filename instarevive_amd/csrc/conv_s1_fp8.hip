@@ -68,6 +68,8 @@ IR_DEVINL c8_i32x8 c8_join(bf16x8 lo, bf16x8 hi) {
 template <class T>
 IR_DEVINL void c8_keep(const T& x) { asm volatile("" ::"v"(x)); }
 
+// UP = 1: the conv runs on the nearest-2x upsampled input (2H x 2W), folded into the halo's source addresses (as conv_halo_s1_kernel<1>)
+template <int UP>
 __global__ __launch_bounds__(256, 1) void conv_halo_s1_fp8_kernel(IGemmParams p, int tiles_y, int tiles_x, int total_vb) {
     using namespace c8;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES];   // halo[0..1] | W ring of 6 ; epilogue: slabs + red in halo[1]
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(256, 1) void conv_halo_s1_fp8_kernel(IGemmParams p,
     const int c16 = lane & 15, kq = lane >> 4;
     const int NT = p.Cout_pad / BN;
     const int MT = p.NB * tiles_y * tiles_x;
-    const int Hc = p.H, Wc = p.W;
+    const int Hc = UP ? 2 * p.H : p.H, Wc = UP ? 2 * p.W : p.W;   // conv-input (== output) extent
     const int chunks = p.Cin / BK;   // 64-channel chunks; even (launcher): a tile is chunks / 2 periods of 9 MFMA steps
     const unsigned char* zero = reinterpret_cast<const unsigned char*>(g_zero_page_s1f8);
     const int unit = 0x7F7F7F7F;     // E8M0 exponent 127 = 1.0 in every block-scale byte
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(256, 1) void conv_halo_s1_fp8_kernel(IGemmParams p,
             const int hy = hpix / HWD, hx = hpix - hy * HWD;
             const int cy = t.oy0 + hy - 1, cx = t.ox0 + hx - 1;
             const bool ok = hpix < HP && cy >= 0 && cy < Hc && cx >= 0 && cx < Wc;
-            const int iy = min(max(cy, 0), Hc - 1), ix = min(max(cx, 0), Wc - 1);
+            const int iy = min(max(cy, 0), Hc - 1) >> UP, ix = min(max(cx, 0), Wc - 1) >> UP;
             const long pix = ((long)t.img * p.H + iy) * p.W + ix;
             const uint32_t sw = (uint32_t)((lane & 3) ^ hkey(hx));
             hp[i] = ok ? (uint32_t)((pix * p.in_cs) >> 3) + sw : (0x80000000u | sw);
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(256, 1) void conv_halo_s1_fp8_kernel(IGemmParams p,
 // per image). Everything else with fp8 operands stays with conv_halo_kernel<.., FP8> (igemm.hip), which is also the plain-kernel reference.
 bool ir_conv_s1_fp8_takes(const IGemmParams& p) {
     static const bool off = getenv("IR_NO_CONV_S1_FP8") != nullptr;   // experiment knob
-    if (off || g_ir_plain_kernels || !p.fp8 || p.force_generic || p.up) return false;
+    if (off || g_ir_plain_kernels || !p.fp8 || p.force_generic) return false;
     if (p.taps != 9 || p.stride != 1 || p.pad != 1 || (p.Cin & 63)) return false;   // Cin counts pairs: 64 pairs = 128 channels
     if (p.Cout != p.Cout_pad || p.Cout_pad % 128) return false;
     if (p.act != IR_ACT_NONE || !p.gate || p.gate_stride != 0 || p.out2 || p.out_f32) return false;
@@ -300,6 +302,7 @@ int ir_launch_conv_s1_fp8(const IGemmParams& p, hipStream_t s) {
         return n & ~7;
     }();
     const long grid = total < cus ? total : cus;
-    hipLaunchKernelGGL(conv_halo_s1_fp8_kernel, dim3((unsigned)grid), dim3(256), 0, s, p, tiles_y, tiles_x, (int)total);
+    if (p.up) hipLaunchKernelGGL(conv_halo_s1_fp8_kernel<1>, dim3((unsigned)grid), dim3(256), 0, s, p, tiles_y, tiles_x, (int)total);
+    else hipLaunchKernelGGL(conv_halo_s1_fp8_kernel<0>, dim3((unsigned)grid), dim3(256), 0, s, p, tiles_y, tiles_x, (int)total);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -208,3 +208,4 @@ int ir_launch_copy_rows(const bf16_t* src, int src_cs, const bf16_t* add, int ad
     hipLaunchKernelGGL(copy_rows_kernel, dim3(grid1d(nv)), dim3(256), 0, s, src, src_cs, add, add_cs, dst, dst_cs, C, nv);
     return LAUNCH_OK();
 }
+

@@ -496,3 +496,21 @@ def test_flash_attention_d512_fp8_spike(ctx, t, gain):
     r = float((got - ref).norm() / ref.norm())
     print(f"fp8 d512 attention spike gain {gain}: flag {flag}, rel-L2 {r:.4f}, spiked row error {spike_err:.4f}")
     assert r <= (0.02 if flag else 0.12)
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout", [(1, 64, 64, 256, 256), (1, 24, 40, 128, 128), (2, 128, 96, 512, 512)])
+def test_conv3x3_fp8_up(ctx, n, h, w, cin, cout):
+    """The fp8 3x3 conv on the nearest-2x upsampled input (conv_halo_s1_fp8_kernel<1>, or conv_halo_kernel<.., UP, FP8> below 32 patch tiles):
+    the VAE decoder's Upsample convs under IR_FLAG_FP8. Against a float64 convolution of the DEQUANTISED, upsampled operands."""
+    g = torch.Generator().manual_seed(n + h + w + cin + cout + 1)
+    x8 = (torch.randn(n, cin, h, w, generator=g) * 4).clamp(-448, 448).to(torch.float8_e4m3fn)
+    w8 = (torch.randn(cout, cin, 3, 3, generator=g) * 64).clamp(-448, 448).to(torch.float8_e4m3fn)
+    deq = torch.rand(cout, generator=g) * 1e-3 + 1e-4
+    bias = torch.randn(cout, generator=g)
+    ref = F.conv2d(F.interpolate(x8.double(), scale_factor=2, mode="nearest"), w8.double(), None, padding=1) * deq.double()[None, :, None, None] + bias.double()[None, :, None, None]
+    xin = x8.permute(0, 2, 3, 1).contiguous().view(torch.uint8).cuda()
+    wp = w8.permute(0, 2, 3, 1).contiguous().view(torch.uint8).cuda()
+    out = torch.empty(n, 2 * h, 2 * w, cout, dtype=torch.int16, device="cuda")
+    ctx.check(ctx.lib.ir_op_conv_fp8_up(ctx.h, ctx.stream(), P(xin), P(wp), P(deq.cuda()), P((bias / deq).cuda()), P(out), n, h, w, cin, cout), "conv_fp8_up")
+    torch.cuda.synchronize()
+    close(L.from_bf16_bits(out).cpu().permute(0, 3, 1, 2).double(), ref, 2 ** -7, 2e-3, "conv fp8 up")
