@@ -189,6 +189,11 @@ int ir_nchw_to_u8(ir_ctx* ctx, void* stream, const float* in, uint8_t* out, int 
 int ir_op_conv(ir_ctx* ctx, void* stream, const uint16_t* in, const uint16_t* wgt, const float* bias, void* out, int n, int h, int w,
                int cin, int cout, int cout_pad, int taps, int stride, int pad, int up, int act, float slope, const void* res,
                int res_f32, int out_f32);
+/* ir_op_conv (stride 1, pad 1 for taps = 9; taps = 1: a linear over n*h*w rows) with split-K allowed: launches with at most 48 output
+ * tiles and at least 24 k-tiles split K over extra workgroups, partial tiles in fp32 slices of ws added in a fixed order (deterministic);
+ * what the ControlLDM path's latent-resolution convs / linears use. *splits receives the split count (0: not split). */
+int ir_op_conv_splitk(ir_ctx* ctx, void* stream, const uint16_t* in, const uint16_t* wgt, const float* bias, void* out, int n, int h, int w,
+                      int cin, int cout, int taps, int act, const void* res, int res_f32, int out_f32, void* ws, size_t ws_bytes, int* splits);
 /* 3x3 conv (stride 1 / 2, optional nearest-2x upsample, optional bf16 residual) with the GroupNorm(32) statistics of its output
  * produced by the conv epilogue, followed by GroupNorm (+SiLU): the fused form of ResnetBlock's conv -> norm
  * (ldm/modules/diffusionmodules/model.py:131-151). *fused receives the number of pixel tiles per image that wrote statistics

@@ -19,7 +19,7 @@ SYMBOLS = [
     "ir_swinir_forward", "ir_vae_encode", "ir_dit_forward", "ir_dit_step", "ir_dit_forward_control", "ir_dit_step_control", "ir_vae_decode", "ir_color_fix",
     "ir_pipeline", "ir_u8_to_nchw", "ir_nchw_to_u8", "ir_profile_begin", "ir_profile_end", "ir_profile_end_kernels", "ir_profile_kernel_count",
     "ir_profile_kernel_name",
-    "ir_op_conv", "ir_op_conv_groupnorm", "ir_op_linear", "ir_op_groupnorm", "ir_op_layernorm", "ir_op_attention", "ir_op_swin_attention",
+    "ir_op_conv", "ir_op_conv_splitk", "ir_op_conv_groupnorm", "ir_op_linear", "ir_op_groupnorm", "ir_op_layernorm", "ir_op_attention", "ir_op_swin_attention",
     "ir_op_softmax_rows", "ir_op_nchw_to_nhwc", "ir_op_nhwc_to_nchw",
     "ir_tiled_count", "ir_tiled_encode", "ir_tiled_dit", "ir_tiled_blend_latent", "ir_tiled_decode", "ir_tiled_blend_pixels", "ir_set_plain_kernels", "ir_set_fp8", "ir_op_conv_fp8", "ir_op_conv_fp8_up", "ir_op_conv_fp8_route", "ir_fp8_features", "ir_op_attention_fp8", "ir_op_attention_d512_fp8",
     "ir_unet_configure", "ir_unet_set_context", "ir_cldm_sample", "ir_cldm_pipeline", "ir_op_groupnorm_any", "ir_op_geglu",
@@ -82,6 +82,7 @@ def load_library():
     lib.ir_u8_to_nchw.argtypes = [vp, vp, vp, vp, i, i, i]
     lib.ir_nchw_to_u8.argtypes = [vp, vp, vp, vp, i, i, i]
     lib.ir_op_conv.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, i, i, i, f, vp, i, i]
+    lib.ir_op_conv_splitk.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, vp, i, i, vp, sz, C.POINTER(C.c_int)]
     lib.ir_op_conv_groupnorm.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i, i, i, vp, i, vp, sz, C.POINTER(C.c_int)]
     lib.ir_op_linear.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, i, vp, vp, i, i, f]
     lib.ir_op_groupnorm.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, f, i, vp, sz]

@@ -2410,6 +2410,24 @@ int ir_op_conv(ir_ctx* c, void* stream, const uint16_t* in, const uint16_t* wgt,
     conv(r, cw, in, n, h, w, cin, out, cout, out_f32, stride, pad, up, act, slope, res, res_f32, cout);
     return finish(r, c, 0);
 }
+// ir_op_conv with split-K allowed (the small-M launches of the ControlLDM path: ir_igemm_splitk); ws: scratch for the partial slices.
+// Returns the split count used (0: the launch did not qualify) through *splits.
+int ir_op_conv_splitk(ir_ctx* c, void* stream, const uint16_t* in, const uint16_t* wgt, const float* bias, void* out, int n, int h, int w,
+                      int cin, int cout, int taps, int act, const void* res, int res_f32, int out_f32, void* ws, size_t ws_bytes, int* splits) {
+    if (!c || !ws) return fail(c, -1, "ir_op_conv_splitk: null argument");
+    Run r = make_run(c, stream, ws, ws_bytes, false);
+    r.splitk = true;
+    Conv cw;
+    cw.w = wgt; cw.b = bias; cw.cin = cin; cw.cout = cout; cw.cout_pad = cout; cw.taps = taps;
+    if (splits) {
+        IGemmParams p;
+        memset(&p, 0, sizeof p);
+        p.Cin = cin; p.taps = taps; p.Cout = p.Cout_pad = cout; p.M = n * h * w; p.allow_splitk = 1;
+        *splits = ir_igemm_splitk(p);
+    }
+    conv(r, cw, in, n, h, w, cin, out, cout, out_f32, 1, 1, 0, act, 0.f, res, res_f32, cout);
+    return finish(r, c, ws_bytes);
+}
 int ir_op_conv_groupnorm(ir_ctx* c, void* stream, const uint16_t* in, const uint16_t* wgt, const float* bias, uint16_t* conv_out, uint16_t* y,
                          const float* gamma, const float* beta, int n, int h, int w, int cin, int cout, int stride, int up, const void* res,
                          int silu, void* ws, size_t ws_bytes, int* fused) {

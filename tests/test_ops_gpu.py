@@ -514,3 +514,35 @@ def test_conv3x3_fp8_up(ctx, n, h, w, cin, cout):
     ctx.check(ctx.lib.ir_op_conv_fp8_up(ctx.h, ctx.stream(), P(xin), P(wp), P(deq.cuda()), P((bias / deq).cuda()), P(out), n, h, w, cin, cout), "conv_fp8_up")
     torch.cuda.synchronize()
     close(L.from_bf16_bits(out).cpu().permute(0, 3, 1, 2).double(), ref, 2 ** -7, 2e-3, "conv fp8 up")
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout,taps,res", [(1, 8, 8, 1280, 1280, 9, True), (1, 16, 16, 2560, 1280, 9, False), (2, 16, 16, 640, 640, 9, True),
+                                                    (1, 16, 16, 5120, 1280, 1, True), (1, 32, 32, 1280, 640, 9, False), (1, 64, 64, 320, 320, 9, False)])
+def test_conv_splitk(ctx, n, h, w, cin, cout, taps, res):
+    """The split-K form of the generic implicit GEMM (igemm.hip: ir_igemm_splitk + splitk_finish_kernel), which the ControlLDM path's small-M
+    convs / linears take: against F.conv2d in fp32 on the same bf16 operands, with bias, SiLU and an fp32 residual in the finishing kernel;
+    bit-identical run to run (fixed summation order). The last shape has too many tiles and too few k-tiles to split."""
+    import ctypes
+    g = torch.Generator().manual_seed(cin + cout + h)
+    x = rb(torch.randn(n, cin, h, w, generator=g))
+    k = 3 if taps == 9 else 1
+    wt = rb(torch.randn(cout, cin, k, k, generator=g) / math.sqrt(taps * cin))
+    b = torch.randn(cout, generator=g)
+    r_ = torch.randn(n, cout, h, w, generator=g) if res else None
+    ref = F.silu(F.conv2d(x, wt, b, padding=k // 2))
+    if res:
+        ref = ref + r_
+    xin = dev_bf16(x.permute(0, 2, 3, 1).contiguous())
+    wp = dev_bf16(wt.permute(0, 2, 3, 1).reshape(cout, taps * cin).contiguous())
+    rd = r_.permute(0, 2, 3, 1).contiguous().cuda() if res else None
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    outs, splits = [], ctypes.c_int(-1)
+    for _ in range(2):
+        out = torch.empty(n, h, w, cout, dtype=torch.int16, device="cuda")
+        ctx.check(ctx.lib.ir_op_conv_splitk(ctx.h, ctx.stream(), P(xin), P(wp), P(b.cuda()), P(out), n, h, w, cin, cout, taps, L.ACT_SILU, P(rd), 1, 0,
+                                            P(ws), ws.numel(), ctypes.byref(splits)), "conv_splitk")
+        torch.cuda.synchronize()
+        outs.append(out)
+    assert (splits.value > 1) == (h < 64), f"split count {splits.value}"
+    assert torch.equal(outs[0], outs[1]), "split-K must be deterministic"
+    close(L.from_bf16_bits(outs[0]).cpu().permute(0, 3, 1, 2), ref, 2 ** -7, 4e-3, f"conv split-K x{splits.value}")
