@@ -24,7 +24,8 @@ typedef struct ir_ctx ir_ctx;
 /* stages for ir_workspace_bytes */
 enum { IR_STAGE_SWINIR = 0, IR_STAGE_VAE_ENCODE = 1, IR_STAGE_DIT = 2, IR_STAGE_VAE_DECODE = 3, IR_STAGE_PIPELINE = 4,
        IR_STAGE_COLORFIX = 5, IR_STAGE_T5 = 6 /* ir_workspace_bytes(ctx, IR_STAGE_T5, batch, tokens, 0, ...) */,
-       IR_STAGE_CLDM = 7 /* ir_cldm_sample: n, h, w = the LATENT size */, IR_STAGE_CLDM_PIPELINE = 8 /* ir_cldm_pipeline: image size */ };
+       IR_STAGE_CLDM = 7 /* ir_cldm_sample: n, h, w = the LATENT size */, IR_STAGE_CLDM_PIPELINE = 8 /* ir_cldm_pipeline: image size */,
+       IR_STAGE_CLIP_TEXT = 9 /* ir_clip_text_encode: n = batch */ };
 /* ir_pipeline flags */
 enum { IR_FLAG_NO_PREPROCESS = 1, IR_FLAG_TILED = 2, IR_FLAG_FIX_WAVELET = 4, IR_FLAG_FIX_ADAIN = 8,
        /* ir_pipeline only, needs ir_dit_control_configure: run the DiT step with the ControlNet-Half branch, condition latent
@@ -91,6 +92,16 @@ int ir_unet_set_context(ir_ctx* ctx, void* stream, const float* context_host, in
  * cldm.py:511-527). ws: ir_workspace_bytes(ctx, IR_STAGE_CLDM, n, h, w, ...). */
 int ir_cldm_sample(ir_ctx* ctx, void* stream, const float* zT, const float* c_latent, float* out, int n, int h, int w, float timestep, int return_v,
                    void* ws, size_t ws_bytes);
+
+/* cond_stage_model of the ControlLDM path: FrozenOpenCLIPEmbedder (ldm/modules/encoders/modules.py:134-196, cldm.yaml:86-90, layer
+ * "penultimate") = the text tower of open_clip's ViT-H-14 (third-party, not in the reference tree): token + positional embedding, n_layers
+ * pre-LN blocks (LayerNorm, nn.MultiheadAttention with the causal mask, LayerNorm, c_fc -> GELU -> c_proj), ln_final. n_layers = the blocks
+ * that RUN (23 of 24 for "penultimate"). Tensors `clip.embed` (bf16 [vocab][width]), `clip.pos` ([max_len][width]), `clip.causal`
+ * ([heads][max_len][max_len] additive mask), `clip.final_ln`, `clip.l{i}.{ln1,ln2,qkv,o,fc,proj}` (q rows of qkv pre-scaled by d_head^-0.5). */
+int ir_clip_text_configure(ir_ctx* ctx, int n_layers, int width, int heads, int d_ff, int vocab, int max_len);
+/* encode_with_transformer (modules.py:176-183): ids device int32 [b][max_len] -> out device fp32 [b][max_len][width]. Like ir_t5_encode it
+ * waits for the stream to fail on an id outside the vocabulary. ws: ir_workspace_bytes(ctx, IR_STAGE_CLIP_TEXT, b, 0, 0, ...). */
+int ir_clip_text_encode(ir_ctx* ctx, void* stream, const int32_t* ids, float* out, int b, void* ws, size_t ws_bytes);
 
 /* get_input + sample_log + decode_first_stage of Reflow_ControlLDM as one launch sequence (cldm.py:494-509,568-588,548-549):
  * control = SwinIR(lq) (skipped under IR_FLAG_NO_PREPROCESS); c_latent = mode(cond_encoder(control * 2 - 1)) * scale_factor (the encoder half

@@ -22,10 +22,10 @@ SYMBOLS = [
     "ir_op_conv", "ir_op_conv_splitk", "ir_op_conv_groupnorm", "ir_op_linear", "ir_op_groupnorm", "ir_op_layernorm", "ir_op_attention", "ir_op_swin_attention",
     "ir_op_softmax_rows", "ir_op_nchw_to_nhwc", "ir_op_nhwc_to_nchw",
     "ir_tiled_count", "ir_tiled_encode", "ir_tiled_dit", "ir_tiled_blend_latent", "ir_tiled_decode", "ir_tiled_blend_pixels", "ir_set_plain_kernels", "ir_set_fp8", "ir_op_conv_fp8", "ir_op_conv_fp8_up", "ir_op_conv_fp8_route", "ir_fp8_features", "ir_op_attention_fp8", "ir_op_attention_d512_fp8",
-    "ir_unet_configure", "ir_unet_set_context", "ir_cldm_sample", "ir_cldm_pipeline", "ir_op_groupnorm_any", "ir_op_geglu",
+    "ir_unet_configure", "ir_unet_set_context", "ir_cldm_sample", "ir_cldm_pipeline", "ir_clip_text_configure", "ir_clip_text_encode", "ir_op_groupnorm_any", "ir_op_geglu",
 ]
 
-STAGE_SWINIR, STAGE_VAE_ENCODE, STAGE_DIT, STAGE_VAE_DECODE, STAGE_PIPELINE, STAGE_COLORFIX, STAGE_T5, STAGE_CLDM, STAGE_CLDM_PIPELINE = range(9)
+STAGE_SWINIR, STAGE_VAE_ENCODE, STAGE_DIT, STAGE_VAE_DECODE, STAGE_PIPELINE, STAGE_COLORFIX, STAGE_T5, STAGE_CLDM, STAGE_CLDM_PIPELINE, STAGE_CLIP_TEXT = range(10)
 FLAG_NO_PREPROCESS, FLAG_TILED, FLAG_FIX_WAVELET, FLAG_FIX_ADAIN, FLAG_CONTROL_LQ, FLAG_GRAPH, FLAG_FP8 = 1, 2, 4, 8, 16, 32, 64
 ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_LRELU, ACT_SILU = range(5)
 
@@ -109,6 +109,8 @@ def load_library():
     lib.ir_unet_configure.argtypes = [vp, i, i, i, C.POINTER(i), i, i, i, i, i]
     lib.ir_unet_set_context.argtypes = [vp, vp, vp, i]
     lib.ir_cldm_sample.argtypes = [vp, vp, vp, vp, vp, i, i, i, f, i, vp, sz]
+    lib.ir_clip_text_configure.argtypes = [vp, i, i, i, i, i, i]
+    lib.ir_clip_text_encode.argtypes = [vp, vp, vp, vp, i, vp, sz]
     lib.ir_cldm_pipeline.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, f, f, vp, sz]
     lib.ir_op_groupnorm_any.argtypes = [vp, vp, vp, vp, vp, vp, i, C.c_long, i, i, f, i, vp, sz]
     lib.ir_op_geglu.argtypes = [vp, vp, vp, vp, C.c_long, i]

@@ -6,9 +6,12 @@ fallback).
   ControlNet           <- diffusion/cldm.py:58-292
   Reflow_ControlLDM    <- diffusion/cldm.py:443-588 (apply_condition_encoder, apply_model, sample_log, decode_first_stage, log_images)
 
-Not reproduced: the frozen OpenCLIP text encoder (`cond_stage_model`, cldm.yaml:86-91; open_clip is not in this image). The text
-conditioning is an input: `c_crossattn` [B, 77, context_dim], e.g. the saved embedding of the empty prompt the reference samples with
-(cldm.py:357-358); get_learned_conditioning raises. One context per call: all rows of a batch must carry the same embedding.
+  FrozenOpenCLIPEmbedder <- ldm/modules/encoders/modules.py:134-196 (the `cond_stage_model`: open_clip's ViT-H-14 text tower; its BPE
+                          tokenizer table is not in this image - the empty prompt the reference samples with is tokenised, other
+                          prompts need a tokenizer callable)
+
+The text conditioning of a call is `c_crossattn` [B, 77, context_dim] (from get_learned_conditioning / get_unconditional_conditioning or a
+saved embedding). One context per call: all rows of a batch must carry the same embedding.
 """
 import ctypes as C
 from types import SimpleNamespace
@@ -85,16 +88,23 @@ class ControlNet(_UNetBase):
 
 
 def _set_context(ctx, context):
-    """Bind c_crossattn [B, n_tok, context_dim] (all rows equal) as the context of every cross-attention; cached by tensor identity."""
-    key = (context.data_ptr(), context._version, tuple(context.shape), str(context.device))
-    if ctx.__dict__.get("_unet_context") == key:
+    """Bind c_crossattn [B, n_tok, context_dim] (all rows equal) as the context of every cross-attention. Cached by tensor OBJECT and version
+    counter - the cache keeps the tensor alive, so its address cannot be handed to another tensor meanwhile (a (data_ptr, shape) key once took
+    a new embedding that reused a freed tensor's memory for the old one); any other tensor, equal or not, rebuilds the K / V caches (~1 ms)."""
+    cached = ctx.__dict__.get("_unet_context")
+    if cached is not None and cached[0] is context and cached[1] == context._version:
         return
     c = context.detach().to("cpu", torch.float32)
     if c.dim() != 3 or not all(torch.equal(c[0], c[i]) for i in range(1, c.shape[0])):
         raise ValueError("c_crossattn must be [B, n_tok, context_dim] with the same embedding in every row (one prompt per call)")
     c0 = c[0].contiguous()
     ctx.check(ctx.lib.ir_unet_set_context(ctx.h, ctx.stream(), C.c_void_p(c0.data_ptr()), c0.shape[0]), "ir_unet_set_context")
-    ctx.__dict__["_unet_context"] = key
+    ctx.__dict__["_unet_context"] = (context, context._version)
+
+
+def _cat1(tensors):
+    """torch.cat(tensors, 1) without a copy for the usual one-element list (the copy would be a new object: a context-cache miss per call)."""
+    return tensors[0] if len(tensors) == 1 else torch.cat(tensors, 1)
 
 
 def _timestep(timesteps):
@@ -121,6 +131,69 @@ def _sample(ctx, x, c_latent, timesteps, context, add_x):
     return out   # zT + v (cldm.py:588), or v alone
 
 
+class FrozenOpenCLIPEmbedder(_DeviceModule):
+    """ldm/modules/encoders/modules.py:134-196 (cldm.yaml: cond_stage_config, layer "penultimate"): the text tower of open_clip's ViT-H-14.
+    `arch` / `version` select nothing here: the weights come through load_state_dict with open_clip's parameter names (the checkpoint's
+    `cond_stage_model.model.*` entries). open_clip's BPE tokenizer table is not in this image: pass `tokenizer` (texts -> LongTensor
+    [B, 77]) for arbitrary prompts; the empty prompt - the only one the reference's samplers use (cldm.py:357-358, positive_prompt="") -
+    is tokenised here (<start_of_text>, <end_of_text>, zero padding)."""
+    FAMILY = "clip"
+    SOT, EOT = 49406, 49407
+
+    def __init__(self, arch="ViT-H-14", version="laion2b_s32b_b79k", max_length=77, freeze=True, layer="last", *, width=1024, heads=16, layers=24,
+                 vocab_size=49408, mlp_ratio=4.0, tokenizer=None):
+        super().__init__()
+        if layer not in ("last", "penultimate"):
+            raise AssertionError(layer)
+        self.cfg = dict(width=width, heads=heads, layers=layers, vocab_size=vocab_size, context_length=max_length, mlp_ratio=mlp_ratio)
+        self.layer, self.layer_idx, self.max_length, self.tokenizer = layer, (0 if layer == "last" else 1), max_length, tokenizer
+
+    def _expected_keys(self):
+        return W.clip_text_expected_keys(self.cfg)
+
+    def load_state_dict(self, state_dict, strict=True):
+        sd = {k[6:] if k.startswith("model.") else k: v for k, v in state_dict.items()}
+        res = self._check_keys(sd, strict, ignore=("visual.", "text_projection", "logit_scale", "attn_mask"))
+        self._sd = {k: v.detach().cpu() for k, v in sd.items()}
+        if self.ctx is not None:
+            self._upload()
+        return res
+
+    def _upload(self):
+        c = self.cfg
+        n_run = c["layers"] - self.layer_idx
+        self.ctx.upload_all(W.pack_clip_text(self._sd, c, n_run))
+        self.ctx.check(self.ctx.lib.ir_clip_text_configure(self.ctx.h, n_run, c["width"], c["heads"], int(c["width"] * c["mlp_ratio"]), c["vocab_size"],
+                                                           c["context_length"]), "ir_clip_text_configure")
+        self._mark_bound()
+
+    def tokenize(self, text):
+        if self.tokenizer is not None:
+            return self.tokenizer(text)
+        if any(t != "" for t in text):
+            raise NotImplementedError("open_clip's BPE table is not part of this build: construct FrozenOpenCLIPEmbedder(tokenizer=...) for non-empty prompts")
+        ids = torch.zeros(len(text), self.max_length, dtype=torch.long)
+        ids[:, 0], ids[:, 1] = self.SOT, self.EOT
+        return ids
+
+    @torch.no_grad()
+    def encode_with_transformer(self, tokens):
+        self._ready()
+        ids = tokens.to(self.device, torch.int32).contiguous()
+        b, t = ids.shape
+        if t != self.max_length:
+            raise ValueError(f"tokens must be [B, {self.max_length}], got {tuple(ids.shape)}")
+        out = torch.empty(b, t, self.cfg["width"], dtype=torch.float32, device=self.device)
+        ws = self.ctx.workspace(self.ctx.ws_bytes(L.STAGE_CLIP_TEXT, b, 0, 0))
+        self.ctx.check(self.ctx.lib.ir_clip_text_encode(self.ctx.h, self.ctx.stream(), L.ptr(ids), L.ptr(out), b, L.ptr(ws), ws.numel()), "ir_clip_text_encode")
+        return out
+
+    def __call__(self, text):
+        return self.encode_with_transformer(self.tokenize(list(text)))
+
+    forward = encode = __call__
+
+
 class Reflow_ControlLDM:
     """Reflow_ControlLDM(control_stage_config, ..., unet_config, first_stage_config, preprocess_config) of configs/cldm.yaml. Each *_config is
     the yaml node ({'target': ..., 'params': {...}}) or its params dict."""
@@ -140,6 +213,7 @@ class Reflow_ControlLDM:
                                                scaling_factor=scale_factor)
         self.cond_encoder = self.first_stage_model
         self.preprocess_model = SwinIR(**par(preprocess_config)) if preprocess_config else None
+        self.cond_stage_model = FrozenOpenCLIPEmbedder(**par(cond_stage_config)) if cond_stage_config else None
         self.control_key, self.only_mid_control, self.control_scales = control_key, only_mid_control, [1.0] * 13
         self.num_timesteps, self.scale_factor, self.channels = timesteps, scale_factor, channels
         self.device, self.ctx = torch.device("cpu"), None
@@ -158,10 +232,12 @@ class Reflow_ControlLDM:
         self.first_stage_model.load_state_dict(W.vae_ldm_to_diffusers(vae, nl, self.first_stage_model.cfg["num_res_blocks"]), strict)
         if self.preprocess_model is not None:
             self.preprocess_model.load_state_dict(sub("preprocess_model."), strict)
+        if self.cond_stage_model is not None and any(k.startswith("cond_stage_model.") for k in state_dict):
+            self.cond_stage_model.load_state_dict(sub("cond_stage_model."), strict)
         return SimpleNamespace(missing_keys=[], unexpected_keys=[])
 
     def to(self, device):
-        for m in (self.model.diffusion_model, self.control_model, self.first_stage_model, self.preprocess_model):
+        for m in (self.model.diffusion_model, self.control_model, self.first_stage_model, self.preprocess_model, self.cond_stage_model):
             if m is not None:
                 m.to(device)
         self.ctx, self.device = self.model.diffusion_model.ctx, self.model.diffusion_model.device
@@ -179,7 +255,13 @@ class Reflow_ControlLDM:
 
     # ---- the reference's methods
     def get_learned_conditioning(self, c):
-        raise NotImplementedError("the OpenCLIP text encoder is not part of this build: pass the prompt embedding as c_crossattn")
+        """LatentDiffusion.get_learned_conditioning: cond_stage_model.encode(c) (the frozen OpenCLIP text tower)."""
+        if self.cond_stage_model is None or self.cond_stage_model._sd is None:
+            raise NotImplementedError("no cond_stage_model weights loaded: pass the prompt embedding as c_crossattn")
+        return self.cond_stage_model.encode(c)
+
+    def get_unconditional_conditioning(self, N):   # cldm.py:529-530
+        return self.get_learned_conditioning([""] * N)
 
     @torch.no_grad()
     def apply_condition_encoder(self, control):
@@ -191,7 +273,7 @@ class Reflow_ControlLDM:
         """cldm.py:511-527: eps = diffusion_model(x, t, context, control = control_model(x, hint = c_latent, t, context) * control_scales)."""
         self._ready()
         c_latent = None if cond["c_latent"] is None else torch.cat(cond["c_latent"], 1)
-        return _sample(self.ctx, x_noisy, c_latent, t, torch.cat(cond["c_crossattn"], 1), add_x=False)
+        return _sample(self.ctx, x_noisy, c_latent, t, _cat1(cond["c_crossattn"]), add_x=False)
 
     @torch.no_grad()
     def sample_log(self, cond, steps=1, *, zT=None):
@@ -202,7 +284,7 @@ class Reflow_ControlLDM:
         if zT is None:
             zT = torch.randn(b, self.channels, h // 8, w // 8, device=self.device)
         c_latent = None if cond["c_latent"] is None else torch.cat(cond["c_latent"], 1)
-        return _sample(self.ctx, zT, c_latent, float(self.num_timesteps - 1), torch.cat(cond["c_crossattn"], 1), add_x=True)
+        return _sample(self.ctx, zT, c_latent, float(self.num_timesteps - 1), _cat1(cond["c_crossattn"]), add_x=True)
 
     @torch.no_grad()
     def decode_first_stage(self, z):

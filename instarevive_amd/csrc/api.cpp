@@ -131,6 +131,22 @@ struct T5Model {
 };
 
 
+// OpenCLIP text tower of the ControlLDM path's cond_stage_model (FrozenOpenCLIPEmbedder.encode_with_transformer, ldm/modules/encoders/modules.py:
+// 176-193: token + positional embedding, pre-LN transformer blocks with a causal mask, ln_final)
+struct ClipLayer {
+    Norm n1, n2;
+    Conv qkv, o, fc, proj;   // in_proj (q rows pre-scaled by d_head^-0.5), out_proj, mlp.c_fc, mlp.c_proj
+};
+struct ClipTextModel {
+    bool ok = false;
+    int L = 0, D = 0, H = 0, dk = 0, F = 0, vocab = 0, T = 0;
+    const bf16_t* embed = nullptr;
+    const float *pos = nullptr, *causal = nullptr;   // [T][D]; [H][T][T] additive mask (0 / -3e38)
+    Norm final_ln;
+    std::vector<ClipLayer> layers;
+    int* bad = nullptr;
+};
+
 // SD-2.1 UNet / ControlNet of the ControlLDM one-step path (ldm/modules/diffusionmodules/openaimodel.py:411-786,
 // diffusion/cldm.py:58-292)
 struct UResW {        // ResBlock (openaimodel.py:163-272, use_scale_shift_norm = False)
@@ -228,6 +244,8 @@ struct ir_ctx {
     DitModel dit;
     T5Model t5;
     UNetW unet[2];                                  // [0] the diffusion UNet, [1] the ControlNet
+    ClipTextModel clip;
+    std::vector<void*> clip_owned;
     std::vector<void*> unet_tabs[2], unet_ctx[2];   // their timestep tables / context K-V caches
     // hipGraph cache of ir_pipeline (IR_FLAG_GRAPH): one instantiated graph per exact call signature. `generation` changes whenever
     // device allocations or bindings may have moved (upload with a new size, *_configure, set_prompt), which drops every graph.
@@ -1908,6 +1926,7 @@ int ir_unet_set_context(ir_ctx* c, void* stream, const float* context_host, int 
     if (!(cond)) return fail(c, -11, msg)
 
 static void t5_run(Run& r, const int* ids, const float* key_mask, const float* bias, float* out, int B, int T);
+static void clip_text_run(Run& r, const int* ids, float* out, int B);
 static int stage_dispatch(ir_ctx* c, Run& r, int stage, int n, int h, int w, int flags, int tile_size, int tile_stride) {
     // dry-run bodies used by ir_workspace_bytes; pointers are fake and never dereferenced
     const float* fin = reinterpret_cast<const float*>((uintptr_t)0x1000);
@@ -1931,6 +1950,10 @@ static int stage_dispatch(ir_ctx* c, Run& r, int stage, int n, int h, int w, int
             break;
         case IR_STAGE_COLORFIX: colorfix_run(r, IR_FLAG_FIX_WAVELET, fin, fin, fout, n, h, w); break;
         case IR_STAGE_T5: t5_run(r, (const int*)fin, nullptr, fin, fout, n, h); break;  // n = batch, h = tokens
+        case IR_STAGE_CLIP_TEXT:
+            if (!c->clip.ok) return fail(c, -11, "CLIP text encoder not configured");
+            clip_text_run(r, (const int*)fin, fout, n);
+            break;
         case IR_STAGE_CLDM:
             if (!c->unet[0].ok) return fail(c, -11, "UNet not configured");
             cldm_run(r, fin, c->unet[1].ok ? fin : nullptr, fout, n, h, w, 0.f);
@@ -2349,6 +2372,82 @@ int ir_t5_encode(ir_ctx* c, void* stream, const int32_t* ids, const float* key_m
     if (bad) {
         HIPOK(c, hipMemset(c->t5.bad, 0, 4));
         return fail(c, -32, "ir_t5_encode: token id outside [0, %d)", c->t5.vocab);
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------- OpenCLIP text tower (ControlLDM's cond_stage_model)
+static void clip_text_run(Run& r, const int* ids, float* out, int B) {
+    ClipTextModel& m = r.c->clip;
+    const int T = m.T, HD = m.H * m.dk;
+    const long BT = (long)B * T;
+    const size_t mk = r.a.mark();
+    float* x = r.a.alloc<float>(BT * m.D);
+    bf16_t* xn = r.a.alloc<bf16_t>(BT * m.D);
+    bf16_t* qkv = r.a.alloc<bf16_t>(BT * 3 * HD);
+    bf16_t* att = r.a.alloc<bf16_t>(BT * HD);
+    bf16_t* hid = r.a.alloc<bf16_t>(BT * m.F);
+    LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_t5_embed(ids, m.embed, x, BT, m.D, m.vocab, m.bad, r.s), "clip_embed");        // token_embedding
+    LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_add_bias_rows(x, m.pos, BT * m.D, T * m.D, r.s), "clip_pos");                  // + positional_embedding
+    for (const ClipLayer& Lw : m.layers) {   // open_clip ResidualAttentionBlock: x + attn(ln_1(x), causal mask); x + mlp(ln_2(x))
+        layernorm(r, x, xn, nullptr, Lw.n1.g, Lw.n1.b, BT, m.D, m.D, m.D, 1e-5f);
+        linear(r, Lw.qkv, xn, (int)BT, m.D, qkv, 3 * HD, 0, ACT_NONE, nullptr, 0, 0);
+        LAUNCH(r, PC_OTHER, 4.0 * B * m.H * (double)T * T * m.dk, 0.0, ir_launch_t5_attn(qkv, m.causal, nullptr, att, B, T, m.H, m.dk, r.s), "clip_attn");
+        linear(r, Lw.o, att, (int)BT, HD, x, m.D, 1, ACT_NONE, x, 1, m.D);
+        layernorm(r, x, xn, nullptr, Lw.n2.g, Lw.n2.b, BT, m.D, m.D, m.D, 1e-5f);
+        linear(r, Lw.fc, xn, (int)BT, m.D, hid, m.F, 0, ACT_GELU_ERF, nullptr, 0, 0);
+        linear(r, Lw.proj, hid, (int)BT, m.F, x, m.D, 1, ACT_NONE, x, 1, m.D);
+    }
+    layernorm(r, x, nullptr, out, m.final_ln.g, m.final_ln.b, BT, m.D, m.D, m.D, 1e-5f);   // ln_final
+    r.a.release(mk);
+}
+
+int ir_clip_text_configure(ir_ctx* c, int n_layers, int width, int heads, int d_ff, int vocab, int max_len) {
+    if (!c || n_layers < 1 || vocab < 1 || heads < 1 || max_len < 1 || max_len > 512) return fail(c, -1, "ir_clip_text_configure: bad argument");
+    const int dk = width / heads;
+    if ((width & 31) || (d_ff & 31) || width % heads || dk > 64 || (dk & 1) || width > 1280)
+        return fail(c, -1, "ir_clip_text_configure: unsupported dims (width %d, heads %d, d_ff %d)", width, heads, d_ff);
+    HIPOK(c, hipSetDevice(c->device));
+    Binder b{c};
+    ClipTextModel m;
+    m.L = n_layers; m.D = width; m.H = heads; m.dk = dk; m.F = d_ff; m.vocab = vocab; m.T = max_len;
+    m.embed = (const bf16_t*)b.get("clip.embed", (size_t)vocab * width * 2);
+    m.pos = b.f32("clip.pos", (size_t)max_len * width);
+    m.causal = b.f32("clip.causal", (size_t)heads * max_len * max_len);
+    m.final_ln = b.norm("clip.final_ln", width);
+    for (int l = 0; l < n_layers; ++l) {
+        ClipLayer L;
+        const std::string p = fmt("clip.l%d", l);
+        L.n1 = b.norm(p + ".ln1", width);
+        L.n2 = b.norm(p + ".ln2", width);
+        L.qkv = b.conv(p + ".qkv", width, 3 * width, 3 * width, 1);
+        L.o = b.conv(p + ".o", width, width, width, 1);
+        L.fc = b.conv(p + ".fc", width, d_ff, d_ff, 1);
+        L.proj = b.conv(p + ".proj", d_ff, width, width, 1);
+        m.layers.push_back(L);
+    }
+    if (!b.ok) return fail(c, -2, "ir_clip_text_configure: tensor %s", b.missing.c_str());
+    release_list(c->clip_owned);
+    if (dev_alloc(c, c->clip_owned, (void**)&m.bad, 256)) return -100;
+    HIPOK(c, hipMemset(m.bad, 0, 4));
+    m.ok = true;
+    c->clip = m;
+    ++c->generation;
+    return 0;
+}
+
+int ir_clip_text_encode(ir_ctx* c, void* stream, const int32_t* ids, float* out, int b, void* ws, size_t ws_bytes) {
+    REQUIRE(c && c->clip.ok, "CLIP text encoder not configured");
+    REQUIRE(ids && out && b > 0, "ir_clip_text_encode: bad argument");
+    Run r = make_run(c, stream, ws, ws_bytes, false);
+    clip_text_run(r, ids, out, b);
+    if (int rc = finish(r, c, ws_bytes)) return rc;
+    int bad = 0;   // runs once per prompt: a synchronous check of the id range, as the reference's embedding lookup fails on a bad id
+    HIPOK(c, hipMemcpyAsync(&bad, c->clip.bad, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPOK(c, hipStreamSynchronize((hipStream_t)stream));
+    if (bad) {
+        HIPOK(c, hipMemset(c->clip.bad, 0, 4));
+        return fail(c, -32, "ir_clip_text_encode: token id outside [0, %d)", c->clip.vocab);
     }
     return 0;
 }

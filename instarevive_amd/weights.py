@@ -699,3 +699,48 @@ def unet_shapes(cfg, control=False):
     else:
         put("out.0", mc); put("out.2", cfg["out_channels"], mc, 3, 3)
     return s
+
+
+# ------------------------------------------------------------------------------------------------ OpenCLIP text tower (ControlLDM's cond_stage_model)
+def clip_text_expected_keys(cfg):
+    keys = ["token_embedding.weight", "positional_embedding", "ln_final.weight", "ln_final.bias"]
+    for i in range(cfg["layers"]):
+        p = f"transformer.resblocks.{i}"
+        keys += [p + s for s in (".ln_1.weight", ".ln_1.bias", ".ln_2.weight", ".ln_2.bias", ".attn.in_proj_weight", ".attn.in_proj_bias",
+                                 ".attn.out_proj.weight", ".attn.out_proj.bias", ".mlp.c_fc.weight", ".mlp.c_fc.bias", ".mlp.c_proj.weight", ".mlp.c_proj.bias")]
+    return keys
+
+
+def clip_text_shapes(cfg):
+    d, f = cfg["width"], int(cfg["width"] * cfg.get("mlp_ratio", 4.0))
+    s = {"token_embedding.weight": (cfg["vocab_size"], d), "positional_embedding": (cfg["context_length"], d), "ln_final.weight": (d,), "ln_final.bias": (d,)}
+    for i in range(cfg["layers"]):
+        p = f"transformer.resblocks.{i}"
+        s.update({p + ".ln_1.weight": (d,), p + ".ln_1.bias": (d,), p + ".ln_2.weight": (d,), p + ".ln_2.bias": (d,),
+                  p + ".attn.in_proj_weight": (3 * d, d), p + ".attn.in_proj_bias": (3 * d,), p + ".attn.out_proj.weight": (d, d), p + ".attn.out_proj.bias": (d,),
+                  p + ".mlp.c_fc.weight": (f, d), p + ".mlp.c_fc.bias": (f,), p + ".mlp.c_proj.weight": (d, f), p + ".mlp.c_proj.bias": (d,)})
+    return s
+
+
+def pack_clip_text(sd, cfg, n_run):
+    """open_clip text-tower parameters -> the tensors ir_clip_text_configure binds. The softmax scale d_head^-0.5 is folded into the q rows of
+    in_proj (the attention kernel, shared with the T5 encoder, does not scale); the causal mask is an additive [heads][T][T] table."""
+    d, H, T = cfg["width"], cfg["heads"], cfg["context_length"]
+    out = {"clip.embed": _bf16(sd["token_embedding.weight"]), "clip.pos": sd["positional_embedding"].float().contiguous(),
+           "clip.final_ln.g": sd["ln_final.weight"].float().contiguous(), "clip.final_ln.b": sd["ln_final.bias"].float().contiguous()}
+    mask = torch.zeros(T, T)
+    mask[torch.triu(torch.ones(T, T, dtype=torch.bool), 1)] = -3.0e38
+    out["clip.causal"] = mask[None].expand(H, T, T).contiguous()
+    scale = (d // H) ** -0.5
+    for i in range(n_run):
+        s, p = f"transformer.resblocks.{i}", f"clip.l{i}"
+        for n, src in (("ln1", ".ln_1"), ("ln2", ".ln_2")):
+            out[f"{p}.{n}.g"], out[f"{p}.{n}.b"] = sd[s + src + ".weight"].float().contiguous(), sd[s + src + ".bias"].float().contiguous()
+        w, b = sd[s + ".attn.in_proj_weight"].float().clone(), sd[s + ".attn.in_proj_bias"].float().clone()
+        w[:d] *= scale
+        b[:d] *= scale
+        _pack_lin(out, p + ".qkv", w, b)
+        _pack_lin(out, p + ".o", sd[s + ".attn.out_proj.weight"], sd[s + ".attn.out_proj.bias"])
+        _pack_lin(out, p + ".fc", sd[s + ".mlp.c_fc.weight"], sd[s + ".mlp.c_fc.bias"])
+        _pack_lin(out, p + ".proj", sd[s + ".mlp.c_proj.weight"], sd[s + ".mlp.c_proj.bias"])
+    return out

@@ -80,7 +80,7 @@ def test_geglu(ctx):
 
 
 # ---------------------------------------------------------------------------------------------- networks
-def make_cldm(cfg=CLDM_SMALL, vae_ch=32, swin_cfg=SWIN_SMALL, seeds=(707, 708, 202, 101)):
+def make_cldm(cfg=CLDM_SMALL, vae_ch=32, swin_cfg=SWIN_SMALL, seeds=(707, 708, 202, 101), clip=None):
     """A Reflow_ControlLDM with deterministic weights, loaded through the reference's checkpoint layout."""
     from instarevive_amd.cldm import Reflow_ControlLDM
     sd_u = det_state_dict(ocldm.state_dict_shapes(cfg), seed=seeds[0])
@@ -101,14 +101,18 @@ def make_cldm(cfg=CLDM_SMALL, vae_ch=32, swin_cfg=SWIN_SMALL, seeds=(707, 708, 2
                           unet_config=dict(target="diffusion.cldm.ControlledUnetModel", params=unet_params),
                           first_stage_config=dict(target="ldm.models.autoencoder.AutoencoderKL", params=fs),
                           preprocess_config=dict(target="diffusion.model.swinir.SwinIR", params=pp), control_key="hint", sd_locked=False,
-                          only_mid_control=False, learning_rate=1e-5, lora_rank=4, timesteps=1000, scale_factor=0.18215)
+                          only_mid_control=False, learning_rate=1e-5, lora_rank=4, timesteps=1000, scale_factor=0.18215,
+                          cond_stage_config=None if clip is None else dict(target="ldm.modules.encoders.modules.FrozenOpenCLIPEmbedder",
+                                                                            params=dict(freeze=True, layer="penultimate", **clip[0])))
     # the reference's checkpoint layout: LDM names for both VAE halves (diffusers -> LDM is the inverse of weights.vae_ldm_to_diffusers)
     ldm_v = diffusers_to_ldm(sd_v)
     ckpt = {**{"model.diffusion_model." + k: v for k, v in sd_u.items()}, **{"control_model." + k: v for k, v in sd_c.items()},
             **{"cond_encoder." + k: v for k, v in ldm_v.items() if k.startswith(("encoder.", "quant_conv."))},
             **{"first_stage_model." + k: v for k, v in ldm_v.items()},
             **{"preprocess_model." + k: v for k, v in sd_s.items()},
-            "betas": torch.zeros(1000), "cond_stage_model.model.positional_embedding": torch.zeros(77, 8)}
+            "betas": torch.zeros(1000)}
+    if clip is not None:
+        ckpt.update({"cond_stage_model.model." + k: v for k, v in clip[1].items()})
     m.load_state_dict(ckpt, strict=False)
     return m.to("cuda"), dict(unet=sd_u, cnet=sd_c, vae=sd_v, swin=sd_s)
 
@@ -289,3 +293,60 @@ def test_pipeline_hipgraph_replay_is_identical(small):
     assert float(outs[0].std()) > 1e-3
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
+
+
+CLIP_SMALL = dict(width=128, heads=4, layers=4, vocab_size=1000, context_length=77, mlp_ratio=4.0)
+
+
+def test_clip_text_tower_vs_oracle():
+    """FrozenOpenCLIPEmbedder (layer "penultimate": 3 of the 4 blocks run) against oracle/clip_text.py on deterministic weights: random token
+    ids, the empty prompt through the built-in tokenisation, an id outside the vocabulary, and its use as get_unconditional_conditioning."""
+    from instarevive_amd.cldm import FrozenOpenCLIPEmbedder
+    from oracle import clip_text as oclip
+    cfg = dict(CLIP_SMALL, layer="penultimate")
+    sd = det_state_dict(oclip.state_dict_shapes(cfg), seed=909)
+    enc = FrozenOpenCLIPEmbedder(layer="penultimate", width=128, heads=4, layers=4, vocab_size=1000)
+    enc.load_state_dict({"model." + k: v for k, v in sd.items()})
+    enc.to("cuda")
+    g = torch.Generator().manual_seed(1)
+    tokens = torch.randint(0, 1000, (3, 77), generator=g)
+    check(enc.encode_with_transformer(tokens), oclip.encode_with_transformer(sd, tokens, cfg), "CLIP text tower (penultimate) vs oracle", l2=0.008, worst=0.015)
+    last = FrozenOpenCLIPEmbedder(layer="last", width=128, heads=4, layers=4, vocab_size=1000)
+    last.load_state_dict(sd)
+    last.to("cuda")
+    check(last.encode_with_transformer(tokens[:1]), oclip.encode_with_transformer(sd, tokens[:1], dict(cfg, layer="last")), "CLIP text tower (last) vs oracle",
+          l2=0.008, worst=0.015)
+    enc._ready()
+    assert enc.tokenize(["", ""]).tolist() == [[49406, 49407] + [0] * 75] * 2   # open_clip.tokenize(""): <start_of_text>, <end_of_text>, zero padding
+    with pytest.raises(RuntimeError):   # ... which is outside this 1000-entry test vocabulary: loud, like the reference's nn.Embedding
+        enc([""])
+    big = FrozenOpenCLIPEmbedder(layer="penultimate", width=128, heads=4, layers=2, vocab_size=49408)
+    sd_big = det_state_dict(oclip.state_dict_shapes(dict(cfg, layers=2, vocab_size=49408)), seed=910)
+    big.load_state_dict(sd_big)
+    big.to("cuda")
+    e = big([""] * 2)   # the reference's get_unconditional_conditioning
+    check(e, oclip.encode_with_transformer(sd_big, big.tokenize(["", ""]), dict(cfg, layers=2, vocab_size=49408)), "empty prompt vs oracle", l2=0.008, worst=0.015)
+    assert torch.equal(e[0], e[1])
+    enc._ready()
+    with pytest.raises(NotImplementedError):
+        enc(["a photo"])
+    with pytest.raises(RuntimeError):
+        enc.encode_with_transformer(torch.full((1, 77), 1000))
+
+
+def test_unconditional_conditioning_through_the_model():
+    """get_unconditional_conditioning (cldm.py:529-530: the empty prompt through cond_stage_model) feeding sample_log, as the reference's samplers
+    do - the text tower, the ControlNet and the UNet of one checkpoint on one device."""
+    from oracle import clip_text as oclip
+    ccfg = dict(width=CLDM_SMALL["context_dim"], heads=2, layers=3, vocab_size=49408, context_length=77, mlp_ratio=4.0, layer="penultimate")
+    sd_clip = det_state_dict(oclip.state_dict_shapes(ccfg), seed=911)
+    m, sds = make_cldm(clip=(dict(width=ccfg["width"], heads=2, layers=3, vocab_size=49408), sd_clip))
+    c = m.get_unconditional_conditioning(2)
+    ids = torch.zeros(2, 77, dtype=torch.long)
+    ids[:, 0], ids[:, 1] = 49406, 49407
+    c_ref = oclip.encode_with_transformer(sd_clip, ids, ccfg)
+    check(c, c_ref, "get_unconditional_conditioning vs oracle", l2=0.008, worst=0.015)
+    zT, c_latent = det_input(65, (2, 4, 16, 16), -2.0, 2.0), det_input(66, (2, 4, 16, 16), -2.0, 2.0)
+    out = m.sample_log({"c_concat": [torch.zeros(2, 3, 128, 128)], "c_crossattn": [c], "c_latent": [c_latent]}, zT=zT)
+    sd = {**{"model.diffusion_model." + k: v for k, v in sds["unet"].items()}, **{"control_model." + k: v for k, v in sds["cnet"].items()}}
+    check(out, ocldm.reflow_sample(sd, zT, c_latent, c_ref, CLDM_SMALL), "sample_log with the model's own conditioning vs oracle")

@@ -256,3 +256,21 @@ def test_unet_shapes_match_the_reference_parameter_table():
     for cfg in (dict(ocldm.DEFAULT_CFG), dict(ocldm.DEFAULT_CFG, model_channels=64, num_head_channels=32, context_dim=64)):
         for control in (False, True):
             assert {k: tuple(v) for k, v in W.unet_shapes(cfg, control).items()} == {k: tuple(v) for k, v in ocldm.state_dict_shapes(cfg, control).items()}
+
+
+def test_clip_text_keys_and_packing():
+    import torch
+    from instarevive_amd import weights as W
+    from oracle import clip_text as oclip
+    from tests.golden._det import det_state_dict
+    cfg = dict(width=64, heads=2, layers=3, vocab_size=100, context_length=77, mlp_ratio=4.0)
+    shapes = oclip.state_dict_shapes(cfg)
+    assert set(W.clip_text_expected_keys(cfg)) == set(shapes) and {k: tuple(v) for k, v in W.clip_text_shapes(cfg).items()} == {k: tuple(v) for k, v in shapes.items()}
+    full = oclip.state_dict_shapes()
+    assert len(full) == 4 + 24 * 12 and full["transformer.resblocks.23.mlp.c_fc.weight"] == (4096, 1024)   # ViT-H-14 text tower
+    sd = det_state_dict(shapes, seed=3)
+    p = W.pack_clip_text(sd, cfg, n_run=2)
+    assert "clip.l1.qkv.w" in p and "clip.l2.qkv.w" not in p and p["clip.causal"].shape == (2, 77, 77) and p["clip.embed"].shape == (100, 64)
+    assert float(p["clip.causal"][0, 5, 6]) < -1e37 and float(p["clip.causal"][0, 6, 5]) == 0.0
+    torch.testing.assert_close(p["clip.l0.qkv.b"][:64], sd["transformer.resblocks.0.attn.in_proj_bias"][:64] * 32 ** -0.5)
+    torch.testing.assert_close(p["clip.l0.qkv.b"][64:], sd["transformer.resblocks.0.attn.in_proj_bias"][64:])
