@@ -350,3 +350,17 @@ def test_unconditional_conditioning_through_the_model():
     out = m.sample_log({"c_concat": [torch.zeros(2, 3, 128, 128)], "c_crossattn": [c], "c_latent": [c_latent]}, zT=zT)
     sd = {**{"model.diffusion_model." + k: v for k, v in sds["unet"].items()}, **{"control_model." + k: v for k, v in sds["cnet"].items()}}
     check(out, ocldm.reflow_sample(sd, zT, c_latent, c_ref, CLDM_SMALL), "sample_log with the model's own conditioning vs oracle")
+
+
+def test_clip_text_tower_full_size():
+    """The ViT-H-14 text tower at its real size (width 1024, 16 heads x 64, 24 blocks of which 23 run, 49408-token vocabulary): the empty
+    prompt the reference samples with, against the oracle."""
+    from instarevive_amd.cldm import FrozenOpenCLIPEmbedder
+    from oracle import clip_text as oclip
+    cfg = dict(oclip.DEFAULT_CFG)
+    sd = det_state_dict(oclip.state_dict_shapes(cfg), seed=912)
+    enc = FrozenOpenCLIPEmbedder(layer="penultimate")
+    enc.load_state_dict(sd)
+    enc.to("cuda")
+    got = enc([""])
+    check(got, oclip.encode_with_transformer(sd, enc.tokenize([""]), cfg), "ViT-H-14 text tower, empty prompt", l2=0.008, worst=0.015)
