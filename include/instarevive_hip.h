@@ -165,6 +165,14 @@ int ir_pipeline(ir_ctx* ctx, void* stream, const uint8_t* in, uint8_t* out, uint
 int ir_tiled_count(int h, int w, int tile_size, int tile_stride);
 int ir_tiled_encode(ir_ctx* ctx, void* stream, const uint8_t* in, uint8_t* stage1, float* control, float* init, int n, int h, int w, int flags,
                     float scaling_factor, void* ws, size_t ws_bytes);
+/* ir_tiled_encode in two parts around the encoder's mid-block attention (model.py:181-205), so that several GPUs working on ONE large frame
+ * (tile sharding) split its T^2 work by query rows instead of each repeating it: part 0 = SwinIR, stage-1 image, control image, the encoder
+ * up to q / k / v and the attention of rows [row0, row1) (multiples of 128) -> those rows of attn_o, plus the block's input -> attn_res;
+ * part 1 = the rest of the encoder from ALL rows of attn_o (the ranks' all-gather) -> init. n == 1; h * w / 64 a multiple of 128;
+ * attn_o / attn_res: device bf16 [h * w / 64][512]. Every row equals the unsharded ir_tiled_encode's (whole 128-query workgroups). */
+int ir_tiled_encode_part(ir_ctx* ctx, void* stream, const uint8_t* in, uint8_t* stage1, float* control, float* init, int n, int h, int w, int flags,
+                         float sf, int part, int row0, int row1, uint16_t* attn_o, uint16_t* attn_res, void* ws, size_t ws_bytes);
+
 int ir_tiled_dit(ir_ctx* ctx, void* stream, const float* init, float* x0_tiles, int n, int h, int w, int tile_size, int tile_stride, int first,
                  int step, float timestep, float alpha_cumprod, int flags, void* ws, size_t ws_bytes);
 int ir_tiled_blend_latent(ir_ctx* ctx, void* stream, const float* x0_tiles, float* nb, int n, int h, int w, int tile_size, int tile_stride);

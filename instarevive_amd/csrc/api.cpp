@@ -624,11 +624,23 @@ int resblock(Run& r, const ResW& w, bf16_t* B[3], int ci, float* gws, int N, int
     conv(r, w.c2, B[t2], N, H, W, cout, B[t1], cout, 0, 1, 1, 0, ACT_NONE, 0.f, res, 0, cout);
     return t1;
 }
+// The encoder's mid-block attention split over ranks by query rows (tile-sharded processing of ONE large frame):
+// part 0 runs the block up to the attention of rows [row0, row1) - o rows into the caller's buffer, the block's input (the residual) too -
+// and stops; after the ranks exchanged their rows, part 1 resumes at the output projection. Rows are whole 128-query workgroups, so every
+// row is the one the unsharded launch computes.
+struct AttnShard {
+    int part = -1, row0 = 0, row1 = 0;
+    bf16_t *o = nullptr, *res = nullptr;   // [T][512] each, caller-owned
+};
 // AttnBlock (model.py:181-205), single head, scores materialised per image in HBM (fp32 S, bf16 P).
-int attnblock(Run& r, const AttnW& w, bf16_t* B[3], int ci, float* gws, int N, int H, int W) {
+int attnblock(Run& r, const AttnW& w, bf16_t* B[3], int ci, float* gws, int N, int H, int W, const AttnShard* sh = nullptr) {
     const int t1 = (ci + 1) % 3, t2 = (ci + 2) % 3;
     const int C = w.n.c;
     const long T = (long)H * W;
+    if (sh && sh->part == 1) {   // resume: proj_out(o) + x with the gathered rows and the saved block input
+        linear(r, w.o, sh->o, (int)(N * T), C, B[t2], C, 0, ACT_NONE, sh->res, 0, C);
+        return t2;
+    }
     const size_t mk = r.a.mark();
     bf16_t* q = r.a.alloc<bf16_t>(N * T * C);
     bf16_t* k = r.a.alloc<bf16_t>(N * T * C);
@@ -654,6 +666,21 @@ int attnblock(Run& r, const AttnW& w, bf16_t* B[3], int ci, float* gws, int N, i
     linear(r, w.v, B[t1], (int)(N * T), C, v, C, 0, ACT_NONE, nullptr, 0, 0);
     const int dsub = (C % 128 == 0) ? 128 : (C % 64 == 0 ? 64 : 32);
     const float sc = 1.0f / sqrtf((float)C);
+    if (sh && sh->part == 0) {   // (shape checked by the caller: N == 1, the d = 512 flash path, rows in whole workgroups)
+        const int rows = sh->row1 - sh->row0;
+        LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_zero_f32(reinterpret_cast<float*>(flag), 1, r.s), "zero");
+        LAUNCH(r, PC_TRANSPOSE, 0.0, 4.0 * (double)T * C, ir_launch_transpose_v_tiles(v, vtt, 1, (int)T, C, T * C, T * C, r.s), "transpose_v_tiles");
+        if (rows > 0)
+            LAUNCHK(r, PK_ATTN_D512, 4.0 * (double)rows * T * C, 0.0,
+                   ir_launch_flash_attn_d512_v2_rows(q + (long)sh->row0 * C, k, vtt, sh->o + (long)sh->row0 * C, (int)T, rows, C, C, sc, flag, r.s), "vae_flash_attn_rows");
+        // overflow fallback (rare): every rank recomputes ALL rows with the rescaling kernel - identical values everywhere, the exchange keeps its slices
+        LAUNCH(r, PC_TRANSPOSE, 0.0, 0.0, ir_launch_transpose_v(v, vt, 0, C, dsub, 1, C / dsub, (int)T, (int)ld, dsub, dsub, r.s, flag), "transpose_v");
+        LAUNCH(r, PC_FLASH_ATTN, 0.0, 0.0, ir_launch_flash_attn_d512(q, k, vt, sh->o, (int)T, C, C, ld, sc, r.s, flag), "vae_flash_attn_fallback");
+        if (r.live()) r.chk(hipMemcpyAsync(sh->res, B[ci], (size_t)T * C * 2, hipMemcpyDeviceToDevice, r.s) == hipSuccess ? 0 : -1, "save the block input");
+        r.chain = nullptr;
+        r.a.release(mk);
+        return -1;   // stop here: the caller exchanges the rows
+    }
     if (f8) {
         LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_zero_f32(reinterpret_cast<float*>(flag), 1, r.s), "zero");
         LAUNCHK(r, PK_ATTN_D512_FP8, 4.0 * (double)N * T * T * C, 0.0,
@@ -716,7 +743,7 @@ long gn_fused_floats(int h, int w) {
 }
 
 // Encoder.forward (model.py:521-546) + quant_conv + mode() (autoencoder.py:82-86). in: fp32 NCHW, v*in_scale+in_shift first.
-void vae_encode_run(Run& r, const float* in, float* lat, int n, int h, int w, float in_scale, float in_shift, float lat_scale) {
+void vae_encode_run(Run& r, const float* in, float* lat, int n, int h, int w, float in_scale, float in_shift, float lat_scale, const AttnShard* sh = nullptr) {
     const VaeHalf& m = r.c->vae.enc;
     const int nl = (int)m.levels.size();
     const size_t mk = r.a.mark();
@@ -727,10 +754,15 @@ void vae_encode_run(Run& r, const float* in, float* lat, int n, int h, int w, fl
     float* gws = r.a.alloc<float>(ir_gn_ws_floats(n, (long)h * w, 512));
     r.gn_buf = r.a.alloc<float>((long)n * gn_fused_floats(h, w));
     r.gn_x = nullptr;
+    int ci = 0, H = h, W = w;
+    if (sh && sh->part == 1) {   // resume behind the exchanged attention rows: nothing in front of the block is needed again
+        H = h >> (nl - 1); W = w >> (nl - 1);
+        ci = attnblock(r, m.attn, B, 0, gws, n, H, W, sh);
+        goto after_attention;
+    }
     LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_nchw_to_nhwc_bf16(in, in32, n, 3, (long)h * w, 32, in_scale, in_shift, r.s), "nchw_to_nhwc");
     r.gn_want = true;
     conv(r, m.conv_in, in32, n, h, w, 32, B[0], m.conv_in.cout, 0, 1, 1, 0, ACT_NONE, 0.f, nullptr, 0, 0);
-    int ci = 0, H = h, W = w;
     for (int l = 0; l < nl; ++l) {
         const size_t nres = m.levels[l].res.size();
         for (size_t i = 0; i < nres; ++i) ci = resblock(r, m.levels[l].res[i], B, ci, gws, n, H, W, i + 1 < nres || !m.levels[l].has_resample);
@@ -743,7 +775,13 @@ void vae_encode_run(Run& r, const float* in, float* lat, int n, int h, int w, fl
         }
     }
     ci = resblock(r, m.mid1, B, ci, gws, n, H, W, true);
-    ci = attnblock(r, m.attn, B, ci, gws, n, H, W);
+    ci = attnblock(r, m.attn, B, ci, gws, n, H, W, sh);
+    if (ci < 0) {   // part 0 of a sharded encode: stopped behind this rank's attention rows
+        r.gn_buf = nullptr;
+        r.a.release(mk);
+        return;
+    }
+after_attention:
     ci = resblock(r, m.mid2, B, ci, gws, n, H, W, true);
     const int t1 = (ci + 1) % 3;
     groupnorm(r, m.norm_out, B[ci], B[t1], gws, n, (long)H * W, 1);
@@ -1334,12 +1372,15 @@ void blend_pixels_run(Run& r, const float* px_tiles, float* img, int n, int h, i
     LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_tile_div(img, n, 3, h, w, g.tp, g.tp, g.sl * 8, g.sl * 8, r.s), "tile_div");
 }
 // prologue shared by ir_pipeline and ir_tiled_encode: uint8 -> fp32, stage-1 restorer, VAE encode * scaling factor (inference.py:91-109)
-void encode_run(Run& r, const uint8_t* in, uint8_t* stage1, float* lq, float* control, float* init, int n, int h, int w, int flags, float sf) {
+void encode_run(Run& r, const uint8_t* in, uint8_t* stage1, float* lq, float* control, float* init, int n, int h, int w, int flags, float sf,
+                const AttnShard* sh = nullptr) {
     const long HW = (long)h * w;
-    LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_u8_to_nchw(in, lq, n, h, w, r.s), "u8_to_nchw");
-    if (!(flags & IR_FLAG_NO_PREPROCESS)) swinir_run(r, lq, control, n, h, w);
-    if (stage1) LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_nchw_to_u8(control, stage1, n, HW, r.s), "stage1_u8");
-    vae_encode_run(r, control, init, n, h, w, 2.f, -1.f, sf);
+    if (!(sh && sh->part == 1)) {   // (part 1 of a sharded encode resumes inside the VAE encoder: `control` is part 0's)
+        LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_u8_to_nchw(in, lq, n, h, w, r.s), "u8_to_nchw");
+        if (!(flags & IR_FLAG_NO_PREPROCESS)) swinir_run(r, lq, control, n, h, w);
+        if (stage1) LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_nchw_to_u8(control, stage1, n, HW, r.s), "stage1_u8");
+    }
+    vae_encode_run(r, control, init, n, h, w, 2.f, -1.f, sf, sh);
 }
 
 void pipeline_run(Run& r, const uint8_t* in, uint8_t* out, uint8_t* stage1, int n, int h, int w, int flags, int tile_size,
@@ -2230,6 +2271,32 @@ int ir_tiled_encode(ir_ctx* c, void* stream, const uint8_t* in, uint8_t* stage1,
     Run r = make_run(c, stream, ws, ws_bytes, false);
     float* lq = (flags & IR_FLAG_NO_PREPROCESS) ? control : r.a.alloc<float>((long)n * 3 * h * w);
     encode_run(r, in, stage1, lq, control, init, n, h, w, flags, sf);
+    return finish(r, c, ws_bytes);
+}
+
+// ir_tiled_encode in two parts around the encoder's mid-block attention, whose query rows [row0, row1) (multiples of 128) this rank computes:
+// part 0 = everything up to them (SwinIR, stage-1 image, control, the encoder's convs, q / k / v, the rows' attention -> attn_o rows; the
+// block's input -> attn_res), part 1 = everything behind (needs all rows of attn_o, i.e. the ranks' all-gather, and attn_res) -> init.
+// One image (n == 1), h * w / 64 a multiple of 128, widest encoder level 512 channels; attn_o / attn_res: device bf16 [h * w / 64][512].
+int ir_tiled_encode_part(ir_ctx* c, void* stream, const uint8_t* in, uint8_t* stage1, float* control, float* init, int n, int h, int w, int flags,
+                         float sf, int part, int row0, int row1, uint16_t* attn_o, uint16_t* attn_res, void* ws, size_t ws_bytes) {
+    REQUIRE(c && c->vae.enc.ok, "tiled encode: VAE encoder not configured");
+    REQUIRE((flags & IR_FLAG_NO_PREPROCESS) || c->swin.ok, "tiled encode: SwinIR not configured");
+    REQUIRE(control && init && sf > 0.f && attn_o && attn_res && (part == 1 || in), "tiled encode part: bad argument");
+    if (int e = check_size(c, n, h, w, 64)) return e;
+    const long T = (long)(h / 8) * (w / 8);
+    REQUIRE(n == 1 && c->vae.enc.attn.n.c == 512 && (T & 127) == 0 && !c->plain, "tiled encode part: needs one image, the 512-channel mid block and h * w / 64 a multiple of 128");
+    REQUIRE((part == 0 || part == 1) && row0 >= 0 && row0 <= row1 && row1 <= T && !(row0 & 127) && !(row1 & 127), "tiled encode part: rows must be multiples of 128 within the token count");
+    struct NoFp8 {   // the sharded form runs the bf16 attention (the fp8 kernel has no row-shard entry)
+        ir_ctx* c; bool old;
+        explicit NoFp8(ir_ctx* c_) : c(c_), old(c_->fp8) { c->fp8 = false; }
+        ~NoFp8() { c->fp8 = old; }
+    } nofp8(c);
+    Run r = make_run(c, stream, ws, ws_bytes, false);
+    AttnShard sh;
+    sh.part = part; sh.row0 = row0; sh.row1 = row1; sh.o = attn_o; sh.res = attn_res;
+    float* lq = (flags & IR_FLAG_NO_PREPROCESS) ? control : r.a.alloc<float>((long)n * 3 * h * w);
+    encode_run(r, in, stage1, lq, control, init, n, h, w, flags, sf, &sh);
     return finish(r, c, ws_bytes);
 }
 

@@ -287,6 +287,16 @@ int ir_launch_flash_attn_d512_v2(const bf16_t* q, const bf16_t* k, const bf16_t*
                        scale * 1.44269504088896340736f, ovf_flag);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+// The same for `rows` query rows starting at q / o (both already offset by the caller) against all T keys of ONE image: the query-row shard
+// of a rank when the encoder's mid-block attention of a large frame is split over several GPUs. rows % 128 == 0; every row's result is the
+// one the full launch computes (a workgroup owns 128 queries and shares nothing with the others).
+int ir_launch_flash_attn_d512_v2_rows(const bf16_t* q, const bf16_t* k, const bf16_t* vt_tiles, bf16_t* o, int T, int rows, int rs, int o_rs,
+                                      float scale, int* ovf_flag, hipStream_t s) {
+    if (T <= 0 || (T & 31) || rows <= 0 || (rows & 127) || rows > T || (rs & 7) || (o_rs & 7) || rs < 512 || o_rs < 512 || !ovf_flag) return -2;
+    hipLaunchKernelGGL(flash_attn_d512_v2_kernel, dim3(rows / 128, 1), dim3(256), 0, s, q, k, vt_tiles, o, T, rs, o_rs, 0L, 0L, 0L,
+                       scale * 1.44269504088896340736f, ovf_flag);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
 
 // =====================================================================================================================
 // flash_attn_pp2_kernel<72>: the DiT self-attention (16 heads x 72, T % 64 == 0, no key bias; reference PixArt_blocks.py:123-158) in the

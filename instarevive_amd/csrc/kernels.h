@@ -124,6 +124,8 @@ int ir_launch_flash_attn_d512(const bf16_t* q, const bf16_t* k, const bf16_t* vt
 int ir_launch_transpose_v_tiles(const bf16_t* v, bf16_t* vt, int B, int T, int rs, long v_bs, long vt_bs, hipStream_t s);
 int ir_launch_flash_attn_d512_v2(const bf16_t* q, const bf16_t* k, const bf16_t* vt_tiles, bf16_t* o, int B, int T, int rs, int o_rs, long qk_bs,
                                  long vt_bs, long o_bs, float scale, int* ovf_flag, hipStream_t s);
+int ir_launch_flash_attn_d512_v2_rows(const bf16_t* q, const bf16_t* k, const bf16_t* vt_tiles, bf16_t* o, int T, int rows, int rs, int o_rs,
+                                      float scale, int* ovf_flag, hipStream_t s);   // a query-row shard (q / o offset by the caller), all T keys
 int ir_launch_transpose_v(const bf16_t* v, bf16_t* vt, long v_bs, int v_rs, int v_hs, int B, int Hh, int T, int Tpad, int D,
                           int DV, hipStream_t s, const int* only_if = nullptr);
 int ir_launch_swin_attn(const bf16_t* qkv, bf16_t* out, const float* biasT, int B, int H, int W, int heads, int ld, int ldo,

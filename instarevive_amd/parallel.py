@@ -146,10 +146,48 @@ def _exchange_tiles(local: torch.Tensor, n_tiles: int, rank: int, world: int, to
     return out.to(local.device)
 
 
+def row_shards(n_rows: int, world: int, quantum: int = 128):
+    """Contiguous [row0, row1) per rank over n_rows rows in whole `quantum`-row blocks (n_rows % quantum == 0): blocks dealt as evenly as
+    possible, the first ranks take the remainder."""
+    blocks = n_rows // quantum
+    out, b0 = [], 0
+    for r in range(world):
+        nb = blocks // world + (1 if r < blocks % world else 0)
+        out.append((b0 * quantum, (b0 + nb) * quantum))
+        b0 += nb
+    return out
+
+
+def sharded_encode(engine, control_imgs, rank: int, world: int):
+    """SwinIR + VAE encode of the frame with the encoder's mid-block attention (T^2 * 512: 35 of the 75 TFLOP every rank used to repeat at
+    4K) split over the ranks by query rows; one all_gather of the attention rows. Every row is bit-identical to the unsharded launch's
+    (whole 128-query workgroups), hence so is everything behind it. Falls back to the replicated encode when the engine cannot split
+    (several images, token count not a multiple of 128, an engine without the two-part encode)."""
+    import torch.distributed as dist
+    if world == 1 or not hasattr(engine, "encode_part0") or not engine.can_shard_encode(control_imgs):
+        return engine.encode(control_imgs)             # replicated: SwinIR and the VAE encoder are untiled in the reference
+    h, w = control_imgs[0].shape[:2]
+    T = (h // 8) * (w // 8)
+    shards = row_shards(T, world)
+    r0, r1 = shards[rank]
+    control, attn_o, attn_res = engine.encode_part0(control_imgs, r0, r1)
+    kmax = max(b - a for a, b in shards)
+    dev = _comm_device(attn_o.device)
+    bits = attn_o.view(torch.uint8)                    # raw bytes: every backend moves uint8 (gloo takes neither bfloat16 nor int16)
+    send = torch.zeros((kmax, bits.shape[1]), dtype=torch.uint8, device=dev)
+    send[: r1 - r0] = bits[r0:r1].to(dev)
+    parts = [torch.empty_like(send) for _ in range(world)]
+    dist.all_gather(parts, send)
+    for r, (a, b) in enumerate(shards):
+        if r != rank:
+            bits[a:b] = parts[r][: b - a].to(bits.device)
+    return control, engine.encode_part1(control, attn_o, attn_res)
+
+
 def sharded_tiled_process(engine, control_imgs, rank: int = None, world: int = None, dst: int = 0):
     """process(..., tiled=True) of ONE image batch with its tiles sharded over the ranks (test_scripts/inference.py:119-153; SURVEY.md
     section 8(e), "tile-level sharding of one large image"). `engine` supplies the five phases (pipeline.HipTileEngine on a GPU).
-    Exchange steps: one all_gather of the x0 latent tiles between the two loops (every rank needs the blended latent for its own
+    Exchange steps: one all_gather of the encoder's mid-block attention rows (sharded_encode), one all_gather of the x0 latent tiles between the two loops (every rank needs the blended latent for its own
     decoder tiles) and one gather of the decoded pixel tiles on rank `dst`, which re-assembles the image. Both sums run over ALL
     tiles in the reference's loop order on the receiving side, so the result equals the single-rank result bit for bit.
     Returns (preds, stage1_preds) on rank `dst`, (None, None) elsewhere."""
@@ -157,7 +195,7 @@ def sharded_tiled_process(engine, control_imgs, rank: int = None, world: int = N
     if rank is None or world is None:
         on = dist.is_available() and dist.is_initialized()
         rank, world = (dist.get_rank(), dist.get_world_size()) if on else (0, 1)
-    control, init = engine.encode(control_imgs)               # replicated: SwinIR and the VAE encoder are untiled in the reference
+    control, init = sharded_encode(engine, control_imgs, rank, world)
     h, w = control.shape[-2:]
     n_tiles = engine.count(h, w)
     x0_all = _exchange_tiles(engine.dit_tiles(init, rank, world), n_tiles, rank, world, to_all=True)

@@ -354,6 +354,40 @@ class HipTileEngine:
         self._stage1 = st.d_st1[0]
         return control, init
 
+    def can_shard_encode(self, control_imgs):
+        """The encoder's mid-block attention can be split by query rows: one image, 512-channel mid block, h * w / 64 a multiple of 128."""
+        n, h, w = _check_images(control_imgs)
+        vae = self.others[0]
+        return n == 1 and ((h // 8) * (w // 8)) % 128 == 0 and vae.config.block_out_channels[-1] == 512
+
+    def encode_part0(self, control_imgs, row0, row1):
+        """ir_tiled_encode_part(part 0): everything up to the attention of query rows [row0, row1) of the encoder's mid block. Returns
+        (control, attn_o, attn_res): this rank's rows of attn_o are filled; the exchange of the rows is the caller's (parallel.py)."""
+        n, h, w = _check_images(control_imgs)
+        self.shape = (n, h, w)
+        _prepare_fused(self.model, self.y, self.y_mask, h, w, True, self.tile_size, self.others)
+        st = _Staging.get(self.ctx, n, h, w)
+        st.fill(0, control_imgs)
+        st.upload(0)
+        T = (h // 8) * (w // 8)
+        control = torch.empty((n, 3, h, w), dtype=torch.float32, device=self.device)
+        self._init = torch.empty((n, 4, h // 8, w // 8), dtype=torch.float32, device=self.device)
+        attn_o = torch.empty((T, 512), dtype=torch.bfloat16, device=self.device)
+        attn_res = torch.empty((T, 512), dtype=torch.bfloat16, device=self.device)
+        ws, c = self._ws(), self.ctx
+        c.check(c.lib.ir_tiled_encode_part(c.h, c.stream(), L.ptr(st.d_in[0]), L.ptr(st.d_st1[0]), L.ptr(control), L.ptr(self._init), n, h, w, self.flags,
+                                           self.sf, 0, row0, row1, L.ptr(attn_o), L.ptr(attn_res), L.ptr(ws), ws.numel()), "ir_tiled_encode_part(0)")
+        self._stage1 = st.d_st1[0]
+        return control, attn_o, attn_res
+
+    def encode_part1(self, control, attn_o, attn_res):
+        """ir_tiled_encode_part(part 1): the rest of the encoder from all rows of attn_o. Returns init."""
+        n, h, w = self.shape
+        ws, c = self._ws(), self.ctx
+        c.check(c.lib.ir_tiled_encode_part(c.h, c.stream(), None, None, L.ptr(control), L.ptr(self._init), n, h, w, self.flags, self.sf, 1, 0, 0,
+                                           L.ptr(attn_o), L.ptr(attn_res), L.ptr(ws), ws.numel()), "ir_tiled_encode_part(1)")
+        return self._init
+
     def stage1(self):
         n = self.shape[0]
         a = self._stage1.cpu().numpy()

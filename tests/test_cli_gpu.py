@@ -183,3 +183,26 @@ def test_make_prompt_writes_the_reference_prompt_file(tmp_path):
     # the CLI's loader reshapes it as the reference does (inference.py:256-259,273-277)
     y = f["caption_embeds"].reshape(1, -1, f["caption_embeds"].shape[-1])
     assert tuple(y.shape) == (1, 24, 64) and tuple(f["emb_mask"].reshape(1, 1, -1).shape) == (1, 1, 24)
+
+
+def test_tile_sharding_two_ranks_on_one_gpu(tmp_path):
+    """SURVEY.md section 8(e), tile-level sharding of ONE frame with real processes and collectives: two gloo ranks (sharing this box's one GPU)
+    run parallel.sharded_tiled_process on a 1024 x 1536 frame - the encoder's mid-block attention split by query rows (one all_gather of the
+    rows), the DiT and decoder tiles dealt round-robin (all_gather of the latent tiles, gather of the pixel tiles) - and rank 0's re-assembled
+    image must equal the single-process result bit for bit."""
+    worker = os.path.join(ROOT, "tests", "support", "shard_tiles_worker.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    one, two = str(tmp_path / "one.npy"), str(tmp_path / "two.npy")
+    r = subprocess.run([sys.executable, worker, one, "1024", "1536"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    import socket
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           worker, two, "1024", "1536"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    a, b = np.load(one), np.load(two)
+    assert a.shape == b.shape == (2, 1024, 1536, 3) and a.std() > 1.0
+    assert np.array_equal(a, b), f"max |diff| {np.abs(a.astype(int) - b.astype(int)).max()}"

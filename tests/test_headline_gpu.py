@@ -460,6 +460,20 @@ def test_tile_engine_equals_ir_pipeline_tiled(full_models):
     for r in range(2):
         px_all[r::2] = parts[r]
     two = eng.blend_pixels(px_all)
+    # the encoder's mid-block attention split by query rows (parallel.sharded_encode): three simulated ranks, rows merged as the all_gather would
+    from instarevive_amd.parallel import row_shards
+    assert eng.can_shard_encode([img])
+    T = (1024 // 8) * (1536 // 8)
+    shards = row_shards(T, 3)
+    assert shards[0][0] == 0 and shards[-1][1] == T and all(a % 128 == 0 and b % 128 == 0 for a, b in shards)
+    merged = None
+    for a, b in shards:
+        c_r, o_r, res_r = eng.encode_part0([img], a, b)
+        merged = o_r.clone() if merged is None else merged
+        merged[a:b] = o_r[a:b]
+        assert torch.equal(c_r, control)
+    init_sharded = eng.encode_part1(control, merged, res_r).clone()
+    assert torch.equal(init_sharded, init), "row-sharded mid-block attention must reproduce the unsharded encoder bit for bit"
     d = np.abs(two[0].astype(int) - want[0].astype(int))
     print(f"two simulated ranks vs one call: max |diff| {d.max()} grey levels, {100 * (d != 0).mean():.4f} % of the values")
     assert d.max() <= 1   # bit-identical re-assembly; the per-tile kernels may differ in the last bit when the row count selects another GEMM tiling

@@ -120,3 +120,14 @@ def test_tile_sharding_is_bit_identical_to_one_rank():
             assert p.exitcode == 0
         assert np.array_equal(got, one[0]) and np.array_equal(got_s1, one_s1[0]), world
     assert one[0].std() > 1.0
+
+
+def test_row_shards_cover_the_rows_in_whole_blocks():
+    from instarevive_amd.parallel import row_shards
+    for n_rows, world in ((130560, 8), (130560, 3), (65536, 8), (1024, 8), (256, 3), (128, 2)):
+        sh = row_shards(n_rows, world)
+        assert len(sh) == world and sh[0][0] == 0 and sh[-1][1] == n_rows
+        assert all(a % 128 == 0 and b % 128 == 0 and a <= b for a, b in sh)
+        assert all(sh[i][1] == sh[i + 1][0] for i in range(world - 1))
+        sizes = [b - a for a, b in sh]
+        assert max(sizes) - min(sizes) <= 128
