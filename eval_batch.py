@@ -59,7 +59,12 @@ def main():
     torch.cuda.set_device(local)
     m = cli.load_models(args, torch.device("cuda", local))
     cond_dir = args.cond_output or args.output.rstrip("/") + "-cond"
-    files = parallel.shard(list_image_files(args.input, follow_links=True), rank, world)
+    # os.walk order is filesystem-dependent: every rank sorts its listing and takes rank 0's copy, so that ownership of a file follows from
+    # ONE list (the same rule as inference.py)
+    files = sorted(list_image_files(args.input, follow_links=True))
+    if world > 1:
+        files = parallel.agree_on_list(files)
+    files = parallel.shard(files, rank, world)
     batches = [files[i:i + args.batch_size] for i in range(0, len(files), args.batch_size)]
 
     def feed():

@@ -169,7 +169,14 @@ int ir_tiled_encode(ir_ctx* ctx, void* stream, const uint8_t* in, uint8_t* stage
  * (tile sharding) split its T^2 work by query rows instead of each repeating it: part 0 = SwinIR, stage-1 image, control image, the encoder
  * up to q / k / v and the attention of rows [row0, row1) (multiples of 128) -> those rows of attn_o, plus the block's input -> attn_res;
  * part 1 = the rest of the encoder from ALL rows of attn_o (the ranks' all-gather) -> init. n == 1; h * w / 64 a multiple of 128;
- * attn_o / attn_res: device bf16 [h * w / 64][512]. Every row equals the unsharded ir_tiled_encode's (whole 128-query workgroups). */
+ * attn_o / attn_res: device bf16 [h * w / 64][512]. Every row equals the unsharded ir_tiled_encode's (whole 128-query workgroups).
+ * Overflow of the fixed softmax reference (rare): the unsharded launch recomputes EVERY row with the rescaling kernel as soon as any row
+ * overflows, so the ranks must agree on it. After part 0 the caller reads ir_tiled_encode_overflow (1 = this rank's rows overflowed and ALL
+ * rows of attn_o were recomputed here), MAX-reduces it over the ranks, and a rank that read 0 while another read 1 repeats part 0 with
+ * part = IR_ENCODE_PART_FORCE_FALLBACK (all rows by the rescaling kernel); when the reduced flag is 1 no rows are exchanged. The sharded form
+ * runs the bf16 attention also under IR_FLAG_FP8 (the e4m3 kernel has no row entry). */
+#define IR_ENCODE_PART_FORCE_FALLBACK 2
+int ir_tiled_encode_overflow(ir_ctx* ctx, void* stream);
 int ir_tiled_encode_part(ir_ctx* ctx, void* stream, const uint8_t* in, uint8_t* stage1, float* control, float* init, int n, int h, int w, int flags,
                          float sf, int part, int row0, int row1, uint16_t* attn_o, uint16_t* attn_res, void* ws, size_t ws_bytes);
 

@@ -261,6 +261,7 @@ struct ir_ctx {
     std::vector<GraphEntry> graphs;
     unsigned long generation = 0, graphs_generation = 0;
     hipStream_t cap_stream = nullptr;  // recording happens on a private stream (the caller's may be the legacy default stream, which cannot capture)
+    int* shard_flag = nullptr;         // device copy of the overflow flag of the last ir_tiled_encode_part(part 0 / 2) (in `owned`)
 };
 
 namespace {
@@ -631,6 +632,8 @@ int resblock(Run& r, const ResW& w, bf16_t* B[3], int ci, float* gws, int N, int
 struct AttnShard {
     int part = -1, row0 = 0, row1 = 0;
     bf16_t *o = nullptr, *res = nullptr;   // [T][512] each, caller-owned
+    bool force_fallback = false;           // part 0 again after ANOTHER rank's rows overflowed: all rows by the rescaling kernel
+    int* flag_out = nullptr;               // device int that receives the overflow flag of part 0
 };
 // AttnBlock (model.py:181-205), single head, scores materialised per image in HBM (fp32 S, bf16 P).
 int attnblock(Run& r, const AttnW& w, bf16_t* B[3], int ci, float* gws, int N, int H, int W, const AttnShard* sh = nullptr) {
@@ -668,15 +671,23 @@ int attnblock(Run& r, const AttnW& w, bf16_t* B[3], int ci, float* gws, int N, i
     const float sc = 1.0f / sqrtf((float)C);
     if (sh && sh->part == 0) {   // (shape checked by the caller: N == 1, the d = 512 flash path, rows in whole workgroups)
         const int rows = sh->row1 - sh->row0;
-        LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_zero_f32(reinterpret_cast<float*>(flag), 1, r.s), "zero");
-        LAUNCH(r, PC_TRANSPOSE, 0.0, 4.0 * (double)T * C, ir_launch_transpose_v_tiles(v, vtt, 1, (int)T, C, T * C, T * C, r.s), "transpose_v_tiles");
-        if (rows > 0)
-            LAUNCHK(r, PK_ATTN_D512, 4.0 * (double)rows * T * C, 0.0,
-                   ir_launch_flash_attn_d512_v2_rows(q + (long)sh->row0 * C, k, vtt, sh->o + (long)sh->row0 * C, (int)T, rows, C, C, sc, flag, r.s), "vae_flash_attn_rows");
-        // overflow fallback (rare): every rank recomputes ALL rows with the rescaling kernel - identical values everywhere, the exchange keeps its slices
+        if (sh->force_fallback) {
+            LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_fill_u32(reinterpret_cast<uint32_t*>(flag), 1, 1u, r.s), "fill");
+        } else {
+            LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_zero_f32(reinterpret_cast<float*>(flag), 1, r.s), "zero");
+            LAUNCH(r, PC_TRANSPOSE, 0.0, 4.0 * (double)T * C, ir_launch_transpose_v_tiles(v, vtt, 1, (int)T, C, T * C, T * C, r.s), "transpose_v_tiles");
+            if (rows > 0)
+                LAUNCHK(r, PK_ATTN_D512, 4.0 * (double)rows * T * C, 0.0,
+                       ir_launch_flash_attn_d512_v2_rows(q + (long)sh->row0 * C, k, vtt, sh->o + (long)sh->row0 * C, (int)T, rows, C, C, sc, flag, r.s), "vae_flash_attn_rows");
+        }
+        // overflow fallback (rare): this rank recomputes ALL rows with the rescaling kernel. The unsharded launch takes the fallback for every
+        // row as soon as ANY row overflows, so the ranks must agree: the flag is handed to the host (ir_tiled_encode_overflow), the caller
+        // MAX-reduces it over the ranks and a rank whose own rows did not overflow repeats part 0 with IR_ENCODE_PART_FORCE_FALLBACK
+        // (parallel.sharded_encode) - then every rank holds all rows from the rescaling kernel, as the unsharded run does.
         LAUNCH(r, PC_TRANSPOSE, 0.0, 0.0, ir_launch_transpose_v(v, vt, 0, C, dsub, 1, C / dsub, (int)T, (int)ld, dsub, dsub, r.s, flag), "transpose_v");
         LAUNCH(r, PC_FLASH_ATTN, 0.0, 0.0, ir_launch_flash_attn_d512(q, k, vt, sh->o, (int)T, C, C, ld, sc, r.s, flag), "vae_flash_attn_fallback");
         if (r.live()) r.chk(hipMemcpyAsync(sh->res, B[ci], (size_t)T * C * 2, hipMemcpyDeviceToDevice, r.s) == hipSuccess ? 0 : -1, "save the block input");
+        if (r.live() && sh->flag_out) r.chk(hipMemcpyAsync(sh->flag_out, flag, sizeof(int), hipMemcpyDeviceToDevice, r.s) == hipSuccess ? 0 : -1, "save the overflow flag");
         r.chain = nullptr;
         r.a.release(mk);
         return -1;   // stop here: the caller exchanges the rows
@@ -1943,6 +1954,12 @@ int ir_unet_set_context(ir_ctx* c, void* stream, const float* context_host, int 
         UNetW& m = c->unet[which];
         if (!m.ok) continue;
         if (m.ctx_dim != ctx_dim) return fail(c, -1, "ir_unet_set_context: UNet and ControlNet disagree on context_dim");
+        // the old caches go first: from here until the final synchronisation succeeded this model has NO context (a failed call must not
+        // leave ctx_ok true over freed or half-built K / V^T caches)
+        m.ctx_ok = false;
+        for (std::vector<UBlock>* set : {&m.in, &m.mid, &m.out})
+            for (UBlock& blk : *set)
+                if (blk.has_xf) blk.xf.kc = nullptr, blk.xf.vtc = nullptr;
         release_list(c->unet_ctx[which]);
         const int DV = ir_attn_dv(m.hd);
         for (std::vector<UBlock>* set : {&m.in, &m.mid, &m.out})
@@ -1955,10 +1972,12 @@ int ir_unet_set_context(ir_ctx* c, void* stream, const float* context_host, int 
                 linear(r, w.ckv, e16, n_tok, ctx_dim, w.kc, 2 * C, 0, ACT_NONE, nullptr, 0, 0);
                 LAUNCH(r, PC_TRANSPOSE, 0.0, 0.0, ir_launch_transpose_v(w.kc + C, w.vtc, 0, 2 * C, m.hd, 1, w.heads, n_tok, tok_pad, m.hd, DV, s), "transpose_v");
             }
-        m.n_tok = n_tok; m.tok_pad = tok_pad; m.ctx_ok = true;
+        m.n_tok = n_tok; m.tok_pad = tok_pad;
     }
     HIPOK(c, hipStreamSynchronize(s));
     if (r.rc) return fail(c, r.rc, "ir_unet_set_context: %s failed", r.where);
+    for (int which = 0; which < 2; ++which)
+        if (c->unet[which].ok) c->unet[which].ctx_ok = true;
     ++c->generation;
     return 0;
 }
@@ -2286,7 +2305,14 @@ int ir_tiled_encode_part(ir_ctx* c, void* stream, const uint8_t* in, uint8_t* st
     if (int e = check_size(c, n, h, w, 64)) return e;
     const long T = (long)(h / 8) * (w / 8);
     REQUIRE(n == 1 && c->vae.enc.attn.n.c == 512 && (T & 127) == 0 && !c->plain, "tiled encode part: needs one image, the 512-channel mid block and h * w / 64 a multiple of 128");
-    REQUIRE((part == 0 || part == 1) && row0 >= 0 && row0 <= row1 && row1 <= T && !(row0 & 127) && !(row1 & 127), "tiled encode part: rows must be multiples of 128 within the token count");
+    REQUIRE((part == 0 || part == 1 || part == IR_ENCODE_PART_FORCE_FALLBACK) && row0 >= 0 && row0 <= row1 && row1 <= T && !(row0 & 127) && !(row1 & 127), "tiled encode part: rows must be multiples of 128 within the token count");
+    if (part != 1 && !c->shard_flag) {
+        HIPOK(c, hipSetDevice(c->device));
+        void* q = nullptr;
+        HIPOK(c, hipMalloc(&q, 256));
+        c->owned.push_back(q);
+        c->shard_flag = (int*)q;
+    }
     struct NoFp8 {   // the sharded form runs the bf16 attention (the fp8 kernel has no row-shard entry)
         ir_ctx* c; bool old;
         explicit NoFp8(ir_ctx* c_) : c(c_), old(c_->fp8) { c->fp8 = false; }
@@ -2294,10 +2320,20 @@ int ir_tiled_encode_part(ir_ctx* c, void* stream, const uint8_t* in, uint8_t* st
     } nofp8(c);
     Run r = make_run(c, stream, ws, ws_bytes, false);
     AttnShard sh;
-    sh.part = part; sh.row0 = row0; sh.row1 = row1; sh.o = attn_o; sh.res = attn_res;
+    sh.part = part == 1 ? 1 : 0; sh.row0 = row0; sh.row1 = row1; sh.o = attn_o; sh.res = attn_res;
+    sh.force_fallback = part == IR_ENCODE_PART_FORCE_FALLBACK; sh.flag_out = c->shard_flag;
     float* lq = (flags & IR_FLAG_NO_PREPROCESS) ? control : r.a.alloc<float>((long)n * 3 * h * w);
     encode_run(r, in, stage1, lq, control, init, n, h, w, flags, sf, &sh);
     return finish(r, c, ws_bytes);
+}
+
+int ir_tiled_encode_overflow(ir_ctx* c, void* stream) {
+    REQUIRE(c && c->shard_flag, "tiled encode overflow: no ir_tiled_encode_part(part 0) has run on this context");
+    HIPOK(c, hipSetDevice(c->device));
+    int v = 0;
+    HIPOK(c, hipMemcpyAsync(&v, c->shard_flag, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPOK(c, hipStreamSynchronize((hipStream_t)stream));
+    return v != 0 ? 1 : 0;
 }
 
 int ir_tiled_dit(ir_ctx* c, void* stream, const float* init, float* x0_tiles, int n, int h, int w, int tile_size, int tile_stride, int first,

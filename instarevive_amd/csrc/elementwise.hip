@@ -282,6 +282,14 @@ int ir_launch_zero_f32(float* p, long n, hipStream_t s) {
     hipLaunchKernelGGL(zero_f32_kernel, GRID1D(n), dim3(256), 0, s, p, n);
     return LAUNCH_OK();
 }
+__global__ void fill_u32_kernel(uint32_t* p, long n, uint32_t v) {
+    FOR_GRID(i, n) p[i] = v;
+}
+int ir_launch_fill_u32(uint32_t* p, long n, uint32_t v, hipStream_t s) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(fill_u32_kernel, GRID1D(n), dim3(256), 0, s, p, n, v);
+    return LAUNCH_OK();
+}
 int ir_launch_tile_add(float* dst, const float* src, int N, int C, int H, int W, int th, int tw, int y0, int x0, hipStream_t s) {
     if (y0 < 0 || x0 < 0 || y0 + th > H || x0 + tw > W) return -2;
     long total = (long)N * C * th * tw;

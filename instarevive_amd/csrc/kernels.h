@@ -168,6 +168,7 @@ int ir_launch_eps_to_x0(const float* tok, const float* lat_in, float* lat_out, i
 int ir_launch_nhwc_to_u8(const float* in, int in_cs, uint8_t* out, long npix, float scale, float shift, hipStream_t s);
 int ir_launch_nchw_to_u8(const float* in, uint8_t* out, int N, long HW, hipStream_t s);
 int ir_launch_zero_f32(float* p, long n, hipStream_t s);
+int ir_launch_fill_u32(uint32_t* p, long n, uint32_t v, hipStream_t s);
 int ir_launch_tile_add(float* dst, const float* src, int N, int C, int H, int W, int th, int tw, int y0, int x0, hipStream_t s);
 int ir_launch_tile_div(float* dst, int N, int C, int H, int W, int th, int tw, int sy, int sx, hipStream_t s);
 int ir_launch_crop_nchw(const float* src, float* dst, int N, int C, int H, int W, int y0, int x0, int th, int tw, float scale,

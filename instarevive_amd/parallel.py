@@ -17,12 +17,28 @@ def env_rank_world():
     return int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
 
 
+def force_collectives() -> bool:
+    """IR_FORCE_COLLECTIVES=1: a ONE-process group still initialises its backend and every exchange step (GatherPlan.gather,
+    _exchange_tiles, sharded_encode) goes through the collective instead of the single-rank shortcut. This is how a one-GPU box runs the
+    RCCL ("nccl") branch on device tensors (tests/support/rccl_single_rank_worker.py); it changes no result."""
+    return os.environ.get("IR_FORCE_COLLECTIVES", "") not in ("", "0")
+
+
 def init_distributed(backend: str = None):
     """Initialise from the torchrun environment (RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT). No-op for one process."""
     import torch.distributed as dist
     rank, world, local = env_rank_world()
-    if world == 1 or dist.is_initialized():
+    if (world == 1 and not force_collectives()) or dist.is_initialized():
         return rank, world, local
+    if world == 1:   # forced one-process group: the rendezvous the launcher would have set
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
     backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
     if backend == "nccl":
         torch.cuda.set_device(local)
@@ -75,7 +91,7 @@ class GatherPlan:
 
     def __init__(self, like: torch.Tensor, dst: int = 0):
         import torch.distributed as dist
-        self.on = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.on = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force_collectives())
         self.dst = dst
         if not self.on:
             return
@@ -126,7 +142,7 @@ def _exchange_tiles(local: torch.Tensor, n_tiles: int, rank: int, world: int, to
     [n_tiles, ...] on every rank (to_all, one all_gather) or on rank `dst` only (one gather; None elsewhere). Ranks hold
     ceil/floor(n_tiles / world) tiles, so the buffers are padded to the maximum and the padding is dropped on arrival."""
     import torch.distributed as dist
-    if world == 1:
+    if world == 1 and not (force_collectives() and dist.is_initialized()):
         return local
     kmax = (n_tiles + world - 1) // world
     dev = _comm_device(local.device)
@@ -161,10 +177,11 @@ def row_shards(n_rows: int, world: int, quantum: int = 128):
 def sharded_encode(engine, control_imgs, rank: int, world: int):
     """SwinIR + VAE encode of the frame with the encoder's mid-block attention (T^2 * 512: 35 of the 75 TFLOP every rank used to repeat at
     4K) split over the ranks by query rows; one all_gather of the attention rows. Every row is bit-identical to the unsharded launch's
-    (whole 128-query workgroups), hence so is everything behind it. Falls back to the replicated encode when the engine cannot split
+    (whole 128-query workgroups; an overflow of the fixed softmax reference on any rank sends every rank to the rescaling kernel, as in
+    the unsharded launch), hence so is everything behind it. Under IR_FLAG_FP8 the sharded form still runs the bf16 attention. Falls back to the replicated encode when the engine cannot split
     (several images, token count not a multiple of 128, an engine without the two-part encode)."""
     import torch.distributed as dist
-    if world == 1 or not hasattr(engine, "encode_part0") or not engine.can_shard_encode(control_imgs):
+    if (world == 1 and not (force_collectives() and dist.is_initialized())) or not hasattr(engine, "encode_part0") or not engine.can_shard_encode(control_imgs):
         return engine.encode(control_imgs)             # replicated: SwinIR and the VAE encoder are untiled in the reference
     h, w = control_imgs[0].shape[:2]
     T = (h // 8) * (w // 8)
@@ -173,6 +190,17 @@ def sharded_encode(engine, control_imgs, rank: int, world: int):
     control, attn_o, attn_res = engine.encode_part0(control_imgs, r0, r1)
     kmax = max(b - a for a, b in shards)
     dev = _comm_device(attn_o.device)
+    if hasattr(engine, "encode_overflow"):
+        # The unsharded launch recomputes EVERY row with the rescaling kernel as soon as any row overflows the fixed softmax reference; a
+        # rank only sees its own rows, so the ranks agree on the flag first (MAX). When it is set, every rank holds all rows from the
+        # rescaling kernel (its own fallback, or part 0 repeated with the fallback forced) and nothing is exchanged.
+        mine = engine.encode_overflow()
+        flag = torch.tensor([mine], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()):
+            if not mine:
+                control, attn_o, attn_res = engine.encode_part0(control_imgs, r0, r1, force_fallback=True)
+            return control, engine.encode_part1(control, attn_o, attn_res)
     bits = attn_o.view(torch.uint8)                    # raw bytes: every backend moves uint8 (gloo takes neither bfloat16 nor int16)
     send = torch.zeros((kmax, bits.shape[1]), dtype=torch.uint8, device=dev)
     send[: r1 - r0] = bits[r0:r1].to(dev)

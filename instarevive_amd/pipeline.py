@@ -360,7 +360,16 @@ class HipTileEngine:
         vae = self.others[0]
         return n == 1 and ((h // 8) * (w // 8)) % 128 == 0 and vae.config.block_out_channels[-1] == 512
 
-    def encode_part0(self, control_imgs, row0, row1):
+    def encode_overflow(self):
+        """1 when the fixed softmax reference of the last encode_part0 overflowed on THIS rank's rows (all rows of attn_o were then
+        recomputed by the rescaling kernel), else 0. Synchronises the stream."""
+        c = self.ctx
+        v = c.lib.ir_tiled_encode_overflow(c.h, c.stream())
+        if v < 0:
+            c.check(v, "ir_tiled_encode_overflow")
+        return int(v)
+
+    def encode_part0(self, control_imgs, row0, row1, force_fallback=False):
         """ir_tiled_encode_part(part 0): everything up to the attention of query rows [row0, row1) of the encoder's mid block. Returns
         (control, attn_o, attn_res): this rank's rows of attn_o are filled; the exchange of the rows is the caller's (parallel.py)."""
         n, h, w = _check_images(control_imgs)
@@ -376,7 +385,8 @@ class HipTileEngine:
         attn_res = torch.empty((T, 512), dtype=torch.bfloat16, device=self.device)
         ws, c = self._ws(), self.ctx
         c.check(c.lib.ir_tiled_encode_part(c.h, c.stream(), L.ptr(st.d_in[0]), L.ptr(st.d_st1[0]), L.ptr(control), L.ptr(self._init), n, h, w, self.flags,
-                                           self.sf, 0, row0, row1, L.ptr(attn_o), L.ptr(attn_res), L.ptr(ws), ws.numel()), "ir_tiled_encode_part(0)")
+                                           self.sf, 2 if force_fallback else 0, row0, row1, L.ptr(attn_o), L.ptr(attn_res), L.ptr(ws), ws.numel()),
+                "ir_tiled_encode_part(0)")
         self._stage1 = st.d_st1[0]
         return control, attn_o, attn_res
 

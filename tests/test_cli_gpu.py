@@ -206,3 +206,21 @@ def test_tile_sharding_two_ranks_on_one_gpu(tmp_path):
     a, b = np.load(one), np.load(two)
     assert a.shape == b.shape == (2, 1024, 1536, 3) and a.std() > 1.0
     assert np.array_equal(a, b), f"max |diff| {np.abs(a.astype(int) - b.astype(int)).max()}"
+
+
+def test_rccl_branch_single_rank(tmp_path):
+    """The "nccl" (RCCL) branch of instarevive_amd/parallel.py, which a one-GPU box never takes with world_size 1 and which the gloo
+    rehearsals replace by host copies: a fresh child process initialises a ONE-rank RCCL group before touching the GPU and runs, with
+    IR_FORCE_COLLECTIVES=1, GatherPlan.gather (cfg-4's in-step gather), _exchange_tiles and sharded_encode on device tensors; every result
+    must equal the no-collective path (tests/support/rccl_single_rank_worker.py)."""
+    import json
+    worker = os.path.join(ROOT, "tests", "support", "rccl_single_rank_worker.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out = str(tmp_path / "rccl.json")
+    r = subprocess.run([sys.executable, worker, out], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    d = json.load(open(out))
+    print(f"RCCL single-rank smoke: {d}")
+    assert d["backend"] == "nccl" and d["world"] == 1 and d["gather_equal"] and d["sharded_equal"] and d["tiles"] == 12 and d["image_std"] > 1.0
+    assert d["max_over_ranks"] == 1.25

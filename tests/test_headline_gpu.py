@@ -389,6 +389,72 @@ def test_headline_2048_untiled_fast_vs_plain_kernels(full_models):
     assert p >= 45.0 and p1 >= 50.0 and fast[0].std() > 1.0 and st1[0].std() > 1.0
 
 
+@pytest.mark.parametrize("size", [1024, 2048])
+def test_headline_vs_oracle_crops(full_models, size):
+    """BASELINE configs[1] pinned AT ITS OWN SIZE against the fp32 oracle: tests/golden/headline_crops.npz holds the
+    x^_0 latent and 128 x 128 uint8 crops of ONE oracle pass per size (1 / 8 minutes of host time, made by the committed
+    tests/golden/make_headline_crops.py from bench.py's seeded weights and synthetic input). The HIP path on the same input must match the
+    crops to >= 45 dB (bf16) and the latent to <= 1.2 % relative L2; fp8 (cfg-5, reported separately) >= 39 dB on the crops. At 2048 this
+    is the first whole-path oracle comparison that runs through gemm_pp_kernel, the 16384-token DiT attention and the 65536-token VAE
+    attention in their real chain."""
+    from instarevive_amd.models import DDPMScheduler
+    from instarevive_amd.pipeline import process
+    from tests.golden.make_headline_crops import CROP, inputs_for
+    swin, vae, dit, sds, y, mask = full_models
+    z = np.load(os.path.join(G, "headline_crops.npz"))
+    img = inputs_for(size)
+    assert img.shape == (size, size, 3)
+    kw = dict(preprocess_model=swin, vae=vae, y=full_models.y_cuda, y_mask=full_models.mask_cuda)
+    bf, st1 = process(dit, [img], 1, "wavelet", False, False, 512, 448, **kw)
+    pos = z[f"pos_{size}"]
+    take = lambda a, pp: np.stack([a[yy:yy + CROP, xx:xx + CROP] for yy, xx in pp])
+    want, want1 = z[f"crops_{size}"], z[f"stage1_{size}"]
+    got, got1 = take(bf[0], pos), take(st1[0], pos[:len(want1)])
+    per = [_psnr(g, w) for g, w in zip(got, want)]
+    p, p1 = _psnr(got, want), _psnr(got1, want1)
+    print(f"{size}x{size} bf16 vs fp32 oracle: crops {p:.2f} dB (worst crop {min(per):.2f}), stage-1 crops {p1:.2f} dB; "
+          f"byte sum {int(bf[0].astype(np.int64).sum())} vs oracle {int(z[f'sum_{size}'])}")
+    assert p >= 45.0 and min(per) >= 43.0 and p1 >= 50.0
+    assert abs(int(bf[0].astype(np.int64).sum()) - int(z[f"sum_{size}"])) <= 0.002 * int(z[f"sum_{size}"])   # no global shift in brightness
+    # the x^_0 latent through the staged calls (SwinIR -> encode -> one DiT step), against the oracle's
+    x = torch.from_numpy(img).cuda().permute(2, 0, 1)[None].float() / 255.0
+    ctl = swin(x)
+    lat = vae.encode(ctl * 2 - 1).latent_dist.mode() * float(vae.config.scaling_factor)
+    x0 = dit.step(lat, 400.0, float(DDPMScheduler().alphas_cumprod[400]), full_models.y_cuda, full_models.mask_cuda)
+    ref0 = torch.from_numpy(z[f"x0_{size}"].astype(np.float32)).cuda()[None]
+    rel = float((x0 - ref0).norm() / ref0.norm())
+    print(f"{size}x{size} x0 latent vs oracle: relative L2 {rel * 100:.3f} % (the fixture stores fp16: 0.03 %)")
+    assert rel <= 0.012
+    vae.enable_fp8(True)
+    try:
+        f8, _ = process(dit, [img], 1, "wavelet", False, False, 512, 448, fp8=True, **kw)
+    finally:
+        vae.enable_fp8(False)
+    p8 = _psnr(take(f8[0], pos), want)
+    print(f"{size}x{size} fp8 (cfg-5 operand set) vs fp32 oracle: crops {p8:.2f} dB")
+    assert p8 >= 39.0
+
+
+def test_batch8_at_2048_matches_batch1(full_models):
+    """BASELINE configs[3]'s per-GPU workload (batch 8 of 512 x 512 LQ, sr_scale 4 -> eight 2048 x 2048 images through ONE ir_pipeline call:
+    17 GB per 256-channel activation, 8.6 G elements - past 2^32 - per tensor): image i of the batch must be bit-identical to its batch-1
+    result, which any 32-bit index overflow in any kernel of the chain would break. Batches of 2, 4 and 8 in turn, so that a failure
+    names the size where an index first wraps."""
+    import bench
+    imgs = [bench.synthetic_lq(1, 2048, 2048, 70 + i)[0].numpy() for i in range(8)]
+    single = {i: _process_full(full_models, imgs[i], False) for i in (0, 1, 3, 7)}
+    from instarevive_amd.pipeline import process
+    swin, vae, dit, sds, y, mask = full_models
+    kw = dict(preprocess_model=swin, vae=vae, y=full_models.y_cuda, y_mask=full_models.mask_cuda)
+    for nb in (2, 4, 8):
+        preds, st1 = process(dit, imgs[:nb], 1, "wavelet", False, False, 512, 448, **kw)
+        assert len(preds) == nb
+        for i in (j for j in single if j < nb):
+            assert np.array_equal(st1[i], single[i][1][0]), f"batch {nb}: stage-1 image {i} differs from its batch-1 result"
+            assert np.array_equal(preds[i], single[i][0][0]), f"batch {nb}: image {i} differs from its batch-1 result"
+    assert not np.array_equal(preds[7], preds[0]) and preds[7].std() > 1.0
+
+
 def test_headline_2048_fp8_vs_bf16(full_models):
     """BASELINE configs[4] at the workload size of its bench line (2048 x 2048 network input): the fp8 form of the path (e4m3 operands
     where ir_fp8_features() says so) against the bf16 path on the same image. e4m3 carries 3 mantissa bits; measured 42.5 dB, gate 38."""

@@ -545,6 +545,40 @@ def test_fp8_whole_path_psnr_guard(full_models):
 
 
 
+def test_psnr_guard_bites_at_realistic_reference_quality(full_models):
+    """north_star's 0.1 dB criterion where it binds: the reference scoring 25 / 30 / 35 dB against the ground truth.
+    No ground truth exists offline, so synthetic ones are built around the oracle's 512 x 512 full-architecture output
+    (tests/support/psnr_guard.py): independent white noise at each level, and the worst case (ground truth on the far side of the
+    oracle, anti-parallel to our error). Asserted: bf16 within 0.1 dB at 25 and 30 dB (independent). Reported: 35 dB, the worst case, the
+    crossing level P_err - 16.33 dB for bf16 and for fp8 (cfg-5), which DESIGN.md section 4 and the fp8 bench line quote."""
+    import bench
+    from instarevive_amd.pipeline import process
+    from tests.support.psnr_guard import crossing_level, guard_table
+    swin, vae, dit, sds, y, mask = full_models
+    imgs = [bench.synthetic_lq(1, 512, 512, 15)[0].numpy()]
+    ref, _ = oglue.process(imgs, lambda x: oswin.swinir_forward(sds["swin"], x), lambda x: ovae.vae_encode_mean(sds["vae"], x),
+                           lambda lat, t, yy, mm: odit.dit_forward(sds["dit"], lat, t, yy, mm), lambda z: ovae.vae_decode(sds["vae"], z),
+                           oglue.alphas_cumprod_diffusers(), y, mask)
+    kw = dict(preprocess_model=swin, vae=vae, y=full_models.y_cuda, y_mask=full_models.mask_cuda)
+    bf, _ = process(dit, imgs, 1, "wavelet", False, False, 512, 448, **kw)
+    vae.enable_fp8(True)
+    try:
+        f8, _ = process(dit, imgs, 1, "wavelet", False, False, 512, 448, fp8=True, **kw)
+    finally:
+        vae.enable_fp8(False)
+    pb, rb = guard_table(bf[0], ref[0])
+    p8, r8 = guard_table(f8[0], ref[0])
+    for name, pe, rows in (("bf16", pb, rb), ("fp8", p8, r8)):
+        txt = ", ".join(f"{lv:.0f} dB: {d[0]:.3f} (worst case {d[1]:.2f})" for lv, d in rows.items())
+        print(f"PSNR guard {name}: {pe:.2f} dB vs oracle; |dPSNR| with the reference at {txt}; within 0.1 dB up to a reference quality of {crossing_level(pe):.1f} dB")
+    assert rb[25.0][0] <= 0.1 and rb[30.0][0] <= 0.1, "bf16 must stay within 0.1 dB of the reference where the reference scores <= 30 dB"
+    assert r8[25.0][0] <= 0.25, "fp8 (reported separately): measured 0.08-0.15 dB at 25 dB"
+    # the estimate the bench line quotes must describe what was measured
+    for pe, rows in ((pb, rb), (p8, r8)):
+        for lv, d in rows.items():
+            assert abs(d[0] - 10 * np.log10(1 + 10 ** ((lv - pe) / 10))) <= 0.03
+
+
 def test_fp8_tiled_and_hipgraph(full_models):
     """cfg-5 under --tiled: the fp8 attention then runs per batch of 1024-token tiles and the fp8 convs on 512 x 512 tiles (the small levels
     stay with the 4-wave fp8 kernel); tiled fp8 against tiled bf16 on a 1024 x 1024 image, and the hipGraph replay of the fp8 path against

@@ -131,3 +131,82 @@ def test_row_shards_cover_the_rows_in_whole_blocks():
         assert all(sh[i][1] == sh[i + 1][0] for i in range(world - 1))
         sizes = [b - a for a, b in sh]
         assert max(sizes) - min(sizes) <= 128
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# sharded_encode: the ranks must agree on the softmax-overflow fallback (a rank only sees its own rows).
+class _FakeShardEngine:
+    """Stands in for pipeline.HipTileEngine's two-part encode: 'fast' rows are row % 128, 'fallback' rows -1 - row % 128 (exact in bf16); a rank whose own
+    rows contain `bad_row` overflows, recomputes ALL rows by the fallback and reports it (encode_overflow), as ir_tiled_encode_part does."""
+
+    def __init__(self, bad_row):
+        self.bad_row, self.calls, self.T = bad_row, [], 512
+
+    def can_shard_encode(self, imgs):
+        return True
+
+    def encode(self, imgs):
+        raise AssertionError("the replicated encode must not run")
+
+    def _rows(self, slow):
+        v = (torch.arange(self.T) % 128).float()
+        return (-1.0 - v if slow else v)[:, None].expand(self.T, 4).contiguous().to(torch.bfloat16)
+
+    def encode_part0(self, imgs, r0, r1, force_fallback=False):
+        self.calls.append((r0, r1, force_fallback))
+        self._over = int(force_fallback or (self.bad_row is not None and r0 <= self.bad_row < r1))
+        o = torch.zeros(self.T, 4, dtype=torch.bfloat16)
+        if self._over:
+            o[:] = self._rows(True)
+        else:
+            o[r0:r1] = self._rows(False)[r0:r1]
+        return torch.zeros(1), o, torch.zeros(1)
+
+    def encode_overflow(self):
+        return self._over
+
+    def encode_part1(self, control, attn_o, attn_res):
+        return attn_o.float().clone()
+
+
+def _overflow_worker(rank, world, port, bad_row, forced, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if forced:
+        os.environ["IR_FORCE_COLLECTIVES"] = "1"
+    sys.path.insert(0, ROOT)
+    import numpy as np
+    import torch.distributed as dist
+    from instarevive_amd import parallel as P
+    P.init_distributed("gloo")
+    assert dist.is_initialized()
+    eng = _FakeShardEngine(bad_row)
+    _, init = P.sharded_encode(eng, [np.zeros((64 * 8, 8 * 8, 3), np.uint8)], rank, world)   # 64 x 8 latent = 512 tokens
+    q.put((rank, init[:, 0].tolist(), eng.calls))
+    if forced and world == 1:   # the other exchange steps through the (one-rank) collective as well
+        t = torch.arange(24, dtype=torch.float32).reshape(3, 2, 4)
+        assert torch.equal(P._exchange_tiles(t, 3, 0, 1, to_all=True), t) and torch.equal(P._exchange_tiles(t, 3, 0, 1, to_all=False), t)
+        plan = P.GatherPlan(torch.zeros(2, 4, 4, 3, dtype=torch.uint8))
+        assert plan.on and torch.equal(plan.gather(torch.ones(2, 4, 4, 3, dtype=torch.uint8)), torch.ones(2, 4, 4, 3, dtype=torch.uint8))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_encode_ranks_agree_on_the_overflow_fallback():
+    fast = [float(r % 128) for r in range(512)]
+    slow = [-1.0 - r % 128 for r in range(512)]
+    for world, bad_row, forced in ((2, None, False), (2, 300, False), (2, 5, False), (1, None, True), (1, 7, True)):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_overflow_worker, args=(r, world, port, bad_row, forced, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = sorted(q.get(timeout=120) for _ in range(world))
+        for p in procs:
+            p.join(timeout=120)
+            assert p.exitcode == 0
+        for rank, rows, calls in res:
+            assert rows == (fast if bad_row is None else slow), (world, bad_row, rank)
+            mine = bad_row is not None and calls[0][0] <= bad_row < calls[0][1]
+            # a rank whose own rows did not overflow repeats part 0 with the fallback forced; nobody else does
+            assert [c[2] for c in calls] == ([False] if (bad_row is None or mine) else [False, True]), (world, bad_row, rank, calls)
