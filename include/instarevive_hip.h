@@ -227,6 +227,18 @@ int ir_op_conv_splitk(ir_ctx* ctx, void* stream, const uint16_t* in, const uint1
 int ir_op_conv_groupnorm(ir_ctx* ctx, void* stream, const uint16_t* in, const uint16_t* wgt, const float* bias, uint16_t* conv_out,
                          uint16_t* y, const float* gamma, const float* beta, int n, int h, int w, int cin, int cout, int stride, int up,
                          const void* res, int silu, void* ws, size_t ws_bytes, int* fused);
+/* The VAE's first and last convolution at full resolution as kernels of their own (csrc/vae_io.hip; what ir_vae_encode / ir_vae_decode launch
+ * for the released VAE's shapes):
+ * ir_op_vae_conv_in: Encoder.conv_in (ldm/modules/diffusionmodules/model.py:384-388 called at :524) on in [n][3][h][w] fp32, read as
+ *   v * in_scale + in_shift rounded to bf16; wgt [128][9][32] bf16 (tap-major, the first 3 of every 32 input channels used), bias [128];
+ *   out [n][h][w][128] bf16; gn_part (or NULL) receives per 8 x 64 pixel tile the GroupNorm(32) sums of the stored values:
+ *   gn_part[((image * tiles + tile) * 2 + {0: sum, 1: sum of squares}) * 32 + group]; *tiles = tiles per image.
+ * ir_op_vae_norm_conv_out: Decoder.norm_out + nonlinearity + conv_out (model.py:650-655): out[pixel][0..2] = conv3x3(silu(x * scale[image][c] +
+ *   shift[image][c]) rounded to bf16) + bias, out[pixel][3] = 0; x [n][h][w][128] bf16, wgt [32][9][128] bf16 (rows 0..2 used), out fp32. */
+int ir_op_vae_conv_in(ir_ctx* ctx, void* stream, const float* in, const uint16_t* wgt, const float* bias, uint16_t* out, float* gn_part, int n, int h,
+                      int w, float in_scale, float in_shift, int* tiles);
+int ir_op_vae_norm_conv_out(ir_ctx* ctx, void* stream, const uint16_t* x, const float* scale, const float* shift, const uint16_t* wgt, const float* bias,
+                            float* out, int n, int h, int w);
 /* 3x3 stride-1 conv on fp8 operands: in8 [n][h][w][cin] e4m3, wgt8 [cout][9][cin] e4m3, out = (acc + bias_div[co]) * dequant[co] (+ res) in bf16 */
 int ir_op_conv_fp8(ir_ctx* ctx, void* stream, const uint8_t* in8, const uint8_t* wgt8, const float* dequant, const float* bias_div, uint16_t* out,
                    int n, int h, int w, int cin, int cout, const uint16_t* res);

@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libinstarevive_hip.so")
-SOURCES = ["igemm.hip", "conv_s1.hip", "conv_s1_fp8.hip", "norm.hip", "attention.hip", "attn_d512.hip", "attn_fp8.hip", "attn_d512_fp8.hip", "swin_fused.hip", "elementwise.hip", "t5.hip", "unet.hip", "api.cpp"]
+SOURCES = ["igemm.hip", "conv_s1.hip", "conv_s1_fp8.hip", "norm.hip", "attention.hip", "attn_d512.hip", "attn_fp8.hip", "attn_d512_fp8.hip", "swin_fused.hip", "elementwise.hip", "vae_io.hip", "t5.hip", "unet.hip", "api.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-ffp-contract=fast"] + os.environ.get("IR_EXTRA_HIPCC_FLAGS", "").split()
 
 

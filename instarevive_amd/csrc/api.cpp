@@ -192,7 +192,7 @@ enum { PC_CONV3X3 = 0, PC_LINEAR, PC_FLASH_ATTN, PC_SWIN_ATTN, PC_GROUPNORM, PC_
 // kernel-level rows of the same measurement (ir_profile_end_kernels): one id per kernel (family) that matters on the 2048 x 2048 path,
 // each with the algorithmic FLOPs (un-padded dims) / bytes of its launches. Keep KERNEL_NAMES and KERNEL_CLASS in step.
 enum { PK_CONV_S1 = 0, PK_CONV_HALO_PP, PK_CONV_HALO, PK_CONV_S1_FP8, PK_CONV_FP8, PK_CONV_IGEMM, PK_GEMM_PP, PK_LINEAR_IGEMM, PK_SWIN_MLP, PK_ATTN_SELF, PK_ATTN_SELF_FP8, PK_ATTN_D512_FP8,
-       PK_ATTN_D512, PK_ATTN_CROSS, PK_ATTN_OTHER, PK_SWIN_ATTN_PROJ, PK_SWIN_ATTN, PK_GN_APPLY, PK_GN_FULL, PK_LAYERNORM, PK_SOFTMAX, PK_TRANSPOSE, PK_OTHER,
+       PK_ATTN_D512, PK_ATTN_CROSS, PK_ATTN_OTHER, PK_SWIN_ATTN_PROJ, PK_SWIN_ATTN, PK_GN_APPLY, PK_GN_FULL, PK_LAYERNORM, PK_SOFTMAX, PK_TRANSPOSE, PK_OTHER, PK_VAE_CONV_IN, PK_VAE_CONV_OUT,
        PK_COUNT };
 static const char* const KERNEL_NAMES[PK_COUNT] = {
     "conv3x3/conv_halo_s1_kernel", "conv3x3/conv_halo_pp_kernel", "conv3x3/conv_halo_kernel", "conv3x3/conv_halo_s1_fp8_kernel",
@@ -202,10 +202,11 @@ static const char* const KERNEL_NAMES[PK_COUNT] = {
     "flash_attn/flash_attn_d512_v2_kernel (VAE mid-block)",
     "flash_attn/flash_attn_kernel<72,true> (DiT cross-attention)", "flash_attn/other", "swin_attn/swin_attn_proj_kernel", "swin_attn/swin_window_attn_kernel",
     "groupnorm/gn_finalize_groups+gn_apply (statistics from the conv epilogue)", "groupnorm/gn_partial+gn_finalize+gn_apply", "layernorm/layernorm_*_kernel",
-    "softmax_rows/softmax_rows_kernel", "transpose/transpose_v*", "other/layout+glue"};
+    "softmax_rows/softmax_rows_kernel", "transpose/transpose_v*", "other/layout+glue",
+    "conv3x3/vae_conv_in_kernel (3->128, store-bound)", "conv3x3/vae_norm_conv_out_kernel (GroupNorm+SiLU+128->3, read-bound)"};
 static const int KERNEL_CLASS[PK_COUNT] = {PC_CONV3X3, PC_CONV3X3, PC_CONV3X3, PC_CONV3X3, PC_CONV3X3, PC_CONV3X3, PC_LINEAR, PC_LINEAR, PC_LINEAR, PC_FLASH_ATTN, PC_FLASH_ATTN,
                                            PC_FLASH_ATTN, PC_FLASH_ATTN, PC_FLASH_ATTN, PC_FLASH_ATTN, PC_SWIN_ATTN, PC_SWIN_ATTN, PC_GROUPNORM, PC_GROUPNORM, PC_LAYERNORM,
-                                           PC_SOFTMAX, PC_TRANSPOSE, PC_OTHER};
+                                           PC_SOFTMAX, PC_TRANSPOSE, PC_OTHER, PC_CONV3X3, PC_CONV3X3};
 static const int CLASS_DEFAULT_KERNEL[PC_COUNT] = {PK_CONV_IGEMM, PK_LINEAR_IGEMM, PK_ATTN_OTHER, PK_SWIN_ATTN, PK_GN_FULL, PK_LAYERNORM, PK_SOFTMAX, PK_TRANSPOSE, PK_OTHER};
 struct ProfRec {
     int cls, kid;
@@ -771,9 +772,21 @@ void vae_encode_run(Run& r, const float* in, float* lat, int n, int h, int w, fl
         ci = attnblock(r, m.attn, B, 0, gws, n, H, W, sh);
         goto after_attention;
     }
-    LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_nchw_to_nhwc_bf16(in, in32, n, 3, (long)h * w, 32, in_scale, in_shift, r.s), "nchw_to_nhwc");
-    r.gn_want = true;
-    conv(r, m.conv_in, in32, n, h, w, 32, B[0], m.conv_in.cout, 0, 1, 1, 0, ACT_NONE, 0.f, nullptr, 0, 0);
+    static const bool no_vae_io = getenv("IR_NO_VAE_IO") != nullptr;   // experiment knob: the generic kernels for conv_in / norm_out + conv_out
+    if (!r.c->plain && !no_vae_io && m.conv_in.cin == 32 && m.conv_in.cout == 128 && m.conv_in.cout_pad == 128) {
+        // conv_in straight from the fp32 planes, with the statistics of norm1 of the first ResnetBlock (vae_io.hip)
+        if (r.live()) {
+            const double px = (double)n * h * w;
+            LAUNCHK(r, PK_VAE_CONV_IN, 2.0 * px * 128 * 27, px * (3 * 4 + 128 * 2),
+                    ir_launch_vae_conv_in(in, m.conv_in.w, m.conv_in.b, B[0], r.gn_buf, n, h, w, in_scale, in_shift, r.s), "vae_conv_in");
+            r.gn_x = B[0];
+            r.gn_chunks = ir_vae_conv_in_tiles(h, w);
+        }
+    } else {
+        LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_nchw_to_nhwc_bf16(in, in32, n, 3, (long)h * w, 32, in_scale, in_shift, r.s), "nchw_to_nhwc");
+        r.gn_want = true;
+        conv(r, m.conv_in, in32, n, h, w, 32, B[0], m.conv_in.cout, 0, 1, 1, 0, ACT_NONE, 0.f, nullptr, 0, 0);
+    }
     for (int l = 0; l < nl; ++l) {
         const size_t nres = m.levels[l].res.size();
         for (size_t i = 0; i < nres; ++i) ci = resblock(r, m.levels[l].res[i], B, ci, gws, n, H, W, i + 1 < nres || !m.levels[l].has_resample);
@@ -835,6 +848,23 @@ void vae_decode_run(Run& r, const float* lat, float in_scale, float* out_nhwc4, 
         }
     }
     const int t1 = (ci + 1) % 3;
+    static const bool no_vae_io = getenv("IR_NO_VAE_IO") != nullptr;
+    if (!r.c->plain && !no_vae_io && m.conv_out.cin == 128 && m.conv_out.cout_pad == 32 && r.gn_x == B[ci] && r.gn_chunks > 0) {
+        // norm_out + SiLU + conv_out in one read of the tensor (vae_io.hip): the statistics come from the producing conv's epilogue, only the
+        // finalise runs here
+        if (r.live()) {
+            const int chunks = r.gn_chunks;
+            r.gn_x = nullptr;
+            const double px = (double)n * H * W;
+            LAUNCHK(r, PK_GN_APPLY, 0.0, 0.0, ir_launch_groupnorm_fused(B[ci], nullptr, m.norm_out.g, m.norm_out.b, r.gn_buf, gws, n, (long)H * W, 128, 32, chunks, 1e-6f, 1, r.s, 0, 1.f),
+                    "groupnorm_finalize");
+            LAUNCHK(r, PK_VAE_CONV_OUT, 2.0 * px * 3 * 9 * 128, px * (128 * 2 + 16),
+                    ir_launch_vae_norm_conv_out(B[ci], gws, gws + (long)n * 128, m.conv_out.w, m.conv_out.b, out_nhwc4, n, H, W, r.s), "vae_norm_conv_out");
+        }
+        r.gn_buf = nullptr;
+        r.a.release(mk);
+        return;
+    }
     groupnorm(r, m.norm_out, B[ci], B[t1], gws, n, (long)H * W, 1);
     r.gn_buf = nullptr;
     conv(r, m.conv_out, B[t1], n, H, W, m.conv_out.cin, out_nhwc4, 4, 1, 1, 1, 0, ACT_NONE, 0.f, nullptr, 0, 0);
@@ -2648,6 +2678,21 @@ int ir_op_conv_groupnorm(ir_ctx* c, void* stream, const uint16_t* in, const uint
     nm.c = cout; nm.g = gamma; nm.b = beta;
     groupnorm(r, nm, conv_out, y, (float*)ws + part_floats, n, (long)ho * wo, silu);
     return finish(r, c, 0);
+}
+int ir_op_vae_conv_in(ir_ctx* c, void* stream, const float* in, const uint16_t* wgt, const float* bias, uint16_t* out, float* gn_part, int n, int h, int w,
+                      float in_scale, float in_shift, int* tiles) {
+    if (!c || !in || !wgt || !out || n <= 0 || h <= 0 || w <= 0) return fail(c, -1, "ir_op_vae_conv_in: bad argument");
+    HIPOK(c, hipSetDevice(c->device));
+    if (tiles) *tiles = ir_vae_conv_in_tiles(h, w);
+    const int rc = ir_launch_vae_conv_in(in, wgt, bias, out, gn_part, n, h, w, in_scale, in_shift, (hipStream_t)stream);
+    return rc ? fail(c, rc, "vae_conv_in failed (%d)", rc) : 0;
+}
+int ir_op_vae_norm_conv_out(ir_ctx* c, void* stream, const uint16_t* x, const float* scale, const float* shift, const uint16_t* wgt, const float* bias, float* out,
+                            int n, int h, int w) {
+    if (!c || !x || !scale || !shift || !wgt || !out || n <= 0 || h <= 0 || w <= 0) return fail(c, -1, "ir_op_vae_norm_conv_out: bad argument");
+    HIPOK(c, hipSetDevice(c->device));
+    const int rc = ir_launch_vae_norm_conv_out(x, scale, shift, wgt, bias, out, n, h, w, (hipStream_t)stream);
+    return rc ? fail(c, rc, "vae_norm_conv_out failed (%d)", rc) : 0;
 }
 int ir_op_conv_fp8(ir_ctx* c, void* stream, const uint8_t* in8, const uint8_t* wgt8, const float* dequant, const float* bias_div, uint16_t* out,
                    int n, int h, int w, int cin, int cout, const uint16_t* res) {

@@ -168,6 +168,12 @@ int ir_launch_eps_to_x0(const float* tok, const float* lat_in, float* lat_out, i
 int ir_launch_nhwc_to_u8(const float* in, int in_cs, uint8_t* out, long npix, float scale, float shift, hipStream_t s);
 int ir_launch_nchw_to_u8(const float* in, uint8_t* out, int N, long HW, hipStream_t s);
 int ir_launch_zero_f32(float* p, long n, hipStream_t s);
+// vae_io.hip: the VAE's first / last convolution at full resolution as HBM-bound kernels of their own
+int ir_vae_conv_in_tiles(int H, int W);   // GroupNorm partial tiles per image ir_launch_vae_conv_in writes (the gn_chunks of the following GroupNorm)
+int ir_launch_vae_conv_in(const float* in, const bf16_t* wgt, const float* bias, bf16_t* out, float* gn_part, int N, int H, int W, float in_scale,
+                          float in_shift, hipStream_t s);
+int ir_launch_vae_norm_conv_out(const bf16_t* x, const float* scale, const float* shift, const bf16_t* wgt, const float* bias, float* out, int N, int H,
+                                int W, hipStream_t s);
 int ir_launch_fill_u32(uint32_t* p, long n, uint32_t v, hipStream_t s);
 int ir_launch_tile_add(float* dst, const float* src, int N, int C, int H, int W, int th, int tw, int y0, int x0, hipStream_t s);
 int ir_launch_tile_div(float* dst, int N, int C, int H, int W, int th, int tw, int sy, int sx, hipStream_t s);

@@ -312,7 +312,7 @@ int ir_launch_groupnorm_fused(const bf16_t* x, bf16_t* y, const float* gamma, co
     } else {
         hipLaunchKernelGGL(gn_finalize_group_kernel, dim3(G, N), dim3(256), 0, s, part, gamma, beta, scale, shift, HW, C, G, chunks, eps);
     }
-    launch_gn_apply(x, y, scale, shift, N, HW, C, do_silu, s, out_fp8, out_mul);
+    if (y) launch_gn_apply(x, y, scale, shift, N, HW, C, do_silu, s, out_fp8, out_mul);   // y == nullptr: finalise only (scale = ws, shift = ws + N * C)
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

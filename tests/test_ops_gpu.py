@@ -546,3 +546,70 @@ def test_conv_splitk(ctx, n, h, w, cin, cout, taps, res):
     assert (splits.value > 1) == (h < 64), f"split count {splits.value}"
     assert torch.equal(outs[0], outs[1]), "split-K must be deterministic"
     close(L.from_bf16_bits(outs[0]).cpu().permute(0, 3, 1, 2), ref, 2 ** -7, 4e-3, f"conv split-K x{splits.value}")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# csrc/vae_io.hip: the VAE's first / last convolution at full resolution as HBM-bound kernels of their own
+@pytest.mark.parametrize("n,h,w", [(1, 64, 64), (2, 72, 192), (1, 256, 320)])
+def test_vae_conv_in(ctx, n, h, w):
+    """Encoder.conv_in (3 -> 128) straight from fp32 NCHW planes with `x * 2 - 1` folded in, against F.conv2d on the same bf16-rounded
+    operands, plus the GroupNorm(32) partial sums of the STORED values per 8 x 64 tile (ragged tiles: 72 rows, 192 / 320 columns)."""
+    import ctypes
+    g = torch.Generator().manual_seed(h * 7 + w)
+    x = torch.rand(n, 3, h, w, generator=g)
+    wt = (torch.rand(128, 3, 3, 3, generator=g) - 0.5) * 0.6
+    b = (torch.rand(128, generator=g) - 0.5) * 0.2
+    wp = torch.zeros(128, 9, 32)
+    wp[:, :, :3] = wt.permute(0, 2, 3, 1).reshape(128, 9, 3)
+    out = torch.empty(n, h, w, 128, dtype=torch.int16, device="cuda")
+    tiles = ctypes.c_int(0)
+    per = ((h + 7) // 8) * ((w + 63) // 64)
+    part = torch.full((n, per, 2, 32), float("nan"), device="cuda")
+    xd = x.cuda().contiguous()
+    ctx.check(ctx.lib.ir_op_vae_conv_in(ctx.h, ctx.stream(), L.ptr(xd), P(dev_bf16(wp)), P(b.cuda()), L.ptr(out), L.ptr(part), n, h, w, 2.0, -1.0,
+                                        ctypes.byref(tiles)), "vae_conv_in")
+    torch.cuda.synchronize()
+    assert tiles.value == per
+    xin = (xd * 2.0 - 1.0).to(torch.bfloat16).float()
+    ref = F.conv2d(xin, rb(wt).cuda(), b.cuda(), padding=1).permute(0, 2, 3, 1)
+    got = out.view(torch.bfloat16).float()
+    err = (got - ref).abs().max().item()
+    print(f"vae_conv_in ({n}, {h}x{w}): max abs err {err:.5f} (|ref| max {ref.abs().max().item():.2f})")
+    assert err <= 2 ** -7 * ref.abs().max().item() + 1e-3       # one bf16 rounding of the result
+    # statistics of the stored (bf16) values, per tile and group
+    gv = got.double().reshape(n, h, w, 32, 4)
+    want = torch.zeros(n, per, 2, 32, dtype=torch.float64, device="cuda")
+    tx = (w + 63) // 64
+    for ty in range((h + 7) // 8):
+        for txi in range(tx):
+            blk = gv[:, ty * 8:(ty + 1) * 8, txi * 64:(txi + 1) * 64]
+            want[:, ty * tx + txi, 0] = blk.sum(dim=(1, 2, 4))
+            want[:, ty * tx + txi, 1] = (blk * blk).sum(dim=(1, 2, 4))
+    rel = ((part.double() - want).abs() / (want.abs() + 1.0)).max().item()
+    assert rel <= 2e-4, rel
+
+
+@pytest.mark.parametrize("n,h,w", [(1, 64, 64), (2, 72, 96), (1, 256, 320)])
+def test_vae_norm_conv_out(ctx, n, h, w):
+    """Decoder.norm_out (as finalised scale / shift) + SiLU + conv_out (128 -> 3) in one pass over the tensor, against
+    F.conv2d(bf16(silu(x * scale + shift))) - exactly what the stand-alone GroupNorm pass stored for the generic conv to read."""
+    g = torch.Generator().manual_seed(h * 5 + w)
+    x = rb(torch.randn(n, h, w, 128, generator=g) * 1.5)
+    sc = 0.5 + torch.rand(n, 128, generator=g)
+    sh = (torch.rand(n, 128, generator=g) - 0.5)
+    wt = (torch.rand(3, 128, 3, 3, generator=g) - 0.5) * 0.1
+    b = (torch.rand(3, generator=g) - 0.5) * 0.2
+    wp = torch.zeros(32, 9, 128)
+    wp[:3] = wt.permute(0, 2, 3, 1).reshape(3, 9, 128)
+    bp = torch.zeros(32)
+    bp[:3] = b
+    out = torch.full((n, h, w, 4), float("nan"), device="cuda")
+    ctx.check(ctx.lib.ir_op_vae_norm_conv_out(ctx.h, ctx.stream(), P(dev_bf16(x)), P(sc.cuda()), P(sh.cuda()), P(dev_bf16(wp)), P(bp.cuda()),
+                                              L.ptr(out), n, h, w), "vae_norm_conv_out")
+    torch.cuda.synchronize()
+    act = F.silu(x.cuda() * sc.cuda()[:, None, None, :] + sh.cuda()[:, None, None, :]).to(torch.bfloat16).float()
+    ref = F.conv2d(act.permute(0, 3, 1, 2), rb(wt).cuda(), b.cuda(), padding=1).permute(0, 2, 3, 1)
+    err = (out[..., :3] - ref).abs().max().item()
+    print(f"vae_norm_conv_out ({n}, {h}x{w}): max abs err {err:.5f} (|ref| max {ref.abs().max().item():.2f})")
+    # the kernel's SiLU is x * rcp(1 + exp2(-x log2 e)) (1 ulp each): an activation may round to the neighbouring bf16 value
+    assert err <= 4e-3 * ref.abs().max().item() + 2e-3 and float(out[..., 3].abs().max()) == 0.0
