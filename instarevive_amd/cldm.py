@@ -16,6 +16,8 @@ saved embedding). One context per call: all rows of a batch must carry the same 
 import ctypes as C
 from types import SimpleNamespace
 
+import os
+
 import torch
 
 from . import _lib as L
@@ -134,9 +136,10 @@ def _sample(ctx, x, c_latent, timesteps, context, add_x):
 class FrozenOpenCLIPEmbedder(_DeviceModule):
     """ldm/modules/encoders/modules.py:134-196 (cldm.yaml: cond_stage_config, layer "penultimate"): the text tower of open_clip's ViT-H-14.
     `arch` / `version` select nothing here: the weights come through load_state_dict with open_clip's parameter names (the checkpoint's
-    `cond_stage_model.model.*` entries). open_clip's BPE tokenizer table is not in this image: pass `tokenizer` (texts -> LongTensor
-    [B, 77]) for arbitrary prompts; the empty prompt - the only one the reference's samplers use (cldm.py:357-358, positive_prompt="") -
-    is tokenised here (<start_of_text>, <end_of_text>, zero padding)."""
+    `cond_stage_model.model.*` entries). open_clip's BPE table (bpe_simple_vocab_16e6.txt.gz) is not in this image: pass `tokenizer` = a
+    folder holding it (or the Hugging Face CLIP vocab.json + merges.txt; instarevive_amd/clip_bpe.py restates open_clip.tokenize over it) or
+    any callable texts -> LongTensor [B, 77]; without one only the empty prompt - the only one the reference's samplers use
+    (cldm.py:357-358, positive_prompt="") - is tokenised (<start_of_text>, <end_of_text>, zero padding)."""
     FAMILY = "clip"
     SOT, EOT = 49406, 49407
 
@@ -146,6 +149,9 @@ class FrozenOpenCLIPEmbedder(_DeviceModule):
         if layer not in ("last", "penultimate"):
             raise AssertionError(layer)
         self.cfg = dict(width=width, heads=heads, layers=layers, vocab_size=vocab_size, context_length=max_length, mlp_ratio=mlp_ratio)
+        if isinstance(tokenizer, (str, os.PathLike)):   # a folder with open_clip's BPE table (or the Hugging Face CLIP tokenizer files)
+            from .clip_bpe import ClipBPETokenizer
+            tokenizer = ClipBPETokenizer.from_folder(os.fspath(tokenizer), max_length)
         self.layer, self.layer_idx, self.max_length, self.tokenizer = layer, (0 if layer == "last" else 1), max_length, tokenizer
 
     def _expected_keys(self):
@@ -171,7 +177,8 @@ class FrozenOpenCLIPEmbedder(_DeviceModule):
         if self.tokenizer is not None:
             return self.tokenizer(text)
         if any(t != "" for t in text):
-            raise NotImplementedError("open_clip's BPE table is not part of this build: construct FrozenOpenCLIPEmbedder(tokenizer=...) for non-empty prompts")
+            raise NotImplementedError("open_clip's BPE table is not part of this build: construct FrozenOpenCLIPEmbedder(tokenizer=<folder with "
+                                      "bpe_simple_vocab_16e6.txt.gz, or vocab.json + merges.txt>) for non-empty prompts")
         ids = torch.zeros(len(text), self.max_length, dtype=torch.long)
         ids[:, 0], ids[:, 1] = self.SOT, self.EOT
         return ids

@@ -274,3 +274,107 @@ def test_clip_text_keys_and_packing():
     assert float(p["clip.causal"][0, 5, 6]) < -1e37 and float(p["clip.causal"][0, 6, 5]) == 0.0
     torch.testing.assert_close(p["clip.l0.qkv.b"][:64], sd["transformer.resblocks.0.attn.in_proj_bias"][:64] * 32 ** -0.5)
     torch.testing.assert_close(p["clip.l0.qkv.b"][64:], sd["transformer.resblocks.0.attn.in_proj_bias"][64:])
+
+
+def test_evaluate_pairs_psnr_ssim_on_y(tmp_path):
+    """tools/evaluate_pairs.py (the paired half of the reference's evaluate_img.py:30-33,40-57; pyiqa's definitions restated): identical
+    folders score the eps-limited PSNR and SSIM 1; a uniform grey shift gives the analytic PSNR on BT.601 Y; Gaussian noise lowers both; files
+    pair up in sorted order."""
+    import importlib.util
+    import numpy as np
+    from PIL import Image
+    spec = importlib.util.spec_from_file_location("evaluate_pairs", os.path.join(ROOT, "tools", "evaluate_pairs.py"))
+    ep = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ep)
+    rng = np.random.default_rng(3)
+    base = np.clip(rng.normal(128, 40, (2, 48, 64, 3)), 20, 230).astype(np.uint8)
+    for sub in ("gt", "same", "shift", "noise"):
+        os.makedirs(tmp_path / sub)
+    for i in range(2):
+        Image.fromarray(base[i]).save(tmp_path / "gt" / f"im{i}.png")
+        Image.fromarray(base[i]).save(tmp_path / "same" / f"im{i}.png")
+        Image.fromarray(base[i] + 4).save(tmp_path / "shift" / f"im{i}.png")
+        Image.fromarray(np.clip(base[i] + rng.normal(0, 12, base[i].shape), 0, 255).astype(np.uint8)).save(tmp_path / "noise" / f"im{i}.png")
+    quiet = lambda *a: None
+    same = ep.evaluate(tmp_path / "same", tmp_path / "gt", log=quiet)
+    assert same["ssim"] == 1.0 and abs(same["psnr"] - 10 * np.log10(255.0 ** 2 / 1e-8)) < 1e-6
+    # +4 grey levels on every channel: Y moves by 219 / 255 * 4 = 3.435 before rounding, i.e. by 3 or 4 after it
+    shift = ep.evaluate(tmp_path / "shift", tmp_path / "gt", log=quiet)
+    assert 10 * np.log10(255.0 ** 2 / 16.0) - 1e-9 <= shift["psnr"] <= 10 * np.log10(255.0 ** 2 / 9.0) + 1e-9 and shift["ssim"] > 0.99
+    noise = ep.evaluate(tmp_path / "noise", tmp_path / "gt", log=quiet)
+    assert 24.0 < noise["psnr"] < 32.0 and 0.3 < noise["ssim"] < 0.97
+    # white on black: Y spans 16 .. 235 (studio swing), as pyiqa's color_space='ycbcr'
+    assert ep.to_y(np.zeros((1, 1, 3)))[0, 0] == 16 and ep.to_y(np.ones((1, 1, 3)))[0, 0] == 235
+
+
+def test_clip_bpe_tokenizer_matches_transformers_and_open_clip_layout(tmp_path):
+    """instarevive_amd/clip_bpe.py (open_clip.tokenize restated; ldm/modules/encoders/modules.py:171) on a BPE table built on the spot:
+    (1) the vocabulary layout open_clip derives from its merges file (bytes, bytes + </w>, merges, the two specials last); (2) the ids agree
+    with transformers.CLIPTokenizer - an independent implementation of the same byte-level BPE, installed here - loaded from the SAME table
+    written in the Hugging Face form; (3) row layout: <start_of_text>, ids, <end_of_text>, zero padding, truncation keeps the end token."""
+    import gzip
+    import json
+    from instarevive_amd.clip_bpe import ClipBPETokenizer, bytes_to_unicode
+    words = "a photo of a cat the quick brown fox jumps over lazy dog restoration high quality image".split()
+    # a small deterministic merge table: the character pairs of these words, most frequent first (any ranked list is a valid BPE table)
+    seq = [tuple(w[:-1]) + (w[-1] + "</w>",) for w in words]
+    merges = []
+    for _ in range(60):
+        cnt = {}
+        for w in seq:
+            for p in zip(w[:-1], w[1:]):
+                cnt[p] = cnt.get(p, 0) + 1
+        if not cnt:
+            break
+        best = max(sorted(cnt), key=lambda p: cnt[p])
+        merges.append(best)
+        seq = [tuple(_merge(w, best)) for w in seq]
+    oc = tmp_path / "oc"
+    os.makedirs(oc)
+    with gzip.open(oc / "bpe_simple_vocab_16e6.txt.gz", "wt", encoding="utf-8") as f:
+        f.write("#version: 0.2\n" + "\n".join(" ".join(m) for m in merges) + "\n")
+    tok = ClipBPETokenizer.from_folder(str(oc))
+    bu = list(bytes_to_unicode().values())
+    assert tok.encoder[bu[0]] == 0 and tok.encoder[bu[0] + "</w>"] == 256 and tok.encoder["".join(merges[0])] == 512
+    assert tok.sot == 512 + len(merges) and tok.eot == tok.sot + 1
+    texts = ["a photo of a cat", "The quick  brown fox's image, 42 dogs!", "", "restoration " * 100]
+    ids = tok(texts)
+    assert ids.shape == (4, 77) and ids.dtype == torch.long
+    assert ids[2].tolist() == [tok.sot, tok.eot] + [0] * 75                    # the empty prompt = the embedder's built-in row
+    assert ids[3, 0] == tok.sot and ids[3, -1] == tok.eot and (ids[3] != 0).all()  # truncated, end token kept
+    n0 = int((ids[0] != 0).sum())
+    assert ids[0, 0] == tok.sot and ids[0, n0 - 1] == tok.eot and (ids[0, n0:] == 0).all()
+    # (2) the same table through transformers' CLIP tokenizer
+    from transformers import CLIPTokenizer
+    hf = tmp_path / "hf"
+    os.makedirs(hf)
+    enc = {k: v for k, v in tok.encoder.items()}
+    enc["<|startoftext|>"] = enc.pop("<start_of_text>")
+    enc["<|endoftext|>"] = enc.pop("<end_of_text>")
+    json.dump(enc, open(hf / "vocab.json", "w"))
+    with open(hf / "merges.txt", "w", encoding="utf-8") as f:
+        f.write("#version: 0.2\n" + "\n".join(" ".join(m) for m in merges) + "\n")
+    ref = CLIPTokenizer(str(hf / "vocab.json"), str(hf / "merges.txt"))
+    for t in texts[:2] + ["high quality image restoration", "jumps over the lazy dog"]:
+        want = ref(t)["input_ids"]
+        got = [int(v) for v in tok(t)[0] if v != 0]
+        assert got == want, (t, got, want)
+    # the Hugging Face form of the folder loads to the same tokenizer
+    tok2 = ClipBPETokenizer.from_folder(str(hf))
+    assert torch.equal(tok2(texts), ids)
+    # and the embedder takes the folder
+    from instarevive_amd.cldm import FrozenOpenCLIPEmbedder
+    emb = FrozenOpenCLIPEmbedder(layer="penultimate", tokenizer=str(oc))
+    assert torch.equal(emb.tokenize(texts), ids)
+
+
+def _merge(word, pair):
+    out, i = [], 0
+    while i < len(word):
+        if i < len(word) - 1 and (word[i], word[i + 1]) == pair:
+            out.append(word[i] + word[i + 1])
+            i += 2
+        else:
+            out.append(word[i])
+            i += 1
+    return out
