@@ -43,7 +43,14 @@ constexpr int V_OFF = 2 * KSLOT;
 constexpr int LDS_BYTES = V_OFF + 2 * VSLOT;   // 132 096 B (the epilogue stages 128 queries x 1 KB of O in the same memory)
 constexpr float MARGIN = 24.0f;          // headroom below the first tile's maximum: probabilities of that tile are <= 2^-24
 constexpr float OVF_LIMIT = 80.0f;       // a later score may exceed the reference by 2^80 before the fallback is needed
-constexpr int LA = 4, NB = LA + 3;       // fragment reads in flight ahead of their MFMA; fragment register sets (see flash_attn_pp_kernel)
+#ifndef IR_D512_LA
+#define IR_D512_LA 4
+#endif
+constexpr int LA = IR_D512_LA, NB = LA + 3;   // fragment reads in flight ahead of their MFMA; fragment register sets (see flash_attn_pp_kernel)
+#ifndef IR_D512_DMA_EVERY
+#define IR_D512_DMA_EVERY 2
+#endif
+constexpr int DMA_EVERY = IR_D512_DMA_EVERY;
 constexpr int SM0 = 35;                  // first stream step that carries a softmax slice: three PV MFMAs behind the last QK^T MFMA
 }  // namespace a5
 
@@ -112,11 +119,30 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d512_v2_kernel(const bf16_t
     const bf16_t* k_lane = k + (long)wu * rs + lane * 8;
     const bf16_t* v_lane = vt + wu * 512 + lane * 8;
     const long k_tile = 32L * rs, k_step = 4L * rs;
+    // A piece = wave-uniform 64-bit base (scalar registers) + the lane's 32-bit byte offset (lane * 16, the same for every piece) in the
+    // `global_load_lds_dwordx4 v_off, s[base]` form, written out: through the builtin hipcc keeps a 64-bit per-lane address and adds the
+    // tile / piece term on the VALU in front of every piece (a v_lshl_add_u64 per piece in the busiest gaps of an issue-bound stream).
+    const uint32_t lane16 = (uint32_t)lane * 16u;
+    const uint32_t lds0_dma = lds_addr(smem);
+    auto dma_piece = [&](const bf16_t* base, uint32_t lds_byte) {
+        const uint32_t m0v = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0_dma + lds_byte));
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane16), "s"(base), "s"(m0v) : "memory");
+    };
+    const bf16_t* k_wave = k + (long)wu * rs;
+    const bf16_t* v_wave = vt + wu * 512;
     auto k_piece = [&](int tile, int i, int slot) {
+#ifdef IR_D512_BUILTIN_DMA
         a5_glds16(k_lane + tile * k_tile + i * k_step, (a5_lds_t)(smem + slot * KSLOT + (wu + 4 * i) * KROW));
+#else
+        dma_piece(k_wave + tile * k_tile + i * k_step, (uint32_t)(slot * KSLOT + (wu + 4 * i) * KROW));
+#endif
     };
     auto v_piece = [&](int tile, int i, int slot) {
+#ifdef IR_D512_BUILTIN_DMA
         a5_glds16(v_lane + (long)tile * (512 * 32) + i * 2048, (a5_lds_t)(smem + V_OFF + slot * VSLOT + (wu + 4 * i) * 1024));
+#else
+        dma_piece(v_wave + (long)tile * (512 * 32) + i * 2048, (uint32_t)(V_OFF + slot * VSLOT + (wu + 4 * i) * 1024));
+#endif
     };
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -169,15 +195,21 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d512_v2_kernel(const bf16_t
         auto step = [&](auto jc) {
             constexpr int j = decltype(jc)::value;
             if constexpr (j + LA < J1) frag_read(std::integral_constant<int, j + LA>{});
-            wait_lds<(J1 - 1 - j < LA ? J1 - 1 - j : LA)>();
+            // one counted wait per TWO MFMAs (at the even one, covering the next fragment as well): a satisfied s_waitcnt still takes an issue
+            // slot, and the gaps that carry a DMA piece or a softmax slice are over their 24 free cycles already
+            constexpr int rem = J1 - 1 - j;
+            if constexpr (((j - J0) & 1) == 0) wait_lds<(rem < LA ? (rem > 0 ? rem - 1 : 0) : LA - 1)>();
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (j == 0) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(sacc) : "v"(fr[j % NB]), "v"(qf[0]));
             else if constexpr (j < 32) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(sacc) : "v"(fr[j % NB]), "v"(qf[j]));
             else a5_mfma_pv<((j - 32) >> 1)>(fr[j % NB], __builtin_bit_cast(bf16x8, pc[j & 1]));
             if constexpr (j - 2 >= J0) asm volatile("" ::"v"(fr[(j - 2) % NB]));  // keep the fragment of MFMA j-2 allocated until here
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (DMA && j < 32 && (j & 1)) {  // the next tiles' pieces, one behind every other QK^T MFMA
-                constexpr int pi = j >> 1;
+            // The next tiles' 16 pieces of this wave, one behind every other QK^T MFMA (DMA_EVERY = 2). Measured in round 4: spreading them over
+            // the tile (every 3rd / 4th MFMA) is SLOWER (6.53 -> 6.70 / 6.84 ms at 65536 tokens) - the gaps of the QK^T half carry nothing but a
+            // fragment read, the later ones carry the softmax slices and are over their 24 free issue cycles already.
+            if constexpr (DMA && (j % DMA_EVERY) == 1 && j / DMA_EVERY < 16) {
+                constexpr int pi = j / DMA_EVERY;
                 // a full stream runs only while t + 1 < NT, so V^T(t+1) exists; past the end K(t+2) re-reads the last tile into the free
                 // slot (never used) instead of branching around the DMA
                 if constexpr (pi < 8) k_piece(min(t + 2, NT - 1), pi, kslot_n);
@@ -331,6 +363,11 @@ constexpr int LDS_O = 8 * 32 * OS * 2;           // 53 248 B
 constexpr int LDS_BYTES = LDS_MAIN > LDS_O ? LDS_MAIN : LDS_O;
 constexpr int NPC = (K_Q + V_Q + 3) / 4;         // pieces per wave and tile (at most)
 constexpr float MARGIN = 24.0f;
+#ifndef IR_PP2_DMA_EVERY
+#define IR_PP2_DMA_EVERY 2
+#endif
+constexpr int DMA_EVERY = IR_PP2_DMA_EVERY;      // one LDS-DMA piece behind every DMA_EVERY-th MFMA of the stream: 2 = behind the first score MFMAs, whose gaps
+                                                 // carry no exponentials (6 / 8: 1.29 -> 1.30 / 1.32 ms per layer, measured in round 4)
 constexpr int LA = 6, NB = LA + 3;
 constexpr int NQK = 20, NPV = 24, NSTEP = NQK + NPV;
 constexpr int O_BASE = 0, Q_BASE = 96;           // AGPR map: O^T a[0:95] (group g, tile dt at 16*(3g+dt)), Q^T a[96:135] (4*(5g+ks))
@@ -378,41 +415,59 @@ __global__ __launch_bounds__(256, 1) void flash_attn_pp2_kernel(AttnParams p) {
     asm volatile(".set ir_pp2_i, 0\n\t.rept 96\n\tv_accvgpr_write_b32 a[ir_pp2_i], 0\n\t.set ir_pp2_i, ir_pp2_i + 1\n\t.endr" ::: IR_AGPR256_CLOBBERS);
 
     // LDS-DMA pieces of a tile pair {K, V^T}: piece idx = wave + 4k belongs to this wave (19 pieces: the fifth piece of wave 3 repeats
-    // its fourth - same bytes to the same place - so that the stream issues its pieces without a branch). Per piece: the lane's source
-    // address in tile 0, the element stride from tile to tile, the LDS offset in slot 0, the slot size, and how far ahead of the PV tile
-    // t the piece's tile is (K: t + 2, V^T: t + 1).
-    const bf16_t* pc_src[NPC];
-    long pc_stride[NPC];
-    int pc_dst[NPC], pc_slot[NPC], pc_ahead[NPC];
+    // its fourth - same bytes to the same place - so that the stream issues its pieces without a branch). A piece's source is a wave-uniform
+    // 64-bit base (the tile's first K row / V^T column: two scalars per TILE, set by tile_bases) plus the lane's 32-bit byte offset, which
+    // never changes - the `global_load_lds ... v_off, s[base]` form: no 64-bit vector add and no per-piece tile arithmetic in the stream
+    // (round 3 recomputed tile * stride per piece: 13 scalar + 1 vector instruction in ONE MFMA gap, about 40 idle matrix cycles per piece).
+    // Pieces k = 0, 1 are always K pieces, k = 3, 4 always V^T pieces, k = 2 is a K piece on wave 0 only.
+    uint32_t pc_off[NPC];
+    int pc_dst[NPC];
+    const bool k2_is_k = wu + 8 < K_Q;
+    const uint32_t lds0_early = lds_addr(smem);
 #pragma unroll
     for (int k = 0; k < NPC; ++k) {
         const int idx = min(wu + 4 * k, K_Q + V_Q - 1);
+        pc_dst[k] = idx < K_Q ? idx * 1024 : V_OFF + (idx - K_Q) * 1024;   // wave-uniform (kept out of the lane-dependent branches: a scalar)
         if (idx < K_Q) {
             const int ci = 64 * idx + lane, row = ci / RCH, ch = ci - row * RCH;
-            pc_src[k] = kp + (long)row * p.k_rs + ch * 8;
-            pc_stride[k] = 64L * p.k_rs;
-            pc_dst[k] = idx * 1024; pc_slot[k] = KSLOT; pc_ahead[k] = 2;
+            pc_off[k] = (uint32_t)(row * p.k_rs + ch * 8) * 2u;
         } else {
             const int j = idx - K_Q;
             const int d = 8 * j + (lane >> 3), c = (lane & 7) ^ ((d >> 1) & 7);
-            pc_src[k] = vtp + (long)d * p.Tk_pad + c * 8;
-            pc_stride[k] = 64;
-            pc_dst[k] = V_OFF + j * 1024; pc_slot[k] = VSLOT; pc_ahead[k] = 1;
+            pc_off[k] = (uint32_t)(d * p.Tk_pad + c * 8) * 2u;
         }
     }
-    auto issue = [&](auto kc, int t) {  // this wave's k-th piece of the tiles that follow PV tile t (t = -2 / -1: the prologue's K(0), V^T(0) / K(1))
-        constexpr int k = decltype(kc)::value;
-        const int tile = min(t + pc_ahead[k], NT - 1);   // past the end the last tile is re-read into the free slot (never used)
-        a5_glds16(pc_src[k] + tile * pc_stride[k], (a5_lds_t)(smem + (tile & 1) * pc_slot[k] + pc_dst[k]));
+    const unsigned char* kbase = reinterpret_cast<const unsigned char*>(kp);    // K rows of the tile being fetched
+    const unsigned char* vbase = reinterpret_cast<const unsigned char*>(vtp);   // V^T columns of the tile being fetched
+    int kslot = 0, vslot = 0;                                                    // LDS slot byte offsets of those tiles
+    auto tile_bases = [&](int t) {   // fetches that ride behind PV tile t: K(t + 2), V^T(t + 1); past the end the last tile again (never used)
+        const int tk = min(t + 2, NT - 1), tv = min(t + 1, NT - 1);
+        kbase = reinterpret_cast<const unsigned char*>(kp + (long)tk * 64 * p.k_rs);
+        vbase = reinterpret_cast<const unsigned char*>(vtp + (long)tv * 64);
+        kslot = (tk & 1) * KSLOT;
+        vslot = (tv & 1) * VSLOT;
     };
-    // prologue: K(0) -> slot 0 and V^T(0) -> slot 0 (t = -2 for K pieces, -1 for V^T pieces), then K(1) -> slot 1
-    [&]<int... K>(std::integer_sequence<int, K...>) {
-        ((issue(std::integral_constant<int, K>{}, -pc_ahead[K])), ...);
-    }(std::make_integer_sequence<int, NPC>{});
+    auto issue = [&](auto kc) {  // this wave's k-th piece of the tiles tile_bases() selected
+        constexpr int k = decltype(kc)::value;
+        const bool isk = k < 2 || (k == 2 && k2_is_k);
+        const unsigned char* base = isk ? kbase : vbase;
+#ifndef IR_PP2_BUILTIN_DMA
+        // scalar base + 32-bit lane offset, written out: hipcc widens pc_off to a register pair and adds the base on the VALU
+        const uint32_t m0v = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0_early + (uint32_t)((isk ? kslot : vslot) + pc_dst[k])));
+        const uint32_t off = pc_off[k];
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(m0v) : "memory");
+#else
+        a5_glds16(base + pc_off[k], (a5_lds_t)(smem + (isk ? kslot : vslot) + pc_dst[k]));
+#endif
+    };
+    // prologue: K(0) -> slot 0 and V^T(0) -> slot 0, then K(1) -> slot 1
+    [&]<int... K>(std::integer_sequence<int, K...>) { ((issue(std::integral_constant<int, K>{})), ...); }(std::make_integer_sequence<int, NPC>{});
     if (NT > 1) {
-#pragma unroll
-        for (int k = 0; k < NPC; ++k)
-            if (pc_ahead[k] == 2) a5_glds16(pc_src[k] + pc_stride[k], (a5_lds_t)(smem + pc_slot[k] + pc_dst[k]));
+        kbase = reinterpret_cast<const unsigned char*>(kp + 64L * p.k_rs);
+        kslot = KSLOT;
+        issue(std::integral_constant<int, 0>{});
+        issue(std::integral_constant<int, 1>{});
+        if (k2_is_k) issue(std::integral_constant<int, 2>{});
     }
     // Q^T fragments -> AGPRs (B operand layout: lane = query, 8 consecutive d per k-step half), scaled; d >= 72 is zero
     [&]<int... I>(std::integer_sequence<int, I...>) {
@@ -474,7 +529,11 @@ __global__ __launch_bounds__(256, 1) void flash_attn_pp2_kernel(AttnParams p) {
             constexpr bool first_use = j < NQK || ((j - NQK) & 1) == 0;  // a PV pair's fragment is read once, for its first MFMA
             if constexpr (first_use) {
                 if constexpr (sl + LA < S1) slot_read(std::integral_constant<int, sl + LA>{});
-                wait_lds<(S1 - 1 - sl < LA ? S1 - 1 - sl : LA)>();
+                // one counted wait per TWO fragment slots (at the even slot, for the odd one behind it as well): the stream is issue-bound -
+                // every instruction between two MFMAs beyond 24 cycles' worth idles the matrix pipe - and a wait that is already
+                // satisfied still takes its issue slot
+                constexpr int rem = S1 - 1 - sl;   // reads issued behind slot sl by now (capped by the look-ahead)
+                if constexpr (((sl - S0) & 1) == 0) wait_lds<(rem < LA ? (rem > 0 ? rem - 1 : 0) : LA - 1)>();
             }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (IR_KO_PP2 == 5) {
@@ -489,8 +548,8 @@ __global__ __launch_bounds__(256, 1) void flash_attn_pp2_kernel(AttnParams p) {
             }
             if constexpr (sl - 2 >= S0) asm volatile("" ::"v"(fr[(sl - 2) % NB]));
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (DMA && IR_KO_PP2 != 2 && j < 2 * NPC && (j & 1)) {   // K(t+2) / V^T(t+1) pieces behind the first score MFMAs
-                issue(std::integral_constant<int, (j >> 1)>{}, t);
+            if constexpr (DMA && IR_KO_PP2 != 2 && (j % DMA_EVERY) == 1 && j / DMA_EVERY < NPC) {   // K(t+2) / V^T(t+1) pieces, spread over the tile (see a5::DMA_EVERY)
+                issue(std::integral_constant<int, (j / DMA_EVERY)>{});
                 __builtin_amdgcn_sched_barrier(0);
             }
             if constexpr (SOFTMAX && IR_KO_PP2 != 3 && j >= 13) {   // two exponentials per MFMA shadow: group 0 from step 13 (three MFMAs behind its
@@ -578,6 +637,7 @@ __global__ __launch_bounds__(256, 1) void flash_attn_pp2_kernel(AttnParams p) {
         ka = k_addr + ((t + 1) & 1) * KSLOT;
 #pragma unroll
         for (int j = 0; j < 4; ++j) va[j] = v_addr[j] + (t & 1) * VSLOT;
+        tile_bases(t);
         if (t + 1 < NT) stream(J0{}, std::true_type{}, std::true_type{}, pc, pn, t);
         else stream(JPV{}, std::false_type{}, std::false_type{}, pc, pn, t);
     };
