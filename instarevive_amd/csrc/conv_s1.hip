@@ -64,10 +64,8 @@ __device__ unsigned long long g_s1_stamps[1024 * 8];   // [wg][0..4] s_memrealti
 #define IR_S1_T(v) do { } while (0)
 #define IR_S1_ACC(k, a, b) do { } while (0)
 #endif
-__device__ uint4 g_zero_page_s1[4096];   // 64 KB of zeros: padding taps read from here, the LDS-DMA never needs a mask
 
 typedef __attribute__((address_space(3))) void* cs1_lds_t;
-IR_DEVINL void cs1_glds16(const void* g, cs1_lds_t l) { __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0); }
 template <int LO>
 IR_DEVINL void cs1_mfma(bf16x8 w, bf16x8 px) {
     asm volatile("v_mfma_f32_16x16x32_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(w), "v"(px), "n"(LO), "n"(LO + 3));
@@ -75,6 +73,8 @@ IR_DEVINL void cs1_mfma(bf16x8 w, bf16x8 px) {
 
 template <int UP>
 __global__ __launch_bounds__(256, 1) void conv_halo_s1_kernel(IGemmParams p, int tiles_y, int tiles_x, int total_vb) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub: the buffer-resource type of the body does not exist there, and with it in
+                                      // sight hipcc (ROCm 7.2) silently drops the stub of a kernel TEMPLATE (undefined __device_stub__ at load time)
     using namespace cs1;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES];   // halo[0..2] | W ring of 4 ; epilogue: slabs + red in ONE halo buffer
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -84,7 +84,6 @@ __global__ __launch_bounds__(256, 1) void conv_halo_s1_kernel(IGemmParams p, int
     const int MT = p.NB * tiles_y * tiles_x;
     const int Hc = UP ? 2 * p.H : p.H, Wc = UP ? 2 * p.W : p.W;   // conv-input (== output) extent
     const int chunks = p.Cin / BK;                                  // a multiple of 4 (launcher): 9 * chunks steps, ring slot = step & 3
-    const bf16_t* zero = reinterpret_cast<const bf16_t*>(g_zero_page_s1);
 
     // Persistent workgroups (one per CU) walk the virtual block ids bid, bid + gridDim.x, ... (gridDim.x is a multiple of 8: the XCD of a
     // virtual block is the XCD of the workgroup that runs it), and the LDS-DMA stream runs THROUGH the tile boundary: during the last two
@@ -103,10 +102,19 @@ __global__ __launch_bounds__(256, 1) void conv_halo_s1_kernel(IGemmParams p, int
         t.oy0 = ty * TH; t.ox0 = tx * TW;
         return true;
     };
-    // ---- LDS-DMA sources of a tile. Halo piece q covers halo pixels 16q .. 16q+15: lane l -> pixel 16q + (l >> 2), LDS slot l & 3.
-    // Kept as 32-bit offsets in 16-byte units from p.in (bit 31: the pixel is padding -> the same offset into the zero page, which is
-    // only ever the chunk offset): two tiles' worth of descriptors must fit beside 128 fragment registers.
+    // ---- LDS-DMA sources of a tile, as BUFFER loads (buffer_load_dwordx4 ... lds): a wave-uniform descriptor {tile base, 2 GB range} in
+    // scalar registers + the lane's 32-bit byte offset + a scalar chunk / tap offset. A padding pixel's offset is out of the descriptor's
+    // range, for which the hardware returns zeros: no zero page, no per-lane base select, and no 64-bit vector arithmetic in the MFMA gaps
+    // (round 3 spent 16 vector instructions per step on the addresses of its four pieces, in gaps that have 8 free issue cycles each).
+    // Halo piece q covers halo pixels 16q .. 16q+15: lane l -> pixel 16q + (l >> 2), LDS slot l & 3. The base is the first input row the
+    // tile's halo touches, so offsets stay below 18 rows x W x in_cs x 2 bytes whatever the tensor's size (17 GB at batch 8).
+    constexpr uint32_t OOB = 0xfffffff0u;
+    auto tile_base = [&](const Tile& t) -> const bf16_t* {
+        const int by = max(t.oy0 - 1, 0) >> UP;
+        return p.in + ((long)t.img * p.H + by) * p.W * p.in_cs;
+    };
     auto describe = [&](const Tile& t, uint32_t (&hp)[H_I], uint32_t (&wp)[2]) {
+        const int by = max(t.oy0 - 1, 0) >> UP;
 #pragma unroll
         for (int i = 0; i < H_I; ++i) {
             const int q = min(wu + 4 * i, H_Q - 1);
@@ -115,16 +123,17 @@ __global__ __launch_bounds__(256, 1) void conv_halo_s1_kernel(IGemmParams p, int
             const int cy = t.oy0 + hy - 1, cx = t.ox0 + hx - 1;
             const bool ok = hpix < HP && cy >= 0 && cy < Hc && cx >= 0 && cx < Wc;
             const int iy = min(max(cy, 0), Hc - 1) >> UP, ix = min(max(cx, 0), Wc - 1) >> UP;
-            const long pix = ((long)t.img * p.H + iy) * p.W + ix;
             const uint32_t sw = (uint32_t)((lane & 3) ^ hkey(hx));
-            hp[i] = ok ? (uint32_t)((pix * p.in_cs) >> 3) + sw : (0x80000000u | sw);
+            hp[i] = ok ? (uint32_t)(((iy - by) * p.W + ix) * p.in_cs) * 2u + sw * 16u : OOB;
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {   // weight pieces wave, wave + 4: rows 16 j + (l >> 2)
             const int row = (wu + 4 * i) * 16 + (lane >> 2);
-            wp[i] = (uint32_t)(((long)(t.n0 + row) * p.wgt_rs) >> 3) + (uint32_t)((lane & 3) ^ hkey(row));
+            wp[i] = (uint32_t)((t.n0 + row) * (int)p.wgt_rs) * 2u + (uint32_t)((lane & 3) ^ hkey(row)) * 16u;
         }
     };
+    auto rsrc_of = [&](const void* base) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000); };
+    const __amdgpu_buffer_rsrc_t w_rsrc = rsrc_of(p.wgt);
     // ---- fragment read addresses. Pixel fragment (patch row 4w + a, half mx) of tap (ky, kx): halo pixel (4w + a + ky, 16 mx + kx + c16),
     // chunk kq; the row term is an immediate. Weight fragment ct: row 16 ct + c16, chunk kq; ct * 1024 is an immediate.
     const uint32_t lds0 = lds_addr(smem);
@@ -143,22 +152,22 @@ __global__ __launch_bounds__(256, 1) void conv_halo_s1_kernel(IGemmParams p, int
     if (bid >= total_vb) return;
     uint32_t h_ptr[H_I], h_nxt[H_I], w_ptr[2], w_nxt[2];
     describe(cur, h_ptr, w_ptr);
+    const bf16_t* base_cur = tile_base(cur);
+    const bf16_t* base_nxt = base_cur;
 
     auto halo_issue = [&](auto ic, int ci, int buf) {   // piece i of this wave of halo chunk ci (>= chunks: of the next tile) into halo buffer buf
         constexpr int i = decltype(ic)::value;
         const int q = min(wu + 4 * i, H_Q - 1);
         const bool mine = ci < chunks;
-        const uint32_t d = mine ? h_ptr[i] : h_nxt[i];
-        const unsigned char* base = reinterpret_cast<const unsigned char*>((d >> 31) ? zero : p.in);
-        const unsigned char* src = base + ((unsigned long long)(d & 0x7fffffffu) << 4) + (mine ? ci : ci - chunks) * (BK * 2);
-        cs1_glds16(src, (cs1_lds_t)(smem + buf * HALO_BYTES + q * 1024));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_of(mine ? base_cur : base_nxt), (cs1_lds_t)(smem + buf * HALO_BYTES + q * 1024), 16,
+                                                 (int)(mine ? h_ptr[i] : h_nxt[i]), (mine ? ci : ci - chunks) * (BK * 2), 0, 0);
     };
     auto w_issue = [&](int chunk, int tap, bool mine, int slot) {
         const int koff = tap * p.Cin + chunk * BK;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-            cs1_glds16(reinterpret_cast<const unsigned char*>(p.wgt) + ((unsigned long long)(mine ? w_ptr[i] : w_nxt[i]) << 4) + koff * 2,
-                       (cs1_lds_t)(smem + W_OFF + slot * WT_BYTES + (wu + 4 * i) * 1024));
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (cs1_lds_t)(smem + W_OFF + slot * WT_BYTES + (wu + 4 * i) * 1024), 16,
+                                                     (int)(mine ? w_ptr[i] : w_nxt[i]), koff * 2, 0, 0);
     };
 
     // ---- prologue of the FIRST tile only: halo of chunk 0, weight tiles of steps 0..3, halo of chunk 1
@@ -181,26 +190,18 @@ __global__ __launch_bounds__(256, 1) void conv_halo_s1_kernel(IGemmParams p, int
         int cw = c + (T + 4 >= 9 ? 1 : 0), tw = TW4;
         const bool wmine = cw < chunks;
         if (!wmine) cw = 0;
-        // The address arithmetic of this step's LDS-DMA pieces is spread over the MFMA gaps, at most three vector instructions per gap (a
-        // wave issues in order: ten instructions in one gap hold the next MFMA back by about 25 cycles). Halo piece A: gaps 0-3, piece B:
-        // gaps 4-7, weight pieces: gaps 9-10 and 12-13.
-        uint32_t hd[2];
-        const unsigned char* hbase[2];
-        const unsigned char* hsrc[2];
-        const unsigned char* wsrc[2];
+        // This step's LDS-DMA pieces: halo piece A behind MFMA 1, piece B behind MFMA 5, the weight pieces behind MFMAs 10 and 13. A piece is
+        // one buffer load: descriptor and scalar offset are wave-uniform (selected between this tile and the next by scalar instructions),
+        // the lane offset is a register that lives for the whole tile.
         const bool hmine = c + 2 < chunks;
         const int hoff = (hmine ? c + 2 : c + 2 - chunks) * (BK * 2);
         const int wkoff = (tw * p.Cin + cw * BK) * 2;
-        auto halo_stage = [&](auto kc, auto stc) {   // piece k (0 / 1) of this step, stage 0..3
-            constexpr int K = decltype(kc)::value, ST = decltype(stc)::value;
+        auto halo_piece = [&](auto kc) {   // piece k (0 / 1) of this step
+            constexpr int K = decltype(kc)::value;
             constexpr int PI = nh(T) > K ? nh_first(T) + K : 0;
-            if constexpr (ST == 0) hd[K] = hmine ? h_ptr[PI] : h_nxt[PI];
-            if constexpr (ST == 1) hbase[K] = reinterpret_cast<const unsigned char*>((hd[K] >> 31) ? zero : p.in);
-            if constexpr (ST == 2) hsrc[K] = hbase[K] + ((unsigned long long)(hd[K] & 0x7fffffffu) << 4);
-            if constexpr (ST == 3) {
-                const int q = min(wu + 4 * PI, H_Q - 1);
-                cs1_glds16(hsrc[K] + hoff, (cs1_lds_t)(smem + hfill * HALO_BYTES + q * 1024));
-            }
+            const int q = min(wu + 4 * PI, H_Q - 1);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_of(hmine ? base_cur : base_nxt), (cs1_lds_t)(smem + hfill * HALO_BYTES + q * 1024), 16,
+                                                     (int)(hmine ? h_ptr[PI] : h_nxt[PI]), hoff, 0, 0);
         };
         [&]<int... I>(std::integer_sequence<int, I...>) {
             ([&] {
@@ -213,22 +214,18 @@ __global__ __launch_bounds__(256, 1) void conv_halo_s1_kernel(IGemmParams p, int
                 __builtin_amdgcn_sched_barrier(0);
                 cs1_mfma<4 * I>(fw[SET][CT], fp[SET][PT]);
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (I < 4 && nh(T) > 0 && IR_KO_S1 != 4) {
-                    halo_stage(std::integral_constant<int, 0>{}, std::integral_constant<int, I>{});
+                if constexpr (I == 1 && nh(T) > 0 && IR_KO_S1 != 4) {
+                    halo_piece(std::integral_constant<int, 0>{});
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if constexpr (I >= 4 && I < 8 && nh(T) > 1 && IR_KO_S1 != 4) {
-                    halo_stage(std::integral_constant<int, 1>{}, std::integral_constant<int, I - 4>{});
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if constexpr ((I == 9 || I == 12) && IR_KO_S1 != 5) {
-                    constexpr int K = I == 9 ? 0 : 1;
-                    wsrc[K] = reinterpret_cast<const unsigned char*>(p.wgt) + ((unsigned long long)(wmine ? w_ptr[K] : w_nxt[K]) << 4);
+                if constexpr (I == 5 && nh(T) > 1 && IR_KO_S1 != 4) {
+                    halo_piece(std::integral_constant<int, 1>{});
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if constexpr ((I == 10 || I == 13) && IR_KO_S1 != 5) {
                     constexpr int K = I == 10 ? 0 : 1;
-                    cs1_glds16(wsrc[K] + wkoff, (cs1_lds_t)(smem + W_OFF + (s & 3) * WT_BYTES + (wu + 4 * K) * 1024));
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (cs1_lds_t)(smem + W_OFF + (s & 3) * WT_BYTES + (wu + 4 * K) * 1024), 16,
+                                                             (int)(wmine ? w_ptr[K] : w_nxt[K]), wkoff, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }(), ...);
@@ -250,6 +247,7 @@ __global__ __launch_bounds__(256, 1) void conv_halo_s1_kernel(IGemmParams p, int
         const bool more = nbid < total_vb;
         if (!more) nxt = cur;
         describe(nxt, h_nxt, w_nxt);
+        base_nxt = tile_base(nxt);
         asm volatile(".set ir_cs1_i, 0\n\t.rept 256\n\tv_accvgpr_write_b32 a[ir_cs1_i], 0\n\t.set ir_cs1_i, ir_cs1_i + 1\n\t.endr" ::: IR_AGPR256_CLOBBERS);
         // everything in flight has landed (first tile: the prologue; later: the pieces fetched through the tile boundary and the previous
         // epilogue's stores) - chunk 1's halo included, which costs nothing after an epilogue and ~1 us once per workgroup
@@ -298,11 +296,13 @@ __global__ __launch_bounds__(256, 1) void conv_halo_s1_kernel(IGemmParams p, int
         if (!more) break;
         bid = nbid;
         cur = nxt;
+        base_cur = base_nxt;
 #pragma unroll
         for (int i = 0; i < H_I; ++i) h_ptr[i] = h_nxt[i];
         w_ptr[0] = w_nxt[0]; w_ptr[1] = w_nxt[1];
     }
     wait_dma();   // the stream's last fetches (a re-read of this tile) must not outlive the workgroup's LDS allocation
+#endif
 }
 
 // Which launches take this kernel (everything else of the halo family stays with conv_halo_pp_kernel / conv_halo_kernel): plain bf16
