@@ -235,6 +235,8 @@ def main():
     ap.add_argument("--tiled", action="store_true")
     ap.add_argument("--net_hw", type=str, default="", help="HxW network input (overrides --lq/--sr_scale), e.g. 2176x3840 for the padded 4K case")
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--fp8_parts", choices=["all", "attention", "no_encoder_convs", "convs"], default="all",
+                    help="with --fp8: which parts take e4m3 operands (default: all that BASELINE.json configs[4] names, plus the VAE mid-block attention)")
     ap.add_argument("--cpu_small", action="store_true", help="CPU baseline from the 512x512 oracle pass only (skips the 1024x1024 pass, about 25 s)")
     ap.add_argument("--control", type=int, default=0, metavar="COPIES", help="diagnostic: run the DiT step with the ControlNet-Half branch "
                     "(COPIES copied blocks, 13 in the reference configs; c = the LQ latent). Not the headline workload: no such weights are released")
@@ -291,8 +293,16 @@ def main():
     flags = ((L.FLAG_TILED | L.FLAG_FIX_WAVELET) if args.tiled else 0) | (L.FLAG_CONTROL_LQ if args.control else 0) | (L.FLAG_FP8 if args.fp8 else 0)
     if args.fp8:
         feats = ctx.lib.ir_fp8_features()   # what THIS build moves to fp8 operands: the workload string says exactly that
+        # --fp8_parts narrows the operand set (ir_set_fp8_mask; tools/fp8_attribution.py: the attention products cost 0.1 dB against the oracle,
+        # the e4m3 conv activations 5.5 dB): "attention" = the three attention parts only, "no_encoder_convs" = everything but the encoder's convs
+        conv_bits = sum(1 << b for b in (4, 5, 6, 7, 8, 12, 13, 14, 15, 16))
+        masks = {"all": 0xffffffff, "attention": 0b111, "no_encoder_convs": 0xffffffff & ~(0x1f << 4), "convs": conv_bits}
+        fmask = masks[args.fp8_parts]
+        ctx.check(ctx.lib.ir_set_fp8_mask(ctx.h, fmask), "ir_set_fp8_mask")
+        conv_words = "the VAE ResnetBlock 3x3 convs" if fmask & conv_bits == conv_bits else ("the VAE decoder's ResnetBlock 3x3 convs" if fmask & conv_bits else None)
         fp8_words = ", fp8 MFMA operands (MX-scaled e4m3) in " + " and ".join(
-            w for bit, w in ((1, "the VAE ResnetBlock 3x3 convs"), (2, "the DiT self-attention products"), (4, "the VAE mid-block attention products")) if feats & bit)
+            w for bit, w, on in ((1, conv_words, bool(fmask & conv_bits)), (2, "the DiT self-attention products", bool(fmask & 1)),
+                                 (4, "the VAE mid-block attention products", bool(fmask & 6))) if (feats & bit) and on)
         vae.enable_fp8(True)                                # packs + uploads the fp8 weight forms of the VAE resnet convs
         ctx.check(ctx.lib.ir_set_fp8(ctx.h, 0), "ir_set_fp8")  # ... the mode itself is switched per call by IR_FLAG_FP8
     if args.graph:

@@ -194,6 +194,13 @@ int ir_tiled_blend_pixels(ir_ctx* ctx, void* stream, const float* px_tiles, uint
 int ir_set_plain_kernels(ir_ctx* ctx, int on);
 /* on != 0: the stage entry points (ir_vae_encode / ir_vae_decode / ir_dit_*) use the fp8 forms as IR_FLAG_FP8 does for ir_pipeline. */
 int ir_set_fp8(ir_ctx* ctx, int on);
+/* Which PARTS take fp8 operands while fp8 is on (default: all of them = what ir_fp8_features() reports). One bit per part, so that the error
+ * of BASELINE.json configs[4] can be attributed part by part (tools/fp8_attribution.py -> DESIGN.md section 4) and an operand set chosen that
+ * meets a PSNR target: the DiT self-attention, the mid-block attention of the VAE encoder / decoder, the ResnetBlock convs of encoder /
+ * decoder level 0..3 (level l = index into ch_mult: 0 is full resolution) and of the two mid blocks. */
+enum { IR_FP8_BIT_DIT_ATTN = 0, IR_FP8_BIT_ENC_ATTN = 1, IR_FP8_BIT_DEC_ATTN = 2, IR_FP8_BIT_ENC_LEVEL0 = 4, IR_FP8_BIT_ENC_MID = 8,
+       IR_FP8_BIT_DEC_LEVEL0 = 12, IR_FP8_BIT_DEC_MID = 16 };
+int ir_set_fp8_mask(ir_ctx* ctx, unsigned mask);
 
 /* Per-launch timing with HIP events recorded on the launch stream (measurement aid for bench.py; no reference
  * counterpart). Classes: 0 conv3x3, 1 linear, 2 flash attention, 3 window attention, 4 groupnorm, 5 layernorm,

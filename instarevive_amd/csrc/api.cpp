@@ -232,6 +232,7 @@ struct ir_ctx {
     int device = 0;
     Profiler prof;
     bool fp8 = false;   // ir_set_fp8 / IR_FLAG_FP8: VAE resnet convs with fp8 operands where fp8 weights were uploaded
+    uint32_t fp8_mask = 0xffffffffu;   // ir_set_fp8_mask: which parts take fp8 operands when fp8 is on (IR_FP8_PART_* bits); all by default
     bool plain = false; // ir_set_plain_kernels: this context's launches take the older 4-wave kernels (make_run publishes it to the launchers)
     std::string err;
     std::unordered_map<std::string, Tensor> t;
@@ -592,10 +593,10 @@ void swinir_run(Run& r, const float* in, float* out, int n, int h, int w) {
 // ================================================================ VAE  (ldm/modules/diffusionmodules/model.py)
 // ResnetBlock (model.py:131-151) on three rotating NHWC bf16 buffers; returns the index holding the result.
 // gn_after: the block's output feeds a GroupNorm next (another ResnetBlock, the AttnBlock or norm_out).
-int resblock(Run& r, const ResW& w, bf16_t* B[3], int ci, float* gws, int N, int H, int W, bool gn_after) {
+int resblock(Run& r, const ResW& w, bf16_t* B[3], int ci, float* gws, int N, int H, int W, bool gn_after, int f8bit) {
     const int t1 = (ci + 1) % 3, t2 = (ci + 2) % 3;
     const int cin = w.c1.cin, cout = w.c1.cout;
-    if (r.c->fp8 && w.c1.w8 && w.c2.w8 && cin % 128 == 0 && cout % 128 == 0) {
+    if (r.c->fp8 && ((r.c->fp8_mask >> f8bit) & 1u) && w.c1.w8 && w.c2.w8 && cin % 128 == 0 && cout % 128 == 0) {
         // fp8 form: both GroupNorm+SiLU outputs are written as e4m3 (half the bytes) and both convs run on fp8 operands. An fp8
         // tensor never shares its buffer with the bf16 tensor it was made from (different element sizes: no in-place pass).
         groupnorm(r, w.n1, B[ci], B[t1], gws, N, (long)H * W, 1, 1);
@@ -637,7 +638,7 @@ struct AttnShard {
     int* flag_out = nullptr;               // device int that receives the overflow flag of part 0
 };
 // AttnBlock (model.py:181-205), single head, scores materialised per image in HBM (fp32 S, bf16 P).
-int attnblock(Run& r, const AttnW& w, bf16_t* B[3], int ci, float* gws, int N, int H, int W, const AttnShard* sh = nullptr) {
+int attnblock(Run& r, const AttnW& w, bf16_t* B[3], int ci, float* gws, int N, int H, int W, const AttnShard* sh = nullptr, int f8bit = 31) {
     const int t1 = (ci + 1) % 3, t2 = (ci + 2) % 3;
     const int C = w.n.c;
     const long T = (long)H * W;
@@ -657,7 +658,7 @@ int attnblock(Run& r, const AttnW& w, bf16_t* B[3], int ci, float* gws, int N, i
     // d = 512 without the redundant score product (attn_d512.hip): the whole batch in one launch, V^T in 32-key tiles
     const bool v2 = flash && !g_ir_plain_kernels;
     // BASELINE.json configs[4]: both products on e4m3 operands (attn_d512_fp8.hip); the bf16 rescaling kernel stays behind it as the fallback
-    const bool f8 = v2 && r.c->fp8 && ir_attn_d512_fp8_takes((int)T);
+    const bool f8 = v2 && r.c->fp8 && ((r.c->fp8_mask >> f8bit) & 1u) && ir_attn_d512_fp8_takes((int)T);
     // (sized whenever the shape allows it, so that ir_workspace_bytes - which does not know the per-call IR_FLAG_FP8 - covers the fp8 call)
     uint8_t* f8tiles = (v2 && ir_attn_d512_fp8_takes((int)T)) ? r.a.alloc<uint8_t>(ir_attn_d512_fp8_tile_bytes(N, (int)T)) : nullptr;
     bf16_t* vtt = v2 ? r.a.alloc<bf16_t>((long)N * T * C) : nullptr;
@@ -769,7 +770,7 @@ void vae_encode_run(Run& r, const float* in, float* lat, int n, int h, int w, fl
     int ci = 0, H = h, W = w;
     if (sh && sh->part == 1) {   // resume behind the exchanged attention rows: nothing in front of the block is needed again
         H = h >> (nl - 1); W = w >> (nl - 1);
-        ci = attnblock(r, m.attn, B, 0, gws, n, H, W, sh);
+        ci = attnblock(r, m.attn, B, 0, gws, n, H, W, sh, IR_FP8_BIT_ENC_ATTN);
         goto after_attention;
     }
     static const bool no_vae_io = getenv("IR_NO_VAE_IO") != nullptr;   // experiment knob: the generic kernels for conv_in / norm_out + conv_out
@@ -789,7 +790,7 @@ void vae_encode_run(Run& r, const float* in, float* lat, int n, int h, int w, fl
     }
     for (int l = 0; l < nl; ++l) {
         const size_t nres = m.levels[l].res.size();
-        for (size_t i = 0; i < nres; ++i) ci = resblock(r, m.levels[l].res[i], B, ci, gws, n, H, W, i + 1 < nres || !m.levels[l].has_resample);
+        for (size_t i = 0; i < nres; ++i) ci = resblock(r, m.levels[l].res[i], B, ci, gws, n, H, W, i + 1 < nres || !m.levels[l].has_resample, IR_FP8_BIT_ENC_LEVEL0 + (l < 4 ? l : 3));
         if (m.levels[l].has_resample) {  // Downsample: pad (0,1,0,1) + stride-2 conv (model.py:82-86)
             const int t1 = (ci + 1) % 3;
             r.gn_want = true;
@@ -798,15 +799,15 @@ void vae_encode_run(Run& r, const float* in, float* lat, int n, int h, int w, fl
             ci = t1; H /= 2; W /= 2;
         }
     }
-    ci = resblock(r, m.mid1, B, ci, gws, n, H, W, true);
-    ci = attnblock(r, m.attn, B, ci, gws, n, H, W, sh);
+    ci = resblock(r, m.mid1, B, ci, gws, n, H, W, true, IR_FP8_BIT_ENC_MID);
+    ci = attnblock(r, m.attn, B, ci, gws, n, H, W, sh, IR_FP8_BIT_ENC_ATTN);
     if (ci < 0) {   // part 0 of a sharded encode: stopped behind this rank's attention rows
         r.gn_buf = nullptr;
         r.a.release(mk);
         return;
     }
 after_attention:
-    ci = resblock(r, m.mid2, B, ci, gws, n, H, W, true);
+    ci = resblock(r, m.mid2, B, ci, gws, n, H, W, true, IR_FP8_BIT_ENC_MID);
     const int t1 = (ci + 1) % 3;
     groupnorm(r, m.norm_out, B[ci], B[t1], gws, n, (long)H * W, 1);
     r.gn_buf = nullptr;
@@ -833,12 +834,12 @@ void vae_decode_run(Run& r, const float* lat, float in_scale, float* out_nhwc4, 
     r.gn_want = true;
     conv(r, m.conv_in, z32, n, h, w, 32, B[0], m.conv_in.cout, 0, 1, 1, 0, ACT_NONE, 0.f, nullptr, 0, 0);
     int ci = 0, H = h, W = w;
-    ci = resblock(r, m.mid1, B, ci, gws, n, H, W, true);
-    ci = attnblock(r, m.attn, B, ci, gws, n, H, W);
-    ci = resblock(r, m.mid2, B, ci, gws, n, H, W, true);
+    ci = resblock(r, m.mid1, B, ci, gws, n, H, W, true, IR_FP8_BIT_DEC_MID);
+    ci = attnblock(r, m.attn, B, ci, gws, n, H, W, nullptr, IR_FP8_BIT_DEC_ATTN);
+    ci = resblock(r, m.mid2, B, ci, gws, n, H, W, true, IR_FP8_BIT_DEC_MID);
     for (int l = nl - 1; l >= 0; --l) {
         const size_t nres = m.levels[l].res.size();
-        for (size_t i = 0; i < nres; ++i) ci = resblock(r, m.levels[l].res[i], B, ci, gws, n, H, W, i + 1 < nres || !m.levels[l].has_resample);
+        for (size_t i = 0; i < nres; ++i) ci = resblock(r, m.levels[l].res[i], B, ci, gws, n, H, W, i + 1 < nres || !m.levels[l].has_resample, IR_FP8_BIT_DEC_LEVEL0 + (l < 4 ? l : 3));
         if (m.levels[l].has_resample) {  // Upsample: nearest x2 folded into the conv's addressing (model.py:63-67)
             const int t1 = (ci + 1) % 3;
             r.gn_want = true;
@@ -914,7 +915,7 @@ void dit_block(Run& r, const DitLayer& Lw, const float* mod, float* x, const Dit
     linear(r, Lw.qkv, b.xn, (int)BT, C, b.qkv, 3 * C, 0, ACT_NONE, nullptr, 0, 0);
     // BASELINE.json configs[4]: both attention products on e4m3 operands (attn_fp8.hip). The bf16 V^T is only built if the kernel's
     // fixed softmax reference was outgrown (flag), for the rescaling fallback behind it.
-    const bool attn8 = r.c->fp8 && b.f8tiles && hd == 72 && (T & 63) == 0 && T >= 256 && !g_ir_plain_kernels;
+    const bool attn8 = r.c->fp8 && (r.c->fp8_mask & (1u << IR_FP8_BIT_DIT_ATTN)) && b.f8tiles && hd == 72 && (T & 63) == 0 && T >= 256 && !g_ir_plain_kernels;
     if (r.live() && attn8) {
         AttnParams p;
         memset(&p, 0, sizeof p);
@@ -2417,6 +2418,12 @@ int ir_tiled_blend_pixels(ir_ctx* c, void* stream, const float* px_tiles, uint8_
 // fast kernels against. Process-wide.
 // fp8 mode of the stage entry points (ir_pipeline: IR_FLAG_FP8): VAE resnet convs whose fp8 weights were uploaded run on fp8 operands
 int ir_fp8_features(void) { return IR_FP8_VAE_RESNET_CONVS | IR_FP8_DIT_SELF_ATTENTION | IR_FP8_VAE_MID_ATTENTION; }
+int ir_set_fp8_mask(ir_ctx* c, unsigned mask) {
+    if (!c) return -1;
+    if (c->fp8_mask != mask) ++c->generation;   // recorded hipGraphs hold the launches of the operand set they were captured with
+    c->fp8_mask = mask;
+    return 0;
+}
 int ir_set_fp8(ir_ctx* c, int on) {
     if (!c) return -1;
     if (c->fp8 != (on != 0)) ++c->generation;   // recorded hipGraphs hold the launches of the mode they were captured in

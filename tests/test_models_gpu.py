@@ -579,6 +579,37 @@ def test_psnr_guard_bites_at_realistic_reference_quality(full_models):
             assert abs(d[0] - 10 * np.log10(1 + 10 ** ((lv - pe) / 10))) <= 0.03
 
 
+def test_fp8_mask_selects_the_operand_set(full_models):
+    """ir_set_fp8_mask: with every part switched off the fp8 call IS the bf16 path (bit for bit); the attention parts alone (DiT self-attention +
+    both VAE mid blocks) stay within 0.3 dB of the bf16 path's PSNR against the oracle - tools/fp8_attribution.py: the e4m3 conv activations
+    carry cfg-5's error, the attention products do not - and the full set is what the unmasked call runs."""
+    import bench
+    from instarevive_amd.pipeline import process
+    swin, vae, dit, sds, y, mask = full_models
+    ctx = dit.ctx
+    imgs = [bench.synthetic_lq(1, 512, 512, 15)[0].numpy()]
+    ref, _ = oglue.process(imgs, lambda x: oswin.swinir_forward(sds["swin"], x), lambda x: ovae.vae_encode_mean(sds["vae"], x),
+                           lambda lat, t, yy, mm: odit.dit_forward(sds["dit"], lat, t, yy, mm), lambda z: ovae.vae_decode(sds["vae"], z),
+                           oglue.alphas_cumprod_diffusers(), y, mask)
+    kw = dict(preprocess_model=swin, vae=vae, y=full_models.y_cuda, y_mask=full_models.mask_cuda)
+    bf, _ = process(dit, imgs, 1, "wavelet", False, False, 512, 448, **kw)
+    vae.enable_fp8(True)
+    try:
+        full, _ = process(dit, imgs, 1, "wavelet", False, False, 512, 448, fp8=True, **kw)
+        out = {}
+        for name, m in (("none", 0), ("attention", 0b111), ("all", 0xffffffff)):
+            ctx.check(ctx.lib.ir_set_fp8_mask(ctx.h, m), "ir_set_fp8_mask")
+            out[name], _ = process(dit, imgs, 1, "wavelet", False, False, 512, 448, fp8=True, **kw)
+    finally:
+        ctx.check(ctx.lib.ir_set_fp8_mask(ctx.h, 0xffffffff), "ir_set_fp8_mask")
+        vae.enable_fp8(False)
+    assert np.array_equal(out["none"][0], bf[0]), "an empty operand set must be the bf16 path"
+    assert np.array_equal(out["all"][0], full[0]) and not np.array_equal(full[0], bf[0])
+    pb, pa, pf = _psnr_u8(bf, ref), _psnr_u8(out["attention"], ref), _psnr_u8(full, ref)
+    print(f"fp8 operand sets vs fp32 oracle: bf16 {pb:.2f} dB, attention parts only {pa:.2f} dB, all parts {pf:.2f} dB")
+    assert not np.array_equal(out["attention"][0], bf[0]) and pa >= pb - 0.3 and pf < pa
+
+
 def test_fp8_tiled_and_hipgraph(full_models):
     """cfg-5 under --tiled: the fp8 attention then runs per batch of 1024-token tiles and the fp8 convs on 512 x 512 tiles (the small levels
     stay with the 4-wave fp8 kernel); tiled fp8 against tiled bf16 on a 1024 x 1024 image, and the hipGraph replay of the fp8 path against
