@@ -24,6 +24,7 @@
 // attention.hip behind this one, which returns at once unless the flag is set.
 // V^T comes tile-major ([T/32][512][32 keys], swizzle baked in) from transpose_v_tiles_kernel below, so a tile is 32 contiguous KB
 // and its LDS image is its memory image.
+#include <stdlib.h>
 #include "common.h"
 #include "kernels.h"
 #include "agpr256.h"
@@ -406,7 +407,16 @@ __global__ __launch_bounds__(256, 1) void flash_attn_pp2_kernel(AttnParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wu = __builtin_amdgcn_readfirstlane(wid);
     const int r = lane & 31, h = lane >> 5;
-    const int q0 = blockIdx.x * 256 + wid * 64, head = blockIdx.y, b = blockIdx.z;
+    // Workgroup -> (head, query tile). gridDim.y == 1: XCD-aware (launcher: Hh % 8 == 0). Workgroups are dealt round-robin over the 8 XCDs, so
+    // b % 8 names the XCD; all query tiles of a head go to ONE XCD, whose 32 CUs then stream that head's K / V^T (4.7 MB at 16384 tokens)
+    // through its 4 MB L2 together instead of every XCD streaming every head (round 3: 751 MB of fabric reads per launch for 151 MB of operands).
+    int qt = blockIdx.x, head = blockIdx.y;
+    if (gridDim.y == 1) {
+        const int QT = (p.Tq + 255) >> 8, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        head = (j / QT) * 8 + xcd;
+        qt = j - (j / QT) * QT;
+    }
+    const int q0 = qt * 256 + wid * 64, b = blockIdx.z;
     const bf16_t* qp = p.q + (long)b * p.q_bs + (long)head * p.q_hs;
     const bf16_t* kp = p.k + (long)b * p.k_bs + (long)head * p.k_hs;
     const bf16_t* vtp = p.vt + (long)b * p.vt_bs + (long)head * 96 * p.Tk_pad;
@@ -679,6 +689,9 @@ __global__ __launch_bounds__(256, 1) void flash_attn_pp2_kernel(AttnParams p) {
 
 int ir_launch_flash_attn_pp2(const AttnParams& p, hipStream_t s) {
     if (p.D != 72 || p.Tq <= 0 || p.Tk < 64 || (p.Tk & 63) || !p.ovf_flag || p.key_bias) return -2;
-    hipLaunchKernelGGL(flash_attn_pp2_kernel, dim3((p.Tq + 255) / 256, p.Hh, p.B), dim3(256), 0, s, p);
+    static const bool no_xcd = getenv("IR_PP2_NO_XCD_MAP") != nullptr;   // experiment knob
+    // (from 32 query tiles per head on - an XCD's 32 CUs then share one head; measured 1.253 -> 1.243 ms at 16384 tokens, 0.093 -> 0.094 at 4096)
+    if ((p.Hh & 7) == 0 && (p.Tq + 255) / 256 >= 32 && !no_xcd) hipLaunchKernelGGL(flash_attn_pp2_kernel, dim3(((p.Tq + 255) / 256) * p.Hh, 1, p.B), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(flash_attn_pp2_kernel, dim3((p.Tq + 255) / 256, p.Hh, p.B), dim3(256), 0, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
