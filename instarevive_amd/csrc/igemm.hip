@@ -1411,10 +1411,17 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(IGemmParams p) {
 
 int g_ir_plain_kernels = 0;
 
+// Shortest reduction gemm_pp_kernel takes: 8 k-tiles. (Its prologue needs 4; with the limit at 6 SwinIR's qkv projection - K = 192, N = 576 =
+// 2 x 288 - runs here: measured in round 4 at 36 us per launch, exactly what igemm_kernel<128, 64> needs for it: no gain, limit left at 8.
+// IR_GEMM_PP_MIN_K: experiment knob.)
+static int gemm_pp_min_k() {
+    static const int v = [] { const char* e = getenv("IR_GEMM_PP_MIN_K"); const int k = e ? atoi(e) : 8 * GemmPP::BK; return k < 4 * GemmPP::BK ? 4 * GemmPP::BK : k; }();
+    return v;
+}
 static bool takes_gemm_pp(const IGemmParams& p) {
     static const bool off = getenv("IR_NO_GEMM_PP") != nullptr;  // experiment knob
     if (off || g_ir_plain_kernels || p.fp8 || p.taps != 1 || p.force_generic || !p.vec || p.gn_part) return false;
-    if (p.Cout != p.Cout_pad || p.Cout % GemmPP::BN || p.Cin % GemmPP::BK || p.Cin < 8 * GemmPP::BK) return false;
+    if (p.Cout != p.Cout_pad || p.Cout % GemmPP::BN || p.Cin % GemmPP::BK || p.Cin < gemm_pp_min_k()) return false;
     const long span = (long)p.M * std::max(std::max(p.out_cs, p.res ? p.res_cs : 0), p.out2 ? p.out2_cs : 0);
     if (span >= (1L << 31)) return false;  // the epilogue's 32-bit element offsets
     const long blocks = (long)((p.M + GemmPP::BM - 1) / GemmPP::BM) * (p.Cout / GemmPP::BN);

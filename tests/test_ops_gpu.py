@@ -65,7 +65,7 @@ def test_linear(ctx, m, k, n):
     close(out.cpu(), ref, 1e-4, 2e-4 * math.sqrt(k), "linear f32")  # fp32 accumulate of exact bf16 products
 
 
-@pytest.mark.parametrize("m,k,n", [(16384, 1152, 1152), (12545, 1152, 3456), (16384, 4608, 1152), (6400, 128, 4608)])
+@pytest.mark.parametrize("m,k,n", [(16384, 1152, 1152), (12545, 1152, 3456), (16384, 4608, 1152), (6400, 128, 4608), (65536, 192, 576), (25000, 192, 576)])
 def test_linear_big_tile(ctx, m, k, n):
     """Shapes the 256 x 288 ping-pong GEMM takes (Cout % 288 == 0, >= 192 workgroups): the DiT linears at 2048 px, whole and ragged M,
     short and long K, with every epilogue form the DiT uses."""
