@@ -189,6 +189,74 @@ def test_conv_at_headline_size(ctx, cin, cout, up):
     print(f"conv {cin}->{cout} up={up} at {ho}x{wo}: crops ok")
 
 
+def test_vae_io_kernels_at_headline_size(ctx):
+    """csrc/vae_io.hip at the size they run at: Encoder.conv_in (3 -> 128) and Decoder.norm_out + SiLU + conv_out (128 -> 3) on 2048 x 2048
+    images - TWO images for the latter, so that the second one's 1 GiB of activations lies wholly past 2^30 elements. Row bands (top, middle,
+    bottom; full width) against F.conv2d on the same bf16-rounded operands; conv_in's GroupNorm partial sums against fp64 sums of what it stored."""
+    import ctypes
+    H = W = 2048
+    g = torch.Generator(device="cuda").manual_seed(77)
+    # ---- conv_in
+    x = torch.rand(1, 3, H, W, generator=g, device="cuda")
+    wt = ((torch.rand(128, 3, 3, 3, generator=g, device="cuda") - 0.5) * 0.6).to(torch.bfloat16)
+    b = (torch.rand(128, generator=g, device="cuda") - 0.5) * 0.2
+    wp = torch.zeros(128, 9, 32, device="cuda", dtype=torch.bfloat16)
+    wp[:, :, :3] = wt.permute(0, 2, 3, 1).reshape(128, 9, 3)
+    out = torch.empty(1, H, W, 128, dtype=torch.int16, device="cuda")
+    per = (H // 8) * (W // 64)
+    part = torch.zeros(1, per, 2, 32, device="cuda")
+    tiles = ctypes.c_int(0)
+    ctx.check(ctx.lib.ir_op_vae_conv_in(ctx.h, ctx.stream(), L.ptr(x), L.ptr(wp.view(torch.int16)), L.ptr(b), L.ptr(out), L.ptr(part), 1, H, W, 2.0, -1.0,
+                                        ctypes.byref(tiles)), "vae_conv_in")
+    torch.cuda.synchronize()
+    assert tiles.value == per
+    xin = (x * 2.0 - 1.0).to(torch.bfloat16).float()
+    got_all = out.view(torch.bfloat16)[0]
+    for r0, r1 in ((0, 18), (H // 2 - 9, H // 2 + 9), (H - 18, H)):
+        lo, hi = max(r0 - 1, 0), min(r1 + 1, H)
+        src = F.pad(xin[:, :, lo:hi], (1, 1, 1 if r0 == 0 else 0, 1 if r1 == H else 0))
+        ref = F.conv2d(src, wt.float(), b)[0].permute(1, 2, 0)[: r1 - r0]
+        err = (got_all[r0:r1].float() - ref).abs()
+        assert not (err > 2e-3 + 2 ** -7 * ref.abs()).any(), f"conv_in rows {r0}:{r1}: max abs err {float(err.max()):.4g}"
+    gv = got_all.view(H // 8, 8, W // 64, 64, 32, 4)
+    s1 = torch.zeros(H // 8, W // 64, 32, dtype=torch.float64, device="cuda")
+    s2 = torch.zeros_like(s1)
+    for ty in range(0, H // 8, 16):   # chunked: no fp64 copy of the gigabyte
+        blk = gv[ty:ty + 16].double()
+        s1[ty:ty + 16] = blk.sum(dim=(1, 3, 5))
+        s2[ty:ty + 16] = (blk * blk).sum(dim=(1, 3, 5))
+    want = torch.stack([s1.view(per, 32), s2.view(per, 32)], dim=1)[None]
+    rel = float(((part.double() - want).abs() / (want.abs() + 1.0)).max())
+    assert rel <= 2e-4, rel
+    del out, gv, got_all
+    # ---- norm_out + SiLU + conv_out, two images
+    xa = (torch.randn(2, H, W, 128, generator=g, device="cuda") * 1.5).to(torch.bfloat16)
+    sc = 0.5 + torch.rand(2, 128, generator=g, device="cuda")
+    sh = torch.rand(2, 128, generator=g, device="cuda") - 0.5
+    wo = ((torch.rand(3, 128, 3, 3, generator=g, device="cuda") - 0.5) * 0.1).to(torch.bfloat16)
+    bo = (torch.rand(3, generator=g, device="cuda") - 0.5) * 0.2
+    wpo = torch.zeros(32, 9, 128, device="cuda", dtype=torch.bfloat16)
+    wpo[:3] = wo.permute(0, 2, 3, 1).reshape(3, 9, 128)
+    bpo = torch.zeros(32, device="cuda")
+    bpo[:3] = bo
+    o4 = torch.full((2, H, W, 4), float("nan"), device="cuda")
+    ctx.check(ctx.lib.ir_op_vae_norm_conv_out(ctx.h, ctx.stream(), L.ptr(xa.view(torch.int16)), L.ptr(sc), L.ptr(sh), L.ptr(wpo.view(torch.int16)), L.ptr(bpo),
+                                              L.ptr(o4), 2, H, W), "vae_norm_conv_out")
+    torch.cuda.synchronize()
+    worst = 0.0
+    for n in range(2):
+        for r0, r1 in ((0, 18), (H // 2 - 9, H // 2 + 9), (H - 18, H)):
+            lo, hi = max(r0 - 1, 0), min(r1 + 1, H)
+            act = F.silu(xa[n, lo:hi].float() * sc[n] + sh[n]).to(torch.bfloat16).float().permute(2, 0, 1)[None]
+            src = F.pad(act, (1, 1, 1 if r0 == 0 else 0, 1 if r1 == H else 0))
+            ref = F.conv2d(src, wo.float(), bo)[0].permute(1, 2, 0)[: r1 - r0]
+            err = (o4[n, r0:r1, :, :3] - ref).abs()
+            worst = max(worst, float(err.max()))
+            assert not (err > 3e-3 + 4e-3 * ref.abs()).any(), f"conv_out image {n} rows {r0}:{r1}: max abs err {float(err.max()):.4g}"
+    assert float(o4[..., 3].abs().max()) == 0.0
+    print(f"vae_io at 2048x2048: conv_in bands + statistics ok (rel {rel:.1e}), norm_conv_out bands ok on both images (max abs err {worst:.4f})")
+
+
 # ------------------------------------------------------------------------------------------------ norms and layout kernels at 2048 x 2048
 def _gn_reference_rows(xb, rows, gamma, beta, silu, groups=32):
     """fp64 GroupNorm statistics over the whole image xb [HW, C] (bf16 device tensor), applied to the sampled rows: -> fp32 [len(rows), C]."""
