@@ -318,6 +318,12 @@ struct Run {
     const void* gn_x = nullptr;
     int gn_chunks = 0;
     hipEvent_t chain = nullptr;  // profiling: the event recorded right after the previous profiled launch of this run (see ProfScope)
+    // transposed second output of the next linear (IGemmParams::vt_out): set by dit_block for the qkv projection; conv() clears it and leaves
+    // vt_done = whether the launch it made writes V^T itself
+    bf16_t* vt_out = nullptr;
+    int vt_col0 = 0, vt_hd = 0, vt_dv = 0, vt_ld = 0, vt_T = 0;
+    long vt_bs = 0;
+    bool vt_done = false;
     bool splitk = false;         // conv() / linear() may split K over extra workgroups (IGemmParams::allow_splitk): set by the UNet path
     bool live() const { return !a.dry && rc == 0 && !a.overflow; }
     void chk(int r, const char* w) {
@@ -405,6 +411,13 @@ void conv(Run& r, const Conv& cw, const bf16_t* in, int N, int H, int W, int in_
         }
     }
     r.gn_want = false;
+    r.vt_done = false;
+    if (r.vt_out) {
+        p.vt_out = r.vt_out; p.vt_col0 = r.vt_col0; p.vt_hd = r.vt_hd; p.vt_dv = r.vt_dv; p.vt_ld = r.vt_ld; p.vt_T = r.vt_T; p.vt_bs = r.vt_bs;
+        r.vt_out = nullptr;
+        r.vt_done = ir_igemm_writes_vt(p) != 0;
+        if (!r.vt_done) p.vt_out = nullptr;
+    }
     static const int kid_of[5] = {PK_CONV_S1, PK_CONV_HALO_PP, PK_GEMM_PP, PK_CONV_HALO, -1};
     int kid = kid_of[ir_igemm_kernel_id(p)];
     if (kid < 0) kid = cw.taps == 9 ? PK_CONV_IGEMM : PK_LINEAR_IGEMM;
@@ -899,6 +912,7 @@ int dit_update_timestep(Run& r, float t) {
 struct DitBufs {
     bf16_t *xb, *xn, *qkv, *vt, *att, *cq, *hid;
     uint8_t* f8tiles;   // e4m3 K / V^T tile images of the fp8 self-attention (attn_fp8.hip), or null
+    bool vt_ready = false;   // vt's ones row / padding were written for this run (ir_launch_vt_pad_init): qkv epilogues may write rows d < hd
     int* attn_flag;
     int n, Tpad, DV;
     long T;
@@ -912,7 +926,13 @@ void dit_block(Run& r, const DitLayer& Lw, const float* mod, float* x, const Dit
     const long T = b.T, BT = n * T;
     const float sl2 = (1.0f / sqrtf((float)hd)) * 1.44269504088896340736f;
     layernorm(r, x, b.xn, nullptr, mod + C, mod, BT, C, C, C, 1e-6f);
+    const bool attn8_pre = r.c->fp8 && (r.c->fp8_mask & (1u << IR_FP8_BIT_DIT_ATTN)) && b.f8tiles && hd == 72 && (T & 63) == 0 && T >= 256 && !g_ir_plain_kernels;
+    if (b.vt_ready && !attn8_pre && !r.c->plain) {   // the projection's epilogue writes V^T itself (gemm_pp_kernel at >= 12 k tokens): no transpose launch
+        r.vt_out = b.vt; r.vt_col0 = 2 * C; r.vt_hd = hd; r.vt_dv = DV; r.vt_ld = Tpad; r.vt_T = (int)T; r.vt_bs = (long)Hh * DV * Tpad;
+    }
     linear(r, Lw.qkv, b.xn, (int)BT, C, b.qkv, 3 * C, 0, ACT_NONE, nullptr, 0, 0);
+    const bool vt_fused = r.vt_done;
+    r.vt_done = false;
     // BASELINE.json configs[4]: both attention products on e4m3 operands (attn_fp8.hip). The bf16 V^T is only built if the kernel's
     // fixed softmax reference was outgrown (flag), for the rescaling fallback behind it.
     const bool attn8 = r.c->fp8 && (r.c->fp8_mask & (1u << IR_FP8_BIT_DIT_ATTN)) && b.f8tiles && hd == 72 && (T & 63) == 0 && T >= 256 && !g_ir_plain_kernels;
@@ -928,7 +948,7 @@ void dit_block(Run& r, const DitLayer& Lw, const float* mod, float* x, const Dit
         LAUNCH(r, PC_TRANSPOSE, 0.0, 0.0, ir_launch_transpose_v(b.qkv + 2 * C, b.vt, T * 3 * C, 3 * C, hd, n, Hh, (int)T, Tpad, hd, DV, r.s, b.attn_flag), "transpose_v");
         LAUNCHK(r, PK_ATTN_OTHER, 0.0, 0.0, ir_launch_flash_attn_fallback(p, r.s), "self_attn_fallback");
     } else if (r.live()) {
-        LAUNCH(r, PC_TRANSPOSE, 0.0, 0.0, ir_launch_transpose_v(b.qkv + 2 * C, b.vt, T * 3 * C, 3 * C, hd, n, Hh, (int)T, Tpad, hd, DV, r.s), "transpose_v");
+        if (!vt_fused) LAUNCH(r, PC_TRANSPOSE, 0.0, 0.0, ir_launch_transpose_v(b.qkv + 2 * C, b.vt, T * 3 * C, 3 * C, hd, n, Hh, (int)T, Tpad, hd, DV, r.s), "transpose_v");
         AttnParams p;
         memset(&p, 0, sizeof p);
         p.q = b.qkv; p.k = b.qkv + C; p.vt = b.vt; p.o = b.att;
@@ -986,6 +1006,10 @@ float* dit_tokens_run(Run& r, const float* lat, int n, int h, int w, float times
     if (m.ncopy > 0) {      // sized whenever the branch is configured, so ir_workspace_bytes covers the conditioned call
         cs = r.a.alloc<float>(BT * C);
         csb = r.a.alloc<bf16_t>(BT * C);
+    }
+    if (hd == 72 && (T & 63) == 0 && T >= 256 && !r.c->plain) {   // (cheap: 50 MB at 16384 tokens, once per step)
+        LAUNCH(r, PC_TRANSPOSE, 0.0, 0.0, ir_launch_vt_pad_init(b.vt, n * Hh, hd, b.DV, (int)T, b.Tpad, r.s), "vt_pad_init");
+        b.vt_ready = r.live();
     }
     LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_patchify(lat, tokp, n, gh, gw, 32, r.s), "patchify");
     linear(r, m.patch, tokp, (int)BT, 32, x, C, 1, ACT_NONE, pos, 1, C, nullptr, 0, nullptr, (int)T);

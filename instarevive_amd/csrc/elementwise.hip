@@ -290,6 +290,21 @@ int ir_launch_fill_u32(uint32_t* p, long n, uint32_t v, hipStream_t s) {
     hipLaunchKernelGGL(fill_u32_kernel, GRID1D(n), dim3(256), 0, s, p, n, v);
     return LAUNCH_OK();
 }
+// V^T [heads_total][DV][Tpad] of the DiT self-attention when the qkv projection's epilogue writes rows d < D itself (IGemmParams::vt_out): the
+// parts it never writes - row D = ones over the real keys (the softmax denominator), rows above zero, and the columns t >= T of every row.
+__global__ void vt_pad_init_kernel(bf16_t* vt, int D, int DV, int T, int Tpad, long total) {
+    FOR_GRID(i, total) {
+        const int t = (int)(i % Tpad);
+        const int d = (int)((i / Tpad) % DV);
+        if (d >= D || t >= T) vt[i] = (d == D && t < T) ? (bf16_t)0x3f80 : (bf16_t)0;
+    }
+}
+int ir_launch_vt_pad_init(bf16_t* vt, int heads_total, int D, int DV, int T, int Tpad, hipStream_t s) {
+    const long total = (long)heads_total * DV * Tpad;
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(vt_pad_init_kernel, GRID1D(total), dim3(256), 0, s, vt, D, DV, T, Tpad, total);
+    return LAUNCH_OK();
+}
 int ir_launch_tile_add(float* dst, const float* src, int N, int C, int H, int W, int th, int tw, int y0, int x0, hipStream_t s) {
     if (y0 < 0 || x0 < 0 || y0 + th > H || x0 + tw > W) return -2;
     long total = (long)N * C * th * tw;

@@ -1351,6 +1351,27 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(IGemmParams p) {
                 const f32x4_t o = *reinterpret_cast<const f32x4_t*>(&slab[row * 144 + c4]);
                 if (m < p.M) *reinterpret_cast<uint2*>(outb + (unsigned)(m * p.out_cs + nw + c4)) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
             }
+            if (p.vt_out && nw >= p.vt_col0) {   // wave-uniform: this wave's 144 columns are two heads of V
+                // The slab holds 32 consecutive tokens x 144 columns: a lane takes a column (three passes over the 144) and writes its 32
+                // tokens as 64 contiguous bytes of the V^T row of that (head, d). Launcher: M % 256 == 0 and vt_T % 64 == 0, so the 32 tokens
+                // never straddle an image and the destination is 64-byte aligned.
+                const int tok0 = mw + hh * 32, bidx = tok0 / p.vt_T, t0 = tok0 - bidx * p.vt_T;
+#pragma unroll
+                for (int pass = 0; pass < 3; ++pass) {
+                    const int c = pass * 64 + lane;
+                    if (c < 144) {
+                        const int nn = nw + c - p.vt_col0, head = nn / p.vt_hd, d = nn - head * p.vt_hd;
+                        bf16_t* dst = p.vt_out + (long)bidx * p.vt_bs + ((long)head * p.vt_dv + d) * p.vt_ld + t0;
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            uint32_t w[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) w[e] = pack2bf(slab[(g4 * 8 + 2 * e) * 144 + c], slab[(g4 * 8 + 2 * e + 1) * 144 + c]);
+                            *reinterpret_cast<uint4*>(dst + g4 * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+                        }
+                    }
+                }
+            }
             done_half();
         }
     } else if (kind == 1) {
@@ -1426,6 +1447,17 @@ static bool takes_gemm_pp(const IGemmParams& p) {
     if (span >= (1L << 31)) return false;  // the epilogue's 32-bit element offsets
     const long blocks = (long)((p.M + GemmPP::BM - 1) / GemmPP::BM) * (p.Cout / GemmPP::BN);
     return blocks >= 192;  // below that the 128 x 128 kernel fills the chip better
+}
+// The transposed second output (IGemmParams::vt_out) is honoured by gemm_pp_kernel's bf16 / no-residual form on whole tiles only
+static bool igemm_vec(const IGemmParams& p);
+int ir_igemm_writes_vt(const IGemmParams& pin) {
+    static const bool off = getenv("IR_NO_VT_FUSE") != nullptr;   // experiment knob
+    IGemmParams p = pin;
+    p.vec = igemm_vec(p);
+    if (p.ks_ws && ir_igemm_splitk(p) > 1) return 0;
+    return !off && p.vt_out && takes_gemm_pp(p) && !p.res && !p.out_f32 && !p.out2 && p.M % GemmPP::BM == 0 && p.vt_T > 0 && p.vt_T % 64 == 0 &&
+           p.vt_col0 % GemmPP::BN == 0 && p.vt_hd * 2 == 144 && (p.Cout - p.vt_col0) % 144 == 0 && (p.vt_ld & 7) == 0 && (p.vt_bs & 7) == 0 &&
+           !(reinterpret_cast<uintptr_t>(p.vt_out) & 15);
 }
 static int launch_gemm_pp(const IGemmParams& p, hipStream_t s) {
     const int MT = (p.M + GemmPP::BM - 1) / GemmPP::BM, NT = p.Cout / GemmPP::BN;
@@ -1614,6 +1646,7 @@ int ir_launch_igemm(const IGemmParams& pin, hipStream_t s) {
     if (ir_conv_s1_takes(p)) return ir_launch_conv_s1(p, s);
     if (ir_conv_s1_fp8_takes(p)) return ir_launch_conv_s1_fp8(p, s);
     if (takes_halo_pp(p)) return launch_halo_pp(p, s);
+    if (p.vt_out && !ir_igemm_writes_vt(p)) p.vt_out = nullptr;   // only gemm_pp_kernel's bf16 form writes the transposed copy: the caller asked first
     if (takes_gemm_pp(p)) return launch_gemm_pp(p, s);
     if (takes_halo(p)) {
         if (p.Cout_pad % 128 == 0) return launch_halo<128>(p, s);

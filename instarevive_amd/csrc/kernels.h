@@ -51,7 +51,16 @@ struct IGemmParams {
     // slices in order and applies the epilogue (deterministic).
     int allow_splitk, ksplit;
     float* ks_ws;
+    // Optional second, TRANSPOSED copy of the output columns >= vt_col0 (gemm_pp_kernel's bf16 form only; M % 256 == 0, vt_T % 64 == 0): column
+    // vt_col0 + head * vt_hd + d of row m = batch * vt_T + t goes to vt_out[batch * vt_bs + (head * vt_dv + d) * vt_ld + t] - the V^T operand of
+    // the DiT self-attention straight from the qkv projection's epilogue (the rows d >= vt_hd of a head - the ones row and the padding - are
+    // written once per run by ir_launch_vt_pad_init). ir_igemm_writes_vt(p) tells whether the launch ir_launch_igemm picks honours it.
+    bf16_t* vt_out;
+    int vt_col0, vt_hd, vt_dv, vt_ld, vt_T;
+    long vt_bs;
 };
+int ir_igemm_writes_vt(const IGemmParams& p);
+int ir_launch_vt_pad_init(bf16_t* vt, int heads_total, int D, int DV, int T, int Tpad, hipStream_t s);
 int ir_launch_igemm(const IGemmParams& p, hipStream_t s);
 // which kernel ir_launch_igemm picks for p: 0 conv_halo_s1, 1 conv_halo_pp, 2 gemm_pp, 3 conv_halo, 4 igemm_kernel (profiler rows)
 int ir_igemm_kernel_id(const IGemmParams& p);
