@@ -407,11 +407,11 @@ __global__ __launch_bounds__(256, 1) void flash_attn_pp2_kernel(AttnParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wu = __builtin_amdgcn_readfirstlane(wid);
     const int r = lane & 31, h = lane >> 5;
-    // Workgroup -> (head, query tile). gridDim.y == 1: XCD-aware (launcher: Hh % 8 == 0). Workgroups are dealt round-robin over the 8 XCDs, so
+    // Workgroup -> (head, query tile). gridDim.y == 1 with several heads: XCD-aware (launcher: Hh % 8 == 0). Workgroups are dealt round-robin over the 8 XCDs, so
     // b % 8 names the XCD; all query tiles of a head go to ONE XCD, whose 32 CUs then stream that head's K / V^T (4.7 MB at 16384 tokens)
     // through its 4 MB L2 together instead of every XCD streaming every head (round 3: 751 MB of fabric reads per launch for 151 MB of operands).
     int qt = blockIdx.x, head = blockIdx.y;
-    if (gridDim.y == 1) {
+    if (gridDim.y == 1 && p.Hh > 1) {   // (a one-head launch has gridDim.y == 1 as well: the plain map)
         const int QT = (p.Tq + 255) >> 8, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
         head = (j / QT) * 8 + xcd;
         qt = j - (j / QT) * QT;
