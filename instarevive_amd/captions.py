@@ -8,7 +8,8 @@ here as data: a table of (pattern, replacement) steps applied in order, with the
     html.parser collecting the text nodes - the same parser family bs4 drives with features='html.parser';
   * basic_clean (t5.py:118-121: ftfy.fix_text + two html.unescape): `basic_clean` below applies the deterministic parts of ftfy's default
     fix_text (HTML entities, Latin ligatures, full-width forms, curly quotes, line breaks, control characters, NFC). ftfy's mojibake
-    repair (re-decoding mis-decoded UTF-8) is NOT restated - neither ftfy nor bs4 exists in this image, and the fixture
+    repair is restated for its dominant case only (`fix_mojibake`: UTF-8 read as cp1252 / Latin-1, up to three layers; **parity unpinned** -
+    tools/repin_with_diffusers.py compares it with ftfy where ftfy exists). Neither ftfy nor bs4 exists in this image, and the fixture
     tests/golden/captions.json was generated from the reference's own clean_caption with pass-through stand-ins for exactly those two
     calls (recorded in the fixture), on captions they leave unchanged.
 """
@@ -82,8 +83,44 @@ _QUOTES = {"\u2018": "'", "\u2019": "'", "\u201a": "'", "\u201b": "'", "\u201c":
 _CONTROL = re.compile("[\x00-\x08\x0b\x0e-\x1f\x7f\u200b-\u200f\u202a-\u202e\ufeff\ufff9-\ufffb]")
 
 
+# UTF-8 text that was decoded as Windows-1252 / Latin-1 (once or twice): "cafÃ©", "itâ€™s", "Ã¢â‚¬â„¢". ftfy finds such spans with a badness
+# heuristic over several single-byte encodings; restated here is the dominant case only: a run of two or more non-ASCII characters that
+# (a) starts like the lead byte of a UTF-8 sequence seen through cp1252 (Ã Â â ...), (b) encodes to cp1252 / latin-1 bytes, and (c) those bytes
+# ARE valid UTF-8. Text that is not mojibake fails (b) or (c) and is left alone ("éà" -> E9 E0 is not UTF-8).
+_MOJIBAKE_RUN = re.compile(r"[\u00c2-\u00f4][^\x00-\x7f]+")
+_C1_GAPS = {0x81, 0x8d, 0x8f, 0x90, 0x9d}   # bytes cp1252 leaves undefined: mis-decoders pass them through as U+0081 ... ("sloppy" cp1252)
+
+
+def _redecode(run: str):
+    out = bytearray()
+    for ch in run:
+        o = ord(ch)
+        if o in _C1_GAPS or 0xa0 <= o <= 0xff:
+            out.append(o)
+        else:
+            try:
+                out += ch.encode("cp1252")
+            except UnicodeEncodeError:
+                return None
+    try:
+        return out.decode("utf-8")
+    except UnicodeDecodeError:
+        return None
+
+
+def fix_mojibake(text: str) -> str:
+    for _ in range(3):   # text mis-decoded more than once unwinds one layer per pass
+        fixed = _MOJIBAKE_RUN.sub(lambda m: _redecode(m.group(0)) or m.group(0), text)
+        if fixed == text:
+            break
+        text = fixed
+    return text
+
+
 def fix_text(text: str) -> str:
-    """The deterministic steps of ftfy.fix_text's default configuration (no mojibake repair, see the module docstring)."""
+    """The steps of ftfy.fix_text's default configuration: the deterministic ones as ftfy defines them, its encoding repair in the restricted
+    form of fix_mojibake above (see the module docstring)."""
+    text = fix_mojibake(text)
     text = html.unescape(text)
     text = "".join(_LIGATURES.get(c, c) for c in text)
     text = "".join(unicodedata.normalize("NFKC", c) if "\uff01" <= c <= "\uff5e" or c == "\u3000" else c for c in text)   # full-width ASCII forms

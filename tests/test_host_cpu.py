@@ -378,3 +378,18 @@ def _merge(word, pair):
             out.append(word[i])
             i += 1
     return out
+
+
+def test_caption_mojibake_repair():
+    """captions.fix_mojibake: the dominant case of ftfy's encoding repair (UTF-8 read as cp1252 / Latin-1, one to three layers), restated
+    because ftfy is absent (diffusion/model/t5.py:118-124 calls ftfy.fix_text first); text that is not mojibake must pass untouched."""
+    from instarevive_amd.captions import clean_caption, fix_mojibake, fix_text
+    assert fix_mojibake("caf\u00c3\u00a9 au lait") == "caf\u00e9 au lait"
+    assert fix_text("it\u00e2\u20ac\u2122s a dog\u00e2\u20ac\u00a6") == "it's a dog\u2026"                 # -> curly apostrophe -> uncurled; the ellipsis stays
+    assert fix_mojibake("\u00c3\u00a2\u00e2\u201a\u00ac\u00e2\u201e\u00a2 twice") == "\u2019 twice"       # two layers
+    assert fix_mojibake("\u00e2\u20ac\u0153quoted\u00e2\u20ac\u009d") == "\u201cquoted\u201d"             # 0x9D: a byte cp1252 leaves undefined
+    for clean in ("na\u00efve caf\u00e9 \u00e9\u00e0 \u00fcn\u00ef", "plain ascii", "\u00c3", "\u4f60\u597d \u00df\u00fc", "a \u00d7 b"):
+        assert fix_mojibake(clean) == clean
+    assert clean_caption("A caf\u00c3\u00a9 in Paris") == "a caf\u00e9 in paris"
+    text = "a photo of a cat"   # ASCII captions (every fixture caption) never reach the repair
+    assert clean_caption(text) == text

@@ -20,6 +20,7 @@ random-initialised models of reduced width pin it exactly as the 4 GB checkpoint
     oracle.clip_text; open_clip.tokenize on sample prompts -> instarevive_amd.clip_bpe (needs open_clip's vocabulary file, which ships inside the
     open_clip package).
  5. pyiqa's PSNR-Y / SSIM-Y (evaluate_img.py:30-33) -> tools/evaluate_pairs.py.
+ 6. ftfy.fix_text (diffusion/model/t5.py:118-124) -> instarevive_amd.captions.fix_text (deterministic steps + the restricted mojibake repair).
 
 The fixture holds inputs, state-dict checksums and the third party's outputs (data, not source); tests/test_oracle_golden.py picks
 tests/golden/diffusers_pins.npz up when it exists (test_diffusers_pins) and compares the oracle against it on every later run, on any box."""
@@ -177,6 +178,19 @@ def pin_iqa(out):
     return abs(p - p_ref) <= 1e-3 and abs(s - s_ref) <= 1e-4
 
 
+def pin_ftfy(out):
+    import ftfy
+    from instarevive_amd.captions import fix_text
+    samples = ["caf\u00c3\u00a9 au lait", "it\u00e2\u20ac\u2122s a dog\u00e2\u20ac\u00a6", "\u00c3\u00a2\u00e2\u201a\u00ac\u00e2\u201e\u00a2 twice",
+               "na\u00efve caf\u00e9", "\ufb01ne \uff21\uff22\uff23 \u201cq\u201d", "plain ascii", "&lt;b&gt; &amp;amp; x", "line\r\nbreak\u2028here"]
+    want = [ftfy.fix_text(t) for t in samples]
+    got = [fix_text(t) for t in samples]
+    bad = [(t, w, g) for t, w, g in zip(samples, want, got) if w != g]
+    print(f"  [6] ftfy.fix_text vs captions.fix_text on {len(samples)} samples: {'identical' if not bad else bad}")
+    out["ftfy_samples"], out["ftfy_fixed"] = np.array(samples), np.array(want)
+    return not bad
+
+
 def main():
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--dit", default=None, help="folder of a diffusers Transformer2DModel (the converted PixArt / InstaRevive transformer): also compare at full size")
@@ -185,7 +199,7 @@ def main():
     a = ap.parse_args()
     out, verdict = {}, {}
     for name, fn, args in (("diffusers DiT (items 1, 2)", pin_dit, (None,)), ("diffusers VAE (item 3)", pin_vae, (None,)),
-                           ("open_clip (item 4)", pin_clip, ()), ("pyiqa (item 5)", pin_iqa, ())):
+                           ("open_clip (item 4)", pin_clip, ()), ("pyiqa (item 5)", pin_iqa, ()), ("ftfy (item 6)", pin_ftfy, ())):
         print(name)
         try:
             verdict[name] = fn(out, *args)
