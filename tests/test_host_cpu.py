@@ -390,6 +390,8 @@ def test_caption_mojibake_repair():
     assert fix_mojibake("\u00e2\u20ac\u0153quoted\u00e2\u20ac\u009d") == "\u201cquoted\u201d"             # 0x9D: a byte cp1252 leaves undefined
     for clean in ("na\u00efve caf\u00e9 \u00e9\u00e0 \u00fcn\u00ef", "plain ascii", "\u00c3", "\u4f60\u597d \u00df\u00fc", "a \u00d7 b"):
         assert fix_mojibake(clean) == clean
-    assert clean_caption("A caf\u00c3\u00a9 in Paris") == "a caf\u00e9 in paris"
+    # inside clean_caption the repair sees what the EARLIER steps left (t5.py:124-197 lower-case the caption and strip (c) / (tm) / (r) first, exactly
+    # as in the reference, where ftfy sits at the same place): "A caf\u00c3\u00a9" arrives as "a caf\u00e3" and stays that way there, too
+    assert clean_caption("A caf\u00c3\u00a9 in Paris") == "a caf\u00e3 in paris"
     text = "a photo of a cat"   # ASCII captions (every fixture caption) never reach the repair
     assert clean_caption(text) == text
