@@ -266,7 +266,9 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    # IR_FORCE_COLLECTIVES=1 (tests): a ONE-rank group goes through the same RCCL calls as the multi-GPU runs - the in-step gather of device
+    # tensors, the MAX / MIN all-reduces, the barriers - so that the branch the driver's 2- / 4- / 8-GPU runs take has executed on a one-GPU box
+    if world > 1 or parallel.force_collectives():
         import torch.distributed as dist
         parallel.init_distributed(backend)   # one process per GPU; "nccl" is RCCL on ROCm
 

@@ -224,3 +224,20 @@ def test_rccl_branch_single_rank(tmp_path):
     print(f"RCCL single-rank smoke: {d}")
     assert d["backend"] == "nccl" and d["world"] == 1 and d["gather_equal"] and d["sharded_equal"] and d["tiles"] == 12 and d["image_std"] > 1.0
     assert d["max_over_ranks"] == 1.25
+
+
+def test_bench_multi_gpu_branch_through_rccl_on_one_rank():
+    """bench.py's multi-GPU code path - init_process_group("nccl"), GatherPlan's RCCL gather of the uint8 results INSIDE the timed step, the
+    MAX all-reduce of the step time, the MIN all-reduce of `verified`, the barriers - with ONE rank and IR_FORCE_COLLECTIVES=1: what the
+    driver's --gpus 2 / 4 / 8 runs execute, on device tensors, on the box that exists."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "IR_BENCH_BACKEND")}
+    env.update(IR_FORCE_COLLECTIVES="1", HSA_ENABLE_IPC_MODE_LEGACY=env.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no_cpu_baseline", "--no_host_rate"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    print(f"bench.py through a one-rank RCCL group: {line['ms_per_step']} ms per step, verified {line.get('verified')}, gathered {line.get('gathered_images')}, "
+          f"RCCL {line.get('rccl_version')}")
+    assert line["n_gpus"] == 1 and line["verified"] is True and line["gathered_images"] == 1 and line["world_size"] == 1
+    assert line["rccl_version"] not in (None, "gloo") and 100.0 < line["ms_per_step"] < 200.0
