@@ -242,6 +242,12 @@ int ir_op_conv_groupnorm(ir_ctx* ctx, void* stream, const uint16_t* in, const ui
  *   gn_part[((image * tiles + tile) * 2 + {0: sum, 1: sum of squares}) * 32 + group]; *tiles = tiles per image.
  * ir_op_vae_norm_conv_out: Decoder.norm_out + nonlinearity + conv_out (model.py:650-655): out[pixel][0..2] = conv3x3(silu(x * scale[image][c] +
  *   shift[image][c]) rounded to bf16) + bias, out[pixel][3] = 0; x [n][h][w][128] bf16, wgt [32][9][128] bf16 (rows 0..2 used), out fp32. */
+/* Upsample.forward of the VAE decoder (ldm/modules/diffusionmodules/model.py:63-67: nearest 2x + 3x3 conv) in its sub-pixel phase form: four
+ * 2x2 convs on the LOW-resolution tensor, 16 instead of 36 tap products per low-resolution pixel. in [n][h][w][cin] bf16, wup = the four phase
+ * matrices [2 dy + dx][cout][2 sy + sx][cin] bf16 (instarevive_amd.weights.pack_conv_up2x2: the 3x3 taps that land on one source pixel summed
+ * in fp32), out [n][2h][2w][cout] bf16. cin, cout multiples of 128. What ir_vae_decode launches for its three Upsample convs. */
+int ir_op_conv_up2x2(ir_ctx* ctx, void* stream, const uint16_t* in, const uint16_t* wup, const float* bias, uint16_t* out, int n, int h, int w,
+                     int cin, int cout);
 int ir_op_vae_conv_in(ir_ctx* ctx, void* stream, const float* in, const uint16_t* wgt, const float* bias, uint16_t* out, float* gn_part, int n, int h,
                       int w, float in_scale, float in_shift, int* tiles);
 int ir_op_vae_norm_conv_out(ir_ctx* ctx, void* stream, const uint16_t* x, const float* scale, const float* shift, const uint16_t* wgt, const float* bias,

@@ -34,6 +34,8 @@ struct Conv {  // packed conv / linear weight: w [cout_pad][taps*cin] bf16, b [c
     // factor per channel (weight scale / activation scale) and the bias divided by it (see IGemmParams::fp8)
     const uint8_t* w8 = nullptr;
     const float *g8 = nullptr, *b8 = nullptr;
+    // optional sub-pixel phase matrices of a conv that follows a nearest-2x upsample: [4][cout][4][cin] bf16 (weights.pack_conv_up2x2)
+    const bf16_t* wup = nullptr;
 };
 constexpr float FP8_ACT_SCALE = 16.0f;  // GroupNorm+SiLU outputs are stored as e4m3(x * 16): |x| up to 28 without clamping, 3 mantissa bits down to 2^-10
 struct Norm {
@@ -400,6 +402,11 @@ void conv(Run& r, const Conv& cw, const bf16_t* in, int N, int H, int W, int in_
         ~Release() { if (m) r.a.release(m - 1); }
     } rel{r, ks_mark};
     if (!r.live()) return;
+    if (up && cw.wup && cw.taps == 9 && stride == 1 && !r.c->plain) {   // nearest-2x upsample + 3x3 as four 2x2 convs on the low-resolution tensor (conv_s1.hip)
+        IGemmParams q = p;
+        q.wgt = cw.wup; q.wgt_rs = 4L * cw.cin; q.up2x2 = 1;
+        if (ir_conv_s1_up2x2_takes(q)) p = q;
+    }
     static const bool no_gn_fuse = getenv("IR_NO_GN_FUSE") != nullptr;  // experiment knob
     if (r.gn_want && r.gn_buf && !out_f32 && cw.cout % 32 == 0 && !no_gn_fuse) {
         p.gn_cpg = cw.cout / 32;
@@ -500,6 +507,10 @@ struct Binder {
         w.w = (const bf16_t*)get(base + ".w", (size_t)cout_pad * taps * cin * 2);
         w.b = (const float*)get(base + ".b", (size_t)cout_pad * 4);
         return w;
+    }
+    void up2x2_optional(Conv& w, const std::string& base) {   // present when the host packed the phase form of this upsampling conv
+        auto it = c->t.find(base + ".wup");
+        if (it != c->t.end() && it->second.bytes >= (size_t)4 * w.cout_pad * 4 * w.cin * 2) w.wup = (const bf16_t*)it->second.p;
     }
     void fp8_optional(Conv& w, const std::string& base) {  // present only when the host packed an fp8 form of this conv
         auto iw = c->t.find(base + ".w8"), ig = c->t.find(base + ".g8"), ib = c->t.find(base + ".b8");
@@ -1690,6 +1701,7 @@ int ir_vae_configure(ir_ctx* c, int ch, int n_levels, const int* ch_mult, int nu
             if (l != 0) {
                 L.has_resample = true;
                 L.resample = b.conv(fmt("vae.dec.up%d.us", l), block_in, block_in, block_in, 9);
+                b.up2x2_optional(L.resample, fmt("vae.dec.up%d.us", l));
             }
             d.levels[l] = L;
         }
@@ -2709,6 +2721,20 @@ int ir_op_conv_groupnorm(ir_ctx* c, void* stream, const uint16_t* in, const uint
     nm.c = cout; nm.g = gamma; nm.b = beta;
     groupnorm(r, nm, conv_out, y, (float*)ws + part_floats, n, (long)ho * wo, silu);
     return finish(r, c, 0);
+}
+int ir_op_conv_up2x2(ir_ctx* c, void* stream, const uint16_t* in, const uint16_t* wup, const float* bias, uint16_t* out, int n, int h, int w, int cin, int cout) {
+    // nearest-2x upsample + 3x3 conv as four 2x2 convs on the low-resolution tensor: wup = weights.pack_conv_up2x2 ([4][cout][4][cin] bf16)
+    if (!c || !in || !wup || !out) return fail(c, -1, "ir_op_conv_up2x2: bad argument");
+    use_ctx(c);
+    IGemmParams p;
+    memset(&p, 0, sizeof p);
+    p.in = in; p.NB = n; p.H = h; p.W = w; p.Cin = cin; p.in_cs = cin; p.taps = 9; p.stride = 1; p.pad = 1; p.up = 1;
+    p.Ho = 2 * h; p.Wo = 2 * w; p.M = n * p.Ho * p.Wo;
+    p.wgt = wup; p.wgt_rs = 4L * cin; p.Cout = cout; p.Cout_pad = cout; p.bias = bias; p.act = ACT_NONE; p.out_scale = 1.f;
+    p.rows_per_batch = 1 << 30; p.out = out; p.out_cs = cout; p.up2x2 = 1;
+    if (!ir_conv_s1_up2x2_takes(p)) return fail(c, -2, "ir_op_conv_up2x2: shape not taken by the phase kernel (cin, cout multiples of 128; enough tiles)");
+    const int rc = ir_launch_igemm(p, (hipStream_t)stream);
+    return rc ? fail(c, rc, "conv_up2x2 failed (%d)", rc) : 0;
 }
 int ir_op_vae_conv_in(ir_ctx* c, void* stream, const float* in, const uint16_t* wgt, const float* bias, uint16_t* out, float* gn_part, int n, int h, int w,
                       float in_scale, float in_shift, int* tiles) {

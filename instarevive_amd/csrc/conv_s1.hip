@@ -46,9 +46,16 @@ constexpr int W_OFF = NHB * HALO_BYTES;        // 119 808
 constexpr int LDS_MAIN = W_OFF + NSB * WT_BYTES;   // 152 576
 static_assert(cs1e::BYTES <= HALO_BYTES, "epilogue slabs + reduction area must fit one halo buffer");
 constexpr int LDS_BYTES = LDS_MAIN;
-// halo pieces issued in the step of tap t (10 per chunk, all before tap 6)
-constexpr int nh(int t) { return t < 4 ? 2 : (t < 6 ? 1 : 0); }
-constexpr int nh_first(int t) { return t < 4 ? 2 * t : (t < 6 ? 4 + t : 0); }
+// The same machine runs a 3 x 3 window (NTAP = 9) or a 2 x 2 window (NTAP = 4, the sub-pixel phases of a nearest-2x upsample + 3 x 3 conv, see
+// conv_halo_s1_kernel): K taps per side, a (TH + K - 1) x (TW + K - 1) halo per 32-channel chunk, H_Q pieces of 16 halo pixels, H_I per wave.
+template <int NTAP>
+struct Geo {
+    static constexpr int K = NTAP == 9 ? 3 : 2, HWD = TW + K - 1, HP = (TH + K - 1) * HWD, H_Q = (HP + 15) / 16, H_I = (H_Q + 3) / 4;
+};
+static_assert(Geo<9>::H_Q == H_Q && Geo<9>::H_I == H_I && Geo<4>::H_Q == 36 && Geo<4>::H_I == 9, "halo piece counts");
+// halo pieces issued in the step of tap t: 3 x 3: 10 per chunk and wave, all before tap 6; 2 x 2: 9 per chunk and wave (3, 2, 2, 2)
+constexpr int nh(int ntap, int t) { return ntap == 9 ? (t < 4 ? 2 : (t < 6 ? 1 : 0)) : (t == 0 ? 3 : 2); }
+constexpr int nh_first(int ntap, int t) { return ntap == 9 ? (t < 4 ? 2 * t : (t < 6 ? 4 + t : 0)) : (t == 0 ? 0 : 1 + 2 * t); }
 constexpr int hkey(int hx) { return ((hx >> 2) & 1) << 1; }
 }  // namespace cs1
 
@@ -71,34 +78,47 @@ IR_DEVINL void cs1_mfma(bf16x8 w, bf16x8 px) {
     asm volatile("v_mfma_f32_16x16x32_bf16 a[%c2:%c3], %0, %1, a[%c2:%c3]" ::"v"(w), "v"(px), "n"(LO), "n"(LO + 3));
 }
 
-template <int UP>
+// NTAP = 4 (with UP = 0): a nearest-2x upsample followed by a 3 x 3 convolution (model.py:63-67, the decoder's three Upsample convs: 5.6 of the
+// path's 57 conv TFLOP) as FOUR 2 x 2 convolutions on the LOW-resolution tensor, one per output phase (dy, dx) = (row, column parity): output
+// pixel (2y + dy, 2x + dx) sees the low-resolution pixels (y - 1 + dy + sy, x - 1 + dx + sx), sy, sx in {0, 1}, through the SUMS of the 3 x 3
+// taps that land on the same source pixel (host: weights.pack_conv_up2x2, summed in fp32, rounded to bf16 once) - 16 instead of 36 tap products
+// per low-resolution pixel and channel pair, the same zero padding (a source pixel outside the low-resolution image is exactly a padding tap of
+// the upsampled one). A tile is 16 x 32 LOW-resolution positions of one phase; its outputs are every other pixel of 32 x 64 high-resolution ones.
+template <int UP, int NTAP>
 __global__ __launch_bounds__(256, 1) void conv_halo_s1_kernel(IGemmParams p, int tiles_y, int tiles_x, int total_vb) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub: the buffer-resource type of the body does not exist there, and with it in
                                       // sight hipcc (ROCm 7.2) silently drops the stub of a kernel TEMPLATE (undefined __device_stub__ at load time)
     using namespace cs1;
+    using G = Geo<NTAP>;
+    constexpr int K = G::K, HWD = G::HWD, HP = G::HP, H_Q = G::H_Q, H_I = G::H_I;   // (shadow the 3 x 3 constants of the namespace)
+    constexpr bool PH = NTAP == 4;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES];   // halo[0..2] | W ring of 4 ; epilogue: slabs + red in ONE halo buffer
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wu = __builtin_amdgcn_readfirstlane(wid);
     const int c16 = lane & 15, kq = lane >> 4;
     const int NT = p.Cout_pad / BN;
-    const int MT = p.NB * tiles_y * tiles_x;
-    const int Hc = UP ? 2 * p.H : p.H, Wc = UP ? 2 * p.W : p.W;   // conv-input (== output) extent
-    const int chunks = p.Cin / BK;                                  // a multiple of 4 (launcher): 9 * chunks steps, ring slot = step & 3
+    const int MT = p.NB * tiles_y * tiles_x * (PH ? 4 : 1);
+    const int Hc = UP ? 2 * p.H : p.H, Wc = UP ? 2 * p.W : p.W;   // conv-input extent (PH: the low-resolution tensor; the tiles walk it, too)
+    const int chunks = p.Cin / BK;                                  // a multiple of 4 (launcher): NTAP * chunks steps, ring slot = step & 3
 
     // Persistent workgroups (one per CU) walk the virtual block ids bid, bid + gridDim.x, ... (gridDim.x is a multiple of 8: the XCD of a
     // virtual block is the XCD of the workgroup that runs it), and the LDS-DMA stream runs THROUGH the tile boundary: during the last two
     // chunks of a tile the "chunk c + 2" fetches bring the first two chunks of the next tile's halo, the last four steps its first four
     // weight tiles, so the epilogue (whose slabs live in the halo buffer of the tile's last chunk) runs with the next tile's data landing
     // and there is no prologue between tiles.
-    struct Tile { int img, trem, oy0, ox0, n0; };
+    struct Tile { int img, trem, oy0, ox0, n0, dy, dx; };   // trem: the tile's slot among the image's GroupNorm partials; dy, dx: its phase (PH)
     auto decode = [&](int bid, Tile& t) -> bool {
         const int xcd = bid & 7, jb = bid >> 3;
         const int mt = (jb / NT) * 8 + xcd, nt = jb % NT;   // an XCD runs the channel tiles of one patch back to back (halo re-read from its L2)
         if (bid >= total_vb || mt >= MT) return false;
         t.n0 = nt * BN;
-        t.img = mt / (tiles_y * tiles_x);
-        t.trem = mt - t.img * tiles_y * tiles_x;
-        const int ty = t.trem / tiles_x, tx = t.trem - ty * tiles_x;
+        const int per_img = tiles_y * tiles_x * (PH ? 4 : 1);
+        t.img = mt / per_img;
+        t.trem = mt - t.img * per_img;
+        // PH: the four phases of a patch back to back (they read the same low-resolution halo: L2 hits)
+        const int ph = PH ? (t.trem & 3) : 0, tile = PH ? (t.trem >> 2) : t.trem;
+        t.dy = ph >> 1; t.dx = ph & 1;
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
         t.oy0 = ty * TH; t.ox0 = tx * TW;
         return true;
     };
@@ -110,17 +130,17 @@ __global__ __launch_bounds__(256, 1) void conv_halo_s1_kernel(IGemmParams p, int
     // tile's halo touches, so offsets stay below 18 rows x W x in_cs x 2 bytes whatever the tensor's size (17 GB at batch 8).
     constexpr uint32_t OOB = 0xfffffff0u;
     auto tile_base = [&](const Tile& t) -> const bf16_t* {
-        const int by = max(t.oy0 - 1, 0) >> UP;
+        const int by = max(t.oy0 - 1 + t.dy, 0) >> UP;
         return p.in + ((long)t.img * p.H + by) * p.W * p.in_cs;
     };
     auto describe = [&](const Tile& t, uint32_t (&hp)[H_I], uint32_t (&wp)[2]) {
-        const int by = max(t.oy0 - 1, 0) >> UP;
+        const int by = max(t.oy0 - 1 + t.dy, 0) >> UP;
 #pragma unroll
         for (int i = 0; i < H_I; ++i) {
             const int q = min(wu + 4 * i, H_Q - 1);
             const int hpix = q * 16 + (lane >> 2);
             const int hy = hpix / HWD, hx = hpix - hy * HWD;
-            const int cy = t.oy0 + hy - 1, cx = t.ox0 + hx - 1;
+            const int cy = t.oy0 + hy - 1 + t.dy, cx = t.ox0 + hx - 1 + t.dx;   // (dy = dx = 0 outside the phase form)
             const bool ok = hpix < HP && cy >= 0 && cy < Hc && cx >= 0 && cx < Wc;
             const int iy = min(max(cy, 0), Hc - 1) >> UP, ix = min(max(cx, 0), Wc - 1) >> UP;
             const uint32_t sw = (uint32_t)((lane & 3) ^ hkey(hx));
@@ -129,7 +149,7 @@ __global__ __launch_bounds__(256, 1) void conv_halo_s1_kernel(IGemmParams p, int
 #pragma unroll
         for (int i = 0; i < 2; ++i) {   // weight pieces wave, wave + 4: rows 16 j + (l >> 2)
             const int row = (wu + 4 * i) * 16 + (lane >> 2);
-            wp[i] = (uint32_t)((t.n0 + row) * (int)p.wgt_rs) * 2u + (uint32_t)((lane & 3) ^ hkey(row)) * 16u;
+            wp[i] = (uint32_t)(((PH ? (2 * t.dy + t.dx) * p.Cout_pad : 0) + t.n0 + row) * (int)p.wgt_rs) * 2u + (uint32_t)((lane & 3) ^ hkey(row)) * 16u;   // PH: [phase][Cout][4][Cin]
         }
     };
     auto rsrc_of = [&](const void* base) { return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000); };
@@ -137,9 +157,9 @@ __global__ __launch_bounds__(256, 1) void conv_halo_s1_kernel(IGemmParams p, int
     // ---- fragment read addresses. Pixel fragment (patch row 4w + a, half mx) of tap (ky, kx): halo pixel (4w + a + ky, 16 mx + kx + c16),
     // chunk kq; the row term is an immediate. Weight fragment ct: row 16 ct + c16, chunk kq; ct * 1024 is an immediate.
     const uint32_t lds0 = lds_addr(smem);
-    uint32_t hrd[3];   // half mx = 1 is 16 pixels = 1024 bytes further (hkey has period 8 in hx): an immediate
+    uint32_t hrd[K];   // half mx = 1 is 16 pixels = 1024 bytes further (hkey has period 8 in hx): an immediate
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
+    for (int kx = 0; kx < K; ++kx) {
         const int hx = kx + c16;
         hrd[kx] = lds0 + ((4 * wid) * HWD + hx) * ROWB + ((kq ^ hkey(hx)) << 4);
     }
@@ -179,15 +199,15 @@ __global__ __launch_bounds__(256, 1) void conv_halo_s1_kernel(IGemmParams p, int
 
     auto step = [&](auto tc, auto setc, int c, int hbuf) {   // hbuf = halo buffer of chunk c
         constexpr int T = decltype(tc)::value, SET = decltype(setc)::value;
-        constexpr int TNX = (T + 1) % 9, KXN = TNX % 3, KYN = TNX / 3;
-        const int s = c * 9 + T;
-        const uint32_t hb = (uint32_t)(T == 8 ? (hbuf == 2 ? 0 : hbuf + 1) : hbuf) * HALO_BYTES;
+        constexpr int TNX = (T + 1) % NTAP, KXN = TNX % K, KYN = TNX / K;
+        const int s = c * NTAP + T;
+        const uint32_t hb = (uint32_t)(T == NTAP - 1 ? (hbuf == 2 ? 0 : hbuf + 1) : hbuf) * HALO_BYTES;
         const int hfill = hbuf == 0 ? 2 : hbuf - 1;   // buffer of chunk c + 2 = the one chunk c - 1 was read from
         const uint32_t ha = hrd[KXN] + hb;
         const uint32_t wa = wrd + (uint32_t)((s + 1) & 3) * WT_BYTES;
         // weight tile s + 4 = (chunk cw, tap tw); past the end: tile s + 4 - steps (chunk 0, taps 0..3) of the next tile
-        constexpr int TW4 = (T + 4) % 9;
-        int cw = c + (T + 4 >= 9 ? 1 : 0), tw = TW4;
+        constexpr int TW4 = (T + 4) % NTAP;
+        int cw = c + (T + 4) / NTAP, tw = TW4;
         const bool wmine = cw < chunks;
         if (!wmine) cw = 0;
         // This step's LDS-DMA pieces: halo piece A behind MFMA 1, piece B behind MFMA 5, the weight pieces behind MFMAs 10 and 13. A piece is
@@ -196,9 +216,9 @@ __global__ __launch_bounds__(256, 1) void conv_halo_s1_kernel(IGemmParams p, int
         const bool hmine = c + 2 < chunks;
         const int hoff = (hmine ? c + 2 : c + 2 - chunks) * (BK * 2);
         const int wkoff = (tw * p.Cin + cw * BK) * 2;
-        auto halo_piece = [&](auto kc) {   // piece k (0 / 1) of this step
-            constexpr int K = decltype(kc)::value;
-            constexpr int PI = nh(T) > K ? nh_first(T) + K : 0;
+        auto halo_piece = [&](auto kc) {   // piece k (0 / 1 / 2) of this step
+            constexpr int KP = decltype(kc)::value;
+            constexpr int PI = nh(NTAP, T) > KP ? nh_first(NTAP, T) + KP : 0;
             const int q = min(wu + 4 * PI, H_Q - 1);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_of(hmine ? base_cur : base_nxt), (cs1_lds_t)(smem + hfill * HALO_BYTES + q * 1024), 16,
                                                      (int)(hmine ? h_ptr[PI] : h_nxt[PI]), hoff, 0, 0);
@@ -214,12 +234,16 @@ __global__ __launch_bounds__(256, 1) void conv_halo_s1_kernel(IGemmParams p, int
                 __builtin_amdgcn_sched_barrier(0);
                 cs1_mfma<4 * I>(fw[SET][CT], fp[SET][PT]);
                 __builtin_amdgcn_sched_barrier(0);
-                if constexpr (I == 1 && nh(T) > 0 && IR_KO_S1 != 4) {
+                if constexpr (I == 1 && nh(NTAP, T) > 0 && IR_KO_S1 != 4) {
                     halo_piece(std::integral_constant<int, 0>{});
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                if constexpr (I == 5 && nh(T) > 1 && IR_KO_S1 != 4) {
+                if constexpr (I == 5 && nh(NTAP, T) > 1 && IR_KO_S1 != 4) {
                     halo_piece(std::integral_constant<int, 1>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (I == 17 && nh(NTAP, T) > 2 && IR_KO_S1 != 4) {
+                    halo_piece(std::integral_constant<int, 2>{});
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if constexpr ((I == 10 || I == 13) && IR_KO_S1 != 5) {
@@ -233,7 +257,7 @@ __global__ __launch_bounds__(256, 1) void conv_halo_s1_kernel(IGemmParams p, int
         wait_lds<0>();
         // everything but the pieces of this step and the previous one has landed: the weight tile of step s + 2 (read during step s + 1)
         // and, before tap 8, the next chunk's halo (its last piece was issued a chunk ago)
-        wait_vm<(IR_KO_S1 == 5 ? 0 : 4) + (IR_KO_S1 == 4 ? 0 : nh((T + 8) % 9) + nh(T))>();
+        wait_vm<(IR_KO_S1 == 5 ? 0 : 4) + (IR_KO_S1 == 4 ? 0 : nh(NTAP, (T + NTAP - 1) % NTAP) + nh(NTAP, T))>();
         __builtin_amdgcn_sched_barrier(0);
         if (IR_KO_S1 != 7) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -267,8 +291,8 @@ __global__ __launch_bounds__(256, 1) void conv_halo_s1_kernel(IGemmParams p, int
         if (IR_KO_S1 != 2 && IR_KO_S1 != 3)
         for (int c = 0; c < chunks; c += 2) {
             const int hb3b = hb3 == 2 ? 0 : hb3 + 1;
-            [&]<int... U>(std::integer_sequence<int, U...>) { (step(std::integral_constant<int, U>{}, std::integral_constant<int, (U & 1)>{}, c, hb3), ...); }(std::make_integer_sequence<int, 9>{});
-            [&]<int... U>(std::integer_sequence<int, U...>) { (step(std::integral_constant<int, U>{}, std::integral_constant<int, ((U + 1) & 1)>{}, c + 1, hb3b), ...); }(std::make_integer_sequence<int, 9>{});
+            [&]<int... U>(std::integer_sequence<int, U...>) { (step(std::integral_constant<int, U>{}, std::integral_constant<int, (U & 1)>{}, c, hb3), ...); }(std::make_integer_sequence<int, NTAP>{});
+            [&]<int... U>(std::integer_sequence<int, U...>) { (step(std::integral_constant<int, U>{}, std::integral_constant<int, ((U + NTAP) & 1)>{}, c + 1, hb3b), ...); }(std::make_integer_sequence<int, NTAP>{});
             hb3 = hb3b == 2 ? 0 : hb3b + 1;
         }
         // hb3 is now the buffer of the next tile's chunk 0; the last chunk of this tile was read from the one before it
@@ -283,10 +307,12 @@ __global__ __launch_bounds__(256, 1) void conv_halo_s1_kernel(IGemmParams p, int
         unsigned char* ebuf = smem + (hb3 == 0 ? 2 : hb3 - 1) * HALO_BYTES;   // every wave passed the last barrier after its last read of it
 #ifdef IR_S1_STAMPS
         unsigned long long st4v = 0;
-        cs1_epilogue<false>(p, ebuf, tid, lane, wid, c16, kq, cur.n0, cur.img, cur.oy0, cur.ox0, cur.trem, IR_KO_S1 != 1 && IR_KO_S1 != 3, IR_KO_S1 == 0, &st4v);
+        cs1_epilogue<false>(p, ebuf, tid, lane, wid, c16, kq, cur.n0, cur.img, cur.oy0, cur.ox0, cur.trem, IR_KO_S1 != 1 && IR_KO_S1 != 3, IR_KO_S1 == 0, &st4v,
+                            PH ? 2 : 1, cur.dy, cur.dx, PH ? p.H : p.Ho, PH ? p.W : p.Wo);
         const unsigned long long st4 = st4v;
 #else
-        cs1_epilogue<false>(p, ebuf, tid, lane, wid, c16, kq, cur.n0, cur.img, cur.oy0, cur.ox0, cur.trem, IR_KO_S1 != 1 && IR_KO_S1 != 3, IR_KO_S1 == 0, nullptr);
+        cs1_epilogue<false>(p, ebuf, tid, lane, wid, c16, kq, cur.n0, cur.img, cur.oy0, cur.ox0, cur.trem, IR_KO_S1 != 1 && IR_KO_S1 != 3, IR_KO_S1 == 0, nullptr,
+                            PH ? 2 : 1, cur.dy, cur.dx, PH ? p.H : p.Ho, PH ? p.W : p.Wo);
 #endif
         IR_S1_T(st5);
         IR_S1_ACC(0, st0, st1); IR_S1_ACC(1, st1, st2); IR_S1_ACC(2, st2, st3); IR_S1_ACC(3, st3, st4); IR_S1_ACC(4, st4, st5);
@@ -323,6 +349,15 @@ bool ir_conv_s1_takes(const IGemmParams& p) {
 }
 int ir_conv_s1_tiles(const IGemmParams& p) { return ((p.Ho + 15) / 16) * ((p.Wo + 31) / 32); }
 
+static int cs1_cus() {
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+        return n & ~7;
+    }();
+    return cus;
+}
+
 int ir_launch_conv_s1(const IGemmParams& p, hipStream_t s) {
     if (!ir_conv_s1_takes(p)) return -2;
     if (p.gn_part && (p.gn_cpg < 4 || p.gn_cpg > 32 || (p.gn_cpg & (p.gn_cpg - 1)) || p.gn_chunks != ir_conv_s1_tiles(p))) return -13;
@@ -330,13 +365,34 @@ int ir_launch_conv_s1(const IGemmParams& p, hipStream_t s) {
     const long MT = (long)p.NB * tiles_y * tiles_x, NT = p.Cout_pad / 128;
     const long total = ((MT + 7) / 8) * 8 * NT;
     if (total > 0x7fffffffL) return -12;
-    static const int cus = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
-        return n & ~7;
-    }();
-    const long grid = total < cus ? total : cus;
-    if (p.up) hipLaunchKernelGGL((conv_halo_s1_kernel<1>), dim3((unsigned)grid), dim3(256), 0, s, p, tiles_y, tiles_x, (int)total);
-    else hipLaunchKernelGGL((conv_halo_s1_kernel<0>), dim3((unsigned)grid), dim3(256), 0, s, p, tiles_y, tiles_x, (int)total);
+    const long grid = total < cs1_cus() ? total : cs1_cus();
+    if (p.up) hipLaunchKernelGGL((conv_halo_s1_kernel<1, 9>), dim3((unsigned)grid), dim3(256), 0, s, p, tiles_y, tiles_x, (int)total);
+    else hipLaunchKernelGGL((conv_halo_s1_kernel<0, 9>), dim3((unsigned)grid), dim3(256), 0, s, p, tiles_y, tiles_x, (int)total);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// ---- the sub-pixel phase form of "nearest-2x upsample + 3 x 3 conv" (conv_halo_s1_kernel<0, 4>). p describes the conv as the generic launcher
+// sees it (p.up = 1, p.H x p.W the LOW-resolution input, p.Ho = 2 H, p.Wo = 2 W, taps = 9), except that p.wgt holds the four phase matrices
+// [phase = 2 dy + dx][Cout][tap = 2 sy + sx][Cin] (weights.pack_conv_up2x2) with p.wgt_rs = 4 * Cin.
+bool ir_conv_s1_up2x2_takes(const IGemmParams& pin) {
+    static const bool off = getenv("IR_NO_UP2X2") != nullptr;   // experiment knob: the 9-tap form on the upsampled grid
+    if (off || !pin.up || pin.res) return false;
+    IGemmParams p = pin;   // the low-resolution tile grid decides (4 phases per patch), everything else as for the 9-tap kernel
+    p.up = 0; p.Ho = pin.H; p.Wo = pin.W;
+    if (!ir_conv_s1_takes(p)) return false;
+    return 4L * ((pin.H + 15) / 16) * ((pin.W + 31) / 32) * (pin.Cout_pad / 128) >= 32;
+}
+int ir_conv_s1_up2x2_tiles(const IGemmParams& p) { return 4 * ((p.H + 15) / 16) * ((p.W + 31) / 32); }   // GroupNorm partial tiles per image
+
+int ir_launch_conv_s1_up2x2(const IGemmParams& p, hipStream_t s) {
+    if (!ir_conv_s1_up2x2_takes(p)) return -2;
+    if (p.wgt_rs != 4L * p.Cin || p.Ho != 2 * p.H || p.Wo != 2 * p.W) return -3;
+    if (p.gn_part && (p.gn_cpg < 4 || p.gn_cpg > 32 || (p.gn_cpg & (p.gn_cpg - 1)) || p.gn_chunks != ir_conv_s1_up2x2_tiles(p))) return -13;
+    const int tiles_y = (p.H + 15) / 16, tiles_x = (p.W + 31) / 32;
+    const long MT = (long)p.NB * 4 * tiles_y * tiles_x, NT = p.Cout_pad / 128;
+    const long total = ((MT + 7) / 8) * 8 * NT;
+    if (total > 0x7fffffffL) return -12;
+    const long grid = total < cs1_cus() ? total : cs1_cus();
+    hipLaunchKernelGGL((conv_halo_s1_kernel<0, 4>), dim3((unsigned)grid), dim3(256), 0, s, p, tiles_y, tiles_x, (int)total);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

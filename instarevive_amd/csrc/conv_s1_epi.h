@@ -24,9 +24,12 @@ IR_DEVINL float cs1_acc_read() {
 
 // ebuf: an LDS buffer of cs1e::BYTES bytes that no wave reads any more; t_*: the tile (first channel, image, patch origin, patch index in
 // the image). do_passes / do_stats / mid_stamp: diagnostics of the callers' knock-out and stamp builds (true, true, nullptr in the product).
+// Output map (the sub-pixel phase form of conv_s1.hip): tile pixel (y, x) is stored at output pixel (omul * y + oyoff, omul * x + oxoff); tile
+// pixels are valid below (hlim, wlim). Identity map: omul = 1, offsets 0, limits = p.Ho, p.Wo. The residual (if any) uses the same map.
 template <bool GATE>
 IR_DEVINL void cs1_epilogue(const IGemmParams& p, unsigned char* ebuf, int tid, int lane, int wid, int c16, int kq, int t_n0, int t_img, int t_oy0,
-                            int t_ox0, int t_trem, bool do_passes, bool do_stats, unsigned long long* mid_stamp) {
+                            int t_ox0, int t_trem, bool do_passes, bool do_stats, unsigned long long* mid_stamp, int omul, int oyoff, int oxoff, int hlim,
+                            int wlim) {
     using namespace cs1e;
     float* slab = reinterpret_cast<float*>(ebuf + wid * SLAB);
     const int co8 = (lane & 15) * 8, xq = lane >> 4;
@@ -51,26 +54,27 @@ IR_DEVINL void cs1_epilogue(const IGemmParams& p, unsigned char* ebuf, int tid, 
     const int oyw = oy0 + 4 * wid, oxl = ox0 + xq;
     unsigned xm = 0;   // bit it: column oxl + 4 it lies inside the image
 #pragma unroll
-    for (int it = 0; it < 8; ++it) xm |= (oxl + 4 * it < p.Wo ? 1u : 0u) << it;
-    const long pix0 = ((long)img * p.Ho + oyw) * p.Wo + oxl;
+    for (int it = 0; it < 8; ++it) xm |= (oxl + 4 * it < wlim ? 1u : 0u) << it;
+    const long pix0 = ((long)img * p.Ho + (long)omul * oyw + oyoff) * p.Wo + (long)omul * oxl + oxoff;
     bf16_t* obase = reinterpret_cast<bf16_t*>(p.out) + pix0 * p.out_cs + n0 + co8;
     const bf16_t* rbase = reinterpret_cast<const bf16_t*>(p.res) + pix0 * p.res_cs + n0 + co8;
-    const bf16_t* rsafe = reinterpret_cast<const bf16_t*>(p.res) + (((long)img * p.Ho + oy0) * p.Wo + ox0) * p.res_cs + n0 + co8;   // always inside
-    const long o_row = (long)p.Wo * p.out_cs, r_row = (long)p.Wo * p.res_cs;
+    const bf16_t* rsafe = reinterpret_cast<const bf16_t*>(p.res) + (((long)img * p.Ho + (long)omul * oy0 + oyoff) * p.Wo + (long)omul * ox0 + oxoff) * p.res_cs + n0 + co8;   // always inside
+    const long o_row = (long)omul * p.Wo * p.out_cs, r_row = (long)omul * p.Wo * p.res_cs;
+    const long o_col = (long)omul * p.out_cs, r_col = (long)omul * p.res_cs;   // element step between tile columns
     const bool do_gn = p.gn_part != nullptr;
     uint4 rrb[2][8];   // residual rows of the pass being finished / of the next pass
     auto res_fetch = [&](int a) {   // rows outside the image read a safe pixel
-        const bool yok = oyw + a < p.Ho;
+        const bool yok = oyw + a < hlim;
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const bool v = yok && ((xm >> it) & 1);
-            rrb[a & 1][it] = *reinterpret_cast<const uint4*>(v ? rbase + a * r_row + (long)(4 * it) * p.res_cs : rsafe);
+            rrb[a & 1][it] = *reinterpret_cast<const uint4*>(v ? rbase + a * r_row + (long)(4 * it) * r_col : rsafe);
         }
     };
     auto pass = [&](auto ac, auto resc) {
         constexpr int A = decltype(ac)::value;
         constexpr bool RES = decltype(resc)::value;
-        const bool yok = oyw + A < p.Ho;
+        const bool yok = oyw + A < hlim;
         uint4 (&rr)[8] = rrb[A & 1];
         if constexpr (RES && A < 3) res_fetch(A + 1);   // the next pass's residual rows fly during this pass
         [&]<int... MXS>(std::integer_sequence<int, MXS...>) {
@@ -104,7 +108,7 @@ IR_DEVINL void cs1_epilogue(const IGemmParams& p, unsigned char* ebuf, int tid, 
                     }
                     const uint4 pk = make_uint4(pack2bf_valu(a[0], a[1]), pack2bf_valu(a[2], a[3]), pack2bf_valu(b[0], b[1]), pack2bf_valu(b[2], b[3]));
                     if (yok && ((xm >> it) & 1)) {
-                        *reinterpret_cast<uint4*>(obase + A * o_row + (long)(4 * it) * p.out_cs) = pk;
+                        *reinterpret_cast<uint4*>(obase + A * o_row + (long)(4 * it) * o_col) = pk;
                         if (do_gn) {   // statistics of the values as stored (bf16-rounded)
                             const f32x4 ar = {bflo(pk.x), bfhi(pk.x), bflo(pk.y), bfhi(pk.y)}, br = {bflo(pk.z), bfhi(pk.z), bflo(pk.w), bfhi(pk.w)};
                             sA4 += ar; qA4 += ar * ar;

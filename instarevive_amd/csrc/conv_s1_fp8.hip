@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256, 1) void conv_halo_s1_fp8_kernel(IGemmParams p,
         // ---- epilogue through slabs in halo buffer 1 (the last chunk's: every wave passed the last barrier after its last read of it;
         // the next tile's chunk 0 is landing in buffer 0, its chunk 1 is fetched during its own first steps)
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMA results -> v_accvgpr_read
-        cs1_epilogue<true>(p, smem + HALO_BYTES, tid, lane, wid, c16, kq, cur.n0, cur.img, cur.oy0, cur.ox0, cur.trem, true, true, nullptr);
+        cs1_epilogue<true>(p, smem + HALO_BYTES, tid, lane, wid, c16, kq, cur.n0, cur.img, cur.oy0, cur.ox0, cur.trem, true, true, nullptr, 1, 0, 0, p.Ho, p.Wo);
         if (!more) break;
         bid = nbid;
         cur = nxt;

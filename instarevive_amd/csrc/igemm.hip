@@ -1592,6 +1592,7 @@ static bool takes_halo_pp(const IGemmParams& p) {  // the 8-wave ping-pong varia
 int ir_igemm_gn_chunks(const IGemmParams& p) {
     if (p.gn_cpg < 4 || (p.gn_cpg & 3) || p.Cout % p.gn_cpg || p.Cout_pad % 64 || (p.Cout & 3) || p.NB <= 0) return 0;
     if ((p.Cout_pad % 128 == 0 ? 128 : 64) % p.gn_cpg) return 0;
+    if (p.up2x2) return (ir_conv_s1_up2x2_takes(p) && p.gn_cpg <= 32 && !(p.gn_cpg & (p.gn_cpg - 1))) ? ir_conv_s1_up2x2_tiles(p) : 0;
     if (ir_conv_s1_takes(p) || ir_conv_s1_fp8_takes(p)) return (p.gn_cpg <= 32 && !(p.gn_cpg & (p.gn_cpg - 1))) ? ir_conv_s1_tiles(p) : 0;   // its reduction wants 4, 8, 16 or 32 channels per group
     if (takes_halo_pp(p)) return ((p.Ho + 15) / 16) * ((p.Wo + 15) / 16);
     if (takes_halo(p)) return ((p.Ho + 7) / 8) * ((p.Wo + 15) / 16);
@@ -1608,6 +1609,7 @@ static bool igemm_vec(const IGemmParams& p) {
 int ir_igemm_kernel_id(const IGemmParams& pin) {
     IGemmParams p = pin;
     p.vec = igemm_vec(p);
+    if (p.up2x2) return 0;
     if (p.ks_ws && ir_igemm_splitk(p) > 1) return 4;
     if (ir_conv_s1_takes(p) || ir_conv_s1_fp8_takes(p)) return 0;
     if (takes_halo_pp(p)) return 1;
@@ -1620,6 +1622,7 @@ int ir_igemm_kernel_id(const IGemmParams& pin) {
 int ir_launch_igemm(const IGemmParams& pin, hipStream_t s) {
     IGemmParams p = pin;
     if (p.M <= 0) return 0;
+    if (p.up2x2) return ir_conv_s1_up2x2_takes(p) ? ir_launch_conv_s1_up2x2(p, s) : -15;   // phase weights are no 9-tap weights: no other kernel may run them
     if (p.taps != 1 && p.taps != 9) return -2;
     if (p.Cin <= 0 || (p.Cin & 31) || (p.in_cs & 7) || p.in_cs < p.Cin) return -3;
     if (p.Cout <= 0 || p.Cout > p.Cout_pad || (p.Cout_pad & 31)) return -4;

@@ -58,6 +58,9 @@ struct IGemmParams {
     bf16_t* vt_out;
     int vt_col0, vt_hd, vt_dv, vt_ld, vt_T;
     long vt_bs;
+    // 1: `wgt` holds the four sub-pixel phase matrices [2 dy + dx][Cout_pad][2 sy + sx][Cin] of an up = 1 conv (wgt_rs = 4 * Cin): only valid when
+    // ir_conv_s1_up2x2_takes(p) - the caller asks first and passes the ordinary 9-tap weights otherwise
+    int up2x2;
 };
 int ir_igemm_writes_vt(const IGemmParams& p);
 int ir_launch_vt_pad_init(bf16_t* vt, int heads_total, int D, int DV, int T, int Tpad, hipStream_t s);
@@ -71,6 +74,10 @@ int ir_igemm_splitk(const IGemmParams& p);
 
 // conv_s1.hip: the one-wave-per-SIMD 3x3 convolution (16 x 32 patches x 128 channels); ir_launch_igemm routes eligible launches to it
 bool ir_conv_s1_takes(const IGemmParams& p);
+// "nearest-2x upsample + 3 x 3 conv" as four 2 x 2 convs on the low-resolution tensor (conv_s1.hip); p.up2x2 = 1, p.wgt = the phase matrices
+bool ir_conv_s1_up2x2_takes(const IGemmParams& p);
+int ir_conv_s1_up2x2_tiles(const IGemmParams& p);
+int ir_launch_conv_s1_up2x2(const IGemmParams& p, hipStream_t s);
 int ir_conv_s1_tiles(const IGemmParams& p);   // pixel tiles per image (fused GroupNorm statistics: one partial per tile)
 int ir_launch_conv_s1(const IGemmParams& p, hipStream_t s);
 // conv_s1_fp8.hip: the same structure on e4m3 operands (p.fp8 launches with Cin a multiple of 128 channels)

@@ -31,6 +31,28 @@ def pack_conv3x3(w, cin_pad, cout_pad, scale=1.0):
     return _bf16(p.reshape(cout_pad, kh * kw * cin_pad))
 
 
+def pack_conv_up2x2(w):
+    """A 3x3 conv that follows a nearest-2x upsample (ldm model.py:63-67) as FOUR 2x2 convs on the low-resolution tensor, one per output
+    phase (dy, dx): output pixel (2y + dy, 2x + dx) reads the upsampled rows 2y + dy - 1 .. + 1, i.e. the low-resolution rows
+    y - 1 + dy + sy (sy = 0, 1) - for dy = 0 tap ky = 0 comes from sy = 0 and taps 1, 2 from sy = 1; for dy = 1 taps 0, 1 from sy = 0 and tap 2
+    from sy = 1 - and likewise for the columns. The taps that land on one source pixel are SUMMED here in fp32 and rounded to bf16 once.
+    w: [Cout][Cin][3][3] -> [4 phases = 2 dy + dx][Cout][4 taps = 2 sy + sx][Cin] bf16 (csrc/conv_s1.hip, conv_halo_s1_kernel<0, 4>)."""
+    co, ci = w.shape[:2]
+    wf = w.to(torch.float32)
+    groups = {0: ((0,), (1, 2)), 1: ((0, 1), (2,))}   # phase offset -> taps of source offset 0 / 1
+    out = torch.zeros(4, co, 4, ci, dtype=torch.float32)
+    for dy in (0, 1):
+        for dx in (0, 1):
+            for sy in (0, 1):
+                for sx in (0, 1):
+                    acc = torch.zeros(co, ci, dtype=torch.float32)
+                    for ky in groups[dy][sy]:
+                        for kx in groups[dx][sx]:
+                            acc += wf[:, :, ky, kx]
+                    out[2 * dy + dx, :, 2 * sy + sx, :] = acc
+    return _bf16(out.reshape(4 * co, 4 * ci))
+
+
 FP8_ACT_SCALE = 16.0   # GroupNorm+SiLU outputs reach the fp8 convs as e4m3(x * 16) (csrc/api.cpp: FP8_ACT_SCALE)
 FP8_MAX = 448.0        # largest finite OCP e4m3 value
 
@@ -261,6 +283,9 @@ def pack_vae(sd, cfg, encoder=True, decoder=True, fp8=False):
                 res(f"vae.dec.up{l}.res{j}", f"decoder.up_blocks.{i}.resnets.{j}")
             if l != 0:
                 conv(f"vae.dec.up{l}.us", f"decoder.up_blocks.{i}.upsamplers.0.conv")
+                wu = sd[f"decoder.up_blocks.{i}.upsamplers.0.conv.weight"]
+                if wu.shape[0] % 128 == 0 and wu.shape[1] % 128 == 0:   # the shapes conv_halo_s1_kernel takes
+                    out[f"vae.dec.up{l}.us.wup"] = pack_conv_up2x2(wu)
         norm("vae.dec.norm_out", "decoder.conv_norm_out")
         conv("vae.dec.conv_out", "decoder.conv_out", cout_pad=32)
         out["vae.post_quant.w"] = sd["post_quant_conv.weight"].float().reshape(4, 4).contiguous()

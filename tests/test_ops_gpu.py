@@ -613,3 +613,37 @@ def test_vae_norm_conv_out(ctx, n, h, w):
     print(f"vae_norm_conv_out ({n}, {h}x{w}): max abs err {err:.5f} (|ref| max {ref.abs().max().item():.2f})")
     # the kernel's SiLU is x * rcp(1 + exp2(-x log2 e)) (1 ulp each): an activation may round to the neighbouring bf16 value
     assert err <= 4e-3 * ref.abs().max().item() + 2e-3 and float(out[..., 3].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout", [(1, 64, 64, 512, 512), (2, 100, 72, 256, 256), (1, 256, 256, 256, 128)])
+def test_conv_up2x2_phase_form(ctx, n, h, w, cin, cout):
+    """nearest-2x upsample + 3x3 conv (the VAE decoder's Upsample, model.py:63-67) as four 2x2 convs on the low-resolution tensor
+    (conv_halo_s1_kernel<0, 4>, weights.pack_conv_up2x2): (1) against the same decomposition in PyTorch on the bf16-rounded phase weights
+    (tight: only accumulation order and the bf16 output rounding differ), (2) against F.conv2d(F.interpolate(x), W) with the fp32 weights -
+    the identity the decomposition rests on (the phase weights are sums of up to four taps rounded to bf16 once). Ragged patches (100 x 72)."""
+    from instarevive_amd.weights import pack_conv_up2x2
+    g = torch.Generator().manual_seed(h * w + cin)
+    x = rb(torch.randn(n, cin, h, w, generator=g))
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)
+    b = torch.randn(cout, generator=g) * 0.1
+    wup = pack_conv_up2x2(wt)                                   # int16 bits [4 * cout][4 * cin]
+    out = torch.empty(n, 2 * h, 2 * w, cout, dtype=torch.int16, device="cuda")
+    xin = dev_bf16(x.permute(0, 2, 3, 1).contiguous())
+    ctx.check(ctx.lib.ir_op_conv_up2x2(ctx.h, ctx.stream(), P(xin), P(wup.cuda()), P(b.cuda()), P(out), n, h, w, cin, cout), "conv_up2x2")
+    torch.cuda.synchronize()
+    got = L.from_bf16_bits(out).cpu().permute(0, 3, 1, 2)       # [n, cout, 2h, 2w]
+    # (1) the four phase convs in PyTorch: phase (dy, dx) is a 2x2 conv whose window starts at (y - 1 + dy, x - 1 + dx)
+    wph = L.from_bf16_bits(wup).reshape(4, cout, 2, 2, cin).permute(0, 1, 4, 2, 3).contiguous()   # [phase][cout][cin][sy][sx]
+    ref = torch.empty(n, cout, 2 * h, 2 * w)
+    for dy in (0, 1):
+        for dx in (0, 1):
+            xp = F.pad(x, (1 - dx, dx, 1 - dy, dy))             # left / right / top / bottom zeros so that a "valid" 2x2 conv gives h x w outputs
+            ref[:, :, dy::2, dx::2] = F.conv2d(xp, wph[2 * dy + dx], b)
+    err = (got - ref).abs()
+    assert not (err > 3e-3 + 2 ** -7 * ref.abs()).any(), f"vs phase convs: max abs err {float(err.max()):.4g}"
+    # (2) the definition
+    full = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), wt, b, padding=1)
+    e2 = (got - full).abs()
+    rel = float((got - full).norm() / full.norm())
+    print(f"conv_up2x2 ({n}, {h}x{w}, {cin}->{cout}): max abs err vs phase convs {float(err.max()):.4f}, vs upsample + 3x3 (fp32 weights) rel L2 {rel:.5f}")
+    assert rel <= 4e-3 and float(e2.max()) <= 0.05 * float(full.abs().max())
