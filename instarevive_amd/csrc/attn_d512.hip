@@ -351,6 +351,14 @@ int ir_launch_flash_attn_d512_v2_rows(const bf16_t* q, const bf16_t* k, const bf
 #ifndef IR_KO_PP2
 #define IR_KO_PP2 0
 #endif
+// Experiment knob (-DIR_PP2_TRUNC=1): the probabilities go to bf16 by truncation (one full-rate v_perm_b32 per pair instead of the quarter-rate
+// v_cvt_pk_bf16_f32: 128 issue cycles less per tile). Correct and as accurate as rounding (see pp2_pack), 6 % faster when the op runs alone
+// (1.349 -> 1.264 ms at 16384 tokens) - and NO faster inside the pipeline (30.15 against 30.16 ms for the 28 layers, A/B twice on one box): there
+// the kernel sits at the power-limited clock (about 1.8 GHz with the matrix pipe 75 % busy), where the time follows the energy of the MFMAs, not
+// the issue slots beside them. Default off: rounding is what every other kernel does.
+#ifndef IR_PP2_TRUNC
+#define IR_PP2_TRUNC 0
+#endif
 namespace pp2 {
 constexpr int D = 72, NKS = 5, NDT = 3, RCH = 9;
 constexpr int KROW = RCH * 16;              // 144-byte K rows, unpadded (9 chunks: conflict-free)
@@ -505,6 +513,21 @@ __global__ __launch_bounds__(256, 1) void flash_attn_pp2_kernel(AttnParams p) {
     uint4 pbA[2][4], pbB[2][4];   // P^T fragments [group][kk] of the tile being multiplied / being exponentiated
     bf16x8 fr[NB];
     float p_hold2[2] = {0.f, 0.f}, pend0[2] = {0.f, 0.f}, pend1[2] = {0.f, 0.f};
+    // P -> bf16: 32 packs per tile in an issue-bound stream. Truncation is one full-rate v_perm_b32 instead of the quarter-rate v_cvt_pk; its mean
+    // bias (-0.27 %) is common to numerator and denominator (the ones row of V^T sums the SAME operand), what is left has round-to-nearest's variance
+    // (16384 tokens, random operands: rms error against fp32 3.88e-5 for 3.80e-5 rounded). Tile 0, computed in the open, keeps the rounding pack: its
+    // 64 keys weigh 0.27 % more than the others', 1e-5 of the result at 16384 tokens and 2e-4 at 1024.
+    const uint32_t psel = __builtin_amdgcn_readfirstlane(0x07060302u);
+    auto pp2_pack0 = [&](float lo, float hi) -> uint32_t { return pack2bf(lo, hi); };   // tile 0 (outside the pinned stream, compiler-scheduled): round to nearest
+    auto pp2_pack_last = [&](float lo, float hi) -> uint32_t {
+        if constexpr (IR_PP2_TRUNC) return pack2bf_trunc_trans(lo, hi, psel);
+        else return pack2bf_valu(lo, hi);
+    };
+    auto pp2_pack = [&](float lo, float hi) -> uint32_t {
+        if constexpr (IR_PP2_TRUNC) {
+            return pack2bf_trunc(lo, hi, psel);
+        } else return pack2bf_valu(lo, hi);
+    };
     if (IR_KO_PP2 == 4) {
 #pragma unroll
         for (int i = 0; i < NB; ++i) fr[i] = __builtin_bit_cast(bf16x8, make_uint4(lane, 0x3c003c00, 0x3c003c00, 0x3c003c00));
@@ -577,8 +600,8 @@ __global__ __launch_bounds__(256, 1) void flash_attn_pp2_kernel(AttnParams p) {
                                 if constexpr (((n >> 1) & 1) == 0) { pend0[0] = p_hold2[g]; pend0[1] = pv; } else { pend1[0] = p_hold2[g]; pend1[1] = pv; }
                                 if constexpr (n >= 3) {
                                     constexpr int gp = pp2_item_g(n - 2), ep = pp2_item_e(n - 2);
-                                    if constexpr (((n >> 1) & 1) == 0) a5_set_word<((ep & 7) >> 1)>(pn[gp][ep >> 3], pack2bf_valu(pend1[0], pend1[1]));
-                                    else a5_set_word<((ep & 7) >> 1)>(pn[gp][ep >> 3], pack2bf_valu(pend0[0], pend0[1]));
+                                    if constexpr (((n >> 1) & 1) == 0) a5_set_word<((ep & 7) >> 1)>(pn[gp][ep >> 3], pp2_pack(pend1[0], pend1[1]));
+                                    else a5_set_word<((ep & 7) >> 1)>(pn[gp][ep >> 3], pp2_pack(pend0[0], pend0[1]));
                                 }
                             } else {
                                 p_hold2[g] = pv;
@@ -588,7 +611,7 @@ __global__ __launch_bounds__(256, 1) void flash_attn_pp2_kernel(AttnParams p) {
                 }(std::make_integer_sequence<int, 4>{});
                 if constexpr (j == NSTEP - 1) {   // the last pair (item 63, pending slot 1)
                     constexpr int gp = pp2_item_g(63), ep = pp2_item_e(63);
-                    a5_set_word<((ep & 7) >> 1)>(pn[gp][ep >> 3], pack2bf_valu(pend1[0], pend1[1]));
+                    a5_set_word<((ep & 7) >> 1)>(pn[gp][ep >> 3], pp2_pack_last(pend1[0], pend1[1]));   // its exponentials are the two just issued
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -634,7 +657,7 @@ __global__ __launch_bounds__(256, 1) void flash_attn_pp2_kernel(AttnParams p) {
             float pv[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) pv[e] = __builtin_amdgcn_exp2f(sacc[g][kk >> 1][(kk & 1) * 8 + e] - m_ref);
-            pbA[g][kk] = make_uint4(pack2bf(pv[0], pv[1]), pack2bf(pv[2], pv[3]), pack2bf(pv[4], pv[5]), pack2bf(pv[6], pv[7]));
+            pbA[g][kk] = make_uint4(pp2_pack0(pv[0], pv[1]), pp2_pack0(pv[2], pv[3]), pp2_pack0(pv[4], pv[5]), pp2_pack0(pv[6], pv[7]));
             pbB[g][kk] = make_uint4(0, 0, 0, 0);
         }
     }

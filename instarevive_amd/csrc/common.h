@@ -40,6 +40,23 @@ IR_DEVINL uint32_t pack2bf_trans(float lo, float hi) {   // operands may come st
     asm("s_nop 0\n\tv_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
     return r;
 }
+// Two fp32 -> packed bf16 by TRUNCATION: one full-rate v_perm_b32 (bytes 2,3 of either source) instead of the quarter-rate v_cvt_pk_bf16_f32
+// (measured 8.8 issue cycles). Only where the consumer normalises by a sum of the SAME truncated values (the softmax probabilities of
+// flash_attn_pp2_kernel: the denominator is the ones row of V^T under the same P operand), so that the mean truncation bias cancels and what is
+// left has the variance of round-to-nearest. sel = 0x07060302 lives in a scalar register (VOP3 takes no literal on gfx9).
+IR_DEVINL uint32_t pack2bf_trunc(float lo, float hi, uint32_t sel) {
+    uint32_t r;
+    asm("v_perm_b32 %0, %1, %2, %3" : "=v"(r) : "v"(hi), "v"(lo), "s"(sel));
+    return r;
+}
+// The same with operands that may be fresh from v_exp_f32. The transcendental unit retires a wave in four passes of 16 lanes, and a full-rate
+// consumer two issue slots behind it (s_nop 0 + v_perm_b32, measured in flash_attn_pp2_kernel's first tile) still read stale values in lanes
+// 16..31 of some waves - results changed from run to run. v_cvt_pk_bf16_f32 is slow enough to hide that behind one wait state; v_perm_b32 is not.
+IR_DEVINL uint32_t pack2bf_trunc_trans(float lo, float hi, uint32_t sel) {
+    uint32_t r;
+    asm("s_nop 4\n\tv_perm_b32 %0, %1, %2, %3" : "=v"(r) : "v"(hi), "v"(lo), "s"(sel));
+    return r;
+}
 IR_DEVINL float bflo(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
 IR_DEVINL float bfhi(uint32_t u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
 
