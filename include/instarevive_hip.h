@@ -206,6 +206,11 @@ int ir_set_fp8_mask(ir_ctx* ctx, unsigned mask);
  * counterpart). Classes: 0 conv3x3, 1 linear, 2 flash attention, 3 window attention, 4 groupnorm, 5 layernorm,
  * 6 row softmax, 7 transpose, 8 other. ir_profile_end synchronises the stream and sums per class. */
 int ir_profile_begin(ir_ctx* ctx);
+/* Restrict the events to the launches of ONE kernel (an id below ir_profile_kernel_count(); -1 = every launch, the default). An event between two
+ * launches is a barrier packet that keeps the second kernel's ramp-up from overlapping the first one's tail: about 700 of them cost 1.4 % of a
+ * 2048 x 2048 image (133.2 against 131.4 ms, A/B on one box). bench.py's timed loop therefore brackets only the dominant kernel (whose live
+ * duration its roofline object needs) and fills the per-kernel table from a second, untimed pass with every launch bracketed. */
+int ir_profile_select(ir_ctx* ctx, int kernel_id);
 int ir_profile_end(ir_ctx* ctx, void* stream, int n_classes, double* ms, double* flops, double* bytes, long long* launches);
 /* The same measurement per KERNEL (ir_profile_kernel_count() rows, named "class/kernel" by ir_profile_kernel_name): milliseconds,
  * ALGORITHMIC FLOPs (un-padded channel counts / head dims) and bytes, launches of every kernel that ran since ir_profile_begin.

@@ -17,7 +17,7 @@ SYMBOLS = [
     "ir_abi_version", "ir_init", "ir_destroy", "ir_last_error", "ir_upload", "ir_has_tensor",
     "ir_swinir_configure", "ir_vae_configure", "ir_dit_configure", "ir_dit_control_configure", "ir_dit_set_prompt", "ir_t5_configure", "ir_t5_encode", "ir_workspace_bytes",
     "ir_swinir_forward", "ir_vae_encode", "ir_dit_forward", "ir_dit_step", "ir_dit_forward_control", "ir_dit_step_control", "ir_vae_decode", "ir_color_fix",
-    "ir_pipeline", "ir_u8_to_nchw", "ir_nchw_to_u8", "ir_profile_begin", "ir_profile_end", "ir_profile_end_kernels", "ir_profile_kernel_count",
+    "ir_pipeline", "ir_u8_to_nchw", "ir_nchw_to_u8", "ir_profile_begin", "ir_profile_select", "ir_profile_end", "ir_profile_end_kernels", "ir_profile_kernel_count",
     "ir_profile_kernel_name",
     "ir_op_conv", "ir_op_conv_splitk", "ir_op_conv_groupnorm", "ir_op_linear", "ir_op_groupnorm", "ir_op_layernorm", "ir_op_attention", "ir_op_swin_attention",
     "ir_op_softmax_rows", "ir_op_nchw_to_nhwc", "ir_op_nhwc_to_nchw",
@@ -74,6 +74,7 @@ def load_library():
     lib.ir_color_fix.argtypes = [vp, vp, i, vp, vp, vp, i, i, i, vp, sz]
     lib.ir_pipeline.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, f, f, f, vp, sz]
     lib.ir_profile_begin.argtypes = [vp]
+    lib.ir_profile_select.argtypes = [vp, i]
     lib.ir_profile_end.argtypes = [vp, vp, i, vp, vp, vp, vp]
     lib.ir_profile_end_kernels.argtypes = [vp, vp, i, vp, vp, vp, vp]
     lib.ir_profile_kernel_count.argtypes = []
@@ -201,7 +202,13 @@ class Context:
 
     PROFILE_CLASSES = ["conv3x3", "linear", "flash_attn", "swin_attn", "groupnorm", "layernorm", "softmax_rows", "transpose", "other"]
 
-    def profile_begin(self):
+    def profile_begin(self, only=None):
+        """only: a "class/kernel" name of profile_end_kernels() - events around that kernel's launches alone (ir_profile_select)."""
+        kid = -1
+        if only is not None:
+            names = [self.lib.ir_profile_kernel_name(i).decode() for i in range(int(self.lib.ir_profile_kernel_count()))]
+            kid = names.index(only)
+        self.check(self.lib.ir_profile_select(self.h, kid), "ir_profile_select")
         self.check(self.lib.ir_profile_begin(self.h), "ir_profile_begin")
 
     def profile_end(self):

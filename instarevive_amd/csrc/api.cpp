@@ -217,6 +217,7 @@ struct ProfRec {
 };
 struct Profiler {
     bool on = false;
+    int only = -1;   // ir_profile_select: kernel id whose launches alone are bracketed (-1: every launch)
     std::vector<ProfRec> recs;
     std::vector<hipEvent_t> pool;
     size_t used = 0;
@@ -344,6 +345,7 @@ struct ProfScope {
         const int cls = KERNEL_CLASS[kid];
         Profiler& pf = r.c->prof;
         if (!pf.on) return;
+        if (pf.only >= 0 && kid != pf.only) { r.chain = nullptr; return; }   // ir_profile_select: events around one kernel's launches only
         hipEvent_t e0 = r.chain;
         if (!e0) {
             e0 = pf.get();
@@ -2628,6 +2630,11 @@ int ir_clip_text_encode(ir_ctx* c, void* stream, const int32_t* ids, float* out,
     return 0;
 }
 
+int ir_profile_select(ir_ctx* c, int kernel_id) {
+    if (!c || kernel_id >= PK_COUNT) return -1;
+    c->prof.only = kernel_id < 0 ? -1 : kernel_id;
+    return 0;
+}
 int ir_profile_begin(ir_ctx* c) {
     if (!c) return -1;
     c->prof.recs.clear();

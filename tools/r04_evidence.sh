@@ -19,8 +19,8 @@ python bench.py --batch 8 --steps 3 --warmup 1 --no_cpu_baseline --no_host_rate 
 echo "[4b] batch 8 (cfg-4 per-GPU workload) done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -o ks -- python3 bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_verify --no_host_rate > $O/prof.log 2>&1 || exit 1
 echo "[5] kernel trace done"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 bench.py --steps 1 --warmup 0 --no_cpu_baseline --no_verify --no_host_rate > $O/pmc_fetch.log 2>&1 || exit 1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python3 bench.py --steps 1 --warmup 0 --no_cpu_baseline --no_verify --no_host_rate > $O/pmc_write.log 2>&1 || exit 1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o f -- python3 bench.py --steps 1 --warmup 0 --no_profile --no_cpu_baseline --no_verify --no_host_rate > $O/pmc_fetch.log 2>&1 || exit 1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o w -- python3 bench.py --steps 1 --warmup 0 --no_profile --no_cpu_baseline --no_verify --no_host_rate > $O/pmc_write.log 2>&1 || exit 1
 python tools/pmc_kernels.py $O/pmc_fetch $O/pmc_write $O/pmc_kernels.json 1 > $O/pmc_kernels.txt 2>&1
 echo "[6] pmc done"
 find $O/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats.csv
