@@ -202,7 +202,7 @@ static const char* const KERNEL_NAMES[PK_COUNT] = {
     "linear/gemm_pp_kernel", "linear/igemm_kernel<taps=1>", "linear/swin_mlp_kernel", "flash_attn/flash_attn_pp2_kernel (DiT self-attention)",
     "flash_attn/flash_attn_fp8_kernel (DiT self-attention, fp8 operands)", "flash_attn/flash_attn_d512_fp8_kernel (VAE mid-block, fp8 operands)",
     "flash_attn/flash_attn_d512_v2_kernel (VAE mid-block)",
-    "flash_attn/flash_attn_kernel<72,true> (DiT cross-attention)", "flash_attn/other", "swin_attn/swin_attn_proj_kernel", "swin_attn/swin_window_attn_kernel",
+    "flash_attn/flash_attn_x72_kernel (DiT cross-attention)", "flash_attn/other", "swin_attn/swin_attn_proj_kernel", "swin_attn/swin_window_attn_kernel",
     "groupnorm/gn_finalize_groups+gn_apply (statistics from the conv epilogue)", "groupnorm/gn_partial+gn_finalize+gn_apply", "layernorm/layernorm_*_kernel",
     "softmax_rows/softmax_rows_kernel", "transpose/transpose_v*", "other/layout+glue",
     "conv3x3/vae_conv_in_kernel (3->128, store-bound)", "conv3x3/vae_norm_conv_out_kernel (GroupNorm+SiLU+128->3, read-bound)"};

@@ -624,6 +624,7 @@ int ir_launch_flash_attn(const AttnParams& p, hipStream_t s) {
         return hipGetLastError() == hipSuccess ? 0 : -1;
     }
     AttnParams q = p;
+    if (ir_flash_attn_x72_takes(p)) return ir_launch_flash_attn_x72(p, s);   // the DiT cross-attention: persistent kernel (handles its own overflow)
     q.ovf_flag = nullptr;  // stand-alone use of the 4-wave kernel below
 #define IR_FA(DD)                                                                                     \
     do {                                                                                              \

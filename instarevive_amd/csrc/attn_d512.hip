@@ -718,3 +718,346 @@ int ir_launch_flash_attn_pp2(const AttnParams& p, hipStream_t s) {
     else hipLaunchKernelGGL(flash_attn_pp2_kernel, dim3((p.Tq + 255) / 256, p.Hh, p.B), dim3(256), 0, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// DiT cross-attention (PixArt_blocks.py MultiHeadCrossAttention: 16 heads x 72, a few hundred prompt keys, an additive bias per key) as a
+// PERSISTENT form of flash_attn_pp2_kernel. The 4-wave kernel spends 66 us per launch at 16384 queries, of which the keys account for 23
+// (tools/xattn_pp2_probe.py: 4.6 us per 64-key tile and launch): the rest is what every workgroup pays around its few tiles - K / V^T of the
+// head into LDS, Q^T into registers, the output transposition - paid serially, four rounds of workgroups deep. Here one workgroup per CU
+// walks a contiguous range of (batch, head, 256-query block) items: K and V^T of a head (<= 5 tiles = 320 keys: 55 + 60 KB) stay resident in
+// LDS while the head does not change, so the tile loop has no barrier, no DMA and no wait; the next block's Q rows are fetched into registers
+// while the current block computes; the output leaves through a wave-private staging area.
+// Same arithmetic as flash_attn_pp2_kernel (S^T = K Q^T - m via the accumulator preset, fixed reference after the first tile, P^T registers as
+// the B operand of O^T = V^T P^T, denominator from the ones row of V^T, overflow -> ovf_flag -> the rescaling kernel behind). New: the additive
+// key bias. K rows are 176 bytes in LDS (11 chunks: odd, conflict-free): 72 head dims + {bias_hi, bias_lo} (bias * log2 e split into two bf16,
+// error 2^-17) + padding, against Q^T = 1 in dims 72 / 73 - the bias enters through the score MFMA of k-step 4, whose upper half was zero
+// padding anyway. Keys beyond Tk are excluded by V^T (transpose_v_kernel: zero columns, zero ones-row entries); their K rows are zeroed here.
+namespace x72 {
+constexpr int D = 72, NKS = 5, NDT = 3, RCH = 9, MAXT = 5;
+constexpr int KROW = 176, KSLOT = 64 * KROW;      // 11 264 B per 64-key tile
+constexpr int VSLOT = 96 * 128;                   // as pp2: 96 rows x 64 keys, chunk-swizzled (rows 80.. never loaded)
+constexpr int V_OFF = MAXT * KSLOT;               // 56 320
+constexpr int O_OFF = V_OFF + MAXT * VSLOT;       // 117 760
+constexpr int OS = 96 + 8;                        // O staging row stride (elements); 32 rows per wave: one query group at a time
+constexpr int LDS_BYTES = O_OFF + 4 * 32 * OS * 2;   // 144 384 B
+constexpr float MARGIN = 24.0f;
+constexpr int LA = 6, NB = LA + 3;
+constexpr int NQK = 20, NPV = 24, NSTEP = NQK + NPV;
+constexpr int O_BASE = 0, Q_BASE = 96, QN_BASE = 136;   // AGPRs: O^T a[0:95], Q^T a[96:135], the next item's raw Q rows a[136:175]
+}  // namespace x72
+__device__ __attribute__((aligned(16))) const uint32_t x72_bias_ones[4] = {0x3f803f80u, 0u, 0u, 0u};   // bf16 {1, 1, 0 x 6}: Q^T dims 72..79
+
+__global__ __launch_bounds__(256, 1) void flash_attn_x72_kernel(AttnParams p, int n_items, int per_wg) {
+    using namespace x72;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int NT = (p.Tk + 63) >> 6, QT = (p.Tq + 255) >> 8;
+    const int it0 = blockIdx.x * per_wg, it1 = min(it0 + per_wg, n_items);
+    if (it0 >= it1) return;
+
+    const uint32_t lds0 = lds_addr(smem);
+    const uint32_t k_addr = lds0 + a5_swap23(r) * KROW + h * 16;           // + tile*KSLOT + kt*32*KROW + ks*32
+    const int vsw = (r >> 1) & 7;
+    uint32_t v_addr[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v_addr[j] = lds0 + V_OFF + r * 128 + ((((2 * j) | h) ^ vsw) << 4);   // + tile*VSLOT + dt*4096
+    bf16_t* ow = reinterpret_cast<bf16_t*>(smem + O_OFF) + wid * 32 * OS;
+
+    // item -> (batch, head, query block); Q rows of a block: lane (r, h) holds dims 16 ks + 8 h .. + 7 of query q0 + 32 g + r, (g, ks) = I / 5, I % 5
+    auto item = [&](int it, int& b, int& head, int& qt) { qt = it % QT; const int hb = it / QT; head = hb % p.Hh; b = hb / p.Hh; };
+    // The next item's Q rows wait in AGPRs a[136:175] (global loads may target the accumulation file directly): 40 arch VGPRs held through the
+    // whole tile loop do not fit beside the stream's own (the arch file ends at v255 whatever the AGPR count).
+    auto q_fetch = [&](int it) {
+        int b, head, qt;
+        item(it, b, head, qt);
+        const bf16_t* qp = p.q + (long)b * p.q_bs + (long)head * p.q_hs;   // wave-uniform: a scalar base
+        const int q0 = qt * 256 + wid * 64;
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+            ([&] {
+                constexpr int g = I / NKS, ks = I % NKS;
+                const uint32_t row = (uint32_t)min(q0 + g * 32 + r, p.Tq - 1) * (uint32_t)p.q_rs;
+                const bf16_t* base = qp;   // (a captured variable is not accepted as an asm operand inside a generic lambda)
+                if constexpr (ks < NKS - 1) {
+                    const uint32_t off = (row + (uint32_t)(ks * 16 + h * 8)) * 2u;
+                    asm volatile("global_load_dwordx4 a[%c0:%c1], %2, %3" ::"n"(QN_BASE + 4 * I), "n"(QN_BASE + 4 * I + 3), "v"(off), "s"(base) : "memory");
+                } else {   // k-step 4: dims 64..71 of the row (h = 0) | {1, 1, 0 x 6} against the bias pair in K dims 72 / 73 (h = 1)
+                    const void* a4 = h ? static_cast<const void*>(x72_bias_ones) : static_cast<const void*>(base + row + 64);
+                    asm volatile("global_load_dwordx4 a[%c0:%c1], %2, off" ::"n"(QN_BASE + 4 * I), "n"(QN_BASE + 4 * I + 3), "v"(a4) : "memory");
+                }
+            }(), ...);
+        }(std::make_integer_sequence<int, 2 * NKS>{});
+    };
+    asm volatile(".set ir_x72_i, 0\n\t.rept 96\n\tv_accvgpr_write_b32 a[ir_x72_i], 0\n\t.set ir_x72_i, ir_x72_i + 1\n\t.endr" ::: IR_AGPR176_CLOBBERS);
+
+    q_fetch(it0);
+    wait_dma();   // (vmcnt(0): the first item's rows; later items' rows are waited for before the previous item's output stores)
+    int cur_b = -1, cur_head = -1;
+    for (int it = it0; it < it1; ++it) {
+        int b, head, qt;
+        item(it, b, head, qt);
+        const int q0 = qt * 256 + wid * 64;
+        // ---- K / V^T of the head -> LDS (when the head, or a batch with its own K / V, changes)
+        if (head != cur_head || (b != cur_b && (p.k_bs != 0 || p.vt_bs != 0 || p.kb_bs != 0))) {
+            __syncthreads();   // every wave is done with the previous head's tiles
+            const bf16_t* kp = p.k + (long)b * p.k_bs + (long)head * p.k_hs;
+            const bf16_t* vtp = p.vt + (long)b * p.vt_bs + (long)head * 96 * p.Tk_pad;
+            const float* kb = p.key_bias ? p.key_bias + (long)b * p.kb_bs : nullptr;
+            // every load of a thread is issued before its first LDS store (fixed trip counts, unrolled: 13 + 13 x 16 bytes in flight per thread):
+            // a load -> store loop costs one memory latency per trip, 25 trips per head
+            constexpr int KTRIP = (MAXT * 64 * 10 + 255) / 256, VTRIP = (MAXT * 80 * 8 + 255) / 256;
+            int tid_o = tid;
+            asm volatile("" : "+v"(tid_o));   // opaque: left transparent, hipcc hoists the 26 trips' index arithmetic out of the item loop and keeps
+                                               // ~100 values alive through the tile streams (AGPR copies, scratch, v_writelane'd scalars)
+            uint4 kx[KTRIP];
+#pragma unroll
+            for (int i = 0; i < KTRIP; ++i) {     // K rows: 9 chunks of the cache row + the bias chunk
+                const int c = tid_o + 256 * i, key = c / 10, ch = c - key * 10;
+                kx[i] = make_uint4(0, 0, 0, 0);
+                if (c < NT * 640 && key < p.Tk) {
+                    if (ch < RCH) {   // softmax scale * log2 e folded into K (once per head and workgroup) instead of into every block's Q rows
+                        const uint4 x = *reinterpret_cast<const uint4*>(kp + (long)key * p.k_rs + ch * 8);
+                        const float sc = p.scale_log2;
+                        kx[i] = make_uint4(pack2bf(bflo(x.x) * sc, bfhi(x.x) * sc), pack2bf(bflo(x.y) * sc, bfhi(x.y) * sc),
+                                           pack2bf(bflo(x.z) * sc, bfhi(x.z) * sc), pack2bf(bflo(x.w) * sc, bfhi(x.w) * sc));
+                    } else if (kb) {
+                        const float v = kb[key] * 1.44269504088896340736f;
+                        const uint32_t hi = pack2bf(v, 0.f) & 0xffffu;
+                        const uint32_t lo = pack2bf(v - bflo(hi), 0.f) & 0xffffu;
+                        kx[i].x = hi | (lo << 16);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < KTRIP; ++i) {
+                const int c = tid_o + 256 * i, key = c / 10, ch = c - key * 10;
+                if (c < NT * 640) *reinterpret_cast<uint4*>(smem + (key >> 6) * KSLOT + (key & 63) * KROW + ch * 16) = kx[i];
+            }
+            __builtin_amdgcn_sched_barrier(0);   // the K batch's registers are free before the V^T batch takes its own
+            uint4 vx[VTRIP];
+#pragma unroll
+            for (int i = 0; i < VTRIP; ++i) {     // V^T rows 0..79 (72 dims, the ones row, zero rows), 8 chunks of 8 keys, chunk-swizzled
+                const int c = tid_o + 256 * i, t = c / 640, rem = c - t * 640, d = rem >> 3, pos = rem & 7;
+                vx[i] = make_uint4(0, 0, 0, 0);
+                if (c < NT * 640) vx[i] = *reinterpret_cast<const uint4*>(vtp + (long)d * p.Tk_pad + t * 64 + ((pos ^ ((d >> 1) & 7)) << 3));
+            }
+#pragma unroll
+            for (int i = 0; i < VTRIP; ++i) {
+                const int c = tid_o + 256 * i, t = c / 640, rem = c - t * 640, d = rem >> 3, pos = rem & 7;
+                if (c < NT * 640) *reinterpret_cast<uint4*>(smem + V_OFF + t * VSLOT + d * 128 + pos * 16) = vx[i];
+            }
+            cur_b = b; cur_head = head;
+            __syncthreads();
+        }
+
+        // ---- Q^T fragments: the staged rows ARE the B operands (bf16 rows, the scale lives in K): 40 accumulator-file moves, then the next item's rows on their way
+        asm volatile(".set ir_x72_i, 0\n\t.rept 40\n\tv_accvgpr_mov_b32 a[96 + ir_x72_i], a[136 + ir_x72_i]\n\t.set ir_x72_i, ir_x72_i + 1\n\t.endr" ::: "memory");
+        asm volatile("s_nop 1" ::: "memory");
+        if (it + 1 < it1) q_fetch(it + 1);
+
+        f32x16 sacc[2][2], negm[2];
+        uint4 pbA[2][4], pbB[2][4];
+        bf16x8 fr[NB];
+        float p_hold2[2] = {0.f, 0.f}, pend0[2] = {0.f, 0.f}, pend1[2] = {0.f, 0.f};
+        uint32_t ka = k_addr, va[4] = {v_addr[0], v_addr[1], v_addr[2], v_addr[3]};
+
+        auto frag_read = [&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            if constexpr (j < NQK) fr[j % NB] = lds_read16<(((j % 10) / 5) * 32 * KROW + (j % 5) * 32)>(ka);
+            else fr[(NQK + ((j - NQK) >> 1)) % NB] = lds_read16<(((j - NQK) >> 3) * 4096)>(va[((j - NQK) >> 1) & 3]);
+        };
+        // one pinned stream per tile pair, as in flash_attn_pp2_kernel without its LDS-DMA pieces: [0, 20) S^T MFMAs of tile t+1, [20, 44) PV MFMAs of tile t
+        auto stream = [&](auto j0c, auto j1c, auto smc, uint4 (&pc)[2][4], uint4 (&pn)[2][4]) {
+            constexpr int J0 = decltype(j0c)::value, J1 = decltype(j1c)::value;   // steps [J0, J1)
+            constexpr bool SOFTMAX = decltype(smc)::value;
+            constexpr int S0 = J0 < NQK ? J0 : NQK + ((J0 - NQK) >> 1), S1 = J1 <= NQK ? J1 : NQK + ((J1 - NQK) >> 1);
+            auto slot_read = [&](auto sc) {
+                constexpr int sl = decltype(sc)::value;
+                if constexpr (sl < NQK) frag_read(std::integral_constant<int, sl>{});
+                else frag_read(std::integral_constant<int, NQK + 2 * (sl - NQK)>{});
+            };
+            auto step = [&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                constexpr int sl = j < NQK ? j : NQK + ((j - NQK) >> 1);
+                constexpr bool first_use = j < NQK || ((j - NQK) & 1) == 0;
+                if constexpr (first_use) {
+                    if constexpr (sl + LA < S1) slot_read(std::integral_constant<int, sl + LA>{});
+                    constexpr int rem = S1 - 1 - sl;
+                    if constexpr (((sl - S0) & 1) == 0) wait_lds<(rem < LA ? (rem > 0 ? rem - 1 : 0) : LA - 1)>();
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (j < NQK) {
+                    constexpr int g = j / 10, kt = (j % 10) / 5, ks = j % 5;
+                    if constexpr (ks == 0) pp2_mfma_qk_first<Q_BASE + 4 * (5 * g + ks)>(sacc[g][kt], fr[sl % NB], negm[g]);
+                    else pp2_mfma_qk<Q_BASE + 4 * (5 * g + ks)>(sacc[g][kt], fr[sl % NB]);
+                } else {
+                    constexpr int q = (j - NQK) >> 1, g = j & 1, dt = q >> 2, kk = q & 3;
+                    pp2_mfma_pv<O_BASE + 16 * (3 * g + dt)>(fr[sl % NB], __builtin_bit_cast(bf16x8, pc[g][kk]));
+                }
+                if constexpr (sl - 2 >= S0) asm volatile("" ::"v"(fr[(sl - 2) % NB]));
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (SOFTMAX && j >= 13) {
+                    constexpr int n0 = j < 23 ? 2 * (j - 13) : 20 + (j - 23) * 44 / 21, n1 = j < 23 ? n0 + 2 : 20 + (j - 22) * 44 / 21;
+                    [&]<int... E>(std::integer_sequence<int, E...>) {
+                        ([&] {
+                            constexpr int n = n0 + E;
+                            if constexpr (n < n1 && n < 64) {
+                                constexpr int g = pp2_item_g(n), e = pp2_item_e(n);
+                                const float pv = __builtin_amdgcn_exp2f(sacc[g][e >> 4][e & 15]);
+                                if constexpr (e & 1) {
+                                    if constexpr (((n >> 1) & 1) == 0) { pend0[0] = p_hold2[g]; pend0[1] = pv; } else { pend1[0] = p_hold2[g]; pend1[1] = pv; }
+                                    if constexpr (n >= 3) {
+                                        constexpr int gp = pp2_item_g(n - 2), ep = pp2_item_e(n - 2);
+                                        if constexpr (((n >> 1) & 1) == 0) a5_set_word<((ep & 7) >> 1)>(pn[gp][ep >> 3], pack2bf_valu(pend1[0], pend1[1]));
+                                        else a5_set_word<((ep & 7) >> 1)>(pn[gp][ep >> 3], pack2bf_valu(pend0[0], pend0[1]));
+                                    }
+                                } else {
+                                    p_hold2[g] = pv;
+                                }
+                            }
+                        }(), ...);
+                    }(std::make_integer_sequence<int, 4>{});
+                    if constexpr (j == NSTEP - 1) {
+                        constexpr int gp = pp2_item_g(63), ep = pp2_item_e(63);
+                        a5_set_word<((ep & 7) >> 1)>(pn[gp][ep >> 3], pack2bf_valu(pend1[0], pend1[1]));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            __builtin_amdgcn_sched_barrier(0);
+            [&]<int... I>(std::integer_sequence<int, I...>) { (slot_read(std::integral_constant<int, S0 + I>{}), ...); }(std::make_integer_sequence<int, LA>{});
+            __builtin_amdgcn_sched_barrier(0);
+            [&]<int... I>(std::integer_sequence<int, I...>) { (step(std::integral_constant<int, J0 + I>{}), ...); }(std::make_integer_sequence<int, J1 - J0>{});
+        };
+        using J0 = std::integral_constant<int, 0>;
+        using JPV = std::integral_constant<int, NQK>;
+        using JEND = std::integral_constant<int, NSTEP>;
+
+        // ---- the reference. First attempt: the maximum of tile 0 + 2^24 headroom, as in flash_attn_pp2_kernel. If a later key outgrows that by about
+        // 2^100 (a denominator that is not a moderate finite number), the wave repeats ITS item with the exact row maxima, found by a scores-only
+        // pass over the resident tiles - no flag, no second kernel behind this one (4.9 us per launch even when it returns at once).
+        bool retry = false;
+        float l0, l1;
+        for (;;) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) negm[g][e] = 0.f;
+        // The zeros are materialised HERE, a few wait states ahead of the MFMA that reads them as its C operand: the MFMAs are asm statements, so hipcc's
+        // hazard recogniser does not see a VALU write -> MFMA SrcC read and may place the v_mov's directly in front of the MFMA. Without this, second
+        // and later items of a workgroup came out wrong in query group 0, differently from run to run (first items have a barrier in between).
+        asm volatile("s_nop 7" : "+v"(negm[0]), "+v"(negm[1]));
+        float mxr[2] = {-INFINITY, -INFINITY};
+        if (retry) {
+            for (int t = 0; t < NT; ++t) {
+                ka = k_addr + t * KSLOT;
+                stream(J0{}, JPV{}, std::false_type{}, pbA, pbB);
+                asm volatile("s_nop 15\n\ts_nop 7" : "+v"(sacc[0][0]), "+v"(sacc[0][1]), "+v"(sacc[1][0]), "+v"(sacc[1][1]));
+#pragma unroll
+                for (int g = 0; g < 2; ++g)
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) mxr[g] = fmaxf(mxr[g], sacc[g][kt][e]);
+            }
+        }
+        // ---- tile 0: scores of both groups (the stream's first 20 steps: fragment reads LA ahead), softmax in the open
+        ka = k_addr;
+        stream(J0{}, JPV{}, std::false_type{}, pbA, pbB);
+        asm volatile("s_nop 15\n\ts_nop 7" : "+v"(sacc[0][0]), "+v"(sacc[0][1]), "+v"(sacc[1][0]), "+v"(sacc[1][1]));
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sacc[g][kt][e]);
+            const float m_ref = retry ? xhalf_max(mxr[g]) : xhalf_max(mx) + MARGIN;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) negm[g][e] = -m_ref;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                float pv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pv[e] = __builtin_amdgcn_exp2f(sacc[g][kk >> 1][(kk & 1) * 8 + e] - m_ref);
+                pbA[g][kk] = make_uint4(pack2bf(pv[0], pv[1]), pack2bf(pv[2], pv[3]), pack2bf(pv[4], pv[5]), pack2bf(pv[6], pv[7]));
+                pbB[g][kk] = make_uint4(0, 0, 0, 0);
+            }
+        }
+        // ---- tiles: no barrier, no DMA - K / V^T are resident
+        auto tile_step = [&](int t, uint4 (&pc)[2][4], uint4 (&pn)[2][4]) {
+            ka = k_addr + (t + 1) * KSLOT;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) va[j] = v_addr[j] + t * VSLOT;
+            if (t + 1 < NT) stream(J0{}, JEND{}, std::true_type{}, pc, pn);
+            else stream(JPV{}, JEND{}, std::false_type{}, pc, pn);
+        };
+        for (int t = 0; t < NT; t += 2) {
+            tile_step(t, pbA, pbB);
+            if (t + 1 < NT) tile_step(t + 1, pbB, pbA);
+        }
+        // ---- finalise: O^T[d][q] / l -> wave-private staging [q][d] -> 16-byte row stores, one query group at a time; then O^T = 0 again
+        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+        l0 = __shfl(a5_acc_read<O_BASE + 16 * 2 + 4>(), r);
+        l1 = __shfl(a5_acc_read<O_BASE + 16 * 5 + 4>(), r);
+        if (retry || !__any(!(l0 < 1e30f) || !(l1 < 1e30f))) break;
+        retry = true;
+        asm volatile(".set ir_x72_i, 0\n\t.rept 96\n\tv_accvgpr_write_b32 a[ir_x72_i], 0\n\t.set ir_x72_i, ir_x72_i + 1\n\t.endr" ::: "memory");
+        }
+        const float inv0 = 1.0f / l0, inv1 = 1.0f / l1;
+        bf16_t* op = p.o + (long)b * p.o_bs + (long)head * p.o_hs;
+        wait_dma();   // the next item's Q rows have landed (issued a whole tile loop ago); nothing else is outstanding, and the stores below are not waited for
+        [&]<int... G>(std::integer_sequence<int, G...>) {
+            ([&] {
+                constexpr int GG = G;   // (a pack of the outer fold must not appear inside the inner one)
+                const float inv = GG ? inv1 : inv0;
+                [&]<int... DT>(std::integer_sequence<int, DT...>) {
+                    ([&] {
+                        constexpr int A0 = O_BASE + 16 * (NDT * GG + DT);
+                        const float x[16] = {a5_acc_read<A0 + 0>(), a5_acc_read<A0 + 1>(), a5_acc_read<A0 + 2>(), a5_acc_read<A0 + 3>(),
+                                             a5_acc_read<A0 + 4>(), a5_acc_read<A0 + 5>(), a5_acc_read<A0 + 6>(), a5_acc_read<A0 + 7>(),
+                                             a5_acc_read<A0 + 8>(), a5_acc_read<A0 + 9>(), a5_acc_read<A0 + 10>(), a5_acc_read<A0 + 11>(),
+                                             a5_acc_read<A0 + 12>(), a5_acc_read<A0 + 13>(), a5_acc_read<A0 + 14>(), a5_acc_read<A0 + 15>()};
+#pragma unroll
+                        for (int gg = 0; gg < 4; ++gg) {
+                            const uint2 w = make_uint2(pack2bf(x[4 * gg] * inv, x[4 * gg + 1] * inv), pack2bf(x[4 * gg + 2] * inv, x[4 * gg + 3] * inv));
+                            *reinterpret_cast<uint2*>(&ow[r * OS + DT * 32 + 8 * gg + 4 * h]) = w;
+                        }
+                    }(), ...);
+                }(std::make_integer_sequence<int, NDT>{});
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                for (int c = lane; c < 32 * RCH; c += 64) {
+                    const int row = c / RCH, ch = c - row * RCH;
+                    const int q = q0 + GG * 32 + row;
+                    const uint4 v = *reinterpret_cast<const uint4*>(&ow[row * OS + ch * 8]);
+                    if (q < p.Tq) *reinterpret_cast<uint4*>(op + (long)q * p.o_rs + ch * 8) = v;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the rows are in registers before the other group overwrites the staging area
+                __builtin_amdgcn_wave_barrier();
+            }(), ...);
+        }(std::integer_sequence<int, 0, 1>{});
+        asm volatile(".set ir_x72_i, 0\n\t.rept 96\n\tv_accvgpr_write_b32 a[ir_x72_i], 0\n\t.set ir_x72_i, ir_x72_i + 1\n\t.endr" ::: IR_AGPR176_CLOBBERS);
+    }
+}
+
+bool ir_flash_attn_x72_takes(const AttnParams& p) {
+    static const bool off = getenv("IR_NO_X72") != nullptr;   // experiment knob: the 4-wave kernel for the cross-attention again
+    return !off && !g_ir_plain_kernels && p.D == 72 && p.Tk > 0 && p.Tk <= 64 * x72::MAXT && p.Tk_pad >= ((p.Tk + 63) & ~63) && p.Tq >= 256 &&
+           (long)p.B * p.Hh * ((p.Tq + 255) / 256) >= 64;
+}
+int ir_launch_flash_attn_x72(const AttnParams& p, hipStream_t s) {
+    if (!ir_flash_attn_x72_takes(p)) return -2;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -1;
+        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int n_items = p.B * p.Hh * ((p.Tq + 255) / 256);
+    const int per_wg = (n_items + cus - 1) / cus, grid = (n_items + per_wg - 1) / per_wg;
+    hipLaunchKernelGGL(flash_attn_x72_kernel, dim3(grid), dim3(256), 0, s, p, n_items, per_wg);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}

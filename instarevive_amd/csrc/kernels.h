@@ -126,6 +126,10 @@ int ir_launch_flash_attn(const AttnParams& p, hipStream_t s);
 bool ir_flash_attn_is_pp2(const AttnParams& p);   // ir_launch_flash_attn routes p to flash_attn_pp2_kernel (profiler rows)
 // DiT self-attention (D = 72, Tk % 64 == 0, no key bias, ovf_flag set) as one wave per SIMD with two query groups (attn_d512.hip)
 int ir_launch_flash_attn_pp2(const AttnParams& p, hipStream_t s);
+// DiT cross-attention (D = 72, <= 320 keys, optional additive key bias, ovf_flag set) as a persistent one-wave-per-SIMD kernel with the head's
+// K / V^T resident in LDS (attn_d512.hip); ir_launch_flash_attn routes to it and queues the rescaling kernel behind it
+bool ir_flash_attn_x72_takes(const AttnParams& p);
+int ir_launch_flash_attn_x72(const AttnParams& p, hipStream_t s);
 // the rescaling 4-wave kernel alone, as the fallback behind a fixed-reference kernel: returns at once unless *p.ovf_flag is set
 int ir_launch_flash_attn_fallback(const AttnParams& p, hipStream_t s);
 // DiT self-attention on fp8 (e4m3) MFMA operands (attn_fp8.hip; BASELINE.json configs[4]). p as for ir_launch_flash_attn's self-attention form

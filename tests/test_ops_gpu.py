@@ -328,6 +328,45 @@ def test_flash_attention(ctx, b, heads, tq, tk, d, bias):
     close(L.from_bf16_bits(o).cpu(), ref, 2 ** -6, 6e-3, "flash attention")
 
 
+@pytest.mark.parametrize("b,heads,tq,tk,bias", [
+    (1, 16, 1024, 300, "quirk"), (1, 16, 4096, 300, "mask"), (2, 16, 1000, 320, "none"), (3, 16, 512, 40, "quirk"), (1, 16, 2048, 129, "mask"),
+    (1, 16, 1024, 300, "spike"), (1, 16, 16384, 300, "quirk"), (6, 16, 1024, 300, "mask"), (25, 16, 1024, 300, "quirk"), (2, 16, 4096, 300, "spike")])
+def test_cross_attention_persistent(ctx, b, heads, tq, tk, bias):
+    """flash_attn_x72_kernel (>= 64 items of 256 queries, <= 320 keys): the DiT cross-attention with the head's K / V^T resident in LDS and the
+    additive key bias riding in K dims 72 / 73. quirk = the 0 / 1 mask ADDED to the logits (what the reference's 3-D mask does in diffusers),
+    mask = 0 / -10000, spike = a late key 200 above everything (beyond the fixed reference: the wave repeats its item with the exact row maxima).
+    The last four shapes give a workgroup 2..7 items in a row (the first ones one each): K / V^T reuse, the Q prefetch and the item-to-item state."""
+    d = 72
+    g = torch.Generator().manual_seed(tq + tk)
+    q = rb(torch.randn(b, tq, heads, d, generator=g))
+    k = rb(torch.randn(b, tk, heads, d, generator=g))
+    v = rb(torch.randn(b, tk, heads, d, generator=g))
+    kb = None
+    if bias == "quirk":
+        kb = (torch.rand(b, tk, generator=g) < 0.3).float()
+    elif bias == "mask":
+        kb = (torch.rand(b, tk, generator=g) < 0.4).float() * -10000.0
+        kb[:, 0] = 0
+    elif bias == "spike":
+        kb = torch.zeros(b, tk)
+        kb[:, tk - 7] = 200.0
+    scale = d ** -0.5
+    mask = kb[:, None, None, :].double() if kb is not None else None
+    ref = F.scaled_dot_product_attention(q.double().transpose(1, 2), k.double().transpose(1, 2), v.double().transpose(1, 2), attn_mask=mask, scale=scale).transpose(1, 2).float()
+    qd, kd, vd = dev_bf16(q), dev_bf16(k), dev_bf16(v)
+    kbd = kb.cuda() if kb is not None else None
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    outs = []
+    for _ in range(2):
+        o = torch.full((b, tq, heads, d), 0x7fc0, dtype=torch.int16, device="cuda")
+        ctx.check(ctx.lib.ir_op_attention(ctx.h, ctx.stream(), P(qd), P(kd), P(vd), P(o), b, heads, tq, tk, d, scale, P(kbd) if kbd is not None else None,
+                                          P(ws), ws.numel()), "attention")
+        torch.cuda.synchronize()
+        outs.append(L.from_bf16_bits(o).cpu())
+    assert torch.equal(outs[0], outs[1]), "the persistent cross-attention must be deterministic run to run"
+    close(outs[0], ref, 2 ** -6, 6e-3, "persistent cross-attention")
+
+
 @pytest.mark.parametrize("t,gain", [(256, 4.0), (512, 8.0), (512, 12.0)])
 def test_flash_attention_spike(ctx, t, gain):
     """A late key dominates one query (the maximum jumps in the last tile). gain 4: inside the fixed-reference range of the
