@@ -164,6 +164,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(AttnParams p) {
     f32x16 negm;
 #pragma unroll
     for (int g = 0; g < 16; ++g) negm[g] = 0.f;
+    asm volatile("s_nop 7" : "+v"(negm));   // pinned here: asm MFMAs are invisible to hipcc's hazard recogniser, which otherwise materialises these zeros directly in front of the MFMA that reads them as its C operand (tools/mfma_hazard_scan.py)
     const int NT = (p.Tk + 63) >> 6;
     const int kr = swap23(r);
     int cur = 0;
@@ -435,6 +436,7 @@ __global__ __launch_bounds__(512, 1) void flash_attn_pp_kernel(AttnParams p) {
         for (int g = 0; g < 16; ++g) o[dt][g] = 0.f;
 #pragma unroll
     for (int g = 0; g < 16; ++g) negm[g] = 0.f;
+    asm volatile("s_nop 7" : "+v"(negm));   // pinned here: asm MFMAs are invisible to hipcc's hazard recogniser, which otherwise materialises these zeros directly in front of the MFMA that reads them as its C operand (tools/mfma_hazard_scan.py)
     float m_i = 0.f;
     bf16x8 pb[2][2];
 

@@ -537,6 +537,7 @@ __global__ __launch_bounds__(256, 1) void flash_attn_pp2_kernel(AttnParams p) {
     for (int g = 0; g < 2; ++g)
 #pragma unroll
         for (int e = 0; e < 16; ++e) negm[g][e] = 0.f;
+    asm volatile("s_nop 7" : "+v"(negm[0]), "+v"(negm[1]));   // pinned here: asm MFMAs are invisible to hipcc's hazard recogniser, which otherwise materialises these zeros directly in front of the MFMA that reads them as its C operand (tools/mfma_hazard_scan.py)
 
     // stream step j: [0, 20) S^T MFMA (group j / 10, key sub-tile (j % 10) / 5, k-step j % 5); [20, 44) PV MFMA (pair (j - 20) >> 1 =
     // dt*4 + kk, group j & 1)

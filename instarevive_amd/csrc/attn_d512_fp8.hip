@@ -249,6 +249,7 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d512_fp8_kernel(AttnD512F8P
     Frag fr[4];   // four fragment sets, reads two MFMAs ahead: a set is refilled two MFMAs after the one that read it
 #pragma unroll
     for (int e = 0; e < 16; ++e) negm[e] = 0.f;
+    asm volatile("s_nop 7" : "+v"(negm));   // pinned here: asm MFMAs are invisible to hipcc's hazard recogniser, which otherwise materialises these zeros directly in front of the MFMA that reads them as its C operand (tools/mfma_hazard_scan.py)
 
     // ---- the score product of one tile: 16 MFMAs, the two key halves alternating (consecutive MFMAs never share an accumulator),
     // fragments two MFMAs ahead in three register sets; `behind(i)` = what else issues behind MFMA i (LDS-DMA pieces)

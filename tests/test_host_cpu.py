@@ -395,3 +395,18 @@ def test_caption_mojibake_repair():
     assert clean_caption("A caf\u00c3\u00a9 in Paris") == "a caf\u00e3 in paris"
     text = "a photo of a cat"   # ASCII captions (every fixture caption) never reach the repair
     assert clean_caption(text) == text
+
+
+def test_no_compiler_placed_hazard_in_front_of_asm_mfmas():
+    """The pinned MFMA streams are `asm` statements, which hipcc's hazard recogniser does not look into: a VALU instruction it schedules directly in
+    front of one (the zeroed C operand of a score MFMA: flash_attn_x72_kernel's round-4 bug, wrong results in some lanes from run to run) or an asm
+    VALU instruction directly behind a transcendental is silent on every functional test that happens not to hit the timing. tools/mfma_hazard_scan.py
+    cross-compiles every kernel source with asm MFMAs to ISA (no GPU needed) and looks for such pairs."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mfma_hazard_scan", os.path.join(ROOT, "tools", "mfma_hazard_scan.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    res = m.scan_all()
+    assert sum(n for _, n in res.values()) > 4000, "the scan must see the kernels' MFMAs"
+    bad = {os.path.basename(f): [(k[:40], w, ins) for k, ins, w, d in fl][:4] for f, (fl, n) in res.items() if fl}
+    assert not bad, bad
