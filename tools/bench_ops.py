@@ -34,6 +34,18 @@ def conv(n, h, w, cin, cout, up=0, stride=1):
     print(f"conv {n}x{h}x{w} {cin}->{cout} up={up} s={stride}: {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s")
 
 
+def conv_up2(n, h, w, c):
+    """Upsample conv (nearest 2x + 3x3, c -> c) in its four-phase 2x2 form (conv_halo_s1_kernel<0, 4>); h x w is the LOW-resolution size"""
+    x = torch.randn(n, h, w, c, device="cuda").to(torch.bfloat16).view(torch.int16)
+    wup = (torch.randn(4 * c, 4 * c, device="cuda") / math.sqrt(4 * c)).to(torch.bfloat16).view(torch.int16)
+    b = torch.zeros(c, device="cuda")
+    out = torch.empty(n, 2 * h, 2 * w, c, dtype=torch.int16, device="cuda")
+    fn = lambda: ctx.check(ctx.lib.ir_op_conv_up2x2(ctx.h, ctx.stream(), L.ptr(x), L.ptr(wup), L.ptr(b), L.ptr(out), n, h, w, c, c), "conv_up2x2")
+    ms = timeit(fn)
+    fl = 2.0 * n * 4 * h * w * c * 9 * c
+    print(f"conv {n}x{h}x{w} {c}->{c} up, four 2x2 phase convs: {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s on the 9-tap FLOPs ({fl * 4 / 9 / ms / 1e9:.1f} executed)")
+
+
 def conv8(n, h, w, cin, cout):
     """3x3 conv on e4m3 operands (conv_halo_s1_fp8_kernel when it takes the shape; IR_NO_CONV_S1_FP8=1 forces conv_halo_kernel<.., FP8>)"""
     x = torch.randint(0, 120, (n, h, w, cin), device="cuda", dtype=torch.uint8)
@@ -123,6 +135,10 @@ if __name__ == "__main__":
         conv(1, 1024, 1024, 256, 256)
         conv(1, 1024, 1024, 512, 512)
         conv(1, 1024, 1024, 256, 256, up=1)
+        conv_up2(1, 1024, 1024, 256)
+        conv(1, 512, 512, 512, 512, up=1)
+        conv_up2(1, 512, 512, 512)
+        conv_up2(1, 256, 256, 512)
         conv(1, 512, 512, 512, 512)
         conv(1, 256, 256, 512, 512)
         conv(1, 2048, 2048, 64, 64)
