@@ -407,7 +407,7 @@ void conv(Run& r, const Conv& cw, const bf16_t* in, int N, int H, int W, int in_
     if (up && cw.wup && cw.taps == 9 && stride == 1 && !r.c->plain) {   // nearest-2x upsample + 3x3 as four 2x2 convs on the low-resolution tensor (conv_s1.hip)
         IGemmParams q = p;
         q.wgt = cw.wup; q.wgt_rs = 4L * cw.cin; q.up2x2 = 1;
-        if (ir_conv_s1_up2x2_takes(q)) p = q;
+        if (ir_igemm_up2x2_takes(q)) p = q;
     }
     static const bool no_gn_fuse = getenv("IR_NO_GN_FUSE") != nullptr;  // experiment knob
     if (r.gn_want && r.gn_buf && !out_f32 && cw.cout % 32 == 0 && !no_gn_fuse) {
@@ -1624,6 +1624,9 @@ int ir_swinir_configure(ir_ctx* c, int embed_dim, int n_layers, const int* depth
     m.up1 = b.conv("swin.up1", num_feat, num_feat, num_feat, 9);
     m.up2 = b.conv("swin.up2", num_feat, num_feat, num_feat, 9);
     m.up3 = b.conv("swin.up3", num_feat, num_feat, num_feat, 9);
+    b.up2x2_optional(m.up1, "swin.up1");   // nearest-2x + 3x3 (swinir.py:880-886) in the sub-pixel phase form when the host packed it
+    b.up2x2_optional(m.up2, "swin.up2");
+    b.up2x2_optional(m.up3, "swin.up3");
     m.hr = b.conv("swin.hr", num_feat, num_feat, num_feat, 9);
     m.last = b.conv("swin.last", num_feat, 3, 32, 9);
     if (!b.ok) return fail(c, -2, "ir_swinir_configure: tensor %s", b.missing.c_str());
@@ -2739,7 +2742,7 @@ int ir_op_conv_up2x2(ir_ctx* c, void* stream, const uint16_t* in, const uint16_t
     p.Ho = 2 * h; p.Wo = 2 * w; p.M = n * p.Ho * p.Wo;
     p.wgt = wup; p.wgt_rs = 4L * cin; p.Cout = cout; p.Cout_pad = cout; p.bias = bias; p.act = ACT_NONE; p.out_scale = 1.f;
     p.rows_per_batch = 1 << 30; p.out = out; p.out_cs = cout; p.up2x2 = 1;
-    if (!ir_conv_s1_up2x2_takes(p)) return fail(c, -2, "ir_op_conv_up2x2: shape not taken by the phase kernel (cin, cout multiples of 128; enough tiles)");
+    if (!ir_igemm_up2x2_takes(p)) return fail(c, -2, "ir_op_conv_up2x2: shape not taken by a phase kernel (cin, cout multiples of 64)");
     const int rc = ir_launch_igemm(p, (hipStream_t)stream);
     return rc ? fail(c, rc, "conv_up2x2 failed (%d)", rc) : 0;
 }

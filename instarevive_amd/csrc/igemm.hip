@@ -521,8 +521,13 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IGemmParams p) {
 template <bool M16>
 IR_DEVINL int halo_key(int hx) { return M16 ? ((hx >> 1) & 3) << 1 : (hx >> 1) & 7; }
 
-template <int BN, int UP, bool M16 = false, bool FP8 = false>
+// PH (16x16x32 form only): the sub-pixel phase form of "nearest-2x upsample + 3x3" (see conv_s1.hip): four 2x2 convs on the low-resolution tensor,
+// p.wgt = [phase][Cout_pad][2x2][Cin] (weights.pack_conv_up2x2), tile index = 4 * patch + phase, output pixel (2y + dy, 2x + dx); the halo is the
+// 9-tap one shifted by (dy, dx) (one row / column of it unused). SwinIR's three 64-channel upsampler convs (swinir.py:880-886).
+template <int BN, int UP, bool M16 = false, bool FP8 = false, bool PH = false>
 __global__ __launch_bounds__(256, 2) void conv_halo_kernel(IGemmParams p, int tiles_y, int tiles_x) {
+    static_assert(!PH || (M16 && !FP8 && UP == 0), "phase form: 16x16x32 bf16 path on the low-resolution grid");
+    constexpr int NTAP = PH ? 4 : 9;
     constexpr int BK = 64, ROWB = 128, SP = 8;
     constexpr int TH = 8, TW = 16, HW = TW + 2, HP = (TH + 2) * HW;  // 180 halo pixels
     constexpr int H_Q = (HP + 7) / 8;                                 // 23 DMA instructions (8 pixels x 8 slots each)
@@ -542,16 +547,19 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(IGemmParams p, int ti
     const int r = lane & 31, h = lane >> 5;
 
     const int NT = p.Cout_pad / BN;
-    const int MT = p.NB * tiles_y * tiles_x;
+    const int MT = p.NB * tiles_y * tiles_x * (PH ? 4 : 1);
     const int bid = blockIdx.x;
     const int xcd = bid & 7, j = bid >> 3;
     const int mt = (j / NT) * 8 + xcd, nt = j % NT;
     if (mt >= MT) return;
     const int n0 = nt * BN;
-    const int img = mt / (tiles_y * tiles_x), trem = mt - img * tiles_y * tiles_x;
+    const int per_img = tiles_y * tiles_x * (PH ? 4 : 1);
+    const int img = mt / per_img, trem_ph = mt - img * per_img;
+    const int phase = PH ? (trem_ph & 3) : 0, trem = PH ? (trem_ph >> 2) : trem_ph;
+    const int dy = phase >> 1, dx = phase & 1;
     const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
     const int oy0 = ty * TH, ox0 = tx * TW;
-    const int Hc = UP ? 2 * p.H : p.H, Wc = UP ? 2 * p.W : p.W;  // conv-input (== output) extent
+    const int Hc = UP ? 2 * p.H : p.H, Wc = UP ? 2 * p.W : p.W;  // conv-input (== output; PH: low-resolution) extent
 
     const int chunks = p.Cin / BK;
     const int lrow = lane >> 3, lslot = lane & 7;
@@ -562,7 +570,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(IGemmParams p, int ti
     for (int i = 0; i < H_I; ++i) {
         const int hp = (wid + 4 * i) * 8 + lrow;
         const int hy = hp / HW, hx = hp - hy * HW;
-        const int cy = oy0 + hy - 1, cx = ox0 + hx - 1;
+        const int cy = oy0 + hy - 1 + dy, cx = ox0 + hx - 1 + dx;
         const bool ok = hp < HP && cy >= 0 && cy < Hc && cx >= 0 && cx < Wc;
         const int iy = min(max(cy, 0), Hc - 1) >> UP, ix = min(max(cx, 0), Wc - 1) >> UP;
         const bf16_t* src = p.in + (((long)img * p.H + iy) * p.W + ix) * p.in_cs;
@@ -572,7 +580,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(IGemmParams p, int ti
 #pragma unroll
     for (int i = 0; i < B_I; ++i) {
         const int row = (wid + 4 * i) * 8 + lrow;
-        b_ptr[i] = p.wgt + (long)(n0 + row) * p.wgt_rs + ((lslot ^ ((row >> 1) & 7)) << 3);
+        b_ptr[i] = p.wgt + (long)(phase * p.Cout_pad + n0 + row) * p.wgt_rs + ((lslot ^ ((row >> 1) & 7)) << 3);
     }
     auto stage_halo = [&](int buf) {  // the chunk the pointers address; then advance to the next chunk
 #pragma unroll
@@ -610,11 +618,11 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(IGemmParams p, int ti
     // Main loop over steps s = (chunk c, tap t); same pinned schedule as igemm_kernel: per k-step first MFMA, reads of the next
     // k-step, remaining MFMAs; the workgroup barrier sits inside the last k-step, and behind it the weight tile of step s+2 (and,
     // at the first tap of a chunk, the whole halo of the next chunk) is issued and the first fragments of step s+1 are read.
-    const int steps = chunks * 9;
+    const int steps = chunks * NTAP;
     IR_STAMP(0);
     stage_halo(0);
     stage_b(0, 0);
-    stage_b(1, p.Cin);  // step 1 = (chunk 0, tap 1); steps >= 9 always
+    stage_b(1, p.Cin);  // step 1 = (chunk 0, tap 1); steps >= 4 always
     wait_dma();
     __syncthreads();
     IR_STAMP(1);
@@ -712,7 +720,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(IGemmParams p, int ti
         auto load16 = [&](int cbuf, int bbuf, int tap, int ks, int set) {
             const unsigned char* Hb = smem + cbuf * HALO_BYTES;
             const unsigned char* Bb = smem + 2 * HALO_BYTES + bbuf * BT_BYTES;
-            const int ky = tap / 3, kx = tap - ky * 3;
+            const int ky = PH ? tap >> 1 : tap / 3, kx = PH ? tap & 1 : tap - ky * 3;
             const int sw = halo_key<true>(c16 + kx);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
@@ -737,7 +745,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(IGemmParams p, int ti
         load16(0, 0, 0, 0, 0);
         for (int s = 0; s < steps; ++s) {
             int tn = t + 1, cn = c;
-            if (tn == 9) { tn = 0; cn = c + 1; }
+            if (tn == NTAP) { tn = 0; cn = c + 1; }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 __builtin_amdgcn_sched_barrier(0);
@@ -756,7 +764,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(IGemmParams p, int ti
                 mfma16s(ks, 2, TM * TN * 4);
             }
             t = tn; c = cn;
-            if (++t2 == 9) { t2 = 0; ++c2; }
+            if (++t2 == NTAP) { t2 = 0; ++c2; }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -767,6 +775,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(IGemmParams p, int ti
                 for (int g = 0; g < 16; ++g) acc[i][jn][g] = c4[i][jn][g >> 2][g & 3];
         igemm_epilogue<TM, TN, 2, 4, true>(p, acc, smem, wid, lane, n0 + wn * (BN / 2), n0, img, trem, [&](int i, int row) {
             const int oy = oy0 + wm * 4 + i * 2 + (row >> 4), ox = ox0 + (row & 15);
+            if constexpr (PH) return (oy < p.H && ox < p.W) ? (img * p.Ho + 2 * oy + dy) * p.Wo + 2 * ox + dx : -1;
             return (oy < p.Ho && ox < p.Wo) ? (img * p.Ho + oy) * p.Wo + ox : -1;
         });
         return;
@@ -1497,6 +1506,26 @@ static int launch_halo(const IGemmParams& p, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
+// Sub-pixel phase form through the 4-wave halo kernel (64- or 128-channel tiles; what conv_halo_s1_kernel<0, 4> does not take)
+static bool takes_halo_up2x2(const IGemmParams& p) {
+    static const bool off = getenv("IR_NO_UP2X2") != nullptr;   // experiment knob (shared with conv_s1.hip)
+    return !off && !g_ir_plain_kernels && p.up && p.taps == 9 && p.stride == 1 && !p.fp8 && !p.res && !p.gn_part && !p.gate && !p.out2 && !p.out_f32 &&
+           p.Cin % 64 == 0 && p.Cout_pad % 64 == 0 && p.Ho == 2 * p.H && p.Wo == 2 * p.W && igemm_vec(p);
+}
+bool ir_igemm_up2x2_takes(const IGemmParams& p) { return ir_conv_s1_up2x2_takes(p) || takes_halo_up2x2(p); }
+static int launch_halo_up2x2(const IGemmParams& pin, hipStream_t s) {
+    IGemmParams p = pin;
+    p.vec = igemm_vec(p);
+    if (p.wgt_rs != 4L * p.Cin) return -3;
+    const int tiles_y = (p.H + 7) / 8, tiles_x = (p.W + 15) / 16;
+    const long MT = (long)p.NB * 4 * tiles_y * tiles_x, NT = p.Cout_pad / (p.Cout_pad % 128 == 0 ? 128 : 64);
+    const long grid = ((MT + 7) / 8) * 8 * NT;
+    if (grid > 0x7fffffffL) return -12;
+    if (p.Cout_pad % 128 == 0) hipLaunchKernelGGL((conv_halo_kernel<128, 0, true, false, true>), dim3((unsigned)grid), dim3(256), 0, s, p, tiles_y, tiles_x);
+    else hipLaunchKernelGGL((conv_halo_kernel<64, 0, true, false, true>), dim3((unsigned)grid), dim3(256), 0, s, p, tiles_y, tiles_x);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 // Second half of a split-K launch: out = act(sum_k ws[k] + bias) * out_scale * gate + res, the epilogue order of igemm_epilogue, slices added in
 // a fixed order. ws: [nsplit][M][Cout_pad] fp32.
 __global__ __launch_bounds__(256) void splitk_finish_kernel(IGemmParams p, const float* __restrict__ ws, int nsplit) {
@@ -1609,7 +1638,7 @@ static bool igemm_vec(const IGemmParams& p) {
 int ir_igemm_kernel_id(const IGemmParams& pin) {
     IGemmParams p = pin;
     p.vec = igemm_vec(p);
-    if (p.up2x2) return 0;
+    if (p.up2x2) return ir_conv_s1_up2x2_takes(p) ? 0 : 3;
     if (p.ks_ws && ir_igemm_splitk(p) > 1) return 4;
     if (ir_conv_s1_takes(p) || ir_conv_s1_fp8_takes(p)) return 0;
     if (takes_halo_pp(p)) return 1;
@@ -1622,7 +1651,11 @@ int ir_igemm_kernel_id(const IGemmParams& pin) {
 int ir_launch_igemm(const IGemmParams& pin, hipStream_t s) {
     IGemmParams p = pin;
     if (p.M <= 0) return 0;
-    if (p.up2x2) return ir_conv_s1_up2x2_takes(p) ? ir_launch_conv_s1_up2x2(p, s) : -15;   // phase weights are no 9-tap weights: no other kernel may run them
+    if (p.up2x2) {   // phase weights are no 9-tap weights: only the two phase kernels may run them
+        if ((reinterpret_cast<uintptr_t>(p.in) & 15) || (reinterpret_cast<uintptr_t>(p.wgt) & 15) || (reinterpret_cast<uintptr_t>(p.out) & 15) || !p.out) return -7;
+        if (ir_conv_s1_up2x2_takes(p)) return ir_launch_conv_s1_up2x2(p, s);
+        return takes_halo_up2x2(p) ? launch_halo_up2x2(p, s) : -15;
+    }
     if (p.taps != 1 && p.taps != 9) return -2;
     if (p.Cin <= 0 || (p.Cin & 31) || (p.in_cs & 7) || p.in_cs < p.Cin) return -3;
     if (p.Cout <= 0 || p.Cout > p.Cout_pad || (p.Cout_pad & 31)) return -4;

@@ -128,6 +128,7 @@ bool ir_flash_attn_is_pp2(const AttnParams& p);   // ir_launch_flash_attn routes
 int ir_launch_flash_attn_pp2(const AttnParams& p, hipStream_t s);
 // DiT cross-attention (D = 72, <= 320 keys, optional additive key bias, ovf_flag set) as a persistent one-wave-per-SIMD kernel with the head's
 // K / V^T resident in LDS (attn_d512.hip); ir_launch_flash_attn routes to it and queues the rescaling kernel behind it
+bool ir_igemm_up2x2_takes(const IGemmParams& p);   // a phase kernel (conv_halo_s1_kernel<0, 4> or conv_halo_kernel<.., PH>) takes this upsampling conv in its sub-pixel form
 bool ir_flash_attn_x72_takes(const AttnParams& p);
 int ir_launch_flash_attn_x72(const AttnParams& p, hipStream_t s);
 // the rescaling 4-wave kernel alone, as the fallback behind a fixed-reference kernel: returns at once unless *p.ovf_flag is set

@@ -212,6 +212,8 @@ def pack_swinir(sd, cfg):
     for src, dst in (("conv_up1", "up1"), ("conv_up2", "up2"), ("conv_up3", "up3"), ("conv_hr", "hr")):
         out[f"swin.{dst}.w"] = pack_conv3x3(sd[src + ".weight"], nf, nf)
         out[f"swin.{dst}.b"] = pad_vec(sd[src + ".bias"], nf)
+        if dst != "hr" and nf % 64 == 0:   # F.interpolate(nearest, x2) + conv (swinir.py:880-886): the sub-pixel phase form (conv_halo_kernel<.., PH>)
+            out[f"swin.{dst}.wup"] = pack_conv_up2x2(sd[src + ".weight"])
     # conv_last with `x / img_range + mean` (swinir.py:903) folded in
     out["swin.last.w"] = pack_conv3x3(sd["conv_last.weight"], nf, 32, scale=1.0 / r)
     out["swin.last.b"] = pad_vec(sd["conv_last.bias"], 32, scale=1.0 / r, shift=torch.tensor(SWIN_MEAN))
