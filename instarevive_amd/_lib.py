@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("INSTAREVIVE_HIP_LIB") or os.path.join(_HERE, "csrc", 
 
 # every symbol include/instarevive_hip.h declares (tests check that the library exports all of them)
 SYMBOLS = [
-    "ir_abi_version", "ir_init", "ir_destroy", "ir_last_error", "ir_upload", "ir_has_tensor",
+    "ir_abi_version", "ir_init", "ir_destroy", "ir_last_error", "ir_upload", "ir_drop_optional", "ir_has_tensor",
     "ir_swinir_configure", "ir_vae_configure", "ir_dit_configure", "ir_dit_control_configure", "ir_dit_set_prompt", "ir_t5_configure", "ir_t5_encode", "ir_workspace_bytes",
     "ir_swinir_forward", "ir_vae_encode", "ir_dit_forward", "ir_dit_step", "ir_dit_forward_control", "ir_dit_step_control", "ir_vae_decode", "ir_color_fix",
     "ir_pipeline", "ir_u8_to_nchw", "ir_nchw_to_u8", "ir_profile_begin", "ir_profile_select", "ir_profile_end", "ir_profile_end_kernels", "ir_profile_kernel_count",
@@ -54,6 +54,7 @@ def load_library():
     lib.ir_last_error.argtypes = [vp]
     lib.ir_last_error.restype = C.c_char_p
     lib.ir_upload.argtypes = [vp, C.c_char_p, vp, sz]
+    lib.ir_drop_optional.argtypes = [vp, C.c_char_p]
     lib.ir_has_tensor.argtypes = [vp, C.c_char_p]
     lib.ir_swinir_configure.argtypes = [vp, i, i, C.POINTER(i), i, i, i, f, C.POINTER(f)]
     lib.ir_vae_configure.argtypes = [vp, i, i, C.POINTER(i), i, i, i]
@@ -187,6 +188,11 @@ class Context:
         self._names.add(name)
 
     def upload_all(self, tensors: dict):
+        """Upload one model's packed tensors. The optional conv forms of the families involved (first name component: "vae", "swin", ...) are
+        dropped first: the table is keyed by name, and a form the previous model of that family had but this one has not would otherwise be bound."""
+        for fam in sorted({k.split(".", 1)[0] for k in tensors}):
+            if self.lib.ir_drop_optional(self.h, fam.encode()) < 0:
+                self.check(-1, f"ir_drop_optional({fam})")
         for k, v in tensors.items():
             self.upload(k, v)
 

@@ -512,12 +512,12 @@ struct Binder {
     }
     void up2x2_optional(Conv& w, const std::string& base) {   // present when the host packed the phase form of this upsampling conv
         auto it = c->t.find(base + ".wup");
-        if (it != c->t.end() && it->second.bytes >= (size_t)4 * w.cout_pad * 4 * w.cin * 2) w.wup = (const bf16_t*)it->second.p;
+        if (it != c->t.end() && it->second.bytes == (size_t)4 * w.cout_pad * 4 * w.cin * 2) w.wup = (const bf16_t*)it->second.p;   // exactly this conv's form
     }
     void fp8_optional(Conv& w, const std::string& base) {  // present only when the host packed an fp8 form of this conv
         auto iw = c->t.find(base + ".w8"), ig = c->t.find(base + ".g8"), ib = c->t.find(base + ".b8");
         if (iw == c->t.end() || ig == c->t.end() || ib == c->t.end()) return;
-        if (iw->second.bytes < (size_t)w.cout_pad * 9 * w.cin || ig->second.bytes < (size_t)w.cout_pad * 4 || ib->second.bytes < (size_t)w.cout_pad * 4) return;
+        if (iw->second.bytes != (size_t)w.cout_pad * 9 * w.cin || ig->second.bytes != (size_t)w.cout_pad * 4 || ib->second.bytes != (size_t)w.cout_pad * 4) return;
         w.w8 = (const uint8_t*)iw->second.p; w.g8 = (const float*)ig->second.p; w.b8 = (const float*)ib->second.p;
     }
     Norm norm(const std::string& base, int c_) {
@@ -1576,6 +1576,30 @@ int ir_upload(ir_ctx* c, const char* name, const void* host, size_t bytes) {
     return 0;
 }
 int ir_has_tensor(ir_ctx* c, const char* name) { return c && name && c->t.count(name) ? 1 : 0; }
+// The tensor table is keyed by name and uploads only add / overwrite: the OPTIONAL forms of a conv (".wup" phase matrices, ".w8" / ".g8" / ".b8" fp8
+// forms), which a *_configure binds when it finds them, would survive from a previously uploaded model of the same family whose packer made them
+// where the new one's did not (seen: a full-size VAE's "vae.dec.up1.us.wup" bound by a 32-channel VAE configured later in the same context).
+// The host loader calls this for a family prefix ("vae", "swin", ...) before it uploads a model; returns the number of tensors dropped.
+int ir_drop_optional(ir_ctx* c, const char* prefix) {
+    if (!c || !prefix) return -1;
+    HIPOK(c, hipSetDevice(c->device));
+    HIPOK(c, hipDeviceSynchronize());   // nothing queued may still read them
+    const std::string pre = std::string(prefix) + ".";
+    int n = 0;
+    for (auto it = c->t.begin(); it != c->t.end();) {
+        const std::string& k = it->first;
+        auto ends = [&](const char* suf) { const size_t l = strlen(suf); return k.size() >= l && k.compare(k.size() - l, l, suf) == 0; };
+        if (k.compare(0, pre.size(), pre) == 0 && (ends(".wup") || ends(".w8") || ends(".g8") || ends(".b8"))) {
+            if (it->second.p) (void)hipFree(it->second.p);
+            it = c->t.erase(it);
+            ++c->generation;
+            ++n;
+        } else {
+            ++it;
+        }
+    }
+    return n;
+}
 
 int ir_swinir_configure(ir_ctx* c, int embed_dim, int n_layers, const int* depths, int heads, int mlp_hidden, int num_feat,
                         float img_range, const float* mean3) {

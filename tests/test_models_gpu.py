@@ -113,6 +113,17 @@ def test_vae_small_vs_golden():
         check(m.decode(torch.from_numpy(fx[k]).cuda()).sample, torch.from_numpy(fx[k + "_dec"]), f"vae decode {k} vs reference fixture", **TOL_VAE)
 
 
+def test_optional_weight_forms_do_not_leak_between_models():
+    """The context's tensor table is keyed by name: a 64-channel VAE leaves "vae.dec.up1.us.wup" (the phase form of its 128 -> 128 upsampling conv)
+    behind, and a 32-channel VAE loaded next has a 64 -> 64 conv under that name whose packer makes no phase form. Before round 4's
+    ir_drop_optional / exact-size binding the second model bound the first one's matrices (caught by the full suite's test order only)."""
+    big, _ = make_vae(dict(ch=64), seed=77)
+    z = det_input(31, (1, 4, 8, 8), -3, 3)
+    big.decode(z.cuda())
+    small, sd = make_vae(VAE_SMALL, seed=78)
+    check(small.decode(z.cuda()).sample, ovae.vae_decode(sd, z, VAE_SMALL), "32-channel VAE decoded after a 64-channel one", **TOL_VAE)
+
+
 def test_vae_full_arch_128():
     m, sd = make_vae(dict(ch=128), seed=222)
     x = det_input(22, (1, 3, 128, 128), -1, 1)

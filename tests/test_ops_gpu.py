@@ -655,7 +655,8 @@ def test_vae_norm_conv_out(ctx, n, h, w):
 
 
 @pytest.mark.parametrize("n,h,w,cin,cout", [(1, 64, 64, 512, 512), (2, 100, 72, 256, 256), (1, 256, 256, 256, 128),
-                                             (1, 64, 64, 64, 64), (2, 50, 39, 64, 64), (1, 24, 40, 128, 64)])   # 64-channel tiles: conv_halo_kernel<.., PH> (SwinIR's upsampler)
+                                             (1, 64, 64, 64, 64), (2, 50, 39, 64, 64), (1, 24, 40, 128, 64), (1, 8, 8, 128, 128), (1, 16, 24, 128, 128),
+                                             (2, 8, 16, 256, 128)])   # 64-channel tiles: conv_halo_kernel<.., PH> (SwinIR's upsampler)
 def test_conv_up2x2_phase_form(ctx, n, h, w, cin, cout):
     """nearest-2x upsample + 3x3 conv (the VAE decoder's Upsample, model.py:63-67) as four 2x2 convs on the low-resolution tensor
     (conv_halo_s1_kernel<0, 4>, weights.pack_conv_up2x2): (1) against the same decomposition in PyTorch on the bf16-rounded phase weights
