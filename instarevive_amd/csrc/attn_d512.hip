@@ -478,6 +478,15 @@ __global__ __launch_bounds__(256, 1) void flash_attn_pp2_kernel(AttnParams p) {
         a5_glds16(base + pc_off[k], (a5_lds_t)(smem + (isk ? kslot : vslot) + pc_dst[k]));
 #endif
     };
+#ifndef IR_PP2_NO_PADZERO
+    // Rows 80..95 of the two V^T slots are never loaded (the 10 pieces of a tile end at row 79) but ARE multiplied: the third 32-row tile of O^T = V^T P^T
+    // spans rows 64..95. Left as whatever the previous kernel had in LDS they cost the multiplier array as much as real data; as zeros they toggle
+    // nothing - and this kernel runs at the power-limited clock (section 3, round 4). 2 x 2 KB, once per workgroup.
+    for (int c = tid; c < 2 * 16 * 8; c += 256) {
+        const int slot = c >> 7, rem = c & 127;
+        *reinterpret_cast<uint4*>(smem + V_OFF + slot * VSLOT + (80 + (rem >> 3)) * 128 + (rem & 7) * 16) = make_uint4(0, 0, 0, 0);
+    }
+#endif
     // prologue: K(0) -> slot 0 and V^T(0) -> slot 0, then K(1) -> slot 1
     [&]<int... K>(std::integer_sequence<int, K...>) { ((issue(std::integral_constant<int, K>{})), ...); }(std::make_integer_sequence<int, NPC>{});
     if (NT > 1) {
@@ -847,6 +856,9 @@ __global__ __launch_bounds__(256, 1) void flash_attn_x72_kernel(AttnParams p, in
                 const int c = tid_o + 256 * i, t = c / 640, rem = c - t * 640, d = rem >> 3, pos = rem & 7;
                 if (c < NT * 640) *reinterpret_cast<uint4*>(smem + V_OFF + t * VSLOT + d * 128 + pos * 16) = vx[i];
             }
+            if (cur_head < 0)   // rows 80..95 of every tile: multiplied (third O^T tile) but never loaded - zeros toggle nothing (see flash_attn_pp2_kernel)
+                for (int c = tid_o; c < MAXT * 16 * 8; c += 256)
+                    *reinterpret_cast<uint4*>(smem + V_OFF + (c >> 7) * VSLOT + (80 + ((c & 127) >> 3)) * 128 + (c & 7) * 16) = make_uint4(0, 0, 0, 0);
             cur_b = b; cur_head = head;
             __syncthreads();
         }
