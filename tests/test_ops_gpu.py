@@ -367,6 +367,51 @@ def test_cross_attention_persistent(ctx, b, heads, tq, tk, bias):
     close(outs[0], ref, 2 ** -6, 6e-3, "persistent cross-attention")
 
 
+def test_cross_attention_persistent_random_shapes(ctx):
+    """flash_attn_x72_kernel over twelve random shapes of its domain (ragged query counts, 1..5 key tiles, 4..24 heads, 1..9 images, bias forms mixed,
+    per-image keys): each against float64 softmax attention, and twice for run-to-run identity."""
+    import numpy as np
+    rng = np.random.default_rng(20261004)
+    d, done = 72, 0
+    while done < 12:
+        heads, b = int(rng.integers(4, 25)), int(rng.integers(1, 10))
+        tq, tk = int(rng.integers(256, 3000)), int(rng.integers(1, 321))
+        if b * heads * ((tq + 255) // 256) < 64:
+            continue
+        done += 1
+        g = torch.Generator().manual_seed(1000 + done)
+        q = rb(torch.randn(b, tq, heads, d, generator=g) * float(rng.uniform(0.5, 2.0)))
+        k = rb(torch.randn(b, tk, heads, d, generator=g))
+        v = rb(torch.randn(b, tk, heads, d, generator=g))
+        form = done % 3
+        kb = None if form == 0 else ((torch.rand(b, tk, generator=g) < 0.5).float() * (1.0 if form == 1 else -10000.0))
+        if kb is not None and form == 2:
+            kb[:, 0] = 0
+        scale = d ** -0.5
+        mask = kb[:, None, None, :].double() if kb is not None else None
+        qt, kt = q.double().transpose(1, 2), k.double().transpose(1, 2)
+        ref = F.scaled_dot_product_attention(qt, kt, v.double().transpose(1, 2), attn_mask=mask, scale=scale).transpose(1, 2).float()
+        # bf16 operands of both products: the probabilities are rounded (2^-9 each) before the second product, and K * scale * log2 e before the
+        # first (with |q| up to 10 here that is up to 1 % in a probability): the error of an element scales with sum_j p_j |v_j|, not with |result|,
+        # which may be small where terms cancel. Measured: max error / that sum = 1.29 % for this kernel AND for the 4-wave kernel it replaces.
+        mag = F.scaled_dot_product_attention(qt, kt, v.double().abs().transpose(1, 2), attn_mask=mask, scale=scale).transpose(1, 2).float()
+        qd, kd, vd = dev_bf16(q), dev_bf16(k), dev_bf16(v)
+        kbd = kb.cuda() if kb is not None else None
+        ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+        outs = []
+        for _ in range(2):
+            o = torch.full((b, tq, heads, d), 0x7fc0, dtype=torch.int16, device="cuda")
+            ctx.check(ctx.lib.ir_op_attention(ctx.h, ctx.stream(), P(qd), P(kd), P(vd), P(o), b, heads, tq, tk, d, scale, P(kbd) if kbd is not None else None,
+                                              P(ws), ws.numel()), "attention")
+            torch.cuda.synchronize()
+            outs.append(L.from_bf16_bits(o).cpu())
+        assert torch.equal(outs[0], outs[1]), f"not deterministic at b={b} heads={heads} tq={tq} tk={tk}"
+        err = (outs[0] - ref).abs()
+        bad = err > 2 ** -6 * mag + 2e-3
+        assert not bad.any(), (f"persistent cross-attention b={b} heads={heads} tq={tq} tk={tk} bias form {form}: {int(bad.sum())}/{bad.numel()} off, "
+                               f"max abs err {float(err.max()):.4g}")
+
+
 @pytest.mark.parametrize("t,gain", [(256, 4.0), (512, 8.0), (512, 12.0)])
 def test_flash_attention_spike(ctx, t, gain):
     """A late key dominates one query (the maximum jumps in the last tile). gain 4: inside the fixed-reference range of the
