@@ -257,6 +257,11 @@ int ir_op_conv_groupnorm(ir_ctx* ctx, void* stream, const uint16_t* in, const ui
  * in fp32), out [n][2h][2w][cout] bf16. cin, cout multiples of 128. What ir_vae_decode launches for its three Upsample convs. */
 int ir_op_conv_up2x2(ir_ctx* ctx, void* stream, const uint16_t* in, const uint16_t* wup, const float* bias, uint16_t* out, int n, int h, int w,
                      int cin, int cout);
+/* ResnetBlock's "norm -> nonlinearity -> conv" (ldm/modules/diffusionmodules/model.py:131-137) with the GroupNorm apply + SiLU folded INTO the conv
+ * (conv_halo_s1_kernel<0, 9, NORM>): in = the un-normalised NHWC bf16 tensor, scale / shift = per image and channel fp32 [n][cin] (gamma * rstd and
+ * beta - mean * gamma * rstd, as the GroupNorm finalise leaves them), res optional. Per-kernel test entry. */
+int ir_op_conv_norm(ir_ctx* ctx, void* stream, const uint16_t* in, const float* scale, const float* shift, const uint16_t* wgt, const float* bias,
+                    const uint16_t* res, uint16_t* out, int n, int h, int w, int cin, int cout);
 int ir_op_vae_conv_in(ir_ctx* ctx, void* stream, const float* in, const uint16_t* wgt, const float* bias, uint16_t* out, float* gn_part, int n, int h,
                       int w, float in_scale, float in_shift, int* tiles);
 int ir_op_vae_norm_conv_out(ir_ctx* ctx, void* stream, const uint16_t* x, const float* scale, const float* shift, const uint16_t* wgt, const float* bias,

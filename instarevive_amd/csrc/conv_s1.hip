@@ -84,15 +84,23 @@ IR_DEVINL void cs1_mfma(bf16x8 w, bf16x8 px) {
 // taps that land on the same source pixel (host: weights.pack_conv_up2x2, summed in fp32, rounded to bf16 once) - 16 instead of 36 tap products
 // per low-resolution pixel and channel pair, the same zero padding (a source pixel outside the low-resolution image is exactly a padding tap of
 // the upsampled one). A tile is 16 x 32 LOW-resolution positions of one phase; its outputs are every other pixel of 32 x 64 high-resolution ones.
-template <int UP, int NTAP>
+// NORM (UP = 0, NTAP = 9): GroupNorm + SiLU of the input applied to every halo IN LDS, one chunk ahead of its use: during the nine steps of chunk c
+// each lane takes the 16-byte vectors of "its" LDS-DMA pieces of chunk c + 1 (the same pixel the lane fetched; the channel group is lane & 3 whatever
+// the slot swizzle) through scale / shift / SiLU and writes them back, rounded to bf16 exactly as gn_apply_kernel would have stored them. Padding
+// pixels (out-of-range buffer loads: zeros) are left alone - the zero padding applies to the NORMALISED tensor. The per-image scale / shift tables
+// of the current and the next tile live behind the weight ring. To make room in the arch register file (the 9-tap stream holds two full fragment
+// sets, 128 VGPRs) this form keeps two weight-fragment sets but streams the pixel fragments through a ring of three.
+template <int UP, int NTAP, bool NORM = false>
 __global__ __launch_bounds__(256, 1) void conv_halo_s1_kernel(IGemmParams p, int tiles_y, int tiles_x, int total_vb) {
+    static_assert(!NORM || (UP == 0 && NTAP == 9), "the in-kernel GroupNorm form exists for the plain 9-tap conv");
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub: the buffer-resource type of the body does not exist there, and with it in
                                       // sight hipcc (ROCm 7.2) silently drops the stub of a kernel TEMPLATE (undefined __device_stub__ at load time)
     using namespace cs1;
     using G = Geo<NTAP>;
     constexpr int K = G::K, HWD = G::HWD, HP = G::HP, H_Q = G::H_Q, H_I = G::H_I;   // (shadow the 3 x 3 constants of the namespace)
     constexpr bool PH = NTAP == 4;
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES];   // halo[0..2] | W ring of 4 ; epilogue: slabs + red in ONE halo buffer
+    constexpr int NP_OFF = LDS_MAIN, NP_SLOT = 2 * 512 * 4;   // NORM: two tables {scale[512], shift[512]} fp32 (this tile's image, the next tile's)
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NORM ? LDS_MAIN + 2 * NP_SLOT : LDS_BYTES];   // halo[0..2] | W ring of 4 ; epilogue: slabs + red in ONE halo buffer
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wu = __builtin_amdgcn_readfirstlane(wid);
     const int c16 = lane & 15, kq = lane >> 4;
@@ -164,7 +172,8 @@ __global__ __launch_bounds__(256, 1) void conv_halo_s1_kernel(IGemmParams p, int
         hrd[kx] = lds0 + ((4 * wid) * HWD + hx) * ROWB + ((kq ^ hkey(hx)) << 4);
     }
     const uint32_t wrd = lds0 + W_OFF + c16 * ROWB + ((kq ^ hkey(c16)) << 4);
-    bf16x8 fw[2][8], fp[2][8];   // [set][channel fragment] / [set][pixel fragment = a * 2 + mx]
+    bf16x8 fw[2][8], fp[NORM ? 1 : 2][NORM ? 1 : 8];   // [set][channel fragment] / [set][pixel fragment = a * 2 + mx]
+    bf16x8 fq[3];                                        // NORM: the pixel fragments stream through a ring of three (fragment PT of tap T in slot (PT + 2 T) % 3)
 
     Tile cur, nxt;
     int bid = blockIdx.x;
@@ -303,6 +312,162 @@ __global__ __launch_bounds__(256, 1) void conv_halo_s1_kernel(IGemmParams p, int
         __builtin_amdgcn_sched_barrier(0);
     };
 
+    // ---- NORM form
+    int tpar = 0;            // table slot of the current tile's image (the next tile's is tpar ^ 1)
+    bool first_tile = true;
+    uint32_t nkm = 0;        // bit i: hkey of the halo pixel of this lane in its piece i (slot = (lane & 3) ^ key, i.e. vector lane ^ key of the piece)
+    if constexpr (NORM) {
+#pragma unroll
+        for (int i = 0; i < H_I; ++i) {
+            const int hpix = min(wu + 4 * i, H_Q - 1) * 16 + (lane >> 2);
+            nkm |= (uint32_t)(hkey(hpix % HWD) >> 1) << i;
+        }
+    }
+    float nsc[NORM ? 8 : 1], nsh[NORM ? 8 : 1];
+    auto load_tab = [&](int slot, int img) {   // plain loads / stores, outside the pinned stream
+        float* tab = reinterpret_cast<float*>(smem + NP_OFF + slot * NP_SLOT);
+        for (int i = tid; i < p.Cin; i += 256) {
+            tab[i] = p.nrm_scale[(long)img * p.Cin + i];
+            tab[512 + i] = p.nrm_shift[(long)img * p.Cin + i];
+        }
+    };
+    // gn_apply_kernel's arithmetic, value for value (silu(a) = a * rcp(1 + __expf(-a)) with __expf(x) = v_exp_f32(x * log2 e), v_cvt_pk rounding), in six
+    // stages that ride in six MFMA gaps. The full-rate part runs as packed fp32 pairs (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: IEEE per lane, the
+    // same bits as the scalar forms, half the issue slots); the exponential and the reciprocal stay one instruction per value.
+    typedef float nf32x2 __attribute__((ext_vector_type(2)));
+    nf32x2 nfa[NORM ? 4 : 1], nfe[NORM ? 4 : 1];
+    auto norm_stage = [&](auto stc, const bf16x8& raw, uint4& out) {
+        constexpr int ST = decltype(stc)::value;
+        if constexpr (ST == 0) {
+            // the vector's read: only the pixel and the weight fragment read issued behind it may still fly. The wait is TIED to the value: a bare
+            // `asm volatile("s_waitcnt")` orders against other volatile asm only, and hipcc scheduled the unpacks of the vector IN FRONT of it
+            // (the value of an asm ds_read looks ready to it) - sporadic stale pieces, different from run to run.
+            bf16x8 rw = raw;
+            asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(rw));
+            const uint4 u = __builtin_bit_cast(uint4, rw);
+            const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                nfa[e] = nf32x2{bflo(w[e]), bfhi(w[e])} * nf32x2{nsc[2 * e], nsc[2 * e + 1]} + nf32x2{nsh[2 * e], nsh[2 * e + 1]};
+        } else if constexpr (ST == 1 || ST == 2) {
+#pragma unroll
+            for (int e = 2 * (ST - 1); e < 2 * ST; ++e) {
+                const nf32x2 t = nfa[e] * -1.44269504088896340736f;   // __expf(-a)
+                nfe[e] = nf32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+            }
+        } else if constexpr (ST == 3 || ST == 4) {
+#pragma unroll
+            for (int e = 2 * (ST - 3); e < 2 * (ST - 2); ++e) {
+                const nf32x2 d = nfe[e] + 1.0f;
+                nfe[e] = nf32x2{fast_rcp(d[0]), fast_rcp(d[1])};
+            }
+        } else {
+            nf32x2 y[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = nfa[e] * nfe[e];
+            out = make_uint4(pack2bf_valu(y[0][0], y[0][1]), pack2bf_valu(y[1][0], y[1][1]), pack2bf_valu(y[2][0], y[2][1]), pack2bf_valu(y[3][0], y[3][1]));
+        }
+    };
+    auto step_n = [&](auto tc, auto setc, int c, int hbuf) {   // the 9-tap step with streamed pixel fragments and the in-LDS norm of chunk c + 1
+        constexpr int T = decltype(tc)::value, SET = decltype(setc)::value;
+        constexpr int KX = T % K, KY = T / K;
+        constexpr int TNX = (T + 1) % NTAP, KXN = TNX % K, KYN = TNX / K;
+        const int s = c * NTAP + T;
+        const uint32_t hbc = (uint32_t)hbuf * HALO_BYTES;
+        const uint32_t hbn = (uint32_t)(T == NTAP - 1 ? (hbuf == 2 ? 0 : hbuf + 1) : hbuf) * HALO_BYTES;
+        const int hfill = hbuf == 0 ? 2 : hbuf - 1;
+        const uint32_t ha_c = hrd[KX] + hbc, ha_n = hrd[KXN] + hbn;
+        const uint32_t wa = wrd + (uint32_t)((s + 1) & 3) * WT_BYTES;
+        constexpr int TW4 = (T + 4) % NTAP;
+        int cw = c + (T + 4) / NTAP, tw = TW4;
+        const bool wmine = cw < chunks;
+        if (!wmine) cw = 0;
+        const bool hmine = c + 2 < chunks;
+        const int hoff = (hmine ? c + 2 : c + 2 - chunks) * (BK * 2);
+        const int wkoff = (tw * p.Cin + cw * BK) * 2;
+        auto halo_piece = [&](auto kc) {
+            constexpr int KP = decltype(kc)::value;
+            constexpr int PI = nh(NTAP, T) > KP ? nh_first(NTAP, T) + KP : 0;
+            const int q = min(wu + 4 * PI, H_Q - 1);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_of(hmine ? base_cur : base_nxt), (cs1_lds_t)(smem + hfill * HALO_BYTES + q * 1024), 16,
+                                                     (int)(hmine ? h_ptr[PI] : h_nxt[PI]), hoff, 0, 0);
+        };
+        // ---- the norm of chunk c + 1 (buffer after hbuf): pieces i = T for T < 6, {6, 8} at T = 6, {7, 9} at T = 7, none at T = 8 - every wave must be done
+        // one barrier before the first fragment of chunk c + 1 is read (during step 8)
+        const bool nx = c + 1 >= chunks;                                         // chunk c + 1 belongs to the next tile
+        const uint32_t nbuf = lds0 + (uint32_t)(hbuf == 2 ? 0 : hbuf + 1) * HALO_BYTES;
+#ifdef IR_S1_NORM_NOUNITS   // timing experiment: the streamed-fragment form alone (results wrong: nothing is normalised)
+        constexpr int NU = 0;
+#else
+        constexpr int NU = T < 6 ? 1 : (T < 8 ? 2 : 0);
+#endif
+        constexpr int UI[2] = {T < 8 ? T : 0, T == 6 ? 8 : 9};
+        // gaps: one unit: read 22, arithmetic 30..45, write 48; two units: A read 6, arithmetic 14..29, write 31; B read 30, arithmetic 38..53, write 56
+        constexpr int RD[2] = {NU == 2 ? 6 : 22, 30}, WR[2] = {NU == 2 ? 31 : 48, 56};
+        bf16x8 nraw;
+        uint4 nout;
+        auto unit_addr = [&](int i) { return nbuf + (uint32_t)(wu + 4 * i) * 1024u + (uint32_t)((lane ^ (((nkm >> i) & 1u) << 1)) * 16); };
+        auto unit_ok = [&](int i) { return wu + 4 * i < H_Q && (nx ? h_nxt[i] : h_ptr[i]) != OOB; };
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+            ([&] {
+                constexpr int PT = I >> 3, CT = I & 7, G8 = I >> 3;
+                if constexpr ((I & 7) == 0) {   // pixel fragment two groups ahead (the last two groups: fragments 0 / 1 of the NEXT step)
+                    if constexpr (I > 0) wait_lds<3>();   // fragment PT of this group has landed: at most the three reads issued behind it are in flight
+                    constexpr int P2 = G8 + 2;
+                    if constexpr (P2 < 8) fq[(P2 + 2 * T) % 3] = lds_read16<((P2 >> 1) + KY) * HWD * ROWB + (P2 & 1) * 1024>(ha_c);
+                    else fq[((P2 - 8) + 2 * TNX) % 3] = lds_read16<(((P2 - 8) >> 1) + KYN) * HWD * ROWB + ((P2 - 8) & 1) * 1024>(ha_n);
+                }
+                if constexpr ((I & 7) == 2) fw[SET ^ 1][G8] = lds_read16<G8 * 1024>(wa);
+                __builtin_amdgcn_sched_barrier(0);
+                cs1_mfma<4 * I>(fw[SET][CT], fq[(PT + 2 * T) % 3]);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (I == 1 && nh(NTAP, T) > 0) { halo_piece(std::integral_constant<int, 0>{}); __builtin_amdgcn_sched_barrier(0); }
+                if constexpr (I == 5 && nh(NTAP, T) > 1) { halo_piece(std::integral_constant<int, 1>{}); __builtin_amdgcn_sched_barrier(0); }
+                if constexpr (I == 17 && nh(NTAP, T) > 2) { halo_piece(std::integral_constant<int, 2>{}); __builtin_amdgcn_sched_barrier(0); }
+                if constexpr (I == 10 || I == 13) {
+                    constexpr int KW = I == 10 ? 0 : 1;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rsrc, (cs1_lds_t)(smem + W_OFF + (s & 3) * WT_BYTES + (wu + 4 * KW) * 1024), 16,
+                                                             (int)(wmine ? w_ptr[KW] : w_nxt[KW]), wkoff, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // ---- norm units
+                constexpr int II = I;   // (a pack of the outer fold must not appear inside the inner one)
+                [&]<int... UU>(std::integer_sequence<int, UU...>) {
+                    ([&] {
+                        constexpr int U = UU;
+                        if constexpr (U < NU) {
+                            if constexpr (II == RD[U]) {
+                                nraw = lds_read16<0>(unit_addr(UI[U])); __builtin_amdgcn_sched_barrier(0); }
+                            // (a group boundary lies between the read and the first stage: its wait_lds<3> has covered the read)
+                            if constexpr (II >= RD[U] + 8 && II <= RD[U] + 23 && (II - RD[U] - 8) % 3 == 0) {
+                                norm_stage(std::integral_constant<int, (II - RD[U] - 8) / 3>{}, nraw, nout);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                            if constexpr (II == WR[U]) {
+                                typedef unsigned int nu32x4 __attribute__((ext_vector_type(4)));
+                                const nu32x4 o = {nout.x, nout.y, nout.z, nout.w};
+                                if (unit_ok(UI[U])) asm volatile("ds_write_b128 %0, %1" ::"v"(unit_addr(UI[U])), "v"(o) : "memory");
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                    }(), ...);
+                }(std::integer_sequence<int, 0, 1>{});
+            }(), ...);
+        }(std::make_integer_sequence<int, 64>{});
+        wait_lds<0>();
+        wait_vm<4 + nh(NTAP, (T + NTAP - 1) % NTAP) + nh(NTAP, T)>();
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (T == NTAP - 1) if (c + 1 < chunks) {   // the lane's scale / shift for the chunk normalised during the NEXT nine steps (chunk c + 2);
+                                                              // behind a tile's last chunk the tile loop loads them (not kept alive across the epilogue)
+            const int c2 = c + 2;
+            const float* tab = reinterpret_cast<const float*>(smem + NP_OFF + ((c2 < chunks ? tpar : tpar ^ 1) * NP_SLOT)) + (c2 < chunks ? c2 : c2 - chunks) * BK + (lane & 3) * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { nsc[e] = tab[e]; nsh[e] = tab[512 + e]; }
+        }
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
     for (;;) {
         IR_S1_T(st0);
         // the next tile of this workgroup (none: the stream re-reads the current one, into buffers nobody reads again)
@@ -312,17 +477,49 @@ __global__ __launch_bounds__(256, 1) void conv_halo_s1_kernel(IGemmParams p, int
         if (!more) nxt = cur;
         describe(nxt, h_nxt, w_nxt);
         base_nxt = tile_base(nxt);
+        if constexpr (NORM) {
+            if (first_tile) load_tab(tpar, cur.img);
+            load_tab(tpar ^ 1, nxt.img);   // (the slot of the tile before this one: its last reader passed the barrier that ended that tile's stream)
+        }
         asm volatile(".set ir_cs1_i, 0\n\t.rept 256\n\tv_accvgpr_write_b32 a[ir_cs1_i], 0\n\t.set ir_cs1_i, ir_cs1_i + 1\n\t.endr" ::: IR_AGPR256_CLOBBERS);
         // everything in flight has landed (first tile: the prologue; later: the pieces fetched through the tile boundary and the previous
         // epilogue's stores) - chunk 1's halo included, which costs nothing after an epilogue and ~1 us once per workgroup
         wait_dma();
         __syncthreads();
+        if constexpr (NORM) {
+            if (first_tile) {   // chunk 0 of a workgroup's FIRST tile has no chunk before it to ride under: normalise it here (later tiles: during the previous tile's last chunk)
+                const float* tab = reinterpret_cast<const float*>(smem + NP_OFF + tpar * NP_SLOT) + (lane & 3) * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { nsc[e] = tab[e]; nsh[e] = tab[512 + e]; }
+                for (int i = 0; i < H_I; ++i) {
+                    if (wu + 4 * i >= H_Q || h_ptr[i] == OOB) continue;
+                    uint4* v = reinterpret_cast<uint4*>(smem + hb3 * HALO_BYTES + (wu + 4 * i) * 1024 + ((lane ^ (((nkm >> i) & 1u) << 1)) * 16));
+                    const uint4 u = *v;
+                    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+                    uint32_t o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = pack2bf_valu(silu(bflo(w[e]) * nsc[2 * e] + nsh[2 * e]), silu(bfhi(w[e]) * nsc[2 * e + 1] + nsh[2 * e + 1]));
+                    *v = make_uint4(o[0], o[1], o[2], o[3]);
+                }
+                __syncthreads();
+                first_tile = false;
+            }
+            const float* tab1 = reinterpret_cast<const float*>(smem + NP_OFF + tpar * NP_SLOT) + BK + (lane & 3) * 8;   // chunk 1 is normalised during chunk 0
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { nsc[e] = tab1[e]; nsh[e] = tab1[512 + e]; }
+        }
+        if constexpr (NORM) {
+            [&]<int... R>(std::integer_sequence<int, R...>) { ((fw[0][R] = lds_read16<R * 1024>(wrd)), ...); }(std::make_integer_sequence<int, 8>{});
+            fq[0] = lds_read16<0>(hrd[0] + (uint32_t)hb3 * HALO_BYTES);
+            fq[1] = lds_read16<1024>(hrd[0] + (uint32_t)hb3 * HALO_BYTES);
+        } else {
         [&]<int... R>(std::integer_sequence<int, R...>) {
             ([&] {
                 if constexpr (R < 8) fw[0][R] = lds_read16<R * 1024>(wrd);
                 else fp[0][R - 8] = lds_read16<((R - 8) >> 1) * HWD * ROWB + ((R - 8) & 1) * 1024>(hrd[0] + (uint32_t)hb3 * HALO_BYTES);
             }(), ...);
         }(std::make_integer_sequence<int, 16>{});
+        }
         wait_lds<0>();
         IR_S1_T(st1);
 #ifdef IR_S1_STAMPS
@@ -331,8 +528,13 @@ __global__ __launch_bounds__(256, 1) void conv_halo_s1_kernel(IGemmParams p, int
         if (IR_KO_S1 != 2 && IR_KO_S1 != 3)
         for (int c = 0; c < chunks; c += 2) {
             const int hb3b = hb3 == 2 ? 0 : hb3 + 1;
+            if constexpr (NORM) {
+                [&]<int... U>(std::integer_sequence<int, U...>) { (step_n(std::integral_constant<int, U>{}, std::integral_constant<int, (U & 1)>{}, c, hb3), ...); }(std::make_integer_sequence<int, NTAP>{});
+                [&]<int... U>(std::integer_sequence<int, U...>) { (step_n(std::integral_constant<int, U>{}, std::integral_constant<int, ((U + NTAP) & 1)>{}, c + 1, hb3b), ...); }(std::make_integer_sequence<int, NTAP>{});
+            } else {
             [&]<int... U>(std::integer_sequence<int, U...>) { (step(std::integral_constant<int, U>{}, std::integral_constant<int, (U & 1)>{}, c, hb3), ...); }(std::make_integer_sequence<int, NTAP>{});
             [&]<int... U>(std::integer_sequence<int, U...>) { (step(std::integral_constant<int, U>{}, std::integral_constant<int, ((U + NTAP) & 1)>{}, c + 1, hb3b), ...); }(std::make_integer_sequence<int, NTAP>{});
+            }
             hb3 = hb3b == 2 ? 0 : hb3b + 1;
         }
         // hb3 is now the buffer of the next tile's chunk 0; the last chunk of this tile was read from the one before it
@@ -360,6 +562,7 @@ __global__ __launch_bounds__(256, 1) void conv_halo_s1_kernel(IGemmParams p, int
         if (tid == 0) g_s1_stamps[blockIdx.x * 8 + 6] += 1;
 #endif
         if (!more) break;
+        tpar ^= 1;
         bid = nbid;
         cur = nxt;
         base_cur = base_nxt;
@@ -398,15 +601,22 @@ static int cs1_cus() {
     return cus;
 }
 
+bool ir_conv_s1_norm_takes(const IGemmParams& p) {
+    static const bool off = getenv("IR_NO_S1_NORM") != nullptr;   // experiment knob: the stand-alone GroupNorm apply pass again
+    return !off && p.nrm_scale && p.nrm_shift && !p.up && !p.up2x2 && p.Cin <= 512 && ir_conv_s1_takes(p);
+}
+
 int ir_launch_conv_s1(const IGemmParams& p, hipStream_t s) {
     if (!ir_conv_s1_takes(p)) return -2;
+    if ((p.nrm_scale || p.nrm_shift) && !ir_conv_s1_norm_takes(p)) return -16;
     if (p.gn_part && (p.gn_cpg < 4 || p.gn_cpg > 32 || (p.gn_cpg & (p.gn_cpg - 1)) || p.gn_chunks != ir_conv_s1_tiles(p))) return -13;
     const int tiles_y = (p.Ho + 15) / 16, tiles_x = (p.Wo + 31) / 32;
     const long MT = (long)p.NB * tiles_y * tiles_x, NT = p.Cout_pad / 128;
     const long total = ((MT + 7) / 8) * 8 * NT;
     if (total > 0x7fffffffL) return -12;
     const long grid = total < cs1_cus() ? total : cs1_cus();
-    if (p.up) hipLaunchKernelGGL((conv_halo_s1_kernel<1, 9>), dim3((unsigned)grid), dim3(256), 0, s, p, tiles_y, tiles_x, (int)total);
+    if (p.nrm_scale) hipLaunchKernelGGL((conv_halo_s1_kernel<0, 9, true>), dim3((unsigned)grid), dim3(256), 0, s, p, tiles_y, tiles_x, (int)total);
+    else if (p.up) hipLaunchKernelGGL((conv_halo_s1_kernel<1, 9>), dim3((unsigned)grid), dim3(256), 0, s, p, tiles_y, tiles_x, (int)total);
     else hipLaunchKernelGGL((conv_halo_s1_kernel<0, 9>), dim3((unsigned)grid), dim3(256), 0, s, p, tiles_y, tiles_x, (int)total);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

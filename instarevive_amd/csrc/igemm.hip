@@ -1656,6 +1656,7 @@ int ir_launch_igemm(const IGemmParams& pin, hipStream_t s) {
         if (ir_conv_s1_up2x2_takes(p)) return ir_launch_conv_s1_up2x2(p, s);
         return takes_halo_up2x2(p) ? launch_halo_up2x2(p, s) : -15;
     }
+    if ((p.nrm_scale || p.nrm_shift) && !ir_conv_s1_norm_takes(p)) return -16;   // only conv_halo_s1_kernel<0, 9, NORM> normalises its input: the caller asks first
     if (p.taps != 1 && p.taps != 9) return -2;
     if (p.Cin <= 0 || (p.Cin & 31) || (p.in_cs & 7) || p.in_cs < p.Cin) return -3;
     if (p.Cout <= 0 || p.Cout > p.Cout_pad || (p.Cout_pad & 31)) return -4;

@@ -61,7 +61,12 @@ struct IGemmParams {
     // 1: `wgt` holds the four sub-pixel phase matrices [2 dy + dx][Cout_pad][2 sy + sx][Cin] of an up = 1 conv (wgt_rs = 4 * Cin): only valid when
     // ir_conv_s1_up2x2_takes(p) - the caller asks first and passes the ordinary 9-tap weights otherwise
     int up2x2;
+    // GroupNorm + SiLU of the INPUT applied inside conv_halo_s1_kernel (NORM form): per image and input channel scale / shift ([NB][Cin] fp32, what
+    // ir_launch_groupnorm_fused(..., y = nullptr) leaves in its workspace); `in` is then the un-normalised tensor. Only when ir_conv_s1_norm_takes(p).
+    const float* nrm_scale;
+    const float* nrm_shift;
 };
+bool ir_conv_s1_norm_takes(const IGemmParams& p);
 int ir_igemm_writes_vt(const IGemmParams& p);
 int ir_launch_vt_pad_init(bf16_t* vt, int heads_total, int D, int DV, int T, int Tpad, hipStream_t s);
 int ir_launch_igemm(const IGemmParams& p, hipStream_t s);

@@ -245,6 +245,47 @@ def test_conv_s1_kernel(ctx, n, h, w, cin, cout, up, res):
     _conv_groupnorm_case(ctx, n, h, w, cin, cout, 1, up, res, True, expect_chunks=((ho + 15) // 16) * ((wo + 31) // 32))
 
 
+@pytest.mark.parametrize("n,h,w,cin,cout,res", [
+    (1, 256, 384, 128, 128, False),    # whole patches, borders on all four sides
+    (2, 200, 488, 128, 128, True),     # ragged patches, two images with different scale / shift through one workgroup's tile walk
+    (1, 128, 384, 256, 256, True),     # 8 chunks, two channel tiles (the halo of a patch is normalised once per channel tile)
+    (2, 128, 256, 512, 128, False),    # 16 chunks (the table's full 512 channels), two images
+    (1, 1024, 1024, 128, 128, True),   # 2048 patches: eight per workgroup in a row (the stream runs through tile boundaries; round 4's unpinned-wait bug showed only here)
+])
+def test_conv_s1_norm_in_kernel(ctx, n, h, w, cin, cout, res):
+    """conv_halo_s1_kernel<0, 9, NORM>: ResnetBlock's norm -> SiLU -> conv with the apply pass folded into the conv - every halo chunk is taken through
+    scale / shift / SiLU in LDS one chunk ahead of its use, padding pixels stay zero AFTER the norm. Against conv2d(bf16(silu(x * scale + shift)))
+    with the scale / shift of an fp64 GroupNorm over the bf16 input."""
+    g = torch.Generator().manual_seed(h * w + cin)
+    x = rb(torch.randn(n, cin, h, w, generator=g) * 1.7 + 0.3)
+    wt = rb(torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5))
+    b = torch.randn(cout, generator=g) * 0.1
+    gamma, beta = torch.randn(cin, generator=g), torch.randn(cin, generator=g)
+    xg = x.double().reshape(n, 32, -1)
+    mean, var = xg.mean(-1), xg.var(-1, unbiased=False)
+    rstd = (var + 1e-6).rsqrt()
+    cpg = cin // 32
+    scale = (rstd.repeat_interleave(cpg, 1) * gamma.double()).float()                       # [n][cin]
+    shift = (beta.double() - mean.repeat_interleave(cpg, 1) * rstd.repeat_interleave(cpg, 1) * gamma.double()).float()
+    xn = rb(F.silu(x * scale[:, :, None, None] + shift[:, :, None, None]))                # what gn_apply_kernel would have stored
+    co = F.conv2d(xn, wt, b, padding=1)
+    r = rb(torch.randn(n, cout, h, w, generator=g)) if res else None
+    if res:
+        co = co + r
+    xin = dev_bf16(x.permute(0, 2, 3, 1).contiguous())
+    wp = dev_bf16(wt.permute(0, 2, 3, 1).reshape(cout, 9 * cin).contiguous())
+    rd = dev_bf16(r.permute(0, 2, 3, 1).contiguous()) if res else None
+    out = torch.full((n, h, w, cout), 0x7fc0, dtype=torch.int16, device="cuda")
+    sd, hd, bd = scale.contiguous().cuda(), shift.contiguous().cuda(), b.cuda()
+    outs = []
+    for _ in range(2):
+        ctx.check(ctx.lib.ir_op_conv_norm(ctx.h, ctx.stream(), P(xin), P(sd), P(hd), P(wp), P(bd), P(rd) if res else None, P(out), n, h, w, cin, cout), "conv_norm")
+        torch.cuda.synchronize()
+        outs.append(L.from_bf16_bits(out).cpu().permute(0, 3, 1, 2).clone())
+    assert torch.equal(outs[0], outs[1]), "not deterministic"
+    close(outs[0], rb(co), 2 ** -7, 6e-3, "conv with the GroupNorm apply + SiLU inside")
+
+
 def _conv_groupnorm_case(ctx, n, h, w, cin, cout, stride, up, res, expect_fused, expect_chunks=None):
     import ctypes
     g = torch.Generator().manual_seed(h * w + cout + stride)

@@ -46,6 +46,19 @@ def conv_up2(n, h, w, c):
     print(f"conv {n}x{h}x{w} {c}->{c} up, four 2x2 phase convs: {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s on the 9-tap FLOPs ({fl * 4 / 9 / ms / 1e9:.1f} executed)")
 
 
+def conv_norm(n, h, w, cin, cout):
+    """3x3 conv with the GroupNorm apply + SiLU of its input inside (conv_halo_s1_kernel<0, 9, NORM>) against apply pass + conv"""
+    x = torch.randn(n, h, w, cin, device="cuda").to(torch.bfloat16).view(torch.int16)
+    wt = (torch.randn(cout, 9 * cin, device="cuda") / math.sqrt(9 * cin)).to(torch.bfloat16).view(torch.int16)
+    b = torch.zeros(cout, device="cuda")
+    sc, sh = torch.rand(n, cin, device="cuda") + 0.5, torch.randn(n, cin, device="cuda") * 0.3
+    out = torch.empty(n, h, w, cout, dtype=torch.int16, device="cuda")
+    fn = lambda: ctx.check(ctx.lib.ir_op_conv_norm(ctx.h, ctx.stream(), L.ptr(x), L.ptr(sc), L.ptr(sh), L.ptr(wt), L.ptr(b), None, L.ptr(out), n, h, w, cin, cout), "conv_norm")
+    ms = timeit(fn)
+    fl = 2.0 * n * h * w * cout * 9 * cin
+    print(f"conv+norm-in {n}x{h}x{w} {cin}->{cout}: {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s")
+
+
 def conv8(n, h, w, cin, cout):
     """3x3 conv on e4m3 operands (conv_halo_s1_fp8_kernel when it takes the shape; IR_NO_CONV_S1_FP8=1 forces conv_halo_kernel<.., FP8>)"""
     x = torch.randint(0, 120, (n, h, w, cin), device="cuda", dtype=torch.uint8)
@@ -143,6 +156,11 @@ if __name__ == "__main__":
         conv(1, 256, 256, 512, 512)
         conv(1, 2048, 2048, 64, 64)
         conv(1, 256, 256, 192, 192)
+    if "convnorm" in which:
+        for shp in ((1, 2048, 2048, 128, 128), (1, 2048, 2048, 256, 128), (1, 1024, 1024, 256, 256), (1, 1024, 1024, 512, 512), (1, 512, 512, 512, 512)):
+            conv(*shp)
+            conv_norm(*shp)
+            gn(shp[0], shp[1] * shp[2], shp[3])
     if "linear" in which:
         linear(16384, 1152, 3456)
         linear(16384, 1152, 1152)
