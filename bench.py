@@ -497,7 +497,9 @@ def main():
                 skipped = n * (fm["tiles"] * upconv_phase_saving(tile_size, tile_size) if args.tiled else upconv_phase_saving(h, w))
                 ex = (v["flops"] / args.steps - skipped) / (v["ms"] / args.steps / 1e3) / 1e12
                 row.update(executed_tflop_per_step=round((v["flops"] / args.steps - skipped) / 1e12, 4), executed_achieved=round(ex, 1), executed_frac=round(ex / pk, 4),
-                           note="achieved/frac price the reference's algorithmic 9-tap FLOPs; the three Upsample convs run as four 2x2 phase convs (4/9 of their MACs), executed_* price what the MFMA pipe really did")
+                           note="achieved/frac price the reference's algorithmic 9-tap FLOPs; the three Upsample convs run as four 2x2 phase convs (4/9 of their MACs), executed_* price what the MFMA pipe really did"
+                                + ("" if os.environ.get("IR_NO_S1_NORM") else "; the 128-output-channel launches also carry the GroupNorm apply + SiLU of their input (about 4.5 ms of "
+                                   "stand-alone passes at 2048 x 2048 moved into this row: +3.5 ms here, IR_NO_S1_NORM=1 gives the two-launch form and 0.62)"))
             if short == "conv_halo_kernel" and not os.environ.get("IR_NO_UP2X2") and row.get("bound") == "mfma":
                 # SwinIR's three 64-channel upsampler convs (outputs at 1/16, 1/4 and 1/1 of the pixels) run in the same phase form
                 skipped = n * 2 * 9 * 64 * 64 * (h * w // 16 + h * w // 4 + h * w) * 5 / 9
