@@ -232,49 +232,9 @@ __global__ __launch_bounds__(256, 1) void conv_halo_s1_kernel(IGemmParams p, int
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_of(hmine ? base_cur : base_nxt), (cs1_lds_t)(smem + hfill * HALO_BYTES + q * 1024), 16,
                                                      (int)(hmine ? h_ptr[PI] : h_nxt[PI]), hoff, 0, 0);
         };
-#ifdef IR_S1_NORM_PROTO
-        // TIMING PROTOTYPE ("GroupNorm + SiLU applied to the halo inside the conv"; never in the library): per step and lane one
-        // 16-byte vector of the NEXT chunk's halo goes LDS -> registers -> scale / shift / SiLU -> bf16 -> LDS, spread over eight MFMA gaps. The
-        // vector written back is the ORIGINAL one (a runtime-false select), so results stay right while the instruction stream is the real one.
-        const uint32_t npa = lds0 + (uint32_t)(hbuf == 2 ? 0 : hbuf + 1) * HALO_BYTES + (uint32_t)(((T * 4 + wid) * 64 + lane) * 16);
-        const bool nflag = p.NB < 0;
-        bf16x8 nraw;
-        float nf[8], ne[8];
-        uint32_t nw[4];
-#endif
         [&]<int... I>(std::integer_sequence<int, I...>) {
             ([&] {
                 constexpr int PT = I >> 3, CT = I & 7;
-#ifdef IR_S1_NORM_PROTO
-                if constexpr (I == 22) nraw = lds_read16<0>(npa);
-                if constexpr (I == 30) {
-                    wait_lds<2>();   // the two fragment reads issued behind it may still fly
-                    const uint4 u = __builtin_bit_cast(uint4, nraw);
-                    const uint32_t w[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { nf[2 * e] = bflo(w[e]) * 1.01f + 0.02f; nf[2 * e + 1] = bfhi(w[e]) * 0.99f - 0.01f; }
-                }
-                if constexpr (I == 33 || I == 36) {
-                    constexpr int E0 = I == 33 ? 0 : 4;
-#pragma unroll
-                    for (int e = E0; e < E0 + 4; ++e) ne[e] = __builtin_amdgcn_exp2f(nf[e] * -1.44269504088896340736f);
-                }
-                if constexpr (I == 39 || I == 42) {
-                    constexpr int E0 = I == 39 ? 0 : 4;
-#pragma unroll
-                    for (int e = E0; e < E0 + 4; ++e) ne[e] = __builtin_amdgcn_rcpf(1.0f + ne[e]);
-                }
-                if constexpr (I == 45) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) nw[e] = pack2bf(nf[2 * e] * ne[2 * e], nf[2 * e + 1] * ne[2 * e + 1]);
-                }
-                if constexpr (I == 48) {
-                    const uint4 u = __builtin_bit_cast(uint4, nraw);
-                    typedef unsigned int nu32x4 __attribute__((ext_vector_type(4)));
-                    const nu32x4 o = nflag ? nu32x4{nw[0], nw[1], nw[2], nw[3]} : nu32x4{u.x, u.y, u.z, u.w};
-                    asm volatile("ds_write_b128 %0, %1" ::"v"(npa), "v"(o) : "memory");
-                }
-#endif
                 if constexpr ((I & 3) == 0 && IR_KO_S1 != 6) {   // one fragment of the next step per four MFMAs, into the other set
                     constexpr int R = I >> 2;
                     if constexpr (R < 8) fw[SET ^ 1][R] = lds_read16<R * 1024>(wa);
