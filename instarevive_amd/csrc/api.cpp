@@ -50,6 +50,7 @@ struct SwinBlock {
     const void* mlp_t = nullptr;   // weight tiles + vectors of the fused LN2 -> fc1 -> GELU -> fc2 -> + x kernel (swin_fused.hip), optional
     const float* mlp_v = nullptr;
     const void* proj_t = nullptr;  // proj weights with columns in accumulator order for the fused window attention + projection kernel, optional
+    const void* qkv_t = nullptr;   // qkv weights as ring tiles of swin_mlp_kernel: the PREVIOUS block's fused MLP launch also makes this block's qkv rows, optional
 };
 struct SwinLayer {
     std::vector<SwinBlock> blocks;
@@ -583,13 +584,17 @@ void swinir_run(Run& r, const float* in, float* out, int n, int h, int w) {
     for (const SwinLayer& L : m.layers) {
         const float* cur = xa;
         bool have_ln1 = false;   // xn already holds norm1 of this block: written by the previous block's fused MLP kernel
-        static const bool no_ln_fuse = getenv("IR_NO_SWIN_LN_FUSE") != nullptr;   // experiment knob
+        bool have_qkv = false;   // qkv already holds this block's q | k | v rows: the previous block's fused MLP kernel went on through norm1 and the projection
+        static const bool no_ln_fuse = getenv("IR_NO_SWIN_LN_FUSE") != nullptr;   // experiment knobs
+        static const bool no_qkv_fuse = getenv("IR_NO_SWIN_QKV_FUSE") != nullptr;
         for (size_t j = 0; j < L.blocks.size(); ++j) {
             const SwinBlock& b = L.blocks[j];
             const bool last = j + 1 == L.blocks.size();
-            if (!have_ln1) layernorm(r, cur, xn, nullptr, b.n1.g, b.n1.b, T, m.C, Cp, Cp, 1e-5f);
-            have_ln1 = false;
-            linear(r, b.qkv, xn, (int)T, Cp, qkv, 3 * m.heads * 32, 0, ACT_NONE, nullptr, 0, 0);
+            if (!have_qkv) {
+                if (!have_ln1) layernorm(r, cur, xn, nullptr, b.n1.g, b.n1.b, T, m.C, Cp, Cp, 1e-5f);
+                linear(r, b.qkv, xn, (int)T, Cp, qkv, 3 * m.heads * 32, 0, ACT_NONE, nullptr, 0, 0);
+            }
+            have_ln1 = have_qkv = false;
             if (b.proj_t && !g_ir_plain_kernels) {  // window attention of all heads -> proj -> + x in one launch, no LDS (swin_fused.hip)
                 LAUNCHK(r, PK_SWIN_ATTN_PROJ, 4.0 * (double)T * 64 * m.C + 2.0 * (double)T * m.C * m.C, 0.0,
                        ir_launch_swin_attn_proj(qkv, cur, xb, b.proj_t, b.proj.b, b.biasT, n, gh, gw, (j & 1) ? 4 : 0, scale, r.s), "swin_attn_proj");
@@ -602,10 +607,15 @@ void swinir_run(Run& r, const float* in, float* out, int n, int h, int w) {
                 // not the last block of the RSTB: the kernel also writes norm1 of the NEXT block (its qkv GEMM's input) into xn
                 const bool fuse_ln = !last && !no_ln_fuse && (m.C & 3) == 0;
                 const SwinBlock* nb = fuse_ln ? &L.blocks[j + 1] : nullptr;
-                LAUNCHK(r, PK_SWIN_MLP, 4.0 * (double)T * m.C * m.hid, 4.0 * (double)T * m.C * 2,
-                       ir_launch_swin_mlp(xb, xb, last ? xc : (fuse_ln ? xn : nullptr), b.mlp_t, b.mlp_v, T, m.C, m.hid_p, 1e-5f, r.s,
-                                          nb ? nb->n1.g : nullptr, nb ? nb->n1.b : nullptr), "swin_mlp");
-                have_ln1 = fuse_ln;
+                // ... and, when the host packed that block's qkv weights as ring tiles, its qkv rows: the window attention is the next launch
+                const bool fuse_qkv = nb && nb->qkv_t && nb->qkv.b && !no_qkv_fuse;
+                LAUNCHK(r, PK_SWIN_MLP, 4.0 * (double)T * m.C * m.hid + (fuse_qkv ? 6.0 * (double)T * m.C * m.C : 0.0),
+                       4.0 * (double)T * m.C * 2 + (fuse_qkv ? 2.0 * (double)T * 3 * m.C : 0.0),
+                       ir_launch_swin_mlp(xb, xb, last ? xc : (fuse_qkv ? qkv : (fuse_ln ? xn : nullptr)), b.mlp_t, b.mlp_v, T, m.C, m.hid_p, 1e-5f, r.s,
+                                          nb ? nb->n1.g : nullptr, nb ? nb->n1.b : nullptr, fuse_qkv ? nb->qkv_t : nullptr, fuse_qkv ? nb->qkv.b : nullptr,
+                                          fuse_qkv ? 3 * m.heads * 32 : 0), "swin_mlp");
+                have_ln1 = fuse_ln && !fuse_qkv;
+                have_qkv = fuse_qkv;
             } else {
                 layernorm(r, xb, xn, nullptr, b.n2.g, b.n2.b, T, m.C, Cp, Cp, 1e-5f);
                 linear(r, b.fc1, xn, (int)T, Cp, hid, m.hid_p, 0, ACT_GELU_ERF, nullptr, 0, 0);
@@ -1620,7 +1630,7 @@ int ir_drop_optional(ir_ctx* c, const char* prefix) {
     for (auto it = c->t.begin(); it != c->t.end();) {
         const std::string& k = it->first;
         auto ends = [&](const char* suf) { const size_t l = strlen(suf); return k.size() >= l && k.compare(k.size() - l, l, suf) == 0; };
-        if (k.compare(0, pre.size(), pre) == 0 && (ends(".wup") || ends(".w8") || ends(".g8") || ends(".b8"))) {
+        if (k.compare(0, pre.size(), pre) == 0 && (ends(".wup") || ends(".w8") || ends(".g8") || ends(".b8") || ends(".qkv_t") || ends(".mlp_t") || ends(".mlp_v") || ends(".proj_t"))) {
             if (it->second.p) (void)hipFree(it->second.p);
             it = c->t.erase(it);
             ++c->generation;
@@ -1668,6 +1678,10 @@ int ir_swinir_configure(ir_ctx* c, int embed_dim, int n_layers, const int* depth
             {   // optional: the fused attention + projection form (6 heads x 32 = 192 only)
                 auto it = c->t.find(p + ".proj_t");
                 if (Cp == 192 && heads == 6 && k.proj.b && it != c->t.end() && it->second.bytes >= (size_t)192 * 192 * 2) k.proj_t = it->second.p;
+            }
+            {   // optional: this block's qkv projection inside the previous block's fused MLP launch (18 tiles of 32 rows = 9 ring slots)
+                auto it = c->t.find(p + ".qkv_t");
+                if (Cp == 192 && heads == 6 && it != c->t.end() && it->second.bytes == (size_t)9 * 28672) k.qkv_t = it->second.p;
             }
             L.blocks.push_back(k);
         }

@@ -162,7 +162,8 @@ static inline int ir_attn_dv(int D) { return (D + 31) & ~31; }
 // ---- fused SwinIR block halves (swin_fused.hip)
 // out = x + fc2(gelu(fc1(LayerNorm(x)))) on the fp32 residual stream [T][192] (in place allowed); out2: optional bf16 copy
 int ir_launch_swin_mlp(const float* x, float* out, bf16_t* out2, const void* w_tiles, const float* vec, long T, int C, int hid_p, float eps,
-                       hipStream_t s, const float* next_g = nullptr, const float* next_b = nullptr);
+                       hipStream_t s, const float* next_g = nullptr, const float* next_b = nullptr, const void* qkv_tiles = nullptr,
+                       const float* qkv_b = nullptr, int qkv_n = 0);   // qkv_tiles: out2 = the next block's qkv rows [T][qkv_n] instead of its norm1
 // window attention of all heads + output projection + residual in one launch (swin_fused.hip): qkv [tokens][576] bf16, xres / out [tokens][192]
 // fp32 (may alias), proj_t = proj weights [192][192] bf16 with columns in accumulator order (weights.pack_swinir)
 int ir_launch_swin_attn_proj(const bf16_t* qkv, const float* xres, float* out, const void* proj_t, const float* proj_b, const float* biasT, int B,

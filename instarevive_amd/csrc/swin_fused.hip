@@ -45,10 +45,15 @@ constexpr int LDS_TOTAL = STG_OFF + 8 * STG_WAVE;   // 161 792 B
 // of the NEXT SwinTransformerBlock (swinir.py:263), whose qkv GEMM reads out2 directly; the stand-alone LayerNorm launch between two
 // blocks of an RSTB disappears. The new token row is still in registers when the last product ends, so this costs one more pass through
 // the wave-private staging area.
-template <bool LN_NEXT>
+// QKV (with LN_NEXT): the next block's qkv projection too (swinir.py:263-271 up to the window partition: per token, so any tiling of the
+// tokens serves). wq: NQ / 2 ring slots of two W1-format tiles each (32 output channels x 192 k positions, weights.pack_swin_qkv_tiles), bq: the
+// 32 NQ biases; LN(new row) is packed straight into B fragments - as LN2(x) is at the top - and out2 receives [T][32 NQ] bf16 (q | k | v of the
+// next block) instead of the normalised row: the qkv GEMM launch between two blocks of an RSTB and its input's round trip disappear.
+template <bool LN_NEXT, bool QKV = false>
 __global__ __launch_bounds__(512, 1) void swin_mlp_kernel(const float* __restrict__ x, float* __restrict__ out, bf16_t* __restrict__ out2,
                                                           const unsigned char* __restrict__ w, const float* __restrict__ vec, long T, int C,
-                                                          int NJ, float eps, const float* __restrict__ next_g, const float* __restrict__ next_b) {
+                                                          int NJ, float eps, const float* __restrict__ next_g, const float* __restrict__ next_b,
+                                                          const unsigned char* __restrict__ wq, const float* __restrict__ bq, int NQ) {
     using namespace swf;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -57,8 +62,9 @@ __global__ __launch_bounds__(512, 1) void swin_mlp_kernel(const float* __restric
     const long tok0 = (long)blockIdx.x * 256 + wu * 32;                  // first token of this wave
 
     // weight ring: piece q of a step's 28 KB goes to wave q % 8 (3.5 pieces per wave: waves 0-3 take four)
+    const int NS = NJ + (QKV ? NQ / 2 : 0);   // ring steps: the MLP's, then the qkv tile pairs
     auto stage = [&](int jt, int slot) {
-        const unsigned char* src = w + (long)jt * SLOT + lane * 16;
+        const unsigned char* src = (QKV && jt >= NJ ? wq + (long)(jt - NJ) * SLOT : w + (long)jt * SLOT) + lane * 16;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (wu + 8 * i < PIECES) sw_glds16(src + (wu + 8 * i) * 1024, (sw_lds_t)(smem + slot * SLOT + (wu + 8 * i) * 1024));
@@ -153,7 +159,7 @@ __global__ __launch_bounds__(512, 1) void swin_mlp_kernel(const float* __restric
     for (int jt = 0; jt < NJ; ++jt) {
         wait_dma();
         __syncthreads();           // tile jt has landed; every wave is done with tile jt - 1
-        if (jt + 1 < NJ) stage(jt + 1, (jt + 1) & 1);
+        if (jt + 1 < NS) stage(jt + 1, (jt + 1) & 1);
         if (jt == NJ - 1) load_half(x, 0);   // the residual rows again (first half), under the last step's arithmetic
         const unsigned char* sl = smem + (jt & 1) * SLOT;
         // H^T = W1[jt] . LN(x)^T
@@ -242,38 +248,89 @@ __global__ __launch_bounds__(512, 1) void swin_mlp_kernel(const float* __restric
     // straight from the accumulator layout: lanes r and r + 32 hold adjacent 8-byte pieces of token r's row (16 B per token and
     // instruction; a write needs no staging - nothing waits for it)
     const long gtok = tok0 + r;
-    if (gtok < T) {
-        bf16_t* orow = out2 + gtok * CP + 4 * h;
+    if constexpr (!QKV) {
+        if (gtok < T) {
+            bf16_t* orow = out2 + gtok * CP + 4 * h;
 #pragma unroll
-        for (int t = 0; t < 6; ++t)
+            for (int t = 0; t < 6; ++t)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int c0 = 32 * t + 8 * i + 4 * h;
+                for (int i = 0; i < 4; ++i) {
+                    const int c0 = 32 * t + 8 * i + 4 * h;
+                    const f32x4 g = *reinterpret_cast<const f32x4*>(vs + NEXT_OFF + c0), b = *reinterpret_cast<const f32x4*>(vs + NEXT_OFF + CP + c0);
+                    const f32x4 v = (xr[t][i] - mean2) * rstd2 * g + b;
+                    *reinterpret_cast<uint2*>(orow + 32 * t + 8 * i) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+                }
+        }
+    } else {
+        // B fragments of LN(new row), as xn above
+        bf16x8 xq[12];
+#pragma unroll
+        for (int s = 0; s < 12; ++s) {
+            uint32_t wv[4];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int t = s >> 1, i = 2 * (s & 1) + q, c0 = 32 * t + 8 * i + 4 * h;
                 const f32x4 g = *reinterpret_cast<const f32x4*>(vs + NEXT_OFF + c0), b = *reinterpret_cast<const f32x4*>(vs + NEXT_OFF + CP + c0);
                 const f32x4 v = (xr[t][i] - mean2) * rstd2 * g + b;
-                *reinterpret_cast<uint2*>(orow + 32 * t + 8 * i) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+                wv[2 * q] = pack2bf(v[0], v[1]);
+                wv[2 * q + 1] = pack2bf(v[2], v[3]);
             }
+            xq[s] = __builtin_bit_cast(bf16x8, make_uint4(wv[0], wv[1], wv[2], wv[3]));
+        }
+        const int LDQ = 32 * NQ;
+        bf16_t* orow = out2 + (gtok < T ? gtok : 0) * LDQ + 4 * h;
+        for (int st = 0; st < NQ / 2; ++st) {
+            const int jt = NJ + st;
+            f32x4 bv[2][4];   // the two tiles' biases (L2-resident, the same for every token): in flight across the barrier
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bv[u][i] = *reinterpret_cast<const f32x4*>(bq + 32 * (2 * st + u) + 8 * i + 4 * h);
+            wait_dma();
+            __syncthreads();       // tile pair st has landed; every wave is done with the previous slot
+            if (jt + 1 < NS) stage(jt + 1, (jt + 1) & 1);
+            const unsigned char* sl = smem + (jt & 1) * SLOT;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                f32x16 acc;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) acc[g] = 0.f;
+#pragma unroll
+                for (int s = 0; s < 12; ++s) acc = mfma32(*reinterpret_cast<const bf16x8*>(sl + u * W1_TILE + a1 + s * 32), xq[s], acc);
+                if (gtok < T) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        *reinterpret_cast<uint2*>(orow + 32 * (2 * st + u) + 8 * i) =
+                            make_uint2(pack2bf(acc[4 * i] + bv[u][i][0], acc[4 * i + 1] + bv[u][i][1]), pack2bf(acc[4 * i + 2] + bv[u][i][2], acc[4 * i + 3] + bv[u][i][3]));
+                }
+            }
+        }
     }
 }
 
 int ir_launch_swin_mlp(const float* x, float* out, bf16_t* out2, const void* w_tiles, const float* vec, long T, int C, int hid_p, float eps,
-                       hipStream_t s, const float* next_g, const float* next_b) {
+                       hipStream_t s, const float* next_g, const float* next_b, const void* qkv_tiles, const float* qkv_b, int qkv_n) {
     if (T <= 0 || C <= 0 || C > swf::CP || hid_p <= 0 || (hid_p & 31) || hid_p > 512) return -2;
     if ((next_g != nullptr) != (next_b != nullptr) || (next_g && (!out2 || (C & 3)))) return -2;
-    const int NJ = hid_p / 32;
+    if (qkv_tiles && (!next_g || !qkv_b || qkv_n <= 0 || (qkv_n & 63))) return -2;   // pairs of 32-channel tiles behind the next block's norm1
+    const int NJ = hid_p / 32, NQ = qkv_tiles ? qkv_n / 32 : 0;
     const size_t lds = swf::LDS_TOTAL;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(swin_mlp_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(swin_mlp_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(swin_mlp_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
         attr_set = true;
     }
-    if (next_g)
-        hipLaunchKernelGGL(swin_mlp_kernel<true>, dim3((unsigned)((T + 255) / 256)), dim3(512), lds, s, x, out, out2, reinterpret_cast<const unsigned char*>(w_tiles),
-                           vec, T, C, NJ, eps, next_g, next_b);
+    const dim3 grid((unsigned)((T + 255) / 256));
+    const unsigned char* wt = reinterpret_cast<const unsigned char*>(w_tiles);
+    const unsigned char* wq = reinterpret_cast<const unsigned char*>(qkv_tiles);
+    if (qkv_tiles)
+        hipLaunchKernelGGL((swin_mlp_kernel<true, true>), grid, dim3(512), lds, s, x, out, out2, wt, vec, T, C, NJ, eps, next_g, next_b, wq, qkv_b, NQ);
+    else if (next_g)
+        hipLaunchKernelGGL((swin_mlp_kernel<true, false>), grid, dim3(512), lds, s, x, out, out2, wt, vec, T, C, NJ, eps, next_g, next_b, wq, qkv_b, NQ);
     else
-        hipLaunchKernelGGL(swin_mlp_kernel<false>, dim3((unsigned)((T + 255) / 256)), dim3(512), lds, s, x, out, out2, reinterpret_cast<const unsigned char*>(w_tiles),
-                           vec, T, C, NJ, eps, next_g, next_b);
+        hipLaunchKernelGGL((swin_mlp_kernel<false, false>), grid, dim3(512), lds, s, x, out, out2, wt, vec, T, C, NJ, eps, next_g, next_b, wq, qkv_b, NQ);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -161,6 +161,19 @@ def pack_swin_mlp(fc1_w, fc1_b, fc2_w, fc2_b, n2_g, n2_b, C, Cp, hid_p):
     return tiles.contiguous(), vec.contiguous()
 
 
+def pack_swin_qkv_tiles(qkv_bits, Cp):
+    """The padded qkv weight [3 Cp][Cp] (bf16 bits, rows already in the q | k | v x head x 32 layout) as ring slots of swin_mlp_kernel's qkv
+    stage: per 32 output channels one W1-format tile (400-byte rows, k positions in _acc_order, 13 KB), two tiles per 28 KB slot."""
+    w = qkv_bits[:, _acc_order(Cp)]
+    nq = w.shape[0] // 32
+    slots = torch.zeros((nq + 1) // 2, 28672, dtype=torch.uint8)
+    for t in range(nq):
+        t1 = torch.zeros(32, 200, dtype=torch.int16)
+        t1[:, :Cp] = w[32 * t:32 * t + 32]
+        slots[t // 2, (t % 2) * 13312:(t % 2) * 13312 + 12800] = t1.reshape(-1).view(torch.uint8)
+    return slots.contiguous()
+
+
 def pack_swinir(sd, cfg):
     C, heads = cfg["embed_dim"], cfg["num_heads"][0]
     hd, Cp = C // heads, heads * 32
@@ -192,6 +205,8 @@ def pack_swinir(sd, cfg):
                 pw = out[d + "proj.w"][:, _acc_order(Cp)]                       # [192 rows][192 permuted columns], bf16 bits
                 pw = pw.reshape(6, 32, 6, 2, 2, 8)                             # [ct][r][head][s2][h][8]
                 out[d + "proj_t"] = pw.permute(2, 0, 3, 4, 1, 5).contiguous()  # [head][ct][s2][h][r][8] -> lane = h * 32 + r
+                if j > 0:   # norm1 + qkv of blocks 1.. of an RSTB run inside the previous block's fused MLP launch
+                    out[d + "qkv_t"] = pack_swin_qkv_tiles(out[d + "qkv.w"], Cp)
             out[d + "fc1.w"] = pack_linear(sd[s + "mlp.fc1.weight"], hid_p, Cp)
             out[d + "fc1.b"] = pad_vec(sd[s + "mlp.fc1.bias"], hid_p)
             out[d + "fc2.w"] = pack_linear(sd[s + "mlp.fc2.weight"], Cp, hid_p)

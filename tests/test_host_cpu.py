@@ -70,6 +70,24 @@ def test_swin_packing_head_padding():
     assert set(W.swinir_expected_keys(cfg)) >= set(sd)
 
 
+def test_swin_qkv_ring_tiles():
+    """pack_swin_qkv_tiles: slot t // 2, tile t % 2 (13312 B apart), row r (400 B apart), k position p holds the padded qkv weight
+    [32 t + r][_acc_order(192)[p]] - the layout swin_mlp_kernel<true, true> streams through its LDS ring; only blocks 1.. of an RSTB get one."""
+    from instarevive_amd import weights as W
+    cfg = dict(embed_dim=60, depths=[2], num_heads=[6], window_size=8, mlp_ratio=2, img_range=1.0)
+    sd = {k: torch.randn(*s) for k, s in W.swinir_shapes(cfg).items()}
+    p = W.pack_swinir(sd, cfg)
+    assert "swin.l0.b0.qkv_t" not in p
+    t, w = p["swin.l0.b1.qkv_t"], p["swin.l0.b1.qkv.w"]
+    assert t.dtype == torch.uint8 and t.shape == (9, 28672)
+    order = W._acc_order(192)
+    for tile, r, pos in ((0, 0, 0), (5, 17, 9), (17, 31, 191), (8, 3, 100)):
+        off = (tile % 2) * 13312 + r * 400 + pos * 2
+        got = t[tile // 2, off:off + 2].view(torch.int16)[0]
+        assert got == w[32 * tile + r, order[pos]]
+    assert t[:, 26624:].abs().sum() == 0   # the slot's tail (the MLP's W2 area) is unused
+
+
 def test_sliding_windows_and_loaders():
     from instarevive_amd.pipeline import _sliding_windows
     from instarevive_amd import utils

@@ -93,6 +93,25 @@ def test_swinir_full_arch_64():
     check(m(x.cuda()), oswin.swinir_forward(sd, x), "swinir full arch 64x64", **TOL_XFMR)
 
 
+def test_swinir_qkv_inside_the_mlp_launch_ragged_tokens():
+    """Blocks 1.. of an RSTB get norm1 and their qkv rows from the previous block's swin_mlp_kernel<true, true> launch (weights.pack_swin_qkv_tiles).
+    24 x 40 token grid = 960 tokens: three full workgroups and a ragged one of 192; two RSTBs of three blocks so that a fused and an
+    unfused first block alternate. Against the fp32 oracle and against the plain kernel set (separate LayerNorm / qkv GEMM launches)."""
+    cfg = dict(depths=[3, 3], num_heads=[6, 6])
+    m, sd = make_swin(cfg, seed=141)
+    x = det_input(25, (1, 3, 192, 320))
+    fast = m(x.cuda())
+    check(fast, oswin.swinir_forward(sd, x, cfg), "swinir 192x320, qkv inside the MLP launch", **TOL_XFMR)
+    ctx = m.ctx
+    assert ctx.has("swin.l0.b1.qkv_t") and ctx.has("swin.l1.b2.qkv_t") and not ctx.has("swin.l0.b0.qkv_t")
+    ctx.check(ctx.lib.ir_set_plain_kernels(ctx.h, 1), "ir_set_plain_kernels")
+    try:
+        plain = m(x.cuda())
+    finally:
+        ctx.check(ctx.lib.ir_set_plain_kernels(ctx.h, 0), "ir_set_plain_kernels")
+    check(fast, plain.float().cpu(), "swinir 192x320 fused vs plain kernels", **TOL_XFMR)
+
+
 @pytest.mark.parametrize("cfg", [dict(embed_dim=64, depths=[2], num_heads=[4]),                 # Cp = 128: no fused MLP / attention+proj form
                                  dict(embed_dim=128, depths=[2], num_heads=[8]),                # Cp = 256
                                  dict(embed_dim=180, depths=[2], num_heads=[6], mlp_ratio=4)])  # Cp = 192 but 736 hidden units > 512: unfused MLP
