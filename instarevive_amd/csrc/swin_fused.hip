@@ -278,7 +278,7 @@ __global__ __launch_bounds__(512, 1) void swin_mlp_kernel(const float* __restric
             xq[s] = __builtin_bit_cast(bf16x8, make_uint4(wv[0], wv[1], wv[2], wv[3]));
         }
         const int LDQ = 32 * NQ;
-        bf16_t* orow = out2 + (gtok < T ? gtok : 0) * LDQ + 4 * h;
+        static_assert(STG_WAVE == 3 * 4096, "the qkv rows leave through the three staging slices in turn");
         for (int st = 0; st < NQ / 2; ++st) {
             const int jt = NJ + st;
             f32x4 bv[2][4];   // the two tiles' biases (L2-resident, the same for every token): in flight across the barrier
@@ -290,6 +290,10 @@ __global__ __launch_bounds__(512, 1) void swin_mlp_kernel(const float* __restric
             __syncthreads();       // tile pair st has landed; every wave is done with the previous slot
             if (jt + 1 < NS) stage(jt + 1, (jt + 1) & 1);
             const unsigned char* sl = smem + (jt & 1) * SLOT;
+            // the pair's 64 channels of the wave's 32 tokens = 128-byte row segments: through a staging slice (16-byte chunk c of token k at slot
+            // c ^ ((k >> 1) & 7), as the token rows above) and out as full segments, 8 lanes per token. Written straight from the accumulator
+            // layout (8 bytes per lane, 32 rows per instruction) the tail was bound by the addresser's line rate, as swin_attn_proj_kernel's was.
+            unsigned char* sb = stg + (st % 3) * 4096;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 f32x16 acc;
@@ -297,12 +301,20 @@ __global__ __launch_bounds__(512, 1) void swin_mlp_kernel(const float* __restric
                 for (int g = 0; g < 16; ++g) acc[g] = 0.f;
 #pragma unroll
                 for (int s = 0; s < 12; ++s) acc = mfma32(*reinterpret_cast<const bf16x8*>(sl + u * W1_TILE + a1 + s * 32), xq[s], acc);
-                if (gtok < T) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        *reinterpret_cast<uint2*>(orow + 32 * (2 * st + u) + 8 * i) =
-                            make_uint2(pack2bf(acc[4 * i] + bv[u][i][0], acc[4 * i + 1] + bv[u][i][1]), pack2bf(acc[4 * i + 2] + bv[u][i][2], acc[4 * i + 3] + bv[u][i][3]));
-                }
+                for (int i = 0; i < 4; ++i)
+                    *reinterpret_cast<uint2*>(sb + r * 128 + (((4 * u + i) ^ ((r >> 1) & 7)) << 4) + 8 * h) =
+                        make_uint2(pack2bf(acc[4 * i] + bv[u][i][0], acc[4 * i + 1] + bv[u][i][1]), pack2bf(acc[4 * i + 2] + bv[u][i][2], acc[4 * i + 3] + bv[u][i][3]));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int pc = 0; pc < 4; ++pc) {
+                const int tk = 8 * pc + ptok;
+                const uint4 v = *reinterpret_cast<const uint4*>(sb + pc * 1024 + lane * 16);
+                const long gt = tok0 + tk;
+                if (gt < T) *reinterpret_cast<uint4*>(out2 + gt * LDQ + 64 * st + 8 * (pslot ^ ((tk >> 1) & 7))) = v;
             }
         }
     }
