@@ -146,11 +146,17 @@ __global__ __launch_bounds__(512, 1) void swin_mlp_kernel(const float* __restric
         xn[s] = __builtin_bit_cast(bf16x8, make_uint4(wv[0], wv[1], wv[2], wv[3]));
     }
 
+    // The output accumulators start at x + b2 (the residual row is in registers in exactly their layout: register 4i + e of tile t is channel
+    // 32t + 8i + 4h + e), so the second product lands on the residual stream directly and the row is not fetched a second time at the end.
     f32x16 y[6];
 #pragma unroll
     for (int ot = 0; ot < 6; ++ot)
 #pragma unroll
-        for (int g = 0; g < 16; ++g) y[ot][g] = 0.f;
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 b2 = *reinterpret_cast<const f32x4*>(vs + 2 * CP + 32 * NJ + 32 * ot + 8 * i + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[ot][4 * i + e] = xr[ot][i][e] + b2[e];
+        }
     const int a1 = r * W1_ROW + h * 16;                 // + s * 32
     const int a2 = W1_TILE + r * W2_ROW + h * 16;       // + ot * 32 * W2_ROW + s2 * 32
     // (Waves w and w + 4 share a SIMD and run this loop in lockstep - both in their MFMAs, then both in their GELU arithmetic: the
@@ -160,7 +166,6 @@ __global__ __launch_bounds__(512, 1) void swin_mlp_kernel(const float* __restric
         wait_dma();
         __syncthreads();           // tile jt has landed; every wave is done with tile jt - 1
         if (jt + 1 < NS) stage(jt + 1, (jt + 1) & 1);
-        if (jt == NJ - 1) load_half(x, 0);   // the residual rows again (first half), under the last step's arithmetic
         const unsigned char* sl = smem + (jt & 1) * SLOT;
         // H^T = W1[jt] . LN(x)^T
         f32x16 hacc;
@@ -188,22 +193,18 @@ __global__ __launch_bounds__(512, 1) void swin_mlp_kernel(const float* __restric
 #pragma unroll
             for (int q = 0; q < 2; ++q) y[ot] = mfma32(*reinterpret_cast<const bf16x8*>(sl + a2 + ot * 32 * W2_ROW + q * 32), hb[q], y[ot]);
     }
-    // ---- + b2 + x -> residual stream, three slices at a time through the staging area: the lane replaces its groups of the staged
-    // input rows by the results (accumulator layout: register 4i + e of tile t is channel 32t + 8i + 4h + e), then the image leaves
-    // with coalesced 16-byte stores (8 lanes per 128-byte line), the bf16 copy as 8-byte stores
+    // ---- the new rows -> residual stream, three slices at a time through the staging area: the lane writes its groups (accumulator layout:
+    // register 4i + e of tile t is channel 32t + 8i + 4h + e), then the image leaves with coalesced 16-byte stores (8 lanes per 128-byte
+    // line), the bf16 copy as 8-byte stores
 #pragma unroll
     for (int hf = 0; hf < 2; ++hf) {
-        if (hf == 1) load_half(x, 3);
-        wait_dma();
 #pragma unroll
         for (int ts = 0; ts < 3; ++ts)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int t = 3 * hf + ts;
-                const f32x4 b2 = *reinterpret_cast<const f32x4*>(vs + 2 * CP + 32 * NJ + 32 * t + 8 * i + 4 * h);
-                f32x4* pa = reinterpret_cast<f32x4*>(frag_addr(ts, i));
-                const f32x4 nx = f32x4{y[t][4 * i], y[t][4 * i + 1], y[t][4 * i + 2], y[t][4 * i + 3]} + b2 + *pa;
-                *pa = nx;
+                const f32x4 nx = f32x4{y[t][4 * i], y[t][4 * i + 1], y[t][4 * i + 2], y[t][4 * i + 3]};
+                *reinterpret_cast<f32x4*>(frag_addr(ts, i)) = nx;
                 if (ln_next) xr[t][i] = nx;   // the new row, kept for the next block's LayerNorm
             }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
