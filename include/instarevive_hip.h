@@ -57,7 +57,7 @@ const char* ir_last_error(ir_ctx* ctx);
  * produced by instarevive_amd/weights.py from the reference checkpoints' own key names. */
 int ir_upload(ir_ctx* ctx, const char* name, const void* host, size_t bytes);
 /* Forget the optional weight forms (".wup" sub-pixel phase matrices, ".w8" / ".g8" / ".b8" fp8 forms, SwinIR's ".mlp_t" / ".mlp_v" / ".proj_t" /
- * ".qkv_t" fused-kernel tiles) under "<prefix>." - called by the host loader
+ * ".qkv_t" / ".biasM" fused-kernel forms) under "<prefix>." - called by the host loader
  * before it uploads a model of that family, so that a *_configure never binds a form left behind by a previously loaded model. No reference
  * counterpart (the reference builds torch modules, `load_state_dict` replaces everything). Returns the number of tensors dropped, < 0 on error. */
 int ir_drop_optional(ir_ctx* ctx, const char* prefix);

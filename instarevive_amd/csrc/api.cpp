@@ -47,6 +47,7 @@ struct SwinBlock {
     Norm n1, n2;
     Conv qkv, proj, fc1, fc2;
     const float* biasT = nullptr;
+    const float* biasM = nullptr;  // shifted blocks: [4 window classes][heads][64][64] bias tables with the attention mask folded in (the fused kernels), optional
     const void* mlp_t = nullptr;   // weight tiles + vectors of the fused LN2 -> fc1 -> GELU -> fc2 -> + x kernel (swin_fused.hip), optional
     const float* mlp_v = nullptr;
     const void* proj_t = nullptr;  // proj weights with columns in accumulator order for the fused window attention + projection kernel, optional
@@ -196,7 +197,7 @@ enum { PC_CONV3X3 = 0, PC_LINEAR, PC_FLASH_ATTN, PC_SWIN_ATTN, PC_GROUPNORM, PC_
 // each with the algorithmic FLOPs (un-padded dims) / bytes of its launches. Keep KERNEL_NAMES and KERNEL_CLASS in step.
 enum { PK_CONV_S1 = 0, PK_CONV_HALO_PP, PK_CONV_HALO, PK_CONV_S1_FP8, PK_CONV_FP8, PK_CONV_IGEMM, PK_GEMM_PP, PK_LINEAR_IGEMM, PK_SWIN_MLP, PK_ATTN_SELF, PK_ATTN_SELF_FP8, PK_ATTN_D512_FP8,
        PK_ATTN_D512, PK_ATTN_CROSS, PK_ATTN_OTHER, PK_SWIN_ATTN_PROJ, PK_SWIN_ATTN, PK_GN_APPLY, PK_GN_FULL, PK_LAYERNORM, PK_SOFTMAX, PK_TRANSPOSE, PK_OTHER, PK_VAE_CONV_IN, PK_VAE_CONV_OUT,
-       PK_COUNT };
+       PK_SWIN_BLOCK, PK_COUNT };
 static const char* const KERNEL_NAMES[PK_COUNT] = {
     "conv3x3/conv_halo_s1_kernel", "conv3x3/conv_halo_pp_kernel", "conv3x3/conv_halo_kernel", "conv3x3/conv_halo_s1_fp8_kernel",
     "conv3x3/conv_halo_kernel<.., fp8>", "conv3x3/igemm_kernel<taps=9>",
@@ -206,10 +207,11 @@ static const char* const KERNEL_NAMES[PK_COUNT] = {
     "flash_attn/flash_attn_x72_kernel (DiT cross-attention)", "flash_attn/other", "swin_attn/swin_attn_proj_kernel", "swin_attn/swin_window_attn_kernel",
     "groupnorm/gn_finalize_groups+gn_apply (statistics from the conv epilogue)", "groupnorm/gn_partial+gn_finalize+gn_apply", "layernorm/layernorm_*_kernel",
     "softmax_rows/softmax_rows_kernel", "transpose/transpose_v*", "other/layout+glue",
-    "conv3x3/vae_conv_in_kernel (3->128, store-bound)", "conv3x3/vae_norm_conv_out_kernel (GroupNorm+SiLU+128->3, read-bound)"};
+    "conv3x3/vae_conv_in_kernel (3->128, store-bound)", "conv3x3/vae_norm_conv_out_kernel (GroupNorm+SiLU+128->3, read-bound)",
+    "linear/swin_block_kernel (window attention + proj + MLP + the next block's norm1 / qkv)"};
 static const int KERNEL_CLASS[PK_COUNT] = {PC_CONV3X3, PC_CONV3X3, PC_CONV3X3, PC_CONV3X3, PC_CONV3X3, PC_CONV3X3, PC_LINEAR, PC_LINEAR, PC_LINEAR, PC_FLASH_ATTN, PC_FLASH_ATTN,
                                            PC_FLASH_ATTN, PC_FLASH_ATTN, PC_FLASH_ATTN, PC_FLASH_ATTN, PC_SWIN_ATTN, PC_SWIN_ATTN, PC_GROUPNORM, PC_GROUPNORM, PC_LAYERNORM,
-                                           PC_SOFTMAX, PC_TRANSPOSE, PC_OTHER, PC_CONV3X3, PC_CONV3X3};
+                                           PC_SOFTMAX, PC_TRANSPOSE, PC_OTHER, PC_CONV3X3, PC_CONV3X3, PC_LINEAR};
 static const int CLASS_DEFAULT_KERNEL[PC_COUNT] = {PK_CONV_IGEMM, PK_LINEAR_IGEMM, PK_ATTN_OTHER, PK_SWIN_ATTN, PK_GN_FULL, PK_LAYERNORM, PK_SOFTMAX, PK_TRANSPOSE, PK_OTHER};
 struct ProfRec {
     int cls, kid;
@@ -595,23 +597,39 @@ void swinir_run(Run& r, const float* in, float* out, int n, int h, int w) {
                 linear(r, b.qkv, xn, (int)T, Cp, qkv, 3 * m.heads * 32, 0, ACT_NONE, nullptr, 0, 0);
             }
             have_ln1 = have_qkv = false;
-            if (b.proj_t && !g_ir_plain_kernels) {  // window attention of all heads -> proj -> + x in one launch, no LDS (swin_fused.hip)
-                LAUNCHK(r, PK_SWIN_ATTN_PROJ, 4.0 * (double)T * 64 * m.C + 2.0 * (double)T * m.C * m.C, 0.0,
-                       ir_launch_swin_attn_proj(qkv, cur, xb, b.proj_t, b.proj.b, b.biasT, n, gh, gw, (j & 1) ? 4 : 0, scale, r.s), "swin_attn_proj");
+            static const bool no_block_fuse = getenv("IR_NO_SWIN_BLOCK_FUSE") != nullptr;   // experiment knob: attention + proj and the MLP as two launches
+            const bool fuse_ln = !last && !no_ln_fuse && (m.C & 3) == 0;      // not the last block of the RSTB: the MLP launch also makes norm1 of the NEXT block ...
+            const SwinBlock* nb = fuse_ln ? &L.blocks[j + 1] : nullptr;
+            const bool fuse_qkv = nb && nb->qkv_t && nb->qkv.b && !no_qkv_fuse;   // ... and, when the host packed that block's qkv weights as ring tiles, its qkv rows
+            const double f_attn = 4.0 * (double)T * 64 * m.C + 2.0 * (double)T * m.C * m.C;
+            const double f_mlp = 4.0 * (double)T * m.C * m.hid + (fuse_qkv ? 6.0 * (double)T * m.C * m.C : 0.0);
+            const double b_mlp = 4.0 * (double)T * m.C * 2 + (fuse_qkv ? 2.0 * (double)T * 3 * m.C : 0.0);
+            bf16_t* mlp_out2 = last ? xc : (fuse_qkv ? qkv : (fuse_ln ? xn : nullptr));
+            const int shift = (j & 1) ? 4 : 0;
+            const float* fbias = shift ? b.biasM : b.biasT;   // the fused attention kernels pick a masked table per window class in a shifted block
+            const bool fused_attn = b.proj_t && fbias && !g_ir_plain_kernels;
+            if (fused_attn && b.mlp_t && !no_block_fuse) {
+                // the whole block behind its qkv projection in ONE launch: the post-attention row stays in registers (swin_block_kernel)
+                LAUNCHK(r, PK_SWIN_BLOCK, f_attn + f_mlp, b_mlp + 2.0 * (double)T * 3 * m.C,
+                       ir_launch_swin_block(qkv, cur, xb, mlp_out2, b.proj_t, b.proj.b, fbias, n, gh, gw, shift, scale, b.mlp_t, b.mlp_v, m.C, m.hid_p,
+                                            1e-5f, r.s, nb ? nb->n1.g : nullptr, nb ? nb->n1.b : nullptr, fuse_qkv ? nb->qkv_t : nullptr,
+                                            fuse_qkv ? nb->qkv.b : nullptr, fuse_qkv ? 3 * m.heads * 32 : 0), "swin_block");
+                have_ln1 = fuse_ln && !fuse_qkv;
+                have_qkv = fuse_qkv;
+                cur = xb;
+                continue;
+            }
+            if (fused_attn) {  // window attention of all heads -> proj -> + x in one launch, no LDS (swin_fused.hip)
+                LAUNCHK(r, PK_SWIN_ATTN_PROJ, f_attn, 0.0,
+                       ir_launch_swin_attn_proj(qkv, cur, xb, b.proj_t, b.proj.b, fbias, n, gh, gw, shift, scale, r.s), "swin_attn_proj");
             } else {
                 LAUNCHK(r, PK_SWIN_ATTN, 4.0 * (double)T * 64 * m.C, 0.0,
                        ir_launch_swin_attn(qkv, att, b.biasT, n, gh, gw, m.heads, 3 * m.heads * 32, Cp, (j & 1) ? 4 : 0, scale, r.s), "swin_attn");
                 linear(r, b.proj, att, (int)T, Cp, xb, Cp, 1, ACT_NONE, cur, 1, Cp);
             }
             if (b.mlp_t && !g_ir_plain_kernels) {  // LN2 -> fc1 -> GELU -> fc2 -> + x in one kernel, the token's state in registers throughout
-                // not the last block of the RSTB: the kernel also writes norm1 of the NEXT block (its qkv GEMM's input) into xn
-                const bool fuse_ln = !last && !no_ln_fuse && (m.C & 3) == 0;
-                const SwinBlock* nb = fuse_ln ? &L.blocks[j + 1] : nullptr;
-                // ... and, when the host packed that block's qkv weights as ring tiles, its qkv rows: the window attention is the next launch
-                const bool fuse_qkv = nb && nb->qkv_t && nb->qkv.b && !no_qkv_fuse;
-                LAUNCHK(r, PK_SWIN_MLP, 4.0 * (double)T * m.C * m.hid + (fuse_qkv ? 6.0 * (double)T * m.C * m.C : 0.0),
-                       4.0 * (double)T * m.C * 2 + (fuse_qkv ? 2.0 * (double)T * 3 * m.C : 0.0),
-                       ir_launch_swin_mlp(xb, xb, last ? xc : (fuse_qkv ? qkv : (fuse_ln ? xn : nullptr)), b.mlp_t, b.mlp_v, T, m.C, m.hid_p, 1e-5f, r.s,
+                LAUNCHK(r, PK_SWIN_MLP, f_mlp, b_mlp,
+                       ir_launch_swin_mlp(xb, xb, mlp_out2, b.mlp_t, b.mlp_v, T, m.C, m.hid_p, 1e-5f, r.s,
                                           nb ? nb->n1.g : nullptr, nb ? nb->n1.b : nullptr, fuse_qkv ? nb->qkv_t : nullptr, fuse_qkv ? nb->qkv.b : nullptr,
                                           fuse_qkv ? 3 * m.heads * 32 : 0), "swin_mlp");
                 have_ln1 = fuse_ln && !fuse_qkv;
@@ -1630,7 +1648,7 @@ int ir_drop_optional(ir_ctx* c, const char* prefix) {
     for (auto it = c->t.begin(); it != c->t.end();) {
         const std::string& k = it->first;
         auto ends = [&](const char* suf) { const size_t l = strlen(suf); return k.size() >= l && k.compare(k.size() - l, l, suf) == 0; };
-        if (k.compare(0, pre.size(), pre) == 0 && (ends(".wup") || ends(".w8") || ends(".g8") || ends(".b8") || ends(".qkv_t") || ends(".mlp_t") || ends(".mlp_v") || ends(".proj_t"))) {
+        if (k.compare(0, pre.size(), pre) == 0 && (ends(".wup") || ends(".w8") || ends(".g8") || ends(".b8") || ends(".qkv_t") || ends(".biasM") || ends(".mlp_t") || ends(".mlp_v") || ends(".proj_t"))) {
             if (it->second.p) (void)hipFree(it->second.p);
             it = c->t.erase(it);
             ++c->generation;
@@ -1678,6 +1696,10 @@ int ir_swinir_configure(ir_ctx* c, int embed_dim, int n_layers, const int* depth
             {   // optional: the fused attention + projection form (6 heads x 32 = 192 only)
                 auto it = c->t.find(p + ".proj_t");
                 if (Cp == 192 && heads == 6 && k.proj.b && it != c->t.end() && it->second.bytes >= (size_t)192 * 192 * 2) k.proj_t = it->second.p;
+            }
+            {   // optional: the masked bias tables of a shifted block (weights.swin_masked_bias)
+                auto it = c->t.find(p + ".biasM");
+                if (heads == 6 && it != c->t.end() && it->second.bytes == (size_t)4 * heads * 4096 * 4) k.biasM = (const float*)it->second.p;
             }
             {   // optional: this block's qkv projection inside the previous block's fused MLP launch (18 tiles of 32 rows = 9 ring slots)
                 auto it = c->t.find(p + ".qkv_t");

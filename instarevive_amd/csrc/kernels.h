@@ -169,6 +169,13 @@ int ir_launch_swin_mlp(const float* x, float* out, bf16_t* out2, const void* w_t
 int ir_launch_swin_attn_proj(const bf16_t* qkv, const float* xres, float* out, const void* proj_t, const float* proj_b, const float* biasT, int B,
                              int H, int W, int shift, float scale, hipStream_t s);
 
+// the whole block behind its qkv projection in one launch (swin_block_kernel): the two above back to back with the post-attention row kept in registers;
+// x_in / x_out may alias, out2 as in ir_launch_swin_mlp (bf16 copy of the new rows, or the next block's norm1 rows, or - with qkv_tiles - its qkv rows)
+int ir_launch_swin_block(const bf16_t* qkv, const float* x_in, float* x_out, bf16_t* out2, const void* proj_t, const float* proj_b, const float* biasT,
+                         int B, int H, int W, int shift, float scale, const void* w_tiles, const float* vec, int C, int hid_p, float eps, hipStream_t s,
+                         const float* next_g = nullptr, const float* next_b = nullptr, const void* qkv_tiles = nullptr, const float* qkv_b = nullptr,
+                         int qkv_n = 0);
+
 // ---- T5 encoder glue (t5.hip)
 int ir_launch_t5_embed(const int* ids, const bf16_t* table, float* x, long rows, int D, int vocab, int* bad, hipStream_t s);
 int ir_launch_t5_rmsnorm(const float* x, const float* w, bf16_t* yb, float* yf, long rows, int D, float eps, hipStream_t s);

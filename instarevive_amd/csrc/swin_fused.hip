@@ -378,7 +378,6 @@ IR_DEVINL uint4 swa_pack8_valu(const f32x16& v, int lo, float mul) {   // for va
                       pack2bf_trans(v[lo + 4] * mul, v[lo + 5] * mul), pack2bf_trans(v[lo + 6] * mul, v[lo + 7] * mul));
 }
 
-template <bool SHIFTED>
 __global__ __launch_bounds__(256, 2) void swin_attn_proj_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ xres, float* __restrict__ out,
                                                              const bf16_t* __restrict__ proj_t, const float* __restrict__ proj_b,
                                                              const float* __restrict__ biasT, int H, int W, int shift, float scale_log2,
@@ -403,24 +402,11 @@ __global__ __launch_bounds__(256, 2) void swin_attn_proj_kernel(const bf16_t* __
     const long tbase = img * H * W;
     const long qtok = tbase + tok(32 * g + r);                       // this lane's query (n index of S^T / O^T / Y^T)
     const long ktok[2] = {tbase + tok(r), tbase + tok(32 + r)};      // this lane's key rows (m index) of the two key tiles
-    // shifted-window mask (swinir.py:227-248): regions of the shifted frame; bit (kt * 16 + reg) set when this lane's key differs in region
-    // from this lane's query. Keys of accumulator register reg: 32 kt + (reg & 3) + 8 (reg >> 2) + 4 h.
-    uint32_t mdiff = 0;
-    if constexpr (SHIFTED) {
-        auto region = [&](int idx) {
-            const int Y = wy * 8 + (idx >> 3), X = wx * 8 + (idx & 7);
-            const int rh = Y < H - 8 ? 0 : (Y < H - shift ? 1 : 2), rw = X < W - 8 ? 0 : (X < W - shift ? 1 : 2);
-            return rh * 3 + rw;
-        };
-        const int rq = region(32 * g + r);
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int key = 32 * kt + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                mdiff |= (region(key) != rq ? 1u : 0u) << (kt * 16 + reg);
-            }
-    }
+    // shifted-window mask (swinir.py:227-248): folded into the bias table on the host. A window of the shifted frame is one of four classes -
+    // interior, last window column, last window row, corner - and biasT holds one [head][key][query] table per class for a shifted block
+    // (weights.swin_masked_bias: class 0 is the plain relative-position bias, the others carry -100 log2(e) where key and query lie in different
+    // regions), so the kernel only picks a table. As 32 per-lane mask bits tested in the head loop the mask cost 64 SGPRs of lane masks.
+    const int cls = shift ? ((wy == nwy - 1 ? 2 : 0) | (wx == nwx - 1 ? 1 : 0)) : 0;
     // identity B operand of the V' product: lane = d = r, k position 16 ks + 8 h + e holds (that position == r)
     bf16x8 idf[2];
 #pragma unroll
@@ -441,7 +427,7 @@ __global__ __launch_bounds__(256, 2) void swin_attn_proj_kernel(const bf16_t* __
     const bf16_t* qrow = qkv + qtok * LD + 8 * h;
     const bf16_t* krow[2] = {qkv + ktok[0] * LD + CP + 8 * h, qkv + ktok[1] * LD + CP + 8 * h};
     const bf16_t* vrow[2] = {qkv + ktok[0] * LD + 2 * CP + 8 * h, qkv + ktok[1] * LD + 2 * CP + 8 * h};
-    const float* brow = biasT + 32 * g + r;   // + (head * 64 + key) * 64
+    const float* brow = biasT + (long)cls * HEADS * 4096 + 32 * g + r;   // + (head * 64 + key) * 64
 
 #pragma unroll 1
     for (int hd = 0; hd < HEADS; ++hd) {
@@ -473,7 +459,6 @@ __global__ __launch_bounds__(256, 2) void swin_attn_proj_kernel(const bf16_t* __
             for (int e = 0; e < 16; ++e) {
                 const int key = 32 * kt + (e & 3) + 8 * (e >> 2) + 4 * h;
                 float v = s[kt][e] * scale_log2 + bt[key * 64];
-                if constexpr (SHIFTED) { if ((mdiff >> (kt * 16 + e)) & 1) v += -100.0f * 1.44269504088896340736f; }
                 s[kt][e] = v;
                 mx = fmaxf(mx, v);
             }
@@ -550,11 +535,431 @@ int ir_launch_swin_attn_proj(const bf16_t* qkv, const float* xres, float* out, c
     const long n_waves = 2L * B * (H >> 3) * (W >> 3);
     const long blocks = (n_waves + 3) / 4;
     if (blocks > 0x7fffffffL) return -4;
-    if (shift)
-        hipLaunchKernelGGL(swin_attn_proj_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, qkv, xres, out, reinterpret_cast<const bf16_t*>(proj_t),
-                           proj_b, biasT, H, W, shift, scale * 1.44269504088896340736f, n_waves);
-    else
-        hipLaunchKernelGGL(swin_attn_proj_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, qkv, xres, out, reinterpret_cast<const bf16_t*>(proj_t),
-                           proj_b, biasT, H, W, shift, scale * 1.44269504088896340736f, n_waves);
+    hipLaunchKernelGGL(swin_attn_proj_kernel, dim3((unsigned)blocks), dim3(256), 0, s, qkv, xres, out, reinterpret_cast<const bf16_t*>(proj_t), proj_b, biasT, H, W,
+                       shift, scale * 1.44269504088896340736f, n_waves);
     return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// =====================================================================================================================
+// swin_block_kernel: a WHOLE SwinTransformerBlock behind its qkv projection in one launch (swinir.py:258-290) - the attention half of
+// swin_attn_proj_kernel and the MLP half of swin_mlp_kernel with nothing between them: a wave owns (window, 32-query half), the projected
+// attention output stays in its 96 accumulator registers, + bias + x (its token rows, gathered through the staging slices) IS the row
+// LayerNorm2 reads and the value the second product of the MLP accumulates onto (swin_mlp_kernel's x + b2 start), so the post-attention residual
+// stream never goes to memory; the tail is swin_mlp_kernel's (the new rows, then optionally norm1 / norm1 + qkv of the NEXT block), with the
+// wave's window tokens as the row addresses. One workgroup = 8 waves = 4 windows; HBM traffic of a block 250 MB (qkv in, x in, x out, qkv out)
+// against 350 MB as two launches. x_in and x_out may alias (a wave touches only its own tokens' rows; qkv likewise: every wave of the workgroup
+// has finished reading K / V of its window - several workgroup barriers ago - when the first q | k | v row of the next block is written).
+template <bool LN_NEXT, bool QKV>
+__global__ __launch_bounds__(512, 1) void swin_block_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ x_in, float* __restrict__ x_out,
+                                                            bf16_t* __restrict__ out2, const bf16_t* __restrict__ proj_t,
+                                                            const float* __restrict__ proj_b, const float* __restrict__ biasT, int H, int W, int shift,
+                                                            float scale_log2, long n_waves, const unsigned char* __restrict__ w,
+                                                            const float* __restrict__ vec, int C, int NJ, float eps, const float* __restrict__ next_g,
+                                                            const float* __restrict__ next_b, const unsigned char* __restrict__ wq,
+                                                            const float* __restrict__ bq, int NQ) {
+    using namespace swf;
+    constexpr int HEADS = 6, LD = 3 * CP;
+#ifdef IR_SWIN_STAMPS
+    unsigned long long stp[8];
+    stp[0] = __builtin_amdgcn_s_memrealtime();
+#define IR_STAMP(k) stp[k] = __builtin_amdgcn_s_memrealtime()
+#else
+#define IR_STAMP(k)
+#endif
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wu = __builtin_amdgcn_readfirstlane(wid);
+    const int r = lane & 31, h = lane >> 5;
+    long wv = (long)blockIdx.x * 8 + wu;               // wave = (window, query half)
+    const bool active = wv < n_waves;                  // a ragged last workgroup: idle waves redo the last wave's work and store nothing
+    if (!active) wv = n_waves - 1;
+
+    // ---- weight ring + vectors, as swin_mlp_kernel (in flight under the whole attention phase)
+    const int NS = NJ + (QKV ? NQ / 2 : 0);
+    auto stage = [&](int jt, int slot) {
+        const unsigned char* src = (QKV && jt >= NJ ? wq + (long)(jt - NJ) * SLOT : w + (long)jt * SLOT) + lane * 16;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (wu + 8 * i < PIECES) sw_glds16(src + (wu + 8 * i) * 1024, (sw_lds_t)(smem + slot * SLOT + (wu + 8 * i) * 1024));
+    };
+    stage(0, 0);
+    float* vs = reinterpret_cast<float*>(smem + VEC_OFF);
+    const int nvec = 3 * CP + 32 * NJ;
+    for (int i = tid; i < nvec; i += 512) vs[i] = vec[i];
+    constexpr bool ln_next = LN_NEXT;
+    if (ln_next)
+        for (int i = tid; i < 2 * CP; i += 512) {
+            const int c = i < CP ? i : i - CP;
+            vs[NEXT_OFF + i] = c < C ? (i < CP ? next_g[c] : next_b[c]) : 0.f;
+        }
+
+    // ---- window geometry (swin_attn_proj_kernel)
+    const int g = (int)(wv & 1);
+    long wlin = wv >> 1;
+    const int nwx = W >> 3, nwy = H >> 3;
+    const int wx = (int)(wlin % nwx); wlin /= nwx;
+    const int wy = (int)(wlin % nwy);
+    const long img = wlin / nwy;
+    auto tok = [&](int i) {
+        int y = wy * 8 + (i >> 3) + shift, x = wx * 8 + (i & 7) + shift;
+        if (y >= H) y -= H;
+        if (x >= W) x -= W;
+        return (long)y * W + x;
+    };
+    const long tbase = img * H * W;
+    const long qtok = tbase + tok(32 * g + r);
+    f32x16 yacc[6];
+    {
+        const long ktok[2] = {tbase + tok(r), tbase + tok(32 + r)};
+        const int cls = shift ? ((wy == nwy - 1 ? 2 : 0) | (wx == nwx - 1 ? 1 : 0)) : 0;   // the window's mask class: its bias table (swin_attn_proj_kernel)
+        bf16x8 idf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint32_t w4[4];
+#pragma unroll
+            for (int e2 = 0; e2 < 4; ++e2) {
+                const int c0 = 16 * ks + 8 * h + 2 * e2;
+                w4[e2] = (c0 == r ? 0x3f80u : 0u) | (c0 + 1 == r ? 0x3f800000u : 0u);
+            }
+            idf[ks] = __builtin_bit_cast(bf16x8, make_uint4(w4[0], w4[1], w4[2], w4[3]));
+        }
+#pragma unroll
+        for (int ct = 0; ct < 6; ++ct)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) yacc[ct][e] = 0.f;
+        // 32-bit byte offsets from the uniform bases (launcher: the qkv tensor is below 4 GB): one address register per row instead of two
+        const unsigned char* qkvb = reinterpret_cast<const unsigned char*>(qkv);
+        const uint32_t qoff = (uint32_t)(qtok * LD + 8 * h) * 2u;
+        const uint32_t koff[2] = {(uint32_t)(ktok[0] * LD + CP + 8 * h) * 2u, (uint32_t)(ktok[1] * LD + CP + 8 * h) * 2u};
+        const float* brow = biasT + (long)cls * HEADS * 4096 + 32 * g + r;
+#pragma unroll 1
+        for (int hd = 0; hd < HEADS; ++hd) {
+            const int co = hd * 32;
+            bf16x8 qf[2], kf[2][2], vf[2][2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                qf[ks] = *reinterpret_cast<const bf16x8*>(qkvb + qoff + 2 * (co + 16 * ks));
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) {
+                    kf[kt][ks] = *reinterpret_cast<const bf16x8*>(qkvb + koff[kt] + 2 * (co + 16 * ks));
+                    vf[kt][ks] = *reinterpret_cast<const bf16x8*>(qkvb + koff[kt] + 2 * (CP + co + 16 * ks));
+                }
+            }
+            f32x16 s[2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) s[kt][e] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) s[kt] = mfma32(kf[kt][ks], qf[ks], s[kt]);
+            }
+            const float* bt = brow + (long)hd * 4096;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int key = 32 * kt + (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const float v = s[kt][e] * scale_log2 + bt[key * 64];
+                    s[kt][e] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = xhalf_max(mx);
+            float rs = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float pv = __builtin_amdgcn_exp2f(s[kt][e] - mx);
+                    s[kt][e] = pv;
+                    rs += pv;
+                }
+            rs += __shfl_xor(rs, 32);
+            f32x16 o;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[e] = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                f32x16 vt;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) vt[e] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) vt = mfma32(vf[kt][ks], idf[ks], vt);
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+                    o = mfma32(__builtin_bit_cast(bf16x8, swa_pack8(vt, 8 * s2, 1.0f)), __builtin_bit_cast(bf16x8, swa_pack8_valu(s[kt], 8 * s2, 1.0f)), o);
+            }
+            const float inv = 1.0f / rs;
+            const bf16x8 ob[2] = {__builtin_bit_cast(bf16x8, swa_pack8_valu(o, 0, inv)), __builtin_bit_cast(bf16x8, swa_pack8_valu(o, 8, inv))};
+#pragma unroll
+            for (int ct = 0; ct < 6; ++ct)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const bf16x8 wp = *reinterpret_cast<const bf16x8*>(proj_t + (((hd * 6 + ct) * 2 + s2) * 64 + lane) * 8);
+                    yacc[ct] = mfma32(wp, ob[s2], yacc[ct]);
+                }
+        }
+    }
+
+    IR_STAMP(1);
+    // ---- x rows of the wave's 32 window tokens through the staging slices; piece pc = window row 4g + pc (8 tokens), lane -> token ptok, slot pslot
+    unsigned char* stg = smem + STG_OFF + wu * STG_WAVE;
+    const int ptok = lane >> 3, pslot = lane & 7;
+    long gtk[4];   // row index of the lane's token in piece pc
+#pragma unroll
+    for (int pc = 0; pc < 4; ++pc) gtk[pc] = tbase + tok(32 * g + 8 * pc + ptok);
+    auto load_half = [&](int t0) {
+#pragma unroll
+        for (int ts = 0; ts < 3; ++ts)
+#pragma unroll
+            for (int pc = 0; pc < 4; ++pc) {
+                const int tk = 8 * pc + ptok;
+                sw_glds16(x_in + gtk[pc] * CP + 32 * (t0 + ts) + 4 * (pslot ^ ((tk >> 1) & 7)), (sw_lds_t)(stg + ts * 4096 + pc * 1024));
+            }
+    };
+    auto frag_addr = [&](int ts, int i) { return stg + ts * 4096 + r * 128 + (((2 * i + h) ^ ((r >> 1) & 7)) << 4); };
+    // the row after the attention residual, accumulator layout: xr[t][i] = channels 32t + 8i + 4h .. +3 = attention + proj bias + x
+    f32x4 xr[6][4];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+        load_half(3 * hf);
+        wait_dma();
+#pragma unroll
+        for (int ts = 0; ts < 3; ++ts)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int t = 3 * hf + ts;
+                const f32x4 pb = *reinterpret_cast<const f32x4*>(proj_b + 32 * t + 8 * i + 4 * h);
+                xr[t][i] = f32x4{yacc[t][4 * i], yacc[t][4 * i + 1], yacc[t][4 * i + 2], yacc[t][4 * i + 3]} + pb + *reinterpret_cast<const f32x4*>(frag_addr(ts, i));
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    IR_STAMP(2);
+    // ---- from here on swin_mlp_kernel with gathered rows
+    float s1 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s1 += (xr[t][i][0] + xr[t][i][1]) + (xr[t][i][2] + xr[t][i][3]);
+    s1 += __shfl_xor(s1, 32);
+    const float mean = s1 / (float)C;
+    float s2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = xr[t][i][e] - mean;
+                s2 += (32 * t + 8 * i + 4 * h + e < C) ? d * d : 0.f;
+            }
+    s2 += __shfl_xor(s2, 32);
+    const float rstd = rsqrtf(s2 / (float)C + eps);
+    __syncthreads();  // the vectors are in LDS
+    bf16x8 xn[12];
+#pragma unroll
+    for (int s = 0; s < 12; ++s) {
+        uint32_t wv4[4];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int t = s >> 1, i = 2 * (s & 1) + q, c0 = 32 * t + 8 * i + 4 * h;
+            const f32x4 gg = *reinterpret_cast<const f32x4*>(vs + c0), bb = *reinterpret_cast<const f32x4*>(vs + CP + c0);
+            const f32x4 v = (xr[t][i] - mean) * rstd * gg + bb;
+            wv4[2 * q] = pack2bf(v[0], v[1]);
+            wv4[2 * q + 1] = pack2bf(v[2], v[3]);
+        }
+        xn[s] = __builtin_bit_cast(bf16x8, make_uint4(wv4[0], wv4[1], wv4[2], wv4[3]));
+    }
+    f32x16 y[6];
+#pragma unroll
+    for (int ot = 0; ot < 6; ++ot)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 b2 = *reinterpret_cast<const f32x4*>(vs + 2 * CP + 32 * NJ + 32 * ot + 8 * i + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[ot][4 * i + e] = xr[ot][i][e] + b2[e];
+        }
+    const int a1 = r * W1_ROW + h * 16;
+    const int a2 = W1_TILE + r * W2_ROW + h * 16;
+    for (int jt = 0; jt < NJ; ++jt) {
+        wait_dma();
+        __syncthreads();
+        if (jt + 1 < NS) stage(jt + 1, (jt + 1) & 1);
+        const unsigned char* sl = smem + (jt & 1) * SLOT;
+        f32x16 hacc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) hacc[e] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 12; ++s) hacc = mfma32(*reinterpret_cast<const bf16x8*>(sl + a1 + s * 32), xn[s], hacc);
+        bf16x8 hb[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            uint32_t wv4[4];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(vs + 2 * CP + 32 * jt + 16 * q + 8 * u + 4 * h);
+                const int g0 = 8 * q + 4 * u;
+                wv4[2 * u] = pack2bf(gelu_erf(hacc[g0] + b1[0]), gelu_erf(hacc[g0 + 1] + b1[1]));
+                wv4[2 * u + 1] = pack2bf(gelu_erf(hacc[g0 + 2] + b1[2]), gelu_erf(hacc[g0 + 3] + b1[3]));
+            }
+            hb[q] = __builtin_bit_cast(bf16x8, make_uint4(wv4[0], wv4[1], wv4[2], wv4[3]));
+        }
+#pragma unroll
+        for (int ot = 0; ot < 6; ++ot)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) y[ot] = mfma32(*reinterpret_cast<const bf16x8*>(sl + a2 + ot * 32 * W2_ROW + q * 32), hb[q], y[ot]);
+    }
+    IR_STAMP(3);
+    // ---- the new rows -> residual stream through the staging slices (and the bf16 copy for the RSTB's conv when this is its last block)
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+        for (int ts = 0; ts < 3; ++ts)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int t = 3 * hf + ts;
+                const f32x4 nx = f32x4{y[t][4 * i], y[t][4 * i + 1], y[t][4 * i + 2], y[t][4 * i + 3]};
+                *reinterpret_cast<f32x4*>(frag_addr(ts, i)) = nx;
+                if (ln_next) xr[t][i] = nx;
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ts = 0; ts < 3; ++ts)
+#pragma unroll
+            for (int pc = 0; pc < 4; ++pc) {
+                const int tk = 8 * pc + ptok;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(stg + ts * 4096 + pc * 1024 + lane * 16);
+                const int ch = 32 * (3 * hf + ts) + 4 * (pslot ^ ((tk >> 1) & 7));
+                if (active) {
+                    *reinterpret_cast<f32x4*>(x_out + gtk[pc] * CP + ch) = v;
+                    if (out2 && !ln_next) *reinterpret_cast<uint2*>(out2 + gtk[pc] * CP + ch) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+                }
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    IR_STAMP(4);
+    if (!ln_next || !out2) return;
+    float t1 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t1 += (xr[t][i][0] + xr[t][i][1]) + (xr[t][i][2] + xr[t][i][3]);
+    t1 += __shfl_xor(t1, 32);
+    const float mean2 = t1 / (float)C;
+    float t2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = xr[t][i][e] - mean2;
+                t2 += (32 * t + 8 * i + 4 * h + e < C) ? d * d : 0.f;
+            }
+    t2 += __shfl_xor(t2, 32);
+    const float rstd2 = rsqrtf(t2 / (float)C + eps);
+    if constexpr (!QKV) {
+        if (active) {
+            bf16_t* orow = out2 + qtok * CP + 4 * h;
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c0 = 32 * t + 8 * i + 4 * h;
+                    const f32x4 gg = *reinterpret_cast<const f32x4*>(vs + NEXT_OFF + c0), bb = *reinterpret_cast<const f32x4*>(vs + NEXT_OFF + CP + c0);
+                    const f32x4 v = (xr[t][i] - mean2) * rstd2 * gg + bb;
+                    *reinterpret_cast<uint2*>(orow + 32 * t + 8 * i) = make_uint2(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]));
+                }
+        }
+    } else {
+        bf16x8 xq[12];
+#pragma unroll
+        for (int s = 0; s < 12; ++s) {
+            uint32_t wv4[4];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int t = s >> 1, i = 2 * (s & 1) + q, c0 = 32 * t + 8 * i + 4 * h;
+                const f32x4 gg = *reinterpret_cast<const f32x4*>(vs + NEXT_OFF + c0), bb = *reinterpret_cast<const f32x4*>(vs + NEXT_OFF + CP + c0);
+                const f32x4 v = (xr[t][i] - mean2) * rstd2 * gg + bb;
+                wv4[2 * q] = pack2bf(v[0], v[1]);
+                wv4[2 * q + 1] = pack2bf(v[2], v[3]);
+            }
+            xq[s] = __builtin_bit_cast(bf16x8, make_uint4(wv4[0], wv4[1], wv4[2], wv4[3]));
+        }
+        const int LDQ = 32 * NQ;
+        for (int st = 0; st < NQ / 2; ++st) {
+            const int jt = NJ + st;
+            f32x4 bv[2][4];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bv[u][i] = *reinterpret_cast<const f32x4*>(bq + 32 * (2 * st + u) + 8 * i + 4 * h);
+            wait_dma();
+            __syncthreads();
+            if (jt + 1 < NS) stage(jt + 1, (jt + 1) & 1);
+            const unsigned char* sl = smem + (jt & 1) * SLOT;
+            unsigned char* sb = stg + (st % 3) * 4096;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                f32x16 acc;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+                for (int s = 0; s < 12; ++s) acc = mfma32(*reinterpret_cast<const bf16x8*>(sl + u * W1_TILE + a1 + s * 32), xq[s], acc);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    *reinterpret_cast<uint2*>(sb + r * 128 + (((4 * u + i) ^ ((r >> 1) & 7)) << 4) + 8 * h) =
+                        make_uint2(pack2bf(acc[4 * i] + bv[u][i][0], acc[4 * i + 1] + bv[u][i][1]), pack2bf(acc[4 * i + 2] + bv[u][i][2], acc[4 * i + 3] + bv[u][i][3]));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int pc = 0; pc < 4; ++pc) {
+                const int tk = 8 * pc + ptok;
+                const uint4 v = *reinterpret_cast<const uint4*>(sb + pc * 1024 + lane * 16);
+                if (active) *reinterpret_cast<uint4*>(out2 + gtk[pc] * LDQ + 64 * st + 8 * (pslot ^ ((tk >> 1) & 7))) = v;
+            }
+        }
+    }
+#ifdef IR_SWIN_STAMPS
+    IR_STAMP(5);
+    if ((blockIdx.x == 3 || blockIdx.x == 131) && (tid == 0 || tid == 448))
+        printf("STAMP wg %d wave %d attn %llu xload %llu ln+mlp %llu store %llu tail %llu (x10ns)\n", (int)blockIdx.x, wu, stp[1] - stp[0], stp[2] - stp[1], stp[3] - stp[2],
+               stp[4] - stp[3], stp[5] - stp[4]);
+#endif
+}
+
+int ir_launch_swin_block(const bf16_t* qkv, const float* x_in, float* x_out, bf16_t* out2, const void* proj_t, const float* proj_b, const float* biasT,
+                         int B, int H, int W, int shift, float scale, const void* w_tiles, const float* vec, int C, int hid_p, float eps, hipStream_t s,
+                         const float* next_g, const float* next_b, const void* qkv_tiles, const float* qkv_b, int qkv_n) {
+    if ((H & 7) || (W & 7) || shift < 0 || shift >= 8 || B <= 0) return -2;
+    if (C <= 0 || C > swf::CP || hid_p <= 0 || (hid_p & 31) || hid_p > 512) return -2;
+    if ((next_g != nullptr) != (next_b != nullptr) || (next_g && (!out2 || (C & 3)))) return -2;
+    if (qkv_tiles && (!next_g || !qkv_b || qkv_n <= 0 || (qkv_n & 63))) return -2;
+    const long n_waves = 2L * B * (H >> 3) * (W >> 3);
+    const long blocks = (n_waves + 7) / 8;
+    if (blocks > 0x7fffffffL) return -4;
+    const int NJ = hid_p / 32, NQ = qkv_tiles ? qkv_n / 32 : 0;
+    const size_t lds = swf::LDS_TOTAL;
+    const float sl2 = scale * 1.44269504088896340736f;
+    const bf16_t* pt = reinterpret_cast<const bf16_t*>(proj_t);
+    const unsigned char* wt = reinterpret_cast<const unsigned char*>(w_tiles);
+    const unsigned char* wq = reinterpret_cast<const unsigned char*>(qkv_tiles);
+    auto go = [&](auto kern) {
+        static bool attr_set = false;   // one per instantiation (the lambda's body is instantiated per kernel type)
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(512), lds, s, qkv, x_in, x_out, out2, pt, proj_b, biasT, H, W, shift, sl2, n_waves, wt, vec, C, NJ, eps,
+                           next_g, next_b, wq, qkv_b, NQ);
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    };
+    if (qkv_tiles) return go(swin_block_kernel<true, true>);
+    if (next_g) return go(swin_block_kernel<true, false>);
+    return go(swin_block_kernel<false, false>);
 }

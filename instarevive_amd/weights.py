@@ -161,6 +161,23 @@ def pack_swin_mlp(fc1_w, fc1_b, fc2_w, fc2_b, n2_g, n2_b, C, Cp, hid_p):
     return tiles.contiguous(), vec.contiguous()
 
 
+def swin_masked_bias(biasT, ws=8, shift=4):
+    """Bias tables of a SHIFTED block for the fused kernels: [4 window classes][head][key][query], log2 domain. The attention mask of
+    SwinTransformerBlock.calculate_mask (swinir.py:227-248) only depends on whether a window of the shifted frame lies in the last window row and / or
+    column: there a token's region is 1 before row / column ws - shift of the window and 2 from it on, elsewhere 0; attn_mask = -100 where key and
+    query regions differ. Class = 2 * (last row) + (last column); class 0 is the plain table."""
+    i = torch.arange(ws * ws)
+    part = lambda c: torch.where(c < ws - shift, 1, 2)
+    out = []
+    for cls in range(4):
+        rh = part(i // ws) if cls & 2 else torch.zeros_like(i)
+        rw = part(i % ws) if cls & 1 else torch.zeros_like(i)
+        rid = rh * 3 + rw
+        mask = (rid[:, None] != rid[None, :]).float() * (-100.0 * math.log2(math.e))   # [key][query] (symmetric)
+        out.append(biasT + mask[None])
+    return torch.stack(out).contiguous()
+
+
 def pack_swin_qkv_tiles(qkv_bits, Cp):
     """The padded qkv weight [3 Cp][Cp] (bf16 bits, rows already in the q | k | v x head x 32 layout) as ring slots of swin_mlp_kernel's qkv
     stage: per 32 output channels one W1-format tile (400-byte rows, k positions in _acc_order, 13 KB), two tiles per 28 KB slot."""
@@ -218,6 +235,8 @@ def pack_swinir(sd, cfg):
             table = sd[s + "attn.relative_position_bias_table"].float()
             bias = table[rpi.view(-1)].view(64, 64, heads)                       # [query][key][head]  (swinir.py:138-140)
             out[d + "biasT"] = (bias.permute(2, 1, 0) * math.log2(math.e)).contiguous()  # [head][key][query], log2 domain
+            if j % 2 == 1 and Cp == 192:   # shifted block (swinir.py:421: shift_size = 0 if i % 2 == 0 else window_size // 2): mask folded into the tables
+                out[d + "biasM"] = swin_masked_bias(out[d + "biasT"], cfg["window_size"], cfg["window_size"] // 2)
         out[f"swin.l{i}.conv.w"] = pack_conv3x3(sd[f"layers.{i}.conv.weight"], Cp, Cp)
         out[f"swin.l{i}.conv.b"] = pad_vec(sd[f"layers.{i}.conv.bias"], Cp)
     out["swin.after_body.w"] = pack_conv3x3(sd["conv_after_body.weight"], Cp, Cp)

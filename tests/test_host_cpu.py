@@ -70,6 +70,35 @@ def test_swin_packing_head_padding():
     assert set(W.swinir_expected_keys(cfg)) >= set(sd)
 
 
+def test_swin_masked_bias_classes():
+    """weights.swin_masked_bias against calculate_mask of the reference (swinir.py:227-248) restated on a 3 x 4 window grid: every window's mask must be
+    the table of its class minus the plain table, class = 2 * (last window row) + (last window column)."""
+    import math
+    from instarevive_amd import weights as W
+    ws, shift, nh, nw = 8, 4, 3, 4
+    H, Wd = nh * ws, nw * ws
+    img = torch.zeros(H, Wd)
+    cnt = 0
+    for hs in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+        for wsl in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+            img[hs, wsl] = cnt
+            cnt += 1
+    mw = img.view(nh, ws, nw, ws).permute(0, 2, 1, 3).reshape(nh * nw, ws * ws)          # window_partition
+    ref = mw[:, None, :] - mw[:, :, None]
+    ref = torch.where(ref != 0, torch.tensor(-100.0), torch.tensor(0.0))                  # [window][query][key]
+    base = torch.randn(6, 64, 64)
+    t = W.swin_masked_bias(base, ws, shift)
+    assert t.shape == (4, 6, 64, 64) and torch.equal(t[0], base)
+    for wy in range(nh):
+        for wx in range(nw):
+            cls = 2 * (wy == nh - 1) + (wx == nw - 1)
+            got = (t[cls] - base)[0] / math.log2(math.e)                                  # [key][query]
+            torch.testing.assert_close(got, ref[wy * nw + wx].t(), atol=1e-4, rtol=0)
+    cfg = dict(embed_dim=60, depths=[2], num_heads=[6], window_size=8, mlp_ratio=2, img_range=1.0)
+    p = W.pack_swinir({k: torch.randn(*sh) for k, sh in W.swinir_shapes(cfg).items()}, cfg)
+    assert "swin.l0.b0.biasM" not in p and p["swin.l0.b1.biasM"].shape == (4, 6, 64, 64)
+
+
 def test_swin_qkv_ring_tiles():
     """pack_swin_qkv_tiles: slot t // 2, tile t % 2 (13312 B apart), row r (400 B apart), k position p holds the padded qkv weight
     [32 t + r][_acc_order(192)[p]] - the layout swin_mlp_kernel<true, true> streams through its LDS ring; only blocks 1.. of an RSTB get one."""
