@@ -94,7 +94,8 @@ def test_swinir_full_arch_64():
 
 
 def test_swinir_qkv_inside_the_mlp_launch_ragged_tokens():
-    """Blocks 1.. of an RSTB get norm1 and their qkv rows from the previous block's swin_mlp_kernel<true, true> launch (weights.pack_swin_qkv_tiles).
+    """A Swin block behind its qkv projection is one launch (swin_block_kernel); blocks 1.. of an RSTB get norm1 and their qkv rows from the previous
+    block's launch (weights.pack_swin_qkv_tiles), shifted blocks read the attention mask out of per-window-class bias tables (weights.swin_masked_bias).
     24 x 40 token grid = 960 tokens: three full workgroups and a ragged one of 192; two RSTBs of three blocks so that a fused and an
     unfused first block alternate. Against the fp32 oracle and against the plain kernel set (separate LayerNorm / qkv GEMM launches)."""
     cfg = dict(depths=[3, 3], num_heads=[6, 6])
@@ -104,6 +105,7 @@ def test_swinir_qkv_inside_the_mlp_launch_ragged_tokens():
     check(fast, oswin.swinir_forward(sd, x, cfg), "swinir 192x320, qkv inside the MLP launch", **TOL_XFMR)
     ctx = m.ctx
     assert ctx.has("swin.l0.b1.qkv_t") and ctx.has("swin.l1.b2.qkv_t") and not ctx.has("swin.l0.b0.qkv_t")
+    assert ctx.has("swin.l0.b1.biasM") and not ctx.has("swin.l0.b0.biasM")   # shifted blocks: the mask folded into four bias tables (3 x 5 windows: all classes occur)
     ctx.check(ctx.lib.ir_set_plain_kernels(ctx.h, 1), "ir_set_plain_kernels")
     try:
         plain = m(x.cuda())
