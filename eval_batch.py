@@ -40,6 +40,7 @@ def parse_args():
     ap.add_argument("--dit_config", default="PixArt-alpha/PixArt-Alpha-DMD-XL-2-512x512")
     ap.add_argument("--prompt_embeds", default=cli.DEFAULT_PROMPT)
     ap.add_argument("--device", default="cuda")
+    ap.add_argument("--workers", type=int, default=-1, help="host threads for decoding / PNG encoding (inference.py --workers)")
     return ap.parse_args()
 
 
@@ -66,20 +67,27 @@ def main():
         files = parallel.agree_on_list(files)
     files = parallel.shard(files, rank, world)
     batches = [files[i:i + args.batch_size] for i in range(0, len(files), args.batch_size)]
+    pools = cli.HostPools(cli.default_workers(int(os.environ.get("LOCAL_WORLD_SIZE", world))) if args.workers < 0 else args.workers)
 
     def feed():
+        # decode + centre crop run ahead of the GPU on the reader threads, in file order
+        crops = pools.read_ahead(lambda f: center_crop_arr(Image.open(f).convert("RGB"), args.image_size), files)
         for group in batches:
-            yield [center_crop_arr(Image.open(f).convert("RGB"), args.image_size) for f in group]
+            yield [next(crops) for _ in group]
+
+    def save(dst, img):
+        os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
+        Image.fromarray(np.ascontiguousarray(img)).save(dst)
 
     results = process_stream(m.model, feed(), "none", args.disable_preprocess_model, False, 512, 448, preprocess_model=m.preprocess_model, vae=m.vae,
                              y=m.y, y_mask=m.y_mask, noise_scheduler=m.noise_scheduler, return_stage1=True)
     for group, (preds, stage1) in zip(batches, results):
         for f, pred, cond in zip(group, preds, stage1):
             for folder, img in ((args.output, pred), (cond_dir, cond)):
-                dst = out_name(folder, args.input, f)
-                os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
-                Image.fromarray(np.ascontiguousarray(img)).save(dst)
-        print(f"[rank {rank}] saved {len(group)} images ({group[0]} ...)")
+                pools.write_behind(save, out_name(folder, args.input, f), img)
+        print(f"[rank {rank}] queued {len(group)} images ({group[0]} ...)")
+    pools.drain()
+    print(f"[rank {rank}] saved {pools.written} files")
 
 
 if __name__ == "__main__":

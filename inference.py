@@ -17,10 +17,14 @@ With torchrun (WORLD_SIZE > 1) the file list is sharded over the ranks, one proc
 """
 import math
 import os
+import threading
+import time
 from argparse import ArgumentParser, Namespace
+from collections import deque
+from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass
 from types import SimpleNamespace
-from typing import Iterable, Iterator, List
+from typing import Callable, Iterable, Iterator, List
 
 import numpy as np
 import torch
@@ -66,7 +70,19 @@ def parse_args() -> Namespace:
     parser.add_argument("--batch_size", type=int, default=1, help="consecutive files of equal network-input size per process() call")
     parser.add_argument("--shard_tiles", action="store_true", help="with --tiled under torchrun: spread the TILES of each image over the "
                         "GPUs (one large image at a time) instead of spreading the files")
+    parser.add_argument("--workers", type=int, default=-1, help="host threads that decode / resize the inputs and resize / PNG-encode the results "
+                        "around the GPU (PIL releases the GIL there); -1 = this process's CPU share, 0 = everything on the main thread like the reference")
     return parser.parse_args()
+
+
+def default_workers(local_world: int = 1) -> int:
+    """CPU threads this rank may keep busy: the cores the process may run on, split between the ranks of the node (at most 32: one
+    MI355X produces ~8 results of 2048 x 2048 a second and a PNG of that size costs 0.8 - 1.7 core-seconds)."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    return max(1, min(32, cores // max(local_world, 1)))
 
 
 def check_device(device: str) -> str:
@@ -125,6 +141,65 @@ def write_job(job: Job, pred: np.ndarray, stage1_pred, args: Namespace) -> None:
     print(f"save to {job.save_path}")
 
 
+class HostPools:
+    """The host side of the stream (one main thread around an 8 images/s GPU delivers 0.6 - 1.2 files/s). Readers run
+    read_job() ahead of the GPU, writers run write_job() behind it; both keep the reference's per-file arithmetic and file names
+    (test_scripts/inference.py:263-291,323-346) - only WHEN a file is decoded or encoded changes, so the PNGs are pixel-identical to the
+    one-thread run. Order is preserved on the read side (batches_of() groups CONSECUTIVE files, and the result list pairs with the job
+    list by position); writes are independent files and may finish in any order. Both queues are bounded: at most `depth` decoded inputs
+    wait for the GPU and at most `depth` results wait for an encoder, so memory stays at a few dozen images whatever the folder size.
+    workers = 0 runs everything inline on the caller's thread (the reference's behaviour)."""
+
+    def __init__(self, workers: int):
+        self.workers = max(workers, 0)
+        self.depth = max(2 * self.workers, 2)
+        # reading (decode + bicubic + pad) is ~10x cheaper than writing (LANCZOS + PNG deflate): a quarter of the threads keeps up
+        self.readers = ThreadPoolExecutor(max(1, self.workers // 4), thread_name_prefix="ir-read") if self.workers else None
+        self.writers = ThreadPoolExecutor(self.workers, thread_name_prefix="ir-write") if self.workers else None
+        self.slots = threading.Semaphore(self.depth)
+        self.pending = deque()
+        self.written = 0
+
+    def read_ahead(self, fn: Callable, items: Iterable) -> Iterator:
+        """fn(item) for every item, results in the items' order, up to `depth` calls running or finished ahead of the consumer."""
+        if not self.readers:
+            for item in items:
+                yield fn(item)
+            return
+        ahead = deque()
+        for item in items:
+            ahead.append(self.readers.submit(fn, item))
+            if len(ahead) >= self.depth:
+                yield ahead.popleft().result()
+        while ahead:
+            yield ahead.popleft().result()
+
+    def write_behind(self, fn: Callable, *a) -> None:
+        """fn(*a) on a writer thread; blocks while `depth` writes are outstanding. A failed write is re-raised by the next call / drain()."""
+        self.written += 1
+        if not self.writers:
+            fn(*a)
+            return
+        while self.pending and self.pending[0].done():
+            self.pending.popleft().result()
+        self.slots.acquire()
+
+        def run():
+            try:
+                fn(*a)
+            finally:
+                self.slots.release()
+
+        self.pending.append(self.writers.submit(run))
+
+    def drain(self) -> None:
+        while self.pending:
+            self.pending.popleft().result()
+        for pool in (self.readers, self.writers):
+            if pool:
+                pool.shutdown(wait=True)
+
+
 def batches_of(jobs: Iterable[Job], limit: int) -> Iterator[List[Job]]:
     """Consecutive jobs of equal network-input shape, at most `limit` per batch (limit 1 = the reference's one image per call)."""
     group: List[Job] = []
@@ -168,6 +243,8 @@ def main() -> None:
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     m = load_models(args, device)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    pools = HostPools(default_workers(local_world) if args.workers < 0 else args.workers)
     if not os.path.isdir(args.input):
         raise SystemExit(f"--input {args.input} is not a directory")
     # os.walk order, like the reference (no sorting) for one process. With several ranks the list is what decides which rank owns
@@ -183,15 +260,15 @@ def main() -> None:
         # one large image at a time, its tiles spread over the GPUs; rank 0 re-assembles and writes
         engine = HipTileEngine(m.model, m.vae, m.preprocess_model, m.y, m.y_mask, args.color_fix_type, args.disable_preprocess_model,
                                args.tile_size, args.tile_stride, m.noise_scheduler)
-        for path in files:
-            for i in range(args.repeat_times):
-                job = read_job(path, i, args)
-                preds, stage1 = parallel.sharded_tiled_process(engine, [job.net_in], rank, world)
-                if rank == 0:
-                    write_job(job, preds[0], stage1[0], args)
+        for job in pools.read_ahead(lambda pi: read_job(pi[0], pi[1], args), [(p, i) for p in files for i in range(args.repeat_times)]):
+            preds, stage1 = parallel.sharded_tiled_process(engine, [job.net_in], rank, world)
+            if rank == 0:
+                pools.write_behind(write_job, job, preds[0], stage1[0], args)
+        pools.drain()
         return
     mine = parallel.shard(files, rank, world)       # images are independent: no collective on the data path
-    jobs = (read_job(path, i, args) for path in mine for i in range(args.repeat_times))
+    t0 = time.perf_counter()
+    jobs = pools.read_ahead(lambda pi: read_job(pi[0], pi[1], args), [(p, i) for p in mine for i in range(args.repeat_times)])
     todo: List[List[Job]] = []
 
     def feed():
@@ -202,7 +279,12 @@ def main() -> None:
     for preds, stage1 in process_stream(m.model, feed(), tiled=args.tiled, return_stage1=args.show_lq and not args.disable_preprocess_model,
                                         **common):
         for k, job in enumerate(todo.pop(0)):
-            write_job(job, preds[k], stage1[k] if stage1 else None, args)
+            pools.write_behind(write_job, job, preds[k], stage1[k] if stage1 else None, args)
+    pools.drain()
+    dt = time.perf_counter() - t0
+    if pools.written:
+        # first read submitted -> last PNG closed, model loading excluded (bench.py --cli_files parses this line)
+        print(f"[rank {rank}] wrote {pools.written} files in {dt:.3f} s = {pools.written / dt:.3f} files/s ({pools.workers} host threads)")
 
 
 if __name__ == "__main__":

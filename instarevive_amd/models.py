@@ -191,15 +191,51 @@ def _load_weights_file(folder):
     raise FileNotFoundError(f"no diffusion_pytorch_model.* / model.safetensors / pytorch_model.bin (or a sharded index) under {folder}")
 
 
+def _hf_cache_dirs():
+    """Where huggingface_hub keeps downloaded repositories, in its own order of precedence (no network access is attempted)."""
+    env = os.environ
+    dirs = [env.get("HF_HUB_CACHE"), env.get("HUGGINGFACE_HUB_CACHE")]
+    if env.get("HF_HOME"):
+        dirs.append(os.path.join(env["HF_HOME"], "hub"))
+    dirs.append(os.path.join(env.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache"), "huggingface", "hub"))
+    return [d for i, d in enumerate(dirs) if d and d not in dirs[:i]]
+
+
+def _hf_snapshots(repo_id):
+    """Snapshot folders of a hub id (`org/name`) in the local hub cache layout `models--org--name/snapshots/<rev>/`: the revision
+    `refs/main` names first (what from_pretrained() resolves without a revision argument), then the others, newest first."""
+    found = []
+    for cache in _hf_cache_dirs():
+        repo = os.path.join(cache, "models--" + repo_id.strip("/").replace("/", "--"))
+        snaps = os.path.join(repo, "snapshots")
+        if not os.path.isdir(snaps):
+            continue
+        revs = sorted((d for d in os.listdir(snaps) if os.path.isdir(os.path.join(snaps, d))),
+                      key=lambda d: os.path.getmtime(os.path.join(snaps, d)), reverse=True)
+        ref = os.path.join(repo, "refs", "main")
+        if os.path.isfile(ref):
+            with open(ref) as f:
+                main = f.read().strip()
+            if main in revs:
+                revs.remove(main)
+                revs.insert(0, main)
+        found += [os.path.join(snaps, d) for d in revs]
+    return found
+
+
 def _resolve_pretrained(name_or_path, subfolder=None):
-    """A local folder, or a hub id resolved inside $HF_HOME-style caches / ./weights (no network access is attempted)."""
+    """A local folder, `./weights/<name>`, or a hub id (`stabilityai/sd-vae-ft-ema`, `PixArt-alpha/PixArt-Alpha-DMD-XL-2-512x512`: what
+    the reference passes to from_pretrained, test_scripts/inference.py:36,236,238) resolved inside the local Hugging Face hub cache
+    ($HF_HUB_CACHE, $HF_HOME/hub, ~/.cache/huggingface/hub) - the place the reference's own run left the weights. Nothing is downloaded."""
     cands = [name_or_path, os.path.join("weights", name_or_path), os.path.join("weights", os.path.basename(name_or_path))]
+    if not os.path.isabs(name_or_path) and name_or_path.count("/") == 1 and not name_or_path.startswith("."):
+        cands += _hf_snapshots(name_or_path)
     for c in cands:
         p = os.path.join(c, subfolder) if subfolder else c
         if os.path.isdir(p):
             return p
-    raise FileNotFoundError(f"'{name_or_path}'{' / ' + subfolder if subfolder else ''} not found locally (looked in {cands}); "
-                            "download the diffusers folder and pass its path")
+    raise FileNotFoundError(f"'{name_or_path}'{' / ' + subfolder if subfolder else ''} not found locally (looked in {cands[:3]} and the hub caches "
+                            f"{_hf_cache_dirs()}); download the diffusers folder and pass its path")
 
 
 class _LatentDist:

@@ -1,5 +1,6 @@
 """CPU-only checks: the C-ABI library builds/loads and exports every symbol include/instarevive_hip.h declares (no compute
 calls), weight packing layouts, host glue (_sliding_windows, loaders, CLI parsing), failure behaviour without a GPU."""
+import json
 import os
 import re
 import sys
@@ -457,3 +458,124 @@ def test_no_compiler_placed_hazard_in_front_of_asm_mfmas():
     assert sum(n for _, n in res.values()) > 4000, "the scan must see the kernels' MFMAs"
     bad = {os.path.basename(f): [(k[:40], w, ins) for k, ins, w, d in fl][:4] for f, (fl, n) in res.items() if fl}
     assert not bad, bad
+
+
+def test_host_pools_order_bounds_and_errors(tmp_path):
+    """inference.HostPools: reads come back in submission order however long each takes, at most `depth` run ahead, writes are bounded,
+    a failed write surfaces at drain(), workers = 0 is the inline (reference) form, and the threaded run writes the same PNG bytes'
+    pixels as the inline one."""
+    import importlib
+    import threading
+    import time
+    from argparse import Namespace
+    from PIL import Image
+    sys.path.insert(0, ROOT)
+    inf = importlib.import_module("inference")
+    pools = inf.HostPools(4)
+    started, lock = [], threading.Lock()
+
+    def slow(i):
+        with lock:
+            started.append(i)
+        time.sleep(0.02 * ((7 - i) % 4))
+        return i * i
+
+    out = []
+    for v in pools.read_ahead(slow, range(40)):
+        out.append(v)
+        with lock:
+            assert len(started) - len(out) <= pools.depth          # bounded look-ahead
+    assert out == [i * i for i in range(40)]
+    running, peak, done = [0], [0], []
+
+    def w(i):
+        with lock:
+            running[0] += 1
+            peak[0] = max(peak[0], running[0])
+        time.sleep(0.005)
+        with lock:
+            running[0] -= 1
+            done.append(i)
+
+    for i in range(50):
+        pools.write_behind(w, i)
+    pools.drain()
+    assert sorted(done) == list(range(50)) and peak[0] <= 4 and pools.written == 50
+    bad = inf.HostPools(2)
+    bad.write_behind(lambda: (_ for _ in ()).throw(OSError("disk full")))
+    with pytest.raises(OSError):
+        bad.drain()
+    inline = inf.HostPools(0)
+    assert list(inline.read_ahead(lambda i: i + 1, range(5))) == [1, 2, 3, 4, 5]
+    seen = []
+    inline.write_behind(seen.append, 3)
+    assert seen == [3]
+    inline.drain()
+    assert inf.default_workers(1) >= 1 and inf.default_workers(10 ** 6) == 1
+    # same files from the threaded and the inline form
+    from tests.golden._det import det_input
+    src = tmp_path / "in"
+    src.mkdir()
+    for i in range(6):
+        Image.fromarray((det_input(10 + i, (40 + 8 * i, 56, 3)) * 255).numpy().astype(np.uint8)).save(src / f"f{i}.png")
+    outs = {}
+    for workers in (0, 3):
+        a = Namespace(input=str(src), output=str(tmp_path / f"out{workers}"), sr_scale=1.5, tiled=False, tile_size=512, use_center_crop=False,
+                      show_lq=True, disable_preprocess_model=False)
+        hp = inf.HostPools(workers)
+        files = sorted(str(p) for p in src.iterdir())
+        for job in hp.read_ahead(lambda f: inf.read_job(f, 0, a), files):
+            hp.write_behind(inf.write_job, job, 255 - job.net_in, job.net_in, a)
+        hp.drain()
+        outs[workers] = {p.name: np.array(Image.open(p)) for p in sorted((tmp_path / f"out{workers}").iterdir())}
+    assert list(outs[0]) == list(outs[3]) and len(outs[0]) == 6
+    assert all(np.array_equal(outs[0][k], outs[3][k]) for k in outs[0])
+
+
+def test_hub_ids_resolve_through_the_hf_cache(tmp_path, monkeypatch):
+    """The reference loads `stabilityai/sd-vae-ft-ema` and `PixArt-alpha/PixArt-Alpha-DMD-XL-2-512x512` (subfolders transformer / scheduler)
+    by hub id (test_scripts/inference.py:36,236,238), i.e. from <cache>/models--org--name/snapshots/<rev>/ with blobs behind symlinks.
+    _resolve_pretrained must find them there without a network: refs/main wins, else the newest snapshot; $HF_HUB_CACHE before $HF_HOME/hub
+    before ~/.cache/huggingface/hub; a missing id raises FileNotFoundError naming the caches."""
+    import time
+    from instarevive_amd import models
+    home = tmp_path / "home"
+    hub = home / ".cache" / "huggingface" / "hub"
+    repo = hub / "models--PixArt-alpha--PixArt-Alpha-DMD-XL-2-512x512"
+    old, new = repo / "snapshots" / "aaaa", repo / "snapshots" / "bbbb"
+    for snap, beta_end in ((old, 0.03), (new, 0.02)):
+        (snap / "scheduler").mkdir(parents=True)
+        blob = repo / "blobs" / f"blob{beta_end}"
+        blob.parent.mkdir(exist_ok=True)
+        blob.write_text(json.dumps({"_class_name": "DDPMScheduler", "num_train_timesteps": 1000, "beta_start": 1e-4, "beta_end": beta_end,
+                                    "beta_schedule": "linear"}))
+        os.symlink(blob, snap / "scheduler" / "scheduler_config.json")      # the cache stores files as links into blobs/
+        (snap / "transformer").mkdir()
+    past = time.time() - 1000
+    os.utime(old, (past, past))
+    for var in ("HF_HOME", "HF_HUB_CACHE", "HUGGINGFACE_HUB_CACHE", "XDG_CACHE_HOME"):
+        monkeypatch.delenv(var, raising=False)
+    monkeypatch.setenv("HOME", str(home))
+    monkeypatch.chdir(tmp_path)                                              # no ./weights here
+    hub_id = "PixArt-alpha/PixArt-Alpha-DMD-XL-2-512x512"
+    assert models._resolve_pretrained(hub_id, "transformer") == str(new / "transformer")        # newest snapshot
+    assert float(models.DDPMScheduler.from_pretrained(hub_id, subfolder="scheduler").config.beta_end) == 0.02
+    (repo / "refs").mkdir()
+    (repo / "refs" / "main").write_text("aaaa\n")
+    assert models._resolve_pretrained(hub_id, "scheduler") == str(old / "scheduler")            # refs/main decides
+    assert float(models.DDPMScheduler.from_pretrained(hub_id, subfolder="scheduler").config.beta_end) == 0.03
+    # $HF_HOME/hub and $HF_HUB_CACHE take precedence over the home cache, in huggingface_hub's order
+    alt = tmp_path / "alt" / "hub" / "models--stabilityai--sd-vae-ft-ema" / "snapshots" / "cccc"
+    alt.mkdir(parents=True)
+    with pytest.raises(FileNotFoundError) as e:
+        models._resolve_pretrained("stabilityai/sd-vae-ft-ema")
+    assert "huggingface" in str(e.value)
+    monkeypatch.setenv("HF_HOME", str(tmp_path / "alt"))
+    assert models._resolve_pretrained("stabilityai/sd-vae-ft-ema") == str(alt)
+    direct = tmp_path / "direct" / "models--stabilityai--sd-vae-ft-ema" / "snapshots" / "dddd"
+    direct.mkdir(parents=True)
+    monkeypatch.setenv("HF_HUB_CACHE", str(tmp_path / "direct"))
+    assert models._resolve_pretrained("stabilityai/sd-vae-ft-ema") == str(direct)
+    # a local folder of the same name still wins (the reference's from_pretrained does the same)
+    (tmp_path / "stabilityai" / "sd-vae-ft-ema").mkdir(parents=True)
+    assert models._resolve_pretrained("stabilityai/sd-vae-ft-ema") == "stabilityai/sd-vae-ft-ema"
