@@ -220,6 +220,39 @@ def cpu_baseline(sds, y, mask, h_full, w_full, log, hip_fn=None, big_pass=True):
     return out
 
 
+def cli_files_leg(k, sds, value, log):
+    """`inference.py --sr_scale 4` as a fresh child process over k synthetic 512 x 512 PNG files with the bench's own full-size weights written
+    in the reference's file formats (tools/cli_artifacts.py). Never raises: a failed leg is reported as {"error": ...}."""
+    import shutil
+    import subprocess
+    import tempfile
+    from tools import cli_artifacts as A
+    d = tempfile.mkdtemp(prefix="ir_cli_")
+    try:
+        t0 = time.time()
+        flags = A.write_full_artifacts(d, sds)
+        A.write_lq_pngs(os.path.join(d, "in"), k)
+        log(f"cli leg: artefacts + {k} PNGs written in {time.time() - t0:.1f}s under {d}")
+        cmd = [sys.executable, os.path.join(ROOT, "inference.py"), "--input", os.path.join(d, "in"), "--output", os.path.join(d, "out"), "--sr_scale", "4"] + flags
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT)
+        rates = A.parse_cli_rate(r.stdout)
+        written = len([f for f in os.listdir(os.path.join(d, "out"))]) if os.path.isdir(os.path.join(d, "out")) else 0
+        if r.returncode != 0 or not rates or written != k:
+            return dict(error=f"rc {r.returncode}, {written} of {k} files written", tail=(r.stdout[-300:] + r.stderr[-600:]))
+        c = rates[0]
+        log(f"cli leg: {c['files']} files in {c['seconds']:.2f}s = {c['files_per_s']:.2f} files/s; after the first result {c['steady_files_per_s']:.2f} files/s "
+            f"({c['workers']} host threads) against {value:.2f} images/s device-resident")
+        return dict(files=k, files_per_s=c["files_per_s"], steady_files_per_s=c["steady_files_per_s"], host_threads=c["workers"],
+                    ratio_to_value=round(c["files_per_s"] / value, 3), steady_ratio_to_value=round(c["steady_files_per_s"] / value, 3),
+                    command="inference.py --sr_scale 4 (child process; 512x512 PNG in, 2048x2048 PNG out, default --workers)",
+                    note="files_per_s: first read submitted -> last PNG closed, including the child's library / workspace warm-up on its first image; "
+                         "steady_*: from the first finished result on. Model loading is excluded from both")
+    except Exception as e:  # noqa: BLE001 - the headline line must still be printed
+        return dict(error=repr(e)[:300])
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def self_launch(n_ranks):
     """Run this script as n_ranks child processes under torch.distributed.run (one rank per GPU) and return the exit code."""
     import socket
@@ -255,6 +288,8 @@ def main():
     ap.add_argument("--no_profile", action="store_true", help="experiment: time the loop without the per-launch HIP events (no roofline)")
     ap.add_argument("--no_verify", action="store_true", help="skip the fast-vs-plain-kernel check of the last timed output")
     ap.add_argument("--no_host_rate", action="store_true", help="skip the host-buffer (PCIe-inclusive) rates")
+    ap.add_argument("--cli_files", type=int, default=32, metavar="K", help="after the timed steps (N = 1, headline workload only): write K synthetic 512 x 512 PNGs and "
+                    "the full-size artefacts, run `inference.py --sr_scale 4` on them as a fresh child process and report its files/s beside `value` (0 = skip)")
     ap.add_argument("--fp8", action="store_true", help="BASELINE configs[4]: fp8 (e4m3) MFMA operands in the parts ir_fp8_features() reports (the JSON line names them)")
     args = ap.parse_args()
 
@@ -470,6 +505,12 @@ def main():
                     note="uint8 HWC host arrays in, prediction + stage-1 image out; stream = process_stream(), sync = one process() per step")
         log(f"host-buffer rate: stream {dt_stream * 1e3:.2f} ms/step, sync {dt_sync * 1e3:.2f} ms/step (device-resident {ms_per_step:.2f})")
 
+    # ---- the shipped command line on FILES: K PNGs in, K PNGs out, through inference.py as a child process with its
+    # reader / writer threads; the rate is the child's own clock from the first read to the last closed PNG (model loading excluded)
+    cli = None
+    if world == 1 and args.cli_files > 0 and not (args.control or args.fp8 or args.tiled or args.net_hw) and (h, w, n) == (2048, 2048, 1):
+        cli = cli_files_leg(args.cli_files, sds, value, log)
+
     if rank == 0:
         fm = flops_model_tiled(h, w, tile_size, tile_stride, copies=args.control) if args.tiled else flops_model(h, w, copies=args.control)
         total_ms = sum(v["ms"] for v in prof.values())
@@ -576,6 +617,8 @@ def main():
             line.update(verify)
         if host is not None:
             line.update(host)
+        if cli is not None:
+            line["cli"] = cli
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -89,6 +89,39 @@ def test_cli_matches_oracle(tmp_path):
         assert p >= 47.0  # measured 52.3 and 53.1 dB on these two files
 
 
+def test_cli_threaded_run_writes_the_single_thread_pixels(tmp_path):
+    """the reader / writer pools of inference.py (--workers) change WHEN a file is decoded or encoded, never what is
+    computed: 14 files of five sizes (so batches_of() regroups while reads run ahead), --sr_scale 2 --show_lq, once with --workers 0 (the
+    reference's one-thread order) and once with 4 threads; every PNG must hold the same pixels, under the same name, and the summary
+    line bench.py --cli_files parses must be printed."""
+    from tools import cli_artifacts as A
+    d = tmp_path
+    _write_artifacts(d)
+    os.makedirs(d / "in" / "deep" / "er", exist_ok=True)
+    sizes = [(64, 64), (40, 56), (64, 64), (64, 64), (33, 90), (64, 64), (40, 56), (72, 72), (64, 64), (64, 64), (50, 50), (64, 64), (64, 64), (40, 56)]
+    for i, hw in enumerate(sizes):
+        sub = ("", "deep/", "deep/er/")[i % 3]
+        Image.fromarray((det_input(300 + i, hw + (3,)) * 255).numpy().astype(np.uint8)).save(d / "in" / f"{sub}im{i:02d}.png")
+    outs = {}
+    for workers in (0, 4):
+        cmd = [sys.executable, os.path.join(ROOT, "inference.py"), "--ckpt", str(d / "weights" / "dit.ckpt"), "--input", str(d / "in"), "--output",
+               str(d / f"out{workers}"), "--swinir_ckpt", str(d / "weights" / "swinir.ckpt"), "--swinir_config", str(d / "swinir.yaml"), "--vae", str(d / "vae"),
+               "--dit_config", str(d / "pixart"), "--prompt_embeds", str(d / "prompt.pth"), "--sr_scale", "2", "--show_lq", "--batch_size", "3",
+               "--workers", str(workers)]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        rate = A.parse_cli_rate(r.stdout)
+        assert len(rate) == 1 and rate[0]["files"] == len(sizes) and rate[0]["workers"] == workers and rate[0]["files_per_s"] > 0, r.stdout[-500:]
+        found = {}
+        for root, _, names in os.walk(d / f"out{workers}"):
+            for nm in names:
+                found[os.path.relpath(os.path.join(root, nm), d / f"out{workers}")] = np.array(Image.open(os.path.join(root, nm)))
+        outs[workers] = found
+    assert sorted(outs[0]) == sorted(outs[4]) and len(outs[0]) == len(sizes)
+    for k in outs[0]:
+        assert outs[0][k].shape == outs[4][k].shape and np.array_equal(outs[0][k], outs[4][k]), k
+
+
 def test_eval_batch_harness_matches_oracle(tmp_path):
     """the batched evaluation harness (eval_batch.py, the role of test_dmd_general.py:112-192) on five images of
     different sizes in batches of 2 — centre crop (center_crop_arr), B > 1 through process_stream, result + condition folders, .jpg -> .png —
