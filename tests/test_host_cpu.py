@@ -345,14 +345,76 @@ def test_evaluate_pairs_psnr_ssim_on_y(tmp_path):
         Image.fromarray(np.clip(base[i] + rng.normal(0, 12, base[i].shape), 0, 255).astype(np.uint8)).save(tmp_path / "noise" / f"im{i}.png")
     quiet = lambda *a: None
     same = ep.evaluate(tmp_path / "same", tmp_path / "gt", log=quiet)
-    assert same["ssim"] == 1.0 and abs(same["psnr"] - 10 * np.log10(255.0 ** 2 / 1e-8)) < 1e-6
-    # +4 grey levels on every channel: Y moves by 219 / 255 * 4 = 3.435 before rounding, i.e. by 3 or 4 after it
+    assert same["ssim"] == 1.0 and abs(same["psnr"] - 80.0) < 1e-6            # eps 1e-8 on the UNIT-scale MSE (pyiqa psnr, data_range 1)
+    # +4 grey levels on every channel: Y moves by exactly 219 / 255 * 4 / 255 on the unit scale (no rounding on pyiqa's default path)
     shift = ep.evaluate(tmp_path / "shift", tmp_path / "gt", log=quiet)
-    assert 10 * np.log10(255.0 ** 2 / 16.0) - 1e-9 <= shift["psnr"] <= 10 * np.log10(255.0 ** 2 / 9.0) + 1e-9 and shift["ssim"] > 0.99
+    assert abs(shift["psnr"] - 10 * np.log10(1.0 / ((219.0 / 255.0 * 4.0 / 255.0) ** 2 + 1e-8))) < 1e-6 and shift["ssim"] > 0.99
     noise = ep.evaluate(tmp_path / "noise", tmp_path / "gt", log=quiet)
     assert 24.0 < noise["psnr"] < 32.0 and 0.3 < noise["ssim"] < 0.97
     # white on black: Y spans 16 .. 235 (studio swing), as pyiqa's color_space='ycbcr'
     assert ep.to_y(np.zeros((1, 1, 3)))[0, 0] == 16 and ep.to_y(np.ones((1, 1, 3)))[0, 0] == 235
+    assert abs(ep.to_y(np.full((1, 1, 3), 0.5), 1.0)[0, 0] - (16 + 219 * 0.5) / 255) < 1e-12       # unit scale: not rounded
+
+
+def test_evaluate_pairs_lpips_against_an_independent_construction(tmp_path):
+    """LPIPS v0.1 / alex as tools/evaluate_pairs.py restates it (utils/metrics.py:41-66, evaluate_img.py:32) against the same network built
+    here from torch.nn modules in torchvision's `features` order (Conv 0, ReLU 1, MaxPool 2, Conv 3, ReLU 4, MaxPool 5, Conv 6, ReLU 7, Conv 8,
+    ReLU 9, Conv 10, ReLU 11) with seeded random weights - the pretrained files do not exist offline (parity unpinned for the weights, not for
+    the arithmetic). Both weight layouts load (torchvision + lin heads; one full lpips state dict); d(x, x) = 0; symmetry; the folder
+    evaluation reports the mean."""
+    import importlib.util
+    from PIL import Image
+    spec = importlib.util.spec_from_file_location("evaluate_pairs", os.path.join(ROOT, "tools", "evaluate_pairs.py"))
+    ep = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ep)
+    nn = torch.nn
+    torch.manual_seed(5)
+    feats = nn.Sequential(nn.Conv2d(3, 64, 11, 4, 2), nn.ReLU(), nn.MaxPool2d(3, 2), nn.Conv2d(64, 192, 5, padding=2), nn.ReLU(), nn.MaxPool2d(3, 2),
+                          nn.Conv2d(192, 384, 3, padding=1), nn.ReLU(), nn.Conv2d(384, 256, 3, padding=1), nn.ReLU(), nn.Conv2d(256, 256, 3, padding=1), nn.ReLU())
+    lins = [torch.rand(1, c, 1, 1) for c in (64, 192, 384, 256, 256)]
+    alex_sd = {"features." + k: v for k, v in feats.state_dict().items()}
+    alex_sd.update({"classifier.1.weight": torch.zeros(2, 2)})                                   # the real file also carries the classifier
+    lin_sd = {f"lin{k}.model.1.weight": w for k, w in enumerate(lins)}
+    torch.save(alex_sd, tmp_path / "alexnet.pth")
+    torch.save(lin_sd, tmp_path / "alex_lin.pth")
+    full = dict(lin_sd)
+    for k, key in enumerate(ep.LPIPS_SLICE_KEY):
+        idx = ep.ALEX_CONVS[k][0]
+        full[key + ".weight"], full[key + ".bias"] = alex_sd[f"features.{idx}.weight"], alex_sd[f"features.{idx}.bias"]
+    torch.save(full, tmp_path / "lpips_full.pth")
+    a, b = torch.rand(2, 3, 96, 80), torch.rand(2, 3, 96, 80)
+
+    def want(x, y):
+        shift, scale = torch.tensor([-.030, -.088, -.188]).view(1, 3, 1, 1), torch.tensor([.458, .448, .450]).view(1, 3, 1, 1)
+        tot = torch.zeros(x.shape[0])
+        fx, fy = (2 * x - 1 - shift) / scale, (2 * y - 1 - shift) / scale
+        k = 0
+        with torch.no_grad():
+            for layer in feats:
+                fx, fy = layer(fx), layer(fy)
+                if isinstance(layer, nn.ReLU):
+                    nx = fx / (fx.norm(dim=1, keepdim=True) + 1e-10)
+                    ny = fy / (fy.norm(dim=1, keepdim=True) + 1e-10)
+                    tot += torch.nn.functional.conv2d((nx - ny) ** 2, lins[k]).mean((1, 2, 3))
+                    k += 1
+        return tot
+
+    for net in (ep.LPIPS(str(tmp_path / "alexnet.pth"), str(tmp_path / "alex_lin.pth")), ep.LPIPS(None, str(tmp_path / "lpips_full.pth"))):
+        got = net(a, b)
+        torch.testing.assert_close(got, want(a, b), rtol=1e-4, atol=1e-6)
+        assert float(net(a, a).abs().max()) == 0.0 and float(got.min()) > 0
+        torch.testing.assert_close(net(b, a), got, rtol=1e-5, atol=1e-7)
+        torch.testing.assert_close(net(2 * a - 1, 2 * b - 1, normalize=False), got, rtol=1e-4, atol=1e-6)
+    with pytest.raises(KeyError):
+        ep.LPIPS(str(tmp_path / "alexnet.pth"), None)
+    for sub in ("x", "y"):
+        os.makedirs(tmp_path / sub)
+    for i in range(2):
+        Image.fromarray((a[i].permute(1, 2, 0) * 255).to(torch.uint8).numpy()).save(tmp_path / "x" / f"{i}.png")
+        Image.fromarray((b[i].permute(1, 2, 0) * 255).to(torch.uint8).numpy()).save(tmp_path / "y" / f"{i}.png")
+    res = ep.evaluate(tmp_path / "x", tmp_path / "y", log=lambda *a_: None, lpips=net)
+    q = lambda t: (t * 255).to(torch.uint8).float() / 255
+    assert abs(res["lpips"] - float(want(q(a), q(b)).mean())) < 1e-4 and "psnr" in res and "ssim" in res
 
 
 def test_clip_bpe_tokenizer_matches_transformers_and_open_clip_layout(tmp_path):
