@@ -31,7 +31,25 @@ sys.path.insert(0, ROOT)
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA peak (/opt/skills/guides/MI355X_MICROARCH.md, chip-level table)
 PEAK_FP8_TFLOPS = 5000.0   # dense fp8 (MX-scaled f8f6f4 MFMA), same table
 PEAK_HBM_GBS = 8000.0
-PMC_FILE = "r04_pmc_kernels.json"  # HBM traffic of the conv / GEMM family, refreshed per round by tools/pmc_traffic.py
+
+
+def pmc_file_for_this_tree():
+    """The newest profiles/r*_pmc_kernels.json collected on THESE kernel sources (its csrc_sha16 = instarevive_amd.build.source_hash()), else
+    (None, why): roofline.traffic must come from the evidence run of the same code, a stale file is refused."""
+    import glob
+    from instarevive_amd.build import source_hash
+    cur = source_hash()
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_kernels.json")), reverse=True)
+    seen = []
+    for f in files:
+        try:
+            sha = json.load(open(f)).get("csrc_sha16")
+        except (OSError, ValueError):
+            continue
+        if sha == cur:
+            return f, None
+        seen.append(f"{os.path.basename(f)} ({sha or 'no hash'})")
+    return None, f"no PMC file for kernel sources {cur}: {', '.join(seen[:2]) or 'none found'} - stale, refused; run tools/r05_evidence.sh"
 
 
 # ---------------------------------------------------------------- algorithmic FLOP model (BASELINE.md section 2, 2*MAC, matmul/conv only)
@@ -277,8 +295,10 @@ def main():
     ap.add_argument("--tiled", action="store_true")
     ap.add_argument("--net_hw", type=str, default="", help="HxW network input (overrides --lq/--sr_scale), e.g. 2176x3840 for the padded 4K case")
     ap.add_argument("--no_cpu_baseline", action="store_true")
-    ap.add_argument("--fp8_parts", choices=["all", "attention", "no_encoder_convs", "convs"], default="all",
-                    help="with --fp8: which parts take e4m3 operands (default: all that BASELINE.json configs[4] names, plus the VAE mid-block attention)")
+    ap.add_argument("--fp8_parts", choices=["default", "all", "attention", "no_encoder_convs", "convs"], default="default",
+                    help="with --fp8: which parts take e4m3 operands. default = the set chosen by north_star's tolerance (>= 46.3 dB against the fp32 oracle at "
+                         "2048 x 2048: the attention parts + the decoder's level-0 / level-2 convs, IR_FP8_MASK_DEFAULT); all = every part BASELINE.json "
+                         "configs[4] names plus the VAE mid-block attention: faster, but OUTSIDE the 0.1 dB tolerance above a 25.8 dB reference")
     ap.add_argument("--cpu_small", action="store_true", help="CPU baseline from the 512x512 oracle pass only (skips the 1024x1024 pass, about 25 s)")
     ap.add_argument("--control", type=int, default=0, metavar="COPIES", help="diagnostic: run the DiT step with the ControlNet-Half branch "
                     "(COPIES copied blocks, 13 in the reference configs; c = the LQ latent). Not the headline workload: no such weights are released")
@@ -288,7 +308,7 @@ def main():
     ap.add_argument("--no_profile", action="store_true", help="experiment: time the loop without the per-launch HIP events (no roofline)")
     ap.add_argument("--no_verify", action="store_true", help="skip the fast-vs-plain-kernel check of the last timed output")
     ap.add_argument("--no_host_rate", action="store_true", help="skip the host-buffer (PCIe-inclusive) rates")
-    ap.add_argument("--cli_files", type=int, default=32, metavar="K", help="after the timed steps (N = 1, headline workload only): write K synthetic 512 x 512 PNGs and "
+    ap.add_argument("--cli_files", type=int, default=48, metavar="K", help="after the timed steps (N = 1, headline workload only): write K synthetic 512 x 512 PNGs and "
                     "the full-size artefacts, run `inference.py --sr_scale 4` on them as a fresh child process and report its files/s beside `value` (0 = skip)")
     ap.add_argument("--fp8", action="store_true", help="BASELINE configs[4]: fp8 (e4m3) MFMA operands in the parts ir_fp8_features() reports (the JSON line names them)")
     args = ap.parse_args()
@@ -301,6 +321,31 @@ def main():
         raise SystemExit(self_launch(args.gpus))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
+    # clock / power trace of this rank's card over the whole run: a child that only reads sysfs, started BEFORE this process's first GPU call
+    sampler, sampler_file = None, None
+    if rank == 0 and not os.environ.get("IR_NO_POWER_TRACE"):
+        import subprocess
+        import tempfile
+        sampler_file = os.path.join(tempfile.gettempdir(), f"ir_power_{os.getpid()}.txt")
+        try:
+            sampler = subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "power_sampler.py"), "--out", sampler_file, "--card", str(local)],
+                                       stdin=subprocess.PIPE, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        except OSError:
+            sampler = None
+        if sampler is not None:
+            import atexit
+
+            def stop_sampler():
+                try:
+                    sampler.stdin.close()
+                    sampler.wait(timeout=5)
+                    if os.environ.get("IR_KEEP_POWER_TRACE") and os.path.exists(sampler_file):   # the raw trace, for profiles/
+                        import shutil
+                        shutil.copy(sampler_file, os.environ["IR_KEEP_POWER_TRACE"])
+                    os.unlink(sampler_file)
+                except (OSError, subprocess.TimeoutExpired):
+                    pass
+            atexit.register(stop_sampler)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X GPU; the product path has no CPU fallback")
     # IR_BENCH_BACKEND=gloo: rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks (ranks share devices, collectives
@@ -342,14 +387,19 @@ def main():
         feats = ctx.lib.ir_fp8_features()   # what THIS build moves to fp8 operands: the workload string says exactly that
         # --fp8_parts narrows the operand set (ir_set_fp8_mask; tools/fp8_attribution.py: the attention products cost 0.1 dB against the oracle,
         # the e4m3 conv activations 5.5 dB): "attention" = the three attention parts only, "no_encoder_convs" = everything but the encoder's convs
-        conv_bits = sum(1 << b for b in (4, 5, 6, 7, 8, 12, 13, 14, 15, 16))
-        masks = {"all": 0xffffffff, "attention": 0b111, "no_encoder_convs": 0xffffffff & ~(0x1f << 4), "convs": conv_bits}
+        conv_bits = L.FP8_CONV_BITS
+        masks = {"default": L.FP8_MASK_DEFAULT, "all": L.FP8_MASK_ALL, "attention": L.FP8_MASK_ATTENTION, "no_encoder_convs": 0xffffffff & ~(0x1f << 4), "convs": conv_bits}
         fmask = masks[args.fp8_parts]
         ctx.check(ctx.lib.ir_set_fp8_mask(ctx.h, fmask), "ir_set_fp8_mask")
-        conv_words = "the VAE ResnetBlock 3x3 convs" if fmask & conv_bits == conv_bits else ("the VAE decoder's ResnetBlock 3x3 convs" if fmask & conv_bits else None)
+        lvl = lambda base, name: [f"{name} level {l}" for l in range(4) if fmask >> (base + l) & 1] + ([f"{name} mid block"] if fmask >> (base + 4) & 1 else [])
+        conv_parts = lvl(4, "encoder") + lvl(12, "decoder")
+        conv_words = ("the VAE ResnetBlock 3x3 convs" if fmask & conv_bits == conv_bits else
+                      ("the VAE ResnetBlock 3x3 convs of " + ", ".join(conv_parts)) if conv_parts else None)
         fp8_words = ", fp8 MFMA operands (MX-scaled e4m3) in " + " and ".join(
             w for bit, w, on in ((1, conv_words, bool(fmask & conv_bits)), (2, "the DiT self-attention products", bool(fmask & 1)),
                                  (4, "the VAE mid-block attention products", bool(fmask & 6))) if (feats & bit) and on)
+        fp8_words += {"default": " [operand set chosen by the 0.1 dB tolerance: >= 46.3 dB vs the fp32 oracle at 2048 x 2048]",
+                      "all": " [ALL parts: OUT OF TOLERANCE above a 25.8 dB reference (42.1 dB vs the oracle); opt-in]"}.get(args.fp8_parts, f" [--fp8_parts {args.fp8_parts}]")
         vae.enable_fp8(True)                                # packs + uploads the fp8 weight forms of the VAE resnet convs
         ctx.check(ctx.lib.ir_set_fp8(ctx.h, 0), "ir_set_fp8")  # ... the mode itself is switched per call by IR_FLAG_FP8
     if args.graph:
@@ -404,11 +454,20 @@ def main():
     barrier()
     if not args.no_profile:
         ctx.profile_begin(only=dominant)
+    wall0 = time.time()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
+    power = None
+    if sampler is not None:   # what the card's clock and socket power were DURING the timed loop (hwmon samples every 20 ms)
+        from tools.power_sampler import summarise
+        time.sleep(0.05)
+        power = summarise(sampler_file, wall0, wall0 + dt)
+        if power is not None:
+            log(f"timed loop: gfx clock {power.get('clock_mhz')} MHz (min {power.get('clock_mhz_min')}, max {power.get('clock_mhz_max')}), socket power {power.get('power_w')} W "
+                f"(max {power.get('power_w_max')}), {power['samples']} samples")
     if args.no_profile:   # diagnostic forms (--graph / --no_profile): the same JSON line without the per-launch measurements
         if rank == 0:
             fm = flops_model_tiled(h, w, tile_size, tile_stride, copies=args.control) if args.tiled else flops_model(h, w, copies=args.control)
@@ -467,8 +526,10 @@ def main():
         psnr = 99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
         std = float(fast.double().std())
         if args.fp8:   # e4m3 operands carry 3 mantissa bits
-            # measured 42.5 dB at 2048 x 2048 (profiles/r02_bench_fp8.log); the gate is that minus a margin
-            verify = dict(verified=bool(psnr >= 38.0 and std > 1.0), psnr_fp8_vs_bf16_plain_kernels_db=round(psnr, 2), output_std=round(std, 2))
+            # the guard-chosen default set: measured 49.5 dB against the bf16 pass at 2048 x 2048; every part: 42.5 dB (profiles/r02_bench_fp8.log);
+            # the gates are those minus a margin
+            gate8 = 47.0 if args.fp8_parts in ("default", "attention") else 38.0
+            verify = dict(verified=bool(psnr >= gate8 and std > 1.0), psnr_fp8_vs_bf16_plain_kernels_db=round(psnr, 2), output_std=round(std, 2), gate_db=gate8)
         else:
             verify = dict(verified=bool(psnr >= 45.0 and std > 1.0), psnr_fast_vs_plain_kernels_db=round(psnr, 2), output_std=round(std, 2))
         if dist is not None:
@@ -480,6 +541,28 @@ def main():
                 verify["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else backend
                 verify["world_size"] = dist.get_world_size()
         log(f"verify: fast vs plain kernels {psnr:.2f} dB, output std {std:.1f}")
+
+    # ---- outside the timed region: the TIMED configuration (bf16, or the fp8 operand set) at the headline size against the fp32 oracle, through
+    # the committed fixture tests/golden/headline_crops.npz (24 crops of 128 x 128 of ONE oracle pass at 2048 x 2048 on bench.py's seeded weights)
+    parity_2048 = None
+    crops_file = os.path.join(ROOT, "tests", "golden", "headline_crops.npz")
+    if rank == 0 and (h, w, n) == (2048, 2048, 1) and not args.tiled and not args.control and os.path.exists(crops_file):
+        from tests.golden.make_headline_crops import CROP, inputs_for
+        zc = np.load(crops_file)
+        cin = torch.from_numpy(inputs_for(2048))[None].to(device)
+        cout = torch.empty_like(cin)
+        ctx.check(ctx.lib.ir_pipeline(ctx.h, ctx.stream(), L.ptr(cin), L.ptr(cout), None, 1, h, w, flags, tile_size, tile_stride, 400.0, acp, sf, L.ptr(ws), ws.numel()), "ir_pipeline")
+        torch.cuda.synchronize()
+        got = cout[0].cpu().numpy()
+        got = np.stack([got[yy:yy + CROP, xx:xx + CROP] for yy, xx in zc["pos_2048"]]).astype(np.float64)
+        mse_c = float(((got - zc["crops_2048"].astype(np.float64)) ** 2).mean()) / 255.0 ** 2
+        p_c = 10.0 * np.log10(1.0 / (mse_c + 1e-12))
+        parity_2048 = dict(psnr_vs_oracle_db=round(p_c, 2), within_0p1_db_up_to_reference_psnr_db=round(p_c + 10.0 * np.log10(10 ** 0.01 - 1.0), 1),
+                           meets_0p1_db_at_30_db_reference=bool(p_c >= 46.3),
+                           note="the timed configuration on the input of tests/golden/headline_crops.npz (512 x 512 LQ, sr_scale 4 -> 2048 x 2048), 24 crops of "
+                                "128 x 128 of its uint8 result against the fp32 oracle's; >= 46.3 dB keeps PSNR(., GT) within 0.1 dB of the reference's up to a 30 dB reference")
+        log(f"parity at 2048 x 2048 (oracle crops): {p_c:.2f} dB -> within 0.1 dB up to a {parity_2048['within_0p1_db_up_to_reference_psnr_db']} dB reference")
+        del cin, cout
 
     # ---- the drop-in boundary hands over HOST arrays (inference.py:91-93,157-166): the same workload through process() (pinned staging,
     # synchronous) and through process_stream() (what the CLI runs: upload / download of neighbouring batches overlapped with compute)
@@ -547,23 +630,37 @@ def main():
                 ex = (v["flops"] / args.steps - skipped) / (v["ms"] / args.steps / 1e3) / 1e12
                 row.update(executed_tflop_per_step=round((v["flops"] / args.steps - skipped) / 1e12, 4), executed_achieved=round(ex, 1), executed_frac=round(ex / pk, 4),
                            note="achieved/frac price the algorithmic 9-tap FLOPs; SwinIR's three upsampler convs run as four 2x2 phase convs")
+            if row.get("bound") == "mfma":
+                # every MFMA-bound row carries BOTH prices: achieved / frac on the reference's algorithmic FLOPs (the contract's definition) and
+                # executed_* on what the matrix pipe ran (equal unless the kernel skips MACs the reference does: the phase-form Upsample convs).
+                row.setdefault("executed_tflop_per_step", row["tflop_per_step"])
+                row.setdefault("executed_achieved", row["achieved"])
+                row.setdefault("executed_frac", row["frac"])
+                if row["frac"] > 1.0:
+                    # only possible when the launches of this row are (mostly) phase-form convs priced on 9-tap FLOPs (the --fp8 lines: the other convs
+                    # moved to the fp8 kernel): the algorithmic figure is not a roofline fraction then - the row's frac is the executed one
+                    row.update(algorithmic_frac=row["frac"], frac=row["executed_frac"], frac_basis="executed (the algorithmic 9-tap FLOPs of this row's phase-form "
+                               "launches exceed what the MFMA pipe ran; algorithmic_frac keeps that figure)")
             per_kernel[short] = row
             log(f"    {short[:58]:58s} {row['ms_per_step']:8.2f} ms/step {row['launches_per_step']:4d} launches  "
-                + (f"{row['achieved']:8.1f} {row['unit']} = {row['frac']:.3f} of {row['bound']} peak" if "frac" in row else ""))
+                + (f"{row['achieved']:8.1f} {row['unit']} = {row['frac']:.3f} of {row['bound']} peak" if "frac" in row else "")
+                + (f" (executed {row['executed_frac']:.3f})" if row.get("executed_frac", row.get("frac")) != row.get("frac") else ""))
         # the dominant KERNEL (not family) by GPU time carries the roofline line; every other kernel is in per_kernel
         dom_name = dominant if dominant is not None else max(kprof, key=lambda k: kprof[k]["ms"])
         d, dshort = kprof[dom_name], dom_name.split("/", 1)[1]
         drow = per_kernel[dshort]
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", PMC_FILE)
-        if os.path.exists(pmc) and not args.tiled and (h, w, n) == (2048, 2048, 1) and not args.fp8 and not args.control:
-            per = json.load(open(pmc)).get("per_kernel", {})
-            keys = [k for k in per if k.split("<")[0] in dshort]   # every template instantiation the timing row aggregates
-            launches = sum(per[k]["launches_per_step"] for k in keys)
-            if keys and launches > 0:
-                traffic = sum(per[k]["read_bytes_per_step"] + per[k]["write_bytes_per_step"] for k in keys) / launches
-                traffic_src = (f"static: profiles/{PMC_FILE} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command, not this run; "
-                               f"{len(keys)} instantiation(s), {launches:.0f} launches per step)")
+        if not args.tiled and (h, w, n) == (2048, 2048, 1) and not args.fp8 and not args.control:
+            pmc, why = pmc_file_for_this_tree()
+            traffic_src = why
+            if pmc is not None:
+                per = json.load(open(pmc)).get("per_kernel", {})
+                keys = [k for k in per if k.split("<")[0] in dshort]   # every template instantiation the timing row aggregates
+                launches = sum(per[k]["launches_per_step"] for k in keys)
+                if keys and launches > 0:
+                    traffic = sum(per[k]["read_bytes_per_step"] + per[k]["write_bytes_per_step"] for k in keys) / launches
+                    traffic_src = (f"static: profiles/{os.path.basename(pmc)} (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command on the SAME "
+                                   f"kernel sources - csrc_sha16 matches -, not this run; {len(keys)} instantiation(s), {launches:.0f} launches per step)")
         roof = dict(bound=drow.get("bound", "mfma"), kernel=dshort, achieved=drow.get("achieved"), peak=drow.get("peak"), unit=drow.get("unit"),
                     frac=drow.get("frac"), traffic=traffic, traffic_source=traffic_src, launches_per_step=drow["launches_per_step"],
                     avg_launch_ms=round(d["ms"] / max(d["launches"], 1), 4), share_of_gpu_time=round(d["ms"] / total_ms, 3),
@@ -617,8 +714,12 @@ def main():
             line.update(verify)
         if host is not None:
             line.update(host)
+        if parity_2048 is not None:
+            line["parity_2048"] = parity_2048
         if cli is not None:
             line["cli"] = cli
+        line["clock_mhz"], line["power_w"] = (power or {}).get("clock_mhz"), (power or {}).get("power_w")
+        line["power_trace"] = power
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

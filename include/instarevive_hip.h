@@ -199,12 +199,19 @@ int ir_tiled_blend_pixels(ir_ctx* ctx, void* stream, const float* px_tiles, uint
 int ir_set_plain_kernels(ir_ctx* ctx, int on);
 /* on != 0: the stage entry points (ir_vae_encode / ir_vae_decode / ir_dit_*) use the fp8 forms as IR_FLAG_FP8 does for ir_pipeline. */
 int ir_set_fp8(ir_ctx* ctx, int on);
-/* Which PARTS take fp8 operands while fp8 is on (default: all of them = what ir_fp8_features() reports). One bit per part, so that the error
+/* Which PARTS take fp8 operands while fp8 is on (default: IR_FP8_MASK_DEFAULT below). One bit per part, so that the error
  * of BASELINE.json configs[4] can be attributed part by part (tools/fp8_attribution.py -> DESIGN.md section 4) and an operand set chosen that
  * meets a PSNR target: the DiT self-attention, the mid-block attention of the VAE encoder / decoder, the ResnetBlock convs of encoder /
  * decoder level 0..3 (level l = index into ch_mult: 0 is full resolution) and of the two mid blocks. */
 enum { IR_FP8_BIT_DIT_ATTN = 0, IR_FP8_BIT_ENC_ATTN = 1, IR_FP8_BIT_DEC_ATTN = 2, IR_FP8_BIT_ENC_LEVEL0 = 4, IR_FP8_BIT_ENC_MID = 8,
        IR_FP8_BIT_DEC_LEVEL0 = 12, IR_FP8_BIT_DEC_MID = 16 };
+/* The DEFAULT operand set (ABI v2) is chosen by north_star's tolerance, not by speed: the largest-saving set of parts whose result stays
+ * >= 46.3 dB against the fp32 oracle at 2048 x 2048 (an error that moves PSNR(., GT) by <= 0.1 dB up to a 30 dB reference), found by
+ * tools/fp8_parts_2048.py (profiles/r05_fp8_parts_2048.txt): the three attention parts + the decoder's level-0 and level-2 ResnetBlock convs
+ * (46.5 dB, -17.9 ms of 119.7). IR_FP8_MASK_ALL (every part ir_fp8_features() reports: 42.1 dB, -26.0 ms) is OUTSIDE that tolerance above a
+ * 25.8 dB reference and must be asked for explicitly. */
+#define IR_FP8_MASK_DEFAULT 0x5007u
+#define IR_FP8_MASK_ALL 0xffffffffu
 int ir_set_fp8_mask(ir_ctx* ctx, unsigned mask);
 
 /* Per-launch timing with HIP events recorded on the launch stream (measurement aid for bench.py; no reference

@@ -75,14 +75,35 @@ def parse_args() -> Namespace:
     return parser.parse_args()
 
 
-def default_workers(local_world: int = 1) -> int:
-    """CPU threads this rank may keep busy: the cores the process may run on, split between the ranks of the node (at most 32: one
-    MI355X produces ~8 results of 2048 x 2048 a second and a PNG of that size costs 0.8 - 1.7 core-seconds)."""
+def cpu_share() -> int:
+    """Cores this process may really use: the affinity mask, cut down to the cgroup's CPU quota when one is set (a GPU box hands each job a
+    share - 16 cores per GPU - of a host whose affinity mask still shows every core; PNG encoders beyond the quota only time-slice against
+    the thread that launches the kernels)."""
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    return max(1, min(32, cores // max(local_world, 1)))
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()), ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: [t.strip(), None])):
+        try:
+            with open(path) as f:
+                quota, period = parse(f.read())
+            if period is None:
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                    period = f.read().strip()
+            if quota not in ("max", "-1") and int(quota) > 0 and int(period) > 0:
+                cores = min(cores, max(1, int(quota) // int(period)))
+            break
+        except (OSError, ValueError):
+            continue
+    return cores
+
+
+def default_workers(local_world: int = 1) -> int:
+    """Host threads for this rank: its part of the CPU share, less two cores for the thread that feeds the GPU and the copy engine's callbacks, at
+    most 16 (one MI355X produces ~8 results of 2048 x 2048 a second and a PNG of that size costs 0.8 - 1.7 core-seconds; $IR_WORKERS overrides)."""
+    if os.environ.get("IR_WORKERS"):
+        return max(0, int(os.environ["IR_WORKERS"]))
+    return max(1, min(16, cpu_share() // max(local_world, 1) - 2))
 
 
 def check_device(device: str) -> str:

@@ -15,6 +15,20 @@ SOURCES = ["igemm.hip", "conv_s1.hip", "conv_s1_fp8.hip", "norm.hip", "attention
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-ffp-contract=fast"] + os.environ.get("IR_EXTRA_HIPCC_FLAGS", "").split()
 
 
+def source_hash() -> str:
+    """16 hex digits over every kernel source / header of the library (csrc/*.hip|cpp|h + include/instarevive_hip.h), in name order: what a
+    measurement file (profiles/rNN_pmc_kernels.json) records so that bench.py can refuse it once a kernel has changed."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".h")))
+    for f in files + [os.path.join(os.path.dirname(HERE), "include", "instarevive_hip.h")]:
+        path = f if os.path.isabs(f) else os.path.join(CSRC, f)
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def _newer(src, dst):
     return (not os.path.exists(dst)) or os.path.getmtime(src) > os.path.getmtime(dst)
 

@@ -238,7 +238,7 @@ struct ir_ctx {
     int device = 0;
     Profiler prof;
     bool fp8 = false;   // ir_set_fp8 / IR_FLAG_FP8: VAE resnet convs with fp8 operands where fp8 weights were uploaded
-    uint32_t fp8_mask = 0xffffffffu;   // ir_set_fp8_mask: which parts take fp8 operands when fp8 is on (IR_FP8_PART_* bits); all by default
+    uint32_t fp8_mask = IR_FP8_MASK_DEFAULT;   // ir_set_fp8_mask: which parts take fp8 operands when fp8 is on (IR_FP8_BIT_*); default = the guard-chosen set
     bool plain = false; // ir_set_plain_kernels: this context's launches take the older 4-wave kernels (make_run publishes it to the launchers)
     std::string err;
     std::unordered_map<std::string, Tensor> t;
@@ -1592,7 +1592,7 @@ int check_size(ir_ctx* c, int n, int h, int w, int mult) {
 // ================================================================ exported C ABI
 extern "C" {
 
-int ir_abi_version(void) { return 1; }
+int ir_abi_version(void) { return 2; }   // 2: ir_tiled_encode_part callers must read + MAX-reduce the overflow flag; the default fp8 operand set is IR_FP8_MASK_DEFAULT
 
 int ir_init(int device, ir_ctx** out) {
     if (!out) return -1;
@@ -1656,6 +1656,18 @@ int ir_drop_optional(ir_ctx* c, const char* prefix) {
         } else {
             ++it;
         }
+    }
+    // The bound model structs of the family hold raw pointers to what was just freed (Conv::wup / w8, SwinBlock::mlp_t, ...): the family is
+    // "not configured" from here on, so that a failed re-upload or *_configure leaves an error ("not configured") and not a model that reads
+    // freed memory. The next successful *_configure re-binds everything.
+    if (n > 0) {
+        if (pre == "swin.") c->swin.ok = false;
+        else if (pre == "vae.") c->vae.enc.ok = c->vae.dec.ok = false;
+        else if (pre == "dit.") c->dit.ok = c->dit.prompt_ok = false;
+        else if (pre == "t5.") c->t5.ok = false;
+        else if (pre == "clip.") c->clip.ok = false;
+        else if (pre == "unet.") c->unet[0].ok = c->unet[0].ctx_ok = false;
+        else if (pre == "cnet.") c->unet[1].ok = c->unet[1].ctx_ok = false;
     }
     return n;
 }

@@ -462,7 +462,8 @@ def test_headline_vs_oracle_crops(full_models, size):
     """BASELINE configs[1] pinned AT ITS OWN SIZE against the fp32 oracle: tests/golden/headline_crops.npz holds the
     x^_0 latent and 128 x 128 uint8 crops of ONE oracle pass per size (1 / 8 minutes of host time, made by the committed
     tests/golden/make_headline_crops.py from bench.py's seeded weights and synthetic input). The HIP path on the same input must match the
-    crops to >= 45 dB (bf16) and the latent to <= 1.2 % relative L2; fp8 (cfg-5, reported separately) >= 39 dB on the crops. At 2048 this
+    crops to >= 45 dB (bf16) and the latent to <= 1.2 % relative L2; fp8 (cfg-5, reported separately): the default operand set >= 46.3 dB on the
+    crops (the 0.1 dB tolerance at a 30 dB reference), the set of every part >= 41 dB (reported as out of tolerance). At 2048 this
     is the first whole-path oracle comparison that runs through gemm_pp_kernel, the 16384-token DiT attention and the 65536-token VAE
     attention in their real chain."""
     from instarevive_amd.models import DDPMScheduler
@@ -493,14 +494,25 @@ def test_headline_vs_oracle_crops(full_models, size):
     rel = float((x0 - ref0).norm() / ref0.norm())
     print(f"{size}x{size} x0 latent vs oracle: relative L2 {rel * 100:.3f} % (the fixture stores fp16: 0.03 %)")
     assert rel <= 0.012
+    # cfg-5 (fp8), reported separately. The DEFAULT operand set (IR_FP8_MASK_DEFAULT) is chosen by north_star's tolerance: an error of >= 46.3 dB
+    # against the oracle moves PSNR(., GT) by <= 0.1 dB up to a 30 dB reference (tests/support/psnr_guard.py). The set of EVERY
+    # part (IR_FP8_MASK_ALL) is faster and out of that tolerance: reported, gated only as "still the same picture".
+    from instarevive_amd import _lib as L
+    ctx = dit.ctx
     vae.enable_fp8(True)
     try:
         f8, _ = process(dit, [img], 1, "wavelet", False, False, 512, 448, fp8=True, **kw)
+        ctx.check(ctx.lib.ir_set_fp8_mask(ctx.h, L.FP8_MASK_ALL), "ir_set_fp8_mask")
+        f8_all, _ = process(dit, [img], 1, "wavelet", False, False, 512, 448, fp8=True, **kw)
     finally:
+        ctx.check(ctx.lib.ir_set_fp8_mask(ctx.h, L.FP8_MASK_DEFAULT), "ir_set_fp8_mask")
         vae.enable_fp8(False)
-    p8 = _psnr(take(f8[0], pos), want)
-    print(f"{size}x{size} fp8 (cfg-5 operand set) vs fp32 oracle: crops {p8:.2f} dB")
-    assert p8 >= 39.0
+    p8, p8_all = _psnr(take(f8[0], pos), want), _psnr(take(f8_all[0], pos), want)
+    print(f"{size}x{size} fp8 vs fp32 oracle: default operand set {p8:.2f} dB (within 0.1 dB up to a {p8 - 16.33:.1f} dB reference), every part {p8_all:.2f} dB "
+          f"(up to {p8_all - 16.33:.1f} dB: out of tolerance, opt-in)")
+    assert not np.array_equal(f8[0], bf[0]) and not np.array_equal(f8_all[0], f8[0])
+    assert p8 >= 46.3, "the default fp8 operand set must stay within 0.1 dB of the reference's PSNR up to a 30 dB reference"
+    assert p8_all >= 41.0
 
 
 def test_batch8_at_2048_matches_batch1(full_models):
@@ -524,24 +536,30 @@ def test_batch8_at_2048_matches_batch1(full_models):
 
 
 def test_headline_2048_fp8_vs_bf16(full_models):
-    """BASELINE configs[4] at the workload size of its bench line (2048 x 2048 network input): the fp8 form of the path (e4m3 operands
-    where ir_fp8_features() says so) against the bf16 path on the same image. e4m3 carries 3 mantissa bits; measured 42.5 dB, gate 38."""
+    """BASELINE configs[4] at the workload size of its bench line (2048 x 2048 network input): the fp8 forms of the path against the bf16 path on
+    the same image. The default operand set (chosen by the 0.1 dB tolerance) measured 49.5 dB against bf16, gate 47; every part 42.5 dB, gate 38
+    (e4m3 carries 3 mantissa bits). Switching fp8 off restores the bf16 result bit for bit."""
     import bench
+    from instarevive_amd import _lib as L
     from instarevive_amd.pipeline import process
     swin, vae, dit, sds, y, mask = full_models
+    ctx = dit.ctx
     img = bench.synthetic_lq(1, 2048, 2048, 33)[0].numpy()
     kw = dict(preprocess_model=swin, vae=vae, y=full_models.y_cuda, y_mask=full_models.mask_cuda)
     bf, _ = process(dit, [img], 1, "wavelet", False, False, 512, 448, **kw)
     vae.enable_fp8(True)
     try:
         f8, _ = process(dit, [img], 1, "wavelet", False, False, 512, 448, fp8=True, **kw)
+        ctx.check(ctx.lib.ir_set_fp8_mask(ctx.h, L.FP8_MASK_ALL), "ir_set_fp8_mask")
+        f8_all, _ = process(dit, [img], 1, "wavelet", False, False, 512, 448, fp8=True, **kw)
     finally:
+        ctx.check(ctx.lib.ir_set_fp8_mask(ctx.h, L.FP8_MASK_DEFAULT), "ir_set_fp8_mask")
         vae.enable_fp8(False)
     again, _ = process(dit, [img], 1, "wavelet", False, False, 512, 448, **kw)
     assert np.array_equal(again[0], bf[0]), "switching fp8 off must restore the bf16 result bit for bit"
-    p = _psnr(f8[0], bf[0])
-    print(f"2048x2048 fp8 vs bf16: {p:.2f} dB")
-    assert not np.array_equal(f8[0], bf[0]) and p >= 38.0
+    p, p_all = _psnr(f8[0], bf[0]), _psnr(f8_all[0], bf[0])
+    print(f"2048x2048 fp8 vs bf16: default operand set {p:.2f} dB, every part {p_all:.2f} dB")
+    assert not np.array_equal(f8[0], bf[0]) and p >= 47.0 and 38.0 <= p_all < p
 
 
 def test_4k_tiled_hipgraph(full_models):

@@ -537,10 +537,13 @@ def test_vae_fp8_resnet_convs(full_models):
     z = det_input(23, (1, 4, 16, 16), -3, 3)
     ref_e, ref_d = ovae.vae_encode_mean(sds["vae"], x), ovae.vae_decode(sds["vae"], z)
     b_e, b_d = vae.encode(x.cuda()).latent_dist.mode().cpu(), vae.decode(z.cuda()).sample.cpu()
+    ctx = vae.ctx
     vae.enable_fp8(True)
+    ctx.check(ctx.lib.ir_set_fp8_mask(ctx.h, 0xffffffff), "ir_set_fp8_mask")   # every conv level of both halves (the default set holds two decoder levels)
     try:
         f_e, f_d = vae.encode(x.cuda()).latent_dist.mode().cpu(), vae.decode(z.cuda()).sample.cpu()
     finally:
+        ctx.check(ctx.lib.ir_set_fp8_mask(ctx.h, 0x5007), "ir_set_fp8_mask")
         vae.enable_fp8(False)
     again = vae.decode(z.cuda()).sample.cpu()
     assert torch.equal(again, b_d), "switching fp8 off must restore the bf16 path bit for bit"
@@ -550,39 +553,13 @@ def test_vae_fp8_resnet_convs(full_models):
         assert rel_l2(f, ref) <= 0.12
 
 
-def test_fp8_whole_path_psnr_guard(full_models):
-    """cfg-5, reported separately from bf16 (SURVEY.md section 8(d) PSNR protocol): the whole path with fp8 VAE convs at full network depth
-    against the fp32 oracle on the same LQ input, after the uint8 conversion; north_star's acceptance form |PSNR(ours, GT) - PSNR(oracle, GT)|
-    <= 0.1 dB with the LQ input as the third image. The bf16 path on the same input is printed beside it."""
-    from instarevive_amd.pipeline import process
-    swin, vae, dit, sds, y, mask = full_models
-    import bench
-    imgs = [bench.synthetic_lq(1, 256, 256, 6)[0].numpy()]
-    ref, ref1 = oglue.process(imgs, lambda x: oswin.swinir_forward(sds["swin"], x), lambda x: ovae.vae_encode_mean(sds["vae"], x),
-                              lambda lat, t, yy, mm: odit.dit_forward(sds["dit"], lat, t, yy, mm), lambda z: ovae.vae_decode(sds["vae"], z),
-                              oglue.alphas_cumprod_diffusers(), y, mask)
-    kw = dict(preprocess_model=swin, vae=vae, y=y.cuda(), y_mask=mask.cuda())
-    bf, _ = process(dit, imgs, 1, "wavelet", False, False, 512, 448, **kw)
-    vae.enable_fp8(True)
-    try:
-        f8, _ = process(dit, imgs, 1, "wavelet", False, False, 512, 448, fp8=True, **kw)
-    finally:
-        vae.enable_fp8(False)
-    gt = [np.asarray(i) for i in imgs]
-    p8, pb = _psnr_u8(f8, ref), _psnr_u8(bf, ref)
-    d8, db = abs(_psnr_u8(f8, gt) - _psnr_u8(ref, gt)), abs(_psnr_u8(bf, gt) - _psnr_u8(ref, gt))
-    print(f"fp8 path vs fp32 oracle {p8:.2f} dB (bf16 path {pb:.2f} dB); |PSNR(., GT) - PSNR(oracle, GT)|: fp8 {d8:.4f} dB, bf16 {db:.4f} dB")
-    assert not np.array_equal(f8[0], bf[0]), "the fp8 path must actually run"
-    assert p8 >= 40.0 and d8 <= 0.1   # measured 42.9 dB
-
-
-
 def test_psnr_guard_bites_at_realistic_reference_quality(full_models):
     """north_star's 0.1 dB criterion where it binds: the reference scoring 25 / 30 / 35 dB against the ground truth.
     No ground truth exists offline, so synthetic ones are built around the oracle's 512 x 512 full-architecture output
     (tests/support/psnr_guard.py): independent white noise at each level, and the worst case (ground truth on the far side of the
     oracle, anti-parallel to our error). Asserted: bf16 within 0.1 dB at 25 and 30 dB (independent). Reported: 35 dB, the worst case, the
-    crossing level P_err - 16.33 dB for bf16 and for fp8 (cfg-5), which DESIGN.md section 4 and the fp8 bench line quote."""
+    crossing level P_err - 16.33 dB for bf16 and for fp8 (cfg-5), which DESIGN.md section 4 and the fp8 bench line quote. Round 5: the DEFAULT
+    fp8 operand set (IR_FP8_MASK_DEFAULT, chosen by this criterion) is asserted like bf16; the set of every part is reported."""
     import bench
     from instarevive_amd.pipeline import process
     from tests.support.psnr_guard import crossing_level, guard_table
@@ -593,26 +570,35 @@ def test_psnr_guard_bites_at_realistic_reference_quality(full_models):
                            oglue.alphas_cumprod_diffusers(), y, mask)
     kw = dict(preprocess_model=swin, vae=vae, y=full_models.y_cuda, y_mask=full_models.mask_cuda)
     bf, _ = process(dit, imgs, 1, "wavelet", False, False, 512, 448, **kw)
+    from instarevive_amd import _lib as L
+    ctx = dit.ctx
     vae.enable_fp8(True)
     try:
-        f8, _ = process(dit, imgs, 1, "wavelet", False, False, 512, 448, fp8=True, **kw)
+        f8, _ = process(dit, imgs, 1, "wavelet", False, False, 512, 448, fp8=True, **kw)            # IR_FP8_MASK_DEFAULT
+        ctx.check(ctx.lib.ir_set_fp8_mask(ctx.h, L.FP8_MASK_ALL), "ir_set_fp8_mask")
+        f8_all, _ = process(dit, imgs, 1, "wavelet", False, False, 512, 448, fp8=True, **kw)
     finally:
+        ctx.check(ctx.lib.ir_set_fp8_mask(ctx.h, L.FP8_MASK_DEFAULT), "ir_set_fp8_mask")
         vae.enable_fp8(False)
     pb, rb = guard_table(bf[0], ref[0])
     p8, r8 = guard_table(f8[0], ref[0])
-    for name, pe, rows in (("bf16", pb, rb), ("fp8", p8, r8)):
+    pa, ra = guard_table(f8_all[0], ref[0])
+    for name, pe, rows in (("bf16", pb, rb), ("fp8 default operand set", p8, r8), ("fp8 every part (opt-in, out of tolerance)", pa, ra)):
         txt = ", ".join(f"{lv:.0f} dB: {d[0]:.3f} (worst case {d[1]:.2f})" for lv, d in rows.items())
         print(f"PSNR guard {name}: {pe:.2f} dB vs oracle; |dPSNR| with the reference at {txt}; within 0.1 dB up to a reference quality of {crossing_level(pe):.1f} dB")
     assert rb[25.0][0] <= 0.1 and rb[30.0][0] <= 0.1, "bf16 must stay within 0.1 dB of the reference where the reference scores <= 30 dB"
-    assert r8[25.0][0] <= 0.25, "fp8 (reported separately): measured 0.08-0.15 dB at 25 dB"
+    # cfg-5: the DEFAULT operand set is held to the same criterion as bf16; the set of every part is reported, not gated on it
+    assert r8[25.0][0] <= 0.1 and r8[30.0][0] <= 0.1, "the default fp8 operand set must stay within 0.1 dB at 25 and 30 dB"
+    assert p8 >= 46.3 and pa < p8
     # the estimate the bench line quotes must describe what was measured
-    for pe, rows in ((pb, rb), (p8, r8)):
+    for pe, rows in ((pb, rb), (p8, r8), (pa, ra)):
         for lv, d in rows.items():
             assert abs(d[0] - 10 * np.log10(1 + 10 ** ((lv - pe) / 10))) <= 0.03
 
 
 def test_fp8_mask_selects_the_operand_set(full_models):
-    """ir_set_fp8_mask: with every part switched off the fp8 call IS the bf16 path (bit for bit); the attention parts alone (DiT self-attention +
+    """ir_set_fp8_mask: with every part switched off the fp8 call IS the bf16 path (bit for bit); the unmasked call runs the default set
+    (IR_FP8_MASK_DEFAULT = 0x5007: attention parts + decoder level-0 / level-2 convs); the attention parts alone (DiT self-attention +
     both VAE mid blocks) stay within 0.3 dB of the bf16 path's PSNR against the oracle - tools/fp8_attribution.py: the e4m3 conv activations
     carry cfg-5's error, the attention products do not - and the full set is what the unmasked call runs."""
     import bench
@@ -627,19 +613,20 @@ def test_fp8_mask_selects_the_operand_set(full_models):
     bf, _ = process(dit, imgs, 1, "wavelet", False, False, 512, 448, **kw)
     vae.enable_fp8(True)
     try:
-        full, _ = process(dit, imgs, 1, "wavelet", False, False, 512, 448, fp8=True, **kw)
+        full, _ = process(dit, imgs, 1, "wavelet", False, False, 512, 448, fp8=True, **kw)          # the context's default: IR_FP8_MASK_DEFAULT
         out = {}
-        for name, m in (("none", 0), ("attention", 0b111), ("all", 0xffffffff)):
+        for name, m in (("none", 0), ("attention", 0b111), ("default", 0x5007), ("all", 0xffffffff)):
             ctx.check(ctx.lib.ir_set_fp8_mask(ctx.h, m), "ir_set_fp8_mask")
             out[name], _ = process(dit, imgs, 1, "wavelet", False, False, 512, 448, fp8=True, **kw)
     finally:
-        ctx.check(ctx.lib.ir_set_fp8_mask(ctx.h, 0xffffffff), "ir_set_fp8_mask")
+        ctx.check(ctx.lib.ir_set_fp8_mask(ctx.h, 0x5007), "ir_set_fp8_mask")
         vae.enable_fp8(False)
     assert np.array_equal(out["none"][0], bf[0]), "an empty operand set must be the bf16 path"
-    assert np.array_equal(out["all"][0], full[0]) and not np.array_equal(full[0], bf[0])
-    pb, pa, pf = _psnr_u8(bf, ref), _psnr_u8(out["attention"], ref), _psnr_u8(full, ref)
-    print(f"fp8 operand sets vs fp32 oracle: bf16 {pb:.2f} dB, attention parts only {pa:.2f} dB, all parts {pf:.2f} dB")
-    assert not np.array_equal(out["attention"][0], bf[0]) and pa >= pb - 0.3 and pf < pa
+    assert np.array_equal(out["default"][0], full[0]) and not np.array_equal(full[0], bf[0]), "the unmasked call runs IR_FP8_MASK_DEFAULT"
+    assert not np.array_equal(out["all"][0], full[0])
+    pb, pa, pd, pf = _psnr_u8(bf, ref), _psnr_u8(out["attention"], ref), _psnr_u8(full, ref), _psnr_u8(out["all"], ref)
+    print(f"fp8 operand sets vs fp32 oracle: bf16 {pb:.2f} dB, attention parts only {pa:.2f} dB, default set {pd:.2f} dB, all parts {pf:.2f} dB")
+    assert not np.array_equal(out["attention"][0], bf[0]) and pa >= pb - 0.3 and pf < pd <= pa + 0.05
 
 
 def test_fp8_tiled_and_hipgraph(full_models):

@@ -42,7 +42,10 @@ def main():
         rd, wr = 2.0 * fetch.get(k, 0.0) * 1024 / passes, write.get(k, 0.0) * 1024 / passes
         per[k] = dict(launches_per_step=launches, read_bytes_per_step=rd, write_bytes_per_step=wr, hbm_bytes_per_launch=(rd + wr) / launches)
     m = re.search(r"r(\d+)_", os.path.basename(sys.argv[3]))
-    out = dict(workload="1x2048x2048 untiled", round=int(m.group(1)) if m else None, per_kernel=per,
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from instarevive_amd.build import source_hash
+    # csrc_sha16: the kernel sources these counters were collected on - bench.py refuses the file as roofline.traffic when it differs from the tree's
+    out = dict(workload="1x2048x2048 untiled", round=int(m.group(1)) if m else None, csrc_sha16=source_hash(), per_kernel=per,
                hbm_bytes_per_step=sum(v["read_bytes_per_step"] + v["write_bytes_per_step"] for v in per.values()),
                note="rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (bench.py --steps 1 --warmup 0); FETCH_SIZE doubled "
                     "(gfx950 reports half the bytes of 16 B/lane reads: profiles/r02_fetch_calibration.txt), WRITE_SIZE exact. The counters sit on the "
