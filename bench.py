@@ -464,7 +464,12 @@ def main():
     if sampler is not None:   # what the card's clock and socket power were DURING the timed loop (hwmon samples every 20 ms)
         from tools.power_sampler import summarise
         time.sleep(0.05)
-        power = summarise(sampler_file, wall0, wall0 + dt)
+        try:
+            pr = torch.cuda.get_device_properties(local)
+            bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        except AttributeError:
+            bdf = None
+        power = summarise(sampler_file, wall0, wall0 + dt, bdf)
         if power is not None:
             log(f"timed loop: gfx clock {power.get('clock_mhz')} MHz (min {power.get('clock_mhz_min')}, max {power.get('clock_mhz_max')}), socket power {power.get('power_w')} W "
                 f"(max {power.get('power_w_max')}), {power['samples']} samples")
@@ -526,9 +531,10 @@ def main():
         psnr = 99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
         std = float(fast.double().std())
         if args.fp8:   # e4m3 operands carry 3 mantissa bits
-            # the guard-chosen default set: measured 49.5 dB against the bf16 pass at 2048 x 2048; every part: 42.5 dB (profiles/r02_bench_fp8.log);
-            # the gates are those minus a margin
-            gate8 = 47.0 if args.fp8_parts in ("default", "attention") else 38.0
+            # against the bf16 pass through the PLAIN kernels (itself 48.6 dB from the fast bf16 kernels): the guard-chosen default set measured
+            # 46.8 dB at 2048 x 2048, every part 42.5 dB (profiles/r02_bench_fp8.log); the gates are those minus a margin. The criterion
+            # itself (>= 46.3 dB against the fp32 ORACLE) is the parity_2048 field
+            gate8 = 45.0 if args.fp8_parts in ("default", "attention") else 38.0
             verify = dict(verified=bool(psnr >= gate8 and std > 1.0), psnr_fp8_vs_bf16_plain_kernels_db=round(psnr, 2), output_std=round(std, 2), gate_db=gate8)
         else:
             verify = dict(verified=bool(psnr >= 45.0 and std > 1.0), psnr_fast_vs_plain_kernels_db=round(psnr, 2), output_std=round(std, 2))
