@@ -308,6 +308,10 @@ def main():
     ap.add_argument("--no_profile", action="store_true", help="experiment: time the loop without the per-launch HIP events (no roofline)")
     ap.add_argument("--no_verify", action="store_true", help="skip the fast-vs-plain-kernel check of the last timed output")
     ap.add_argument("--no_host_rate", action="store_true", help="skip the host-buffer (PCIe-inclusive) rates")
+    ap.add_argument("--logit_gain", type=float, nargs="*", default=[], metavar="G", help="diagnostic leg after the timed steps: every self-attention logit (DiT blocks, "
+                    "VAE mid blocks) times G - q and k projections scaled by sqrt(G), tests/support/stress_weights.py - and the same steps timed again, with the "
+                    "number of attention launches that raised the fixed-reference overflow flag and took the rescaling fallback (the seeded weights give "
+                    "near-uniform softmax rows: logit spread about 8)")
     ap.add_argument("--cli_files", type=int, default=48, metavar="K", help="after the timed steps (N = 1, headline workload only): write K synthetic 512 x 512 PNGs and "
                     "the full-size artefacts, run `inference.py --sr_scale 4` on them as a fresh child process and report its files/s beside `value` (0 = skip)")
     ap.add_argument("--fp8", action="store_true", help="BASELINE configs[4]: fp8 (e4m3) MFMA operands in the parts ir_fp8_features() reports (the JSON line names them)")
@@ -594,6 +598,45 @@ def main():
                     note="uint8 HWC host arrays in, prediction + stage-1 image out; stream = process_stream(), sync = one process() per step")
         log(f"host-buffer rate: stream {dt_stream * 1e3:.2f} ms/step, sync {dt_sync * 1e3:.2f} ms/step (device-resident {ms_per_step:.2f})")
 
+    # ---- peaky softmax rows: the same steps with every self-attention logit scaled; what the overflow fallback costs when it fires
+    peaky = None
+    if args.logit_gain and world == 1 and not args.control:
+        from tests.support.stress_weights import stress_state_dicts
+        peaky = []
+        try:
+            for gain in args.logit_gain:
+                st = stress_state_dicts(sds, frac=0.0, gain=1.0, logit_gain=gain)
+                vae.load_state_dict(st["vae"])
+                dit.load_state_dict(st["dit"])
+                if args.fp8:
+                    vae.enable_fp8(True)
+                    ctx.check(ctx.lib.ir_set_fp8(ctx.h, 0), "ir_set_fp8")
+                dit.set_prompt(y_dev, mask_dev)
+                dit.ensure_pos(tile_size // 16 if args.tiled else h // 16, tile_size // 16 if args.tiled else w // 16)
+                ctx.check(ctx.lib.ir_attn_fallback_count(ctx.h, ctx.stream(), 1), "ir_attn_fallback_count")
+                step()
+                torch.cuda.synchronize()
+                per_step = ctx.lib.ir_attn_fallback_count(ctx.h, ctx.stream(), 0)
+                ctx.check(ctx.lib.ir_attn_fallback_count(ctx.h, ctx.stream(), -1), "ir_attn_fallback_count")
+                step()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    step()
+                torch.cuda.synchronize()
+                ms_g = (time.perf_counter() - t1) / args.steps * 1e3
+                peaky.append(dict(logit_gain=gain, ms_per_step=round(ms_g, 2), flat_ms_per_step=round(ms_per_step, 2), attention_launches_per_step=30 * n if not args.tiled else None,
+                                  fallback_launches_per_step=per_step, output_std=round(float(dout.double().std()), 2)))
+                log(f"logit gain {gain:g}: {ms_g:.2f} ms/step (flat {ms_per_step:.2f}), {per_step} attention launches per step took the rescaling fallback")
+        finally:
+            vae.load_state_dict(sds["vae"])
+            dit.load_state_dict(sds["dit"])
+            if args.fp8:
+                vae.enable_fp8(True)
+                ctx.check(ctx.lib.ir_set_fp8(ctx.h, 0), "ir_set_fp8")
+            dit.set_prompt(y_dev, mask_dev)
+            dit.ensure_pos(tile_size // 16 if args.tiled else h // 16, tile_size // 16 if args.tiled else w // 16)
+
     # ---- the shipped command line on FILES: K PNGs in, K PNGs out, through inference.py as a child process with its
     # reader / writer threads; the rate is the child's own clock from the first read to the last closed PNG (model loading excluded)
     cli = None
@@ -722,6 +765,8 @@ def main():
             line.update(host)
         if parity_2048 is not None:
             line["parity_2048"] = parity_2048
+        if peaky is not None:
+            line["peaky_attention"] = peaky
         if cli is not None:
             line["cli"] = cli
         line["clock_mhz"], line["power_w"] = (power or {}).get("clock_mhz"), (power or {}).get("power_w")

@@ -197,6 +197,11 @@ int ir_tiled_blend_pixels(ir_ctx* ctx, void* stream, const float* px_tiles, uint
  * second implementation of the same arithmetic that bench.py ("verified") and the tests cross-check the fast kernels against. Recorded
  * hipGraphs of the other mode are dropped. */
 int ir_set_plain_kernels(ir_ctx* ctx, int on);
+/* Diagnostic (no reference counterpart): the DiT self-attention and the VAE mid-block attention run kernels whose softmax reference is fixed after
+ * the first key tile; a query whose scores outgrow it raises a flag and the rescaling kernel launched behind recomputes the launch (the result is
+ * right either way - the flag only costs time). op = 1: zero the counter and count from now on (one tiny launch behind each such attention);
+ * op = 0: synchronise `stream` and return the number of attention launches that took the fallback since; op = -1: stop counting. */
+int ir_attn_fallback_count(ir_ctx* ctx, void* stream, int op);
 /* on != 0: the stage entry points (ir_vae_encode / ir_vae_decode / ir_dit_*) use the fp8 forms as IR_FLAG_FP8 does for ir_pipeline. */
 int ir_set_fp8(ir_ctx* ctx, int on);
 /* Which PARTS take fp8 operands while fp8 is on (default: IR_FP8_MASK_DEFAULT below). One bit per part, so that the error

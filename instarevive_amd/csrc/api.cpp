@@ -270,6 +270,8 @@ struct ir_ctx {
     unsigned long generation = 0, graphs_generation = 0;
     hipStream_t cap_stream = nullptr;  // recording happens on a private stream (the caller's may be the legacy default stream, which cannot capture)
     int* shard_flag = nullptr;         // device copy of the overflow flag of the last ir_tiled_encode_part(part 0 / 2) (in `owned`)
+    int* attn_fb = nullptr;            // ir_attn_fallback_count: [0] attention launches whose fixed-reference kernel raised its overflow flag (in `owned`)
+    bool count_fb = false;             // diagnostic: one counting launch behind every flagged attention (off in the product path)
 };
 
 namespace {
@@ -607,7 +609,8 @@ void swinir_run(Run& r, const float* in, float* out, int n, int h, int w) {
             bf16_t* mlp_out2 = last ? xc : (fuse_qkv ? qkv : (fuse_ln ? xn : nullptr));
             const int shift = (j & 1) ? 4 : 0;
             const float* fbias = shift ? b.biasM : b.biasT;   // the fused attention kernels pick a masked table per window class in a shifted block
-            const bool fused_attn = b.proj_t && fbias && !g_ir_plain_kernels;
+            // (the fused kernels address the [T][576] qkv tensor with 32-bit byte offsets: beyond 4 GB - 3.7 M tokens - the unfused path takes over)
+            const bool fused_attn = b.proj_t && fbias && !g_ir_plain_kernels && (long)T * 576 * 2 < (1L << 32);
             if (fused_attn && b.mlp_t && !no_block_fuse) {
                 // the whole block behind its qkv projection in ONE launch: the post-attention row stays in registers (swin_block_kernel)
                 LAUNCHK(r, PK_SWIN_BLOCK, f_attn + f_mlp, b_mlp + 2.0 * (double)T * 3 * m.C,
@@ -789,6 +792,7 @@ int attnblock(Run& r, const AttnW& w, bf16_t* B[3], int ci, float* gws, int N, i
         LAUNCHK(r, PK_ATTN_D512, 4.0 * (double)N * T * T * C, 0.0,
                ir_launch_flash_attn_d512_v2(q, k, vtt, o, N, (int)T, C, C, T * C, T * C, T * C, sc, flag, r.s), "vae_flash_attn");
     }
+    if (v2 && r.c->count_fb) LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_count_flag(flag, r.c->attn_fb, r.s), "count_flag");
     for (int b = 0; b < N; ++b) {
         if (v2) {  // fallback with the rescaling softmax: both launches return at once unless the kernel above raised the flag
             LAUNCH(r, PC_TRANSPOSE, 0.0, 0.0, ir_launch_transpose_v(v + b * T * C, vt, 0, C, dsub, 1, C / dsub, (int)T, (int)ld, dsub, dsub, r.s, flag), "transpose_v");
@@ -1019,6 +1023,7 @@ void dit_block(Run& r, const DitLayer& Lw, const float* mod, float* x, const Dit
         LAUNCHK(r, PK_ATTN_SELF_FP8, 4.0 * n * Hh * (double)T * T * hd, 0.0, ir_launch_flash_attn_fp8(p, b.qkv + 2 * C, b.f8tiles, r.s), "self_attn_fp8");
         LAUNCH(r, PC_TRANSPOSE, 0.0, 0.0, ir_launch_transpose_v(b.qkv + 2 * C, b.vt, T * 3 * C, 3 * C, hd, n, Hh, (int)T, Tpad, hd, DV, r.s, b.attn_flag), "transpose_v");
         LAUNCHK(r, PK_ATTN_OTHER, 0.0, 0.0, ir_launch_flash_attn_fallback(p, r.s), "self_attn_fallback");
+        if (r.c->count_fb) LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_count_flag(b.attn_flag, r.c->attn_fb, r.s), "count_flag");
     } else if (r.live()) {
         if (!vt_fused) LAUNCH(r, PC_TRANSPOSE, 0.0, 0.0, ir_launch_transpose_v(b.qkv + 2 * C, b.vt, T * 3 * C, 3 * C, hd, n, Hh, (int)T, Tpad, hd, DV, r.s), "transpose_v");
         AttnParams p;
@@ -1028,7 +1033,9 @@ void dit_block(Run& r, const DitLayer& Lw, const float* mod, float* x, const Dit
         p.q_rs = p.k_rs = 3 * C; p.o_rs = C; p.q_hs = p.k_hs = p.o_hs = hd;
         p.B = n; p.Hh = Hh; p.Tq = (int)T; p.Tk = (int)T; p.Tk_pad = Tpad; p.D = hd; p.scale_log2 = sl2;
         p.ovf_flag = b.attn_flag;
-        LAUNCHK(r, ir_flash_attn_is_pp2(p) ? PK_ATTN_SELF : PK_ATTN_OTHER, 4.0 * n * Hh * (double)T * T * hd, 0.0, ir_launch_flash_attn(p, r.s), "self_attn");
+        const bool pp2 = ir_flash_attn_is_pp2(p);
+        LAUNCHK(r, pp2 ? PK_ATTN_SELF : PK_ATTN_OTHER, 4.0 * n * Hh * (double)T * T * hd, 0.0, ir_launch_flash_attn(p, r.s), "self_attn");
+        if (pp2 && r.c->count_fb) LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_count_flag(b.attn_flag, r.c->attn_fb, r.s), "count_flag");
     }
     linear(r, Lw.ao, b.att, (int)BT, C, x, C, 1, ACT_NONE, x, 1, C, b.xb, C, mod + 2 * C);
     // cross attention on the un-normalised stream (PixArtMS.py:76); K/V of the prompt are cached per layer
@@ -2573,6 +2580,32 @@ int ir_set_fp8(ir_ctx* c, int on) {
     if (c->fp8 != (on != 0)) ++c->generation;   // recorded hipGraphs hold the launches of the mode they were captured in
     c->fp8 = on != 0;
     return 0;
+}
+
+// Diagnostic (tests, bench.py --logit_gain): how often did a fixed-reference attention kernel (DiT self-attention bf16 / fp8, VAE mid-block
+// attention bf16 / fp8) raise its overflow flag, i.e. how often did the rescaling fallback behind it really run? op 1: zero the counter and
+// start counting (one tiny launch behind every such attention from now on); op 0: synchronise the stream and return the count; op -1: stop.
+int ir_attn_fallback_count(ir_ctx* c, void* stream, int op) {
+    if (!c) return -1;
+    HIPOK(c, hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (op == 1) {
+        if (!c->attn_fb && dev_alloc(c, c->owned, (void**)&c->attn_fb, 256)) return -100;
+        HIPOK(c, hipMemsetAsync(c->attn_fb, 0, 256, s));
+        if (!c->count_fb) ++c->generation;   // recorded hipGraphs do not hold the counting launches
+        c->count_fb = true;
+        return 0;
+    }
+    if (op == -1) {
+        if (c->count_fb) ++c->generation;
+        c->count_fb = false;
+        return 0;
+    }
+    if (!c->attn_fb) return 0;
+    int v = 0;
+    HIPOK(c, hipStreamSynchronize(s));
+    HIPOK(c, hipMemcpy(&v, c->attn_fb, sizeof v, hipMemcpyDeviceToHost));
+    return v;
 }
 
 int ir_set_plain_kernels(ir_ctx* c, int on) {

@@ -290,6 +290,14 @@ int ir_launch_fill_u32(uint32_t* p, long n, uint32_t v, hipStream_t s) {
     hipLaunchKernelGGL(fill_u32_kernel, GRID1D(n), dim3(256), 0, s, p, n, v);
     return LAUNCH_OK();
 }
+__global__ void count_flag_kernel(const int* flag, int* counter) {
+    if (threadIdx.x == 0 && *flag != 0) atomicAdd(counter, 1);
+}
+int ir_launch_count_flag(const int* flag, int* counter, hipStream_t s) {
+    if (!flag || !counter) return -2;
+    hipLaunchKernelGGL(count_flag_kernel, dim3(1), dim3(64), 0, s, flag, counter);
+    return LAUNCH_OK();
+}
 // V^T [heads_total][DV][Tpad] of the DiT self-attention when the qkv projection's epilogue writes rows d < D itself (IGemmParams::vt_out): the
 // parts it never writes - row D = ones over the real keys (the softmax denominator), rows above zero, and the columns t >= T of every row.
 __global__ void vt_pad_init_kernel(bf16_t* vt, int D, int DV, int T, int Tpad, long total) {

@@ -209,6 +209,7 @@ int ir_launch_vae_conv_in(const float* in, const bf16_t* wgt, const float* bias,
 int ir_launch_vae_norm_conv_out(const bf16_t* x, const float* scale, const float* shift, const bf16_t* wgt, const float* bias, float* out, int N, int H,
                                 int W, hipStream_t s);
 int ir_launch_fill_u32(uint32_t* p, long n, uint32_t v, hipStream_t s);
+int ir_launch_count_flag(const int* flag, int* counter, hipStream_t s);   // *counter += 1 if *flag != 0 (diagnostic: ir_attn_fallback_count)
 int ir_launch_tile_add(float* dst, const float* src, int N, int C, int H, int W, int th, int tw, int y0, int x0, hipStream_t s);
 int ir_launch_tile_div(float* dst, int N, int C, int H, int W, int th, int tw, int sy, int sx, hipStream_t s);
 int ir_launch_crop_nchw(const float* src, float* dst, int N, int C, int H, int W, int y0, int x0, int th, int tw, float scale,

@@ -532,6 +532,7 @@ __global__ __launch_bounds__(256, 2) void swin_attn_proj_kernel(const bf16_t* __
 int ir_launch_swin_attn_proj(const bf16_t* qkv, const float* xres, float* out, const void* proj_t, const float* proj_b, const float* biasT, int B,
                              int H, int W, int shift, float scale, hipStream_t s) {
     if ((H & 7) || (W & 7) || shift < 0 || shift >= 8 || B <= 0) return -2;
+    if ((long)B * H * W * 576 * 2 >= (1L << 32)) return -4;   // the kernels address the qkv tensor with 32-bit byte offsets (ir_swin_fused_fits)
     const long n_waves = 2L * B * (H >> 3) * (W >> 3);
     const long blocks = (n_waves + 3) / 4;
     if (blocks > 0x7fffffffL) return -4;
@@ -937,6 +938,7 @@ int ir_launch_swin_block(const bf16_t* qkv, const float* x_in, float* x_out, bf1
                          int B, int H, int W, int shift, float scale, const void* w_tiles, const float* vec, int C, int hid_p, float eps, hipStream_t s,
                          const float* next_g, const float* next_b, const void* qkv_tiles, const float* qkv_b, int qkv_n) {
     if ((H & 7) || (W & 7) || shift < 0 || shift >= 8 || B <= 0) return -2;
+    if ((long)B * H * W * 576 * 2 >= (1L << 32)) return -4;   // 32-bit byte offsets into the qkv tensor (row stride 576 elements)
     if (C <= 0 || C > swf::CP || hid_p <= 0 || (hid_p & 31) || hid_p > 512) return -2;
     if ((next_g != nullptr) != (next_b != nullptr) || (next_g && (!out2 || (C & 3)))) return -2;
     if (qkv_tiles && (!next_g || !qkv_b || qkv_n <= 0 || (qkv_n & 63))) return -2;
