@@ -31,6 +31,16 @@ def regs(tok):
     return []
 
 
+def aregs(text):
+    """AGPR indices named in an instruction's operand text: a7, a[4:7]."""
+    out = set()
+    for m in re.finditer(r"\ba\[(\d+):(\d+)\]", text):
+        out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    for m in re.finditer(r"\ba(\d+)\b", text):
+        out.add(int(m.group(1)))
+    return out
+
+
 def scan(path):
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "k.s")
@@ -39,11 +49,23 @@ def scan(path):
         subprocess.run(cmd, check=True, capture_output=True)
         text = open(out).read().splitlines()
     flagged, kernel, last, lastt, clock, in_asm, n_mfma = [], None, {}, {}, 0, False, 0
+    # third check: kernels keep state in LITERAL accumulation registers across separate asm statements (a[0:255] of the one-wave-per-
+    # SIMD kernels, a[0:175] of flash_attn_x72_kernel); nothing but a clobber list tells hipcc so. Every AGPR an asm statement of a kernel names
+    # is "owned" by the asm; a compiler-emitted instruction of the same kernel that touches an owned AGPR (an MFMA accumulator of its own, a spill)
+    # is flagged.
+    owned, foreign = {}, {}
     for line in text:
         t = line.strip()
         if re.match(r"^_Z\w+:", t) or re.match(r"^[A-Za-z_]\w*:\s*(;.*)?$", t) and not t.startswith(".L"):
             kernel, last, lastt, clock = t.split(":")[0], {}, {}, 0
             continue
+        if kernel and t and not t.startswith((";", ".")) and not t.endswith(":"):
+            ar = aregs(t.split(";")[0])
+            if ar:
+                if in_asm:
+                    owned.setdefault(kernel, set()).update(ar)
+                else:
+                    foreign.setdefault(kernel, []).append((t.split(";")[0].strip(), ar))
         if t.startswith(";;#ASMSTART"):
             in_asm = True
             continue
@@ -79,6 +101,11 @@ def scan(path):
                     lastt[r] = (clock, ins)
                 else:
                     lastt.pop(r, None)
+    for k, items in foreign.items():
+        for ins, ar in items:
+            hit = ar & owned.get(k, set())
+            if hit:
+                flagged.append((k, ins, f"compiler-emitted instruction touches a{min(hit)}..a{max(hit)}, which the kernel's asm statements own", 0))
     return flagged, n_mfma
 
 
