@@ -684,10 +684,12 @@ def test_stress_weights_vs_oracle(full_models):
           f"{fallbacks} of 30 attention launches raised the overflow flag and took the rescaling fallback; fp8: " + ", ".join(f"{k} {v:.2f} dB" for k, v in p8.items()))
     assert fallbacks >= 0
     assert p >= 45.0 and p1 >= 50.0 and rel <= 0.015
-    # fp8 under peaky rows: an e4m3 q . k carries 3.7 % of the logit's size as error - at a logit spread of 34 that is a factor e^0.6 on a softmax weight -
-    # and a row dominated by one or two keys no longer averages the P . V rounding away: the attention parts lose the tolerance on such weights (measured
-    # 37 dB), the conv parts keep it. Reported (DESIGN.md section 4 quotes it); asserted only: the conv parts stay within 1.5 dB of bf16, nothing breaks.
-    assert p8["decoder level-0 / level-2 convs only"] >= p - 1.5 and min(p8.values()) >= 30.0
+    # fp8 under such weights (REPORTED; profiles/r05_stress_parity.txt): an e4m3 q . k carries 3.7 % of the logit's size as error -
+    # at a logit spread of 34 that is a factor e^0.6 on a softmax weight - and a row dominated by one or two keys no longer averages the P . V rounding
+    # away: the DiT attention part alone falls to 37 dB (the VAE's single 512-wide head to 44 dB), and the e4m3 convs cost 3 dB instead of 1 once 1 % of
+    # the channels carry 30x the scale. cfg-5's tolerance claim therefore holds for the flat-softmax seeded weights it was chosen on, not for these.
+    # Asserted only: nothing breaks (every operand set still produces the picture), the conv parts stay within 4 dB of bf16.
+    assert p8["decoder level-0 / level-2 convs only"] >= p - 4.0 and min(p8.values()) >= 33.0
     # and the session's weights are back: the seeded-weight result is what it was
     again, _ = process(dit, [img], 1, "wavelet", False, False, 512, 448, **kw)
     assert not np.array_equal(again[0], bf[0])

@@ -101,6 +101,12 @@ def scan(path):
                     lastt[r] = (clock, ins)
                 else:
                     lastt.pop(r, None)
+    # only sources whose asm names accumulation registers LITERALLY ("a[%c..." / a clobber list); a kernel whose asm takes "+a" operands lets the
+    # compiler allocate them, and its own v_accvgpr_* around them are legitimate (attention.hip's 4-wave kernels)
+    with open(path) as f:
+        src = f.read()
+    if "a[%c" not in src and "IR_AGPR" not in src:
+        foreign = {}
     for k, items in foreign.items():
         for ins, ar in items:
             hit = ar & owned.get(k, set())
