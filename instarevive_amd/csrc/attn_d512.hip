@@ -44,6 +44,9 @@ constexpr int V_OFF = 2 * KSLOT;
 constexpr int LDS_BYTES = V_OFF + 2 * VSLOT;   // 132 096 B (the epilogue stages 128 queries x 1 KB of O in the same memory)
 constexpr float MARGIN = 24.0f;          // headroom below the first tile's maximum: probabilities of that tile are <= 2^-24
 constexpr float OVF_LIMIT = 80.0f;       // a later score may exceed the reference by 2^80 before the fallback is needed
+constexpr float RETRIG = 48.0f;          // flash_attn_d512_v2_kernel moves its reference in place once a score lies 2^48 above it (probabilities <= 2^48:
+                                         // far inside fp32 / bf16 range, so nothing has overflowed when the check at the end of a tile sees it ...
+                                         // unless ONE tile jumps by more than 2^128, which the in-place path handles by recomputing that tile)
 #ifndef IR_D512_LA
 #define IR_D512_LA 4
 #endif
@@ -265,8 +268,37 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d512_v2_kernel(const bf16_t
         ka = k_addr + kcur * KSLOT;
         va0 = v_addr0 + vcur * VSLOT;
         va1 = v_addr1 + vcur * VSLOT;
+        const float l_snap = l_i;   // the denominator before this trip's softmax slices (the re-referencing path below starts from it)
         if (t + 1 < NT) stream(I0{}, I64{}, std::true_type{}, std::true_type{}, pc, pn, t, t & 1, (t + 1) & 1);
         else stream(I32{}, I64{}, std::false_type{}, std::false_type{}, pc, pn, t, 0, 0);
+        // ---- Round 5: the reference moves IN PLACE when a later tile outgrows it (rare, wave-uniform branch; 3 instructions per tile otherwise).
+        // Before, a score 2^80 above the reference raised ovf_flag and the rescaling 4-wave kernel recomputed the WHOLE launch: 11.8 ms at 65536
+        // tokens, already with the encoder's logits times 4 on the bench image (profiles/r05_stress_parity.txt) - and released SD-VAE weights are
+        // the ones known for extreme logits. Here: once a score of tile t + 1 lies RETRIG above the reference, the wave waits for PV(t), multiplies
+        // its 256 accumulators and the denominator by 2^-K (K a whole number per query: every rescaling is EXACT, results do not depend on
+        // whether or when it happens beyond the usual fp32 rounding of later sums), sets the reference to the row maximum so far + MARGIN and
+        // recomputes the probabilities of tile t + 1 from the scores still in sacc (the ones the stream made may have overflowed).
+        if (t + 1 < NT && __any(ovf - m_ref > RETRIG)) {
+            asm volatile("s_nop 15\n\ts_nop 7" : "+v"(sacc) : : "memory");   // PV(t) has written the accumulators; the scores are readable
+            const float top = xhalf_max(ovf);                                  // both key halves of a query agree
+            const float K = fmaxf(ceilf(top + MARGIN - m_ref), 0.f);
+            const int nk = -(int)fminf(K, 1.0e6f);
+            float tmp;
+            asm volatile(".set ir_a5_r, 0\n\t.rept 256\n\tv_accvgpr_read_b32 %0, a[ir_a5_r]\n\ts_nop 0\n\tv_ldexp_f32 %0, %0, %1\n\ts_nop 0\n\t"
+                         "v_accvgpr_write_b32 a[ir_a5_r], %0\n\t.set ir_a5_r, ir_a5_r + 1\n\t.endr\n\ts_nop 7"
+                         : "=&v"(tmp) : "v"(nk) : "memory");
+            m_ref += K;
+            float l_new = __builtin_ldexpf(l_snap, nk);
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) {
+                const float p0 = __builtin_amdgcn_exp2f(sacc[e] - m_ref), p1 = __builtin_amdgcn_exp2f(sacc[e + 1] - m_ref);
+                l_new += p0 + p1;
+                const uint32_t w = pack2bf(p0, p1);
+                if (e == 0) pn[0].x = w; else if (e == 2) pn[0].y = w; else if (e == 4) pn[0].z = w; else if (e == 6) pn[0].w = w;
+                else if (e == 8) pn[1].x = w; else if (e == 10) pn[1].y = w; else if (e == 12) pn[1].z = w; else pn[1].w = w;
+            }
+            l_i = l_new;
+        }
     };
     for (int t = 0; t < NT; t += 2) {
         tile_step(t, pbA, pbB);
