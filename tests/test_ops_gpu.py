@@ -546,7 +546,12 @@ def test_flash_attention_d512_spike(ctx, t, gains):
     if max(gains) >= 2.0:
         for qi in rows:
             assert (got[0, qi, 0] - v[0, last[qi], 0]).abs().max() < 2 ** -6, f"query {qi} must return the value row of its largest spike"
-    close(got, ref, 2 ** -6, 6e-3, "d512 attention spike")
+    # (the spiked keys are long vectors: other queries see them with 4-8x the usual logit spread, i.e. moderately peaky rows whose bf16 probabilities
+    # average over few keys - hence 2^-5 here against 2^-6 on flat rows; a wrong rescaling would be off by factors, not by 0.02)
+    close(got, ref, 2 ** -5, 6e-3, "d512 attention spike")
+    mates = [r for qi in rows for r in range(qi - qi % 32, qi - qi % 32 + 32) if r not in rows]   # the other queries of the waves that moved their reference
+    err = (got[0, mates, 0] - ref[0, mates, 0]).abs().max()
+    assert err < 2 ** -5, f"wave mates of the spiked queries: max abs error {float(err):.4f}"
 
 
 @pytest.mark.parametrize("h,w,shift", [(8, 8, 0), (16, 24, 0), (16, 24, 4), (64, 64, 4)])
