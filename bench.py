@@ -690,6 +690,9 @@ def main():
                     # moved to the fp8 kernel): the algorithmic figure is not a roofline fraction then - the row's frac is the executed one
                     row.update(algorithmic_frac=row["frac"], frac=row["executed_frac"], frac_basis="executed (the algorithmic 9-tap FLOPs of this row's phase-form "
                                "launches exceed what the MFMA pipe ran; algorithmic_frac keeps that figure)")
+            elif "frac" in row:   # HBM-bound rows move exactly their algorithmic bytes: the two prices coincide
+                row.setdefault("executed_achieved", row["achieved"])
+                row.setdefault("executed_frac", row["frac"])
             per_kernel[short] = row
             log(f"    {short[:58]:58s} {row['ms_per_step']:8.2f} ms/step {row['launches_per_step']:4d} launches  "
                 + (f"{row['achieved']:8.1f} {row['unit']} = {row['frac']:.3f} of {row['bound']} peak" if "frac" in row else "")

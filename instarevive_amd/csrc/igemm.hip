@@ -1565,8 +1565,12 @@ int ir_igemm_splitk(const IGemmParams& p) {
     if (!p.allow_splitk || off || p.fp8 || p.gn_part || (p.Cin & 63) || (p.Cout_pad & 3)) return 0;
     const int BN = p.Cout_pad % 128 == 0 ? 128 : (p.Cout_pad % 64 == 0 ? 64 : 32);
     const int tiles = ((p.M + 127) / 128) * (p.Cout_pad / BN), KT = p.taps * (p.Cin / 64);
-    if (tiles > 48 || KT < 24) return 0;
-    int ks = std::min(384 / tiles, KT / 6);
+    // experiment knobs (defaults = the shipped heuristic): most tiles a split launch may have, fewest k-tiles it must have, workgroups aimed at,
+    // fewest k-tiles per split
+    static const int max_tiles = getenv("IR_SPLITK_TILES") ? atoi(getenv("IR_SPLITK_TILES")) : 48, min_kt = getenv("IR_SPLITK_KT") ? atoi(getenv("IR_SPLITK_KT")) : 24;
+    static const int target = getenv("IR_SPLITK_TARGET") ? atoi(getenv("IR_SPLITK_TARGET")) : 384, per_min = getenv("IR_SPLITK_PER") ? atoi(getenv("IR_SPLITK_PER")) : 6;
+    if (tiles > max_tiles || KT < min_kt) return 0;
+    int ks = std::min(target / tiles, KT / std::max(per_min, 1));
     if (ks < 2) return 0;
     const int per = (KT + ks - 1) / ks;
     return (KT + per - 1) / per;   // no empty split
