@@ -641,3 +641,76 @@ def test_hub_ids_resolve_through_the_hf_cache(tmp_path, monkeypatch):
     # a local folder of the same name still wins (the reference's from_pretrained does the same)
     (tmp_path / "stabilityai" / "sd-vae-ft-ema").mkdir(parents=True)
     assert models._resolve_pretrained("stabilityai/sd-vae-ft-ema") == "stabilityai/sd-vae-ft-ema"
+
+
+def test_bench_helpers_of_round_5(tmp_path, monkeypatch):
+    """bench.py's round-5 helpers without a GPU: (1) roofline.traffic comes only from a PMC file collected on the CURRENT kernel sources
+    (instarevive_amd.build.source_hash) - a file without the hash or with another one is refused, with the reason; (2) tools/power_sampler.summarise picks
+    the card by PCI address (falling back to the busiest one) and averages over the timed window only; (3) tools/cli_artifacts.parse_cli_rate reads the
+    summary line inference.py prints; (4) tests/support/stress_weights scales exactly the advertised rows and leaves the input dicts alone."""
+    import importlib
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    from instarevive_amd.build import source_hash
+    h = source_hash()
+    assert re.fullmatch(r"[0-9a-f]{16}", h) and h == source_hash()
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    f, why = bench.pmc_file_for_this_tree()
+    assert f is None and "none found" in why
+    (prof / "r04_pmc_kernels.json").write_text(json.dumps({"per_kernel": {}}))
+    (prof / "r05_pmc_kernels.json").write_text(json.dumps({"csrc_sha16": "0" * 16, "per_kernel": {}}))
+    f, why = bench.pmc_file_for_this_tree()
+    assert f is None and "stale" in why and "r05_pmc_kernels.json" in why and h in why
+    (prof / "r06_pmc_kernels.json").write_text(json.dumps({"csrc_sha16": h, "per_kernel": {}}))
+    f, why = bench.pmc_file_for_this_tree()
+    assert f.endswith("r06_pmc_kernels.json") and why is None
+    # (2)
+    from tools.power_sampler import summarise
+    tr = tmp_path / "trace.txt"
+    lines = ["# cards ['/sys/devices/pci0000:00/0000:05:00.0', '/sys/devices/pci0000:c0/0000:dc:00.0']; columns: t_unix card sclk_mhz power_w mclk_mhz temp_c"]
+    for i in range(100):
+        t = 1000.0 + 0.02 * i
+        lines += [f"{t:.4f} 0 95 237.0 2000 nan", f"{t:.4f} 1 {2100 if 20 <= i < 60 else 300} {1250.0 if 20 <= i < 60 else 240.0} 2000 55.0"]
+    tr.write_text("\n".join(lines) + "\n")
+    s1 = summarise(str(tr), 1000.4, 1001.18, "0000:dc:00.0")
+    assert s1["card"] == 1 and s1["clock_mhz"] == 2100.0 and s1["power_w"] == 1250.0 and s1["samples"] == 40 and "PCI address" in s1["selection"]
+    assert summarise(str(tr), 1000.4, 1001.18, "0000:05:00.0")["clock_mhz"] == 95.0
+    assert summarise(str(tr), 1000.4, 1001.18)["card"] == 1                                 # no address: the busiest card
+    assert summarise(str(tr), 5.0, 6.0) is None and summarise(str(tmp_path / "absent"), 0, 1) is None
+    # (3)
+    from tools.cli_artifacts import parse_cli_rate
+    txt = "save to x\n[rank 0] wrote 48 files in 6.500 s = 7.385 files/s (14 host threads); after the first result: 47 files in 6.100 s = 7.705 files/s\n"
+    r = parse_cli_rate(txt)
+    assert r == [dict(rank=0, files=48, seconds=6.5, files_per_s=7.385, workers=14, steady_files=47, steady_seconds=6.1, steady_files_per_s=7.705)]
+    assert parse_cli_rate("nothing") == []
+    # (4)
+    from tests.support.stress_weights import stress_state_dicts
+    g = torch.Generator().manual_seed(0)
+    dit = {}
+    for l in range(2):
+        p = f"transformer_blocks.{l}."
+        for n, shp in (("attn1.to_q", (8, 8)), ("attn1.to_k", (8, 8)), ("attn1.to_v", (8, 8)), ("attn1.to_out.0", (8, 8)), ("attn2.to_out.0", (8, 8)), ("ff.net.0.proj", (32, 8)),
+                       ("ff.net.2", (8, 32))):
+            dit[p + n + ".weight"], dit[p + n + ".bias"] = torch.rand(shp, generator=g), torch.rand(shp[0], generator=g)
+    vae = {"decoder.up_blocks.0.resnets.0.conv1.weight": torch.rand(8, 8, 3, 3, generator=g), "decoder.up_blocks.0.resnets.0.conv1.bias": torch.rand(8, generator=g),
+           "decoder.mid_block.attentions.0.to_q.weight": torch.rand(8, 8, generator=g), "decoder.mid_block.attentions.0.to_q.bias": torch.rand(8, generator=g),
+           "decoder.conv_out.weight": torch.rand(3, 8, 3, 3, generator=g)}
+    sds = {"swin": {}, "vae": vae, "dit": dit}
+    keep = {k: v.clone() for k, v in dit.items()}
+    out = stress_state_dicts(sds, frac=0.125, gain=30.0, logit_gain={"dit": [4.0, 1.0], "vae_encoder": 1.0, "vae_decoder": 9.0})
+    assert all(torch.equal(dit[k], keep[k]) for k in dit), "the input state dicts must stay untouched"
+    w0, w1 = dit["transformer_blocks.0.attn1.to_out.0.weight"], out["dit"]["transformer_blocks.0.attn1.to_out.0.weight"]
+    ratio = (w1 / w0)[:, 0]
+    assert int((ratio > 29).sum()) == 1 and int(((ratio - 1).abs() < 1e-6).sum()) == 7                       # one of eight stream channels x30 ...
+    r2 = (out["dit"]["transformer_blocks.1.ff.net.2.weight"] / dit["transformer_blocks.1.ff.net.2.weight"])[:, 0]
+    assert torch.equal(r2 > 29, ratio > 29)                                                                  # ... the SAME channel in every block and writer
+    assert int(((out["dit"]["transformer_blocks.0.ff.net.0.proj.bias"] / dit["transformer_blocks.0.ff.net.0.proj.bias"]) > 29).sum()) == 4   # 1/8 of 32 hidden units
+    torch.testing.assert_close(out["dit"]["transformer_blocks.0.attn1.to_q.weight"], dit["transformer_blocks.0.attn1.to_q.weight"] * 2.0)   # sqrt(4) on q and on k
+    torch.testing.assert_close(out["dit"]["transformer_blocks.0.attn1.to_k.bias"], dit["transformer_blocks.0.attn1.to_k.bias"] * 2.0)
+    assert torch.equal(out["dit"]["transformer_blocks.1.attn1.to_q.weight"], dit["transformer_blocks.1.attn1.to_q.weight"])                 # block 1: gain 1
+    assert torch.equal(out["dit"]["transformer_blocks.0.attn1.to_v.weight"], dit["transformer_blocks.0.attn1.to_v.weight"])
+    torch.testing.assert_close(out["vae"]["decoder.mid_block.attentions.0.to_q.weight"], vae["decoder.mid_block.attentions.0.to_q.weight"] * 3.0)
+    assert torch.equal(out["vae"]["decoder.conv_out.weight"], vae["decoder.conv_out.weight"])
+    assert int(((out["vae"]["decoder.up_blocks.0.resnets.0.conv1.bias"] / vae["decoder.up_blocks.0.resnets.0.conv1.bias"]) > 29).sum()) == 1
