@@ -489,7 +489,9 @@ def main():
                 "dtype": "fp8" if args.fp8 else "bf16", "data": "synthetic",
                 "config": {"workload": f"{src}, {('tiled 512/448 + wavelet, %d tiles' % fm['tiles']) if args.tiled else 'untiled'}, batch {n} per GPU, "
                                        "full SwinIR->VAE-enc->DiT(t=400)->VAE-dec path"
-                                       + (", whole step replayed as ONE hipGraph (IR_FLAG_GRAPH)" if args.graph else ", plain launches, no per-launch events"),
+                                       + (", whole step replayed as ONE hipGraph (IR_FLAG_GRAPH) - the step is GPU-bound (kernel time = wall time in the profiled "
+                                          "form), so the graph buys nothing over plain launches: 237.9 against 238.7 ms per padded 4K frame, profiles/r05_bench_4k_tiled*.log"
+                                          if args.graph else ", plain launches, no per-launch events"),
                            "global_batch": n * world, "parallelism": f"dp{world}", "weights": "seeded random, full-size architectures"},
                 "algorithmic_tflop_per_image": round(fm["total"] / 1e12, 2), "path_tflops": round(fm["total"] * n * world / (ms / 1e3) / 1e12, 1),
                 "roofline": None, "cpu_baseline": None}), flush=True)
