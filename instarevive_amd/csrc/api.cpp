@@ -782,10 +782,17 @@ int attnblock(Run& r, const AttnW& w, bf16_t* B[3], int ci, float* gws, int N, i
         r.a.release(mk);
         return -1;   // stop here: the caller exchanges the rows
     }
+    int* flag4 = flag;   // the flag the 4-wave rescaling kernel at the end of the chain waits for
     if (f8) {
-        LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_zero_f32(reinterpret_cast<float*>(flag), 1, r.s), "zero");
+        // Round 5: the fp8 kernel's fallback is the bf16 one-wave-per-SIMD kernel (which moves its reference in place and costs 6.5 ms at 65536 tokens),
+        // not the 4-wave rescaling kernel (11.8 ms): flag[0] = "the fp8 kernel could not handle a query" starts transpose_v_tiles + the v2 kernel,
+        // flag[1] = the v2 kernel's own (never seen) overflow starts the 4-wave pair behind.
+        LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_zero_f32(reinterpret_cast<float*>(flag), 2, r.s), "zero");
         LAUNCHK(r, PK_ATTN_D512_FP8, 4.0 * (double)N * T * T * C, 0.0,
                ir_launch_flash_attn_d512_fp8(q, k, v, o, f8tiles, N, (int)T, C, C, T * C, T * C, sc, flag, r.s), "vae_flash_attn_fp8");
+        LAUNCH(r, PC_TRANSPOSE, 0.0, 0.0, ir_launch_transpose_v_tiles(v, vtt, N, (int)T, C, T * C, T * C, r.s, flag), "transpose_v_tiles");
+        LAUNCHK(r, PK_ATTN_D512, 0.0, 0.0, ir_launch_flash_attn_d512_v2(q, k, vtt, o, N, (int)T, C, C, T * C, T * C, T * C, sc, flag + 1, r.s, flag), "vae_flash_attn_fallback_v2");
+        flag4 = flag + 1;
     } else if (v2) {
         LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_zero_f32(reinterpret_cast<float*>(flag), 1, r.s), "zero");
         LAUNCH(r, PC_TRANSPOSE, 0.0, 4.0 * (double)N * T * C, ir_launch_transpose_v_tiles(v, vtt, N, (int)T, C, T * C, T * C, r.s), "transpose_v_tiles");
@@ -795,8 +802,8 @@ int attnblock(Run& r, const AttnW& w, bf16_t* B[3], int ci, float* gws, int N, i
     if (v2 && r.c->count_fb) LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_count_flag(flag, r.c->attn_fb, r.s), "count_flag");
     for (int b = 0; b < N; ++b) {
         if (v2) {  // fallback with the rescaling softmax: both launches return at once unless the kernel above raised the flag
-            LAUNCH(r, PC_TRANSPOSE, 0.0, 0.0, ir_launch_transpose_v(v + b * T * C, vt, 0, C, dsub, 1, C / dsub, (int)T, (int)ld, dsub, dsub, r.s, flag), "transpose_v");
-            LAUNCH(r, PC_FLASH_ATTN, 0.0, 0.0, ir_launch_flash_attn_d512(q + b * T * C, k + b * T * C, vt, o + b * T * C, (int)T, C, C, ld, sc, r.s, flag),
+            LAUNCH(r, PC_TRANSPOSE, 0.0, 0.0, ir_launch_transpose_v(v + b * T * C, vt, 0, C, dsub, 1, C / dsub, (int)T, (int)ld, dsub, dsub, r.s, flag4), "transpose_v");
+            LAUNCH(r, PC_FLASH_ATTN, 0.0, 0.0, ir_launch_flash_attn_d512(q + b * T * C, k + b * T * C, vt, o + b * T * C, (int)T, C, C, ld, sc, r.s, flag4),
                    "vae_flash_attn_fallback");
             continue;
         }

@@ -60,8 +60,9 @@ constexpr int SM0 = 35;                  // first stream step that carries a sof
 
 // V [B][T][512] (token stride rs) -> V^T tiles [B][T/32][512][32] bf16; chunk c (keys 8c .. 8c+7) of row d at 16-byte slot c ^ ((d >> 2) & 3)
 __global__ __launch_bounds__(256) void transpose_v_tiles_kernel(const bf16_t* __restrict__ v, bf16_t* __restrict__ vt, int rs, long v_bs,
-                                                                long vt_bs) {
+                                                                long vt_bs, const int* __restrict__ only_if) {
     __shared__ __attribute__((aligned(16))) bf16_t tile[32][512 + 8];
+    if (only_if && *reinterpret_cast<volatile const int*>(only_if) == 0) return;   // preparation of a fallback that is not needed
     const int tid = threadIdx.x, b = blockIdx.y;
     const bf16_t* src = v + (long)b * v_bs + (long)blockIdx.x * 32 * rs;
 #pragma unroll
@@ -105,9 +106,11 @@ IR_DEVINL float a5_acc_read() {
 __global__ __launch_bounds__(256, 1) void flash_attn_d512_v2_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                                     const bf16_t* __restrict__ vt, bf16_t* __restrict__ o, int T, int rs,
                                                                     int o_rs, long qk_bs, long vt_bs, long o_bs, float scale_log2,
-                                                                    int* __restrict__ ovf_flag) {
+                                                                    int* __restrict__ ovf_flag, const int* __restrict__ only_if) {
     using namespace a5;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES];
+    // launched behind flash_attn_d512_fp8_kernel as ITS fallback (round 5): nothing to do unless that kernel flagged a query it could not handle
+    if (only_if && *reinterpret_cast<volatile const int*>(only_if) == 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wu = __builtin_amdgcn_readfirstlane(wid);
     const int r = lane & 31, h = lane >> 5;
@@ -339,17 +342,17 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d512_v2_kernel(const bf16_t
     }
 }
 
-int ir_launch_transpose_v_tiles(const bf16_t* v, bf16_t* vt, int B, int T, int rs, long v_bs, long vt_bs, hipStream_t s) {
+int ir_launch_transpose_v_tiles(const bf16_t* v, bf16_t* vt, int B, int T, int rs, long v_bs, long vt_bs, hipStream_t s, const int* only_if) {
     if (T <= 0 || (T & 31) || (rs & 7) || rs < 512 || B <= 0) return -2;
-    hipLaunchKernelGGL(transpose_v_tiles_kernel, dim3(T / 32, B), dim3(256), 0, s, v, vt, rs, v_bs, vt_bs);
+    hipLaunchKernelGGL(transpose_v_tiles_kernel, dim3(T / 32, B), dim3(256), 0, s, v, vt, rs, v_bs, vt_bs, only_if);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
 int ir_launch_flash_attn_d512_v2(const bf16_t* q, const bf16_t* k, const bf16_t* vt_tiles, bf16_t* o, int B, int T, int rs, int o_rs, long qk_bs,
-                                 long vt_bs, long o_bs, float scale, int* ovf_flag, hipStream_t s) {
+                                 long vt_bs, long o_bs, float scale, int* ovf_flag, hipStream_t s, const int* only_if) {
     if (T <= 0 || (T & 31) || (rs & 7) || (o_rs & 7) || rs < 512 || o_rs < 512 || B <= 0 || !ovf_flag) return -2;
     hipLaunchKernelGGL(flash_attn_d512_v2_kernel, dim3((T + 127) / 128, B), dim3(256), 0, s, q, k, vt_tiles, o, T, rs, o_rs, qk_bs, vt_bs, o_bs,
-                       scale * 1.44269504088896340736f, ovf_flag);
+                       scale * 1.44269504088896340736f, ovf_flag, only_if);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 // The same for `rows` query rows starting at q / o (both already offset by the caller) against all T keys of ONE image: the query-row shard
@@ -359,7 +362,7 @@ int ir_launch_flash_attn_d512_v2_rows(const bf16_t* q, const bf16_t* k, const bf
                                       float scale, int* ovf_flag, hipStream_t s) {
     if (T <= 0 || (T & 31) || rows <= 0 || (rows & 127) || rows > T || (rs & 7) || (o_rs & 7) || rs < 512 || o_rs < 512 || !ovf_flag) return -2;
     hipLaunchKernelGGL(flash_attn_d512_v2_kernel, dim3(rows / 128, 1), dim3(256), 0, s, q, k, vt_tiles, o, T, rs, o_rs, 0L, 0L, 0L,
-                       scale * 1.44269504088896340736f, ovf_flag);
+                       scale * 1.44269504088896340736f, ovf_flag, (const int*)nullptr);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

@@ -147,9 +147,9 @@ int ir_launch_flash_attn_d512(const bf16_t* q, const bf16_t* k, const bf16_t* vt
                               float scale, hipStream_t s, const int* only_if = nullptr);
 // d = 512 without the redundant score product (attn_d512.hip): V^T in 32-key tiles [B][T/32][512][32]; a set *ovf_flag afterwards
 // means the result must be recomputed by ir_launch_flash_attn_d512 (which is given the flag as `only_if` and returns at once otherwise)
-int ir_launch_transpose_v_tiles(const bf16_t* v, bf16_t* vt, int B, int T, int rs, long v_bs, long vt_bs, hipStream_t s);
+int ir_launch_transpose_v_tiles(const bf16_t* v, bf16_t* vt, int B, int T, int rs, long v_bs, long vt_bs, hipStream_t s, const int* only_if = nullptr);
 int ir_launch_flash_attn_d512_v2(const bf16_t* q, const bf16_t* k, const bf16_t* vt_tiles, bf16_t* o, int B, int T, int rs, int o_rs, long qk_bs,
-                                 long vt_bs, long o_bs, float scale, int* ovf_flag, hipStream_t s);
+                                 long vt_bs, long o_bs, float scale, int* ovf_flag, hipStream_t s, const int* only_if = nullptr);   // only_if: run only when *only_if != 0
 int ir_launch_flash_attn_d512_v2_rows(const bf16_t* q, const bf16_t* k, const bf16_t* vt_tiles, bf16_t* o, int T, int rows, int rs, int o_rs,
                                       float scale, int* ovf_flag, hipStream_t s);   // a query-row shard (q / o offset by the caller), all T keys
 int ir_launch_transpose_v(const bf16_t* v, bf16_t* vt, long v_bs, int v_rs, int v_hs, int B, int Hh, int T, int Tpad, int D,

@@ -20,6 +20,8 @@ import bench  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gains", type=float, nargs="+", default=[4.0, 16.0, 64.0])
+    ap.add_argument("--fp8_vae_attention", action="store_true", help="run the VAE mid-block attention parts on fp8 operands (ir_set_fp8_mask 0b110): what does ITS "
+                    "fallback cost (since round 5: the bf16 one-wave-per-SIMD kernel, not the 4-wave one), and does the result equal the bf16 path's")
     a = ap.parse_args()
     from instarevive_amd import _lib as L
     from tests.support.stress_weights import stress_state_dicts
@@ -32,7 +34,16 @@ def main():
     din = bench.upscale_bicubic(bench.synthetic_lq(1, 512, 512, 1000), 4.0).to(dev)
     dout = torch.empty_like(din)
     acp, sf = float(sched.alphas_cumprod[400]), float(vae.config.scaling_factor)
-    ws = ctx.workspace(ctx.ws_bytes(L.STAGE_PIPELINE, 1, S, S, 0, 512, 448))
+    ws = ctx.workspace(ctx.ws_bytes(L.STAGE_PIPELINE, 1, S, S, L.FLAG_FP8 if a.fp8_vae_attention else 0, 512, 448))
+    fl = [0]
+    if a.fp8_vae_attention:
+        vae.enable_fp8(True)
+        ctx.check(ctx.lib.ir_set_fp8(ctx.h, 0), "ir_set_fp8")
+        ctx.check(ctx.lib.ir_set_fp8_mask(ctx.h, 0b110), "ir_set_fp8_mask")
+
+    def psnr(x, y):
+        mse = float(((x.double() - y.double()) ** 2).mean())
+        return 99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
 
     def run():
         dit.set_prompt(yd, md)
@@ -45,7 +56,7 @@ def main():
                 ctx.check(ctx.lib.ir_attn_fallback_count(ctx.h, ctx.stream(), -1), "count")
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            ctx.check(ctx.lib.ir_pipeline(ctx.h, ctx.stream(), L.ptr(din), L.ptr(dout), None, 1, S, S, 0, 512, 448, 400.0, acp, sf, L.ptr(ws), ws.numel()), "ir_pipeline")
+            ctx.check(ctx.lib.ir_pipeline(ctx.h, ctx.stream(), L.ptr(din), L.ptr(dout), None, 1, S, S, fl[0], 512, 448, 400.0, acp, sf, L.ptr(ws), ws.numel()), "ir_pipeline")
             e1.record()
             torch.cuda.synchronize()
             if i:
@@ -54,6 +65,10 @@ def main():
 
     t0, f0 = run()
     print(f"seeded weights (flat softmax): {t0:.2f} ms, {f0} fallbacks")
+    if a.fp8_vae_attention:
+        fl[0] = L.FLAG_FP8
+        t8, f8 = run()
+        print(f"the same with the VAE attention parts on fp8 operands: {t8:.2f} ms ({t8 - t0:+.2f}), {f8} fallbacks")
     one = {"dit": [1.0] * 28, "vae_encoder": 1.0, "vae_decoder": 1.0}
     for fam in ("vae_encoder", "vae_decoder", "dit"):
         for g in a.gains:
@@ -61,8 +76,15 @@ def main():
             gains[fam] = [g] * 28 if fam == "dit" else g
             st = stress_state_dicts(sds, frac=0.0, gain=1.0, logit_gain=gains)
             (vae if fam != "dit" else dit).load_state_dict(st["vae" if fam != "dit" else "dit"])
+            if a.fp8_vae_attention:   # (load_state_dict re-packed the fp8 weight forms: enable_fp8 stays on)
+                ctx.check(ctx.lib.ir_set_fp8(ctx.h, 0), "ir_set_fp8")
+                fl[0] = 0
+                tb, _ = run()
+                ref = dout.clone()
+                fl[0] = L.FLAG_FP8
             t, f = run()
-            print(f"{fam:12s} logits x{g:<4g}: {t:7.2f} ms ({t - t0:+6.2f}), {f} attention launch(es) took the fallback", flush=True)
+            extra = f"; fp8 VAE attention: {t - tb:+.2f} ms against the bf16 pass of the same weights, {psnr(dout, ref):.2f} dB against it" if a.fp8_vae_attention else ""
+            print(f"{fam:12s} logits x{g:<4g}: {t:7.2f} ms ({t - t0:+6.2f}), {f} attention launch(es) took the fallback{extra}", flush=True)
         (vae if fam != "dit" else dit).load_state_dict(sds["vae" if fam != "dit" else "dit"])
 
 
