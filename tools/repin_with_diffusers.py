@@ -20,6 +20,7 @@ random-initialised models of reduced width pin it exactly as the 4 GB checkpoint
     oracle.clip_text; open_clip.tokenize on sample prompts -> instarevive_amd.clip_bpe (needs open_clip's vocabulary file, which ships inside the
     open_clip package).
  5. pyiqa's PSNR-Y / SSIM-Y (evaluate_img.py:30-33) -> tools/evaluate_pairs.py.
+ 7. the `lpips` package's LPIPS(net="alex") (utils/metrics.py:41-66, evaluate_img.py:32) -> tools/evaluate_pairs.py::LPIPS on the package's own weights.
  6. ftfy.fix_text (diffusion/model/t5.py:118-124) -> instarevive_amd.captions.fix_text (deterministic steps + the restricted mojibake repair).
 
 The fixture holds inputs, state-dict checksums and the third party's outputs (data, not source); tests/test_oracle_golden.py picks
@@ -178,6 +179,26 @@ def pin_iqa(out):
     return abs(p - p_ref) <= 1e-3 and abs(s - s_ref) <= 1e-4
 
 
+def pin_lpips(out):
+    """LPIPS v0.1 / alex as tools/evaluate_pairs.py restates it against the `lpips` package itself (utils/metrics.py:41-66), on the package's own weights."""
+    import importlib.util
+    import lpips
+    spec = importlib.util.spec_from_file_location("evaluate_pairs", os.path.join(ROOT, "tools", "evaluate_pairs.py"))
+    ep = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ep)
+    ref = lpips.LPIPS(net="alex").eval()
+    mine = ep.LPIPS(None, {k: v for k, v in ref.state_dict().items()})
+    g = torch.Generator().manual_seed(9)
+    a = torch.rand(2, 3, 128, 160, generator=g)
+    b = (a + 0.1 * torch.randn(a.shape, generator=g)).clamp(0, 1)
+    with torch.no_grad():
+        want = ref(a, b, normalize=True).reshape(-1)
+    got = mine(a, b, normalize=True)
+    print(f"  [7] lpips package {want.tolist()} vs evaluate_pairs {got.tolist()}")
+    out["lpips_a"], out["lpips_b"], out["lpips_ref"] = a.numpy(), b.numpy(), want.numpy()
+    return bool(torch.allclose(got, want, rtol=1e-4, atol=1e-6))
+
+
 def pin_ftfy(out):
     import ftfy
     from instarevive_amd.captions import fix_text
@@ -199,7 +220,7 @@ def main():
     a = ap.parse_args()
     out, verdict = {}, {}
     for name, fn, args in (("diffusers DiT (items 1, 2)", pin_dit, (None,)), ("diffusers VAE (item 3)", pin_vae, (None,)),
-                           ("open_clip (item 4)", pin_clip, ()), ("pyiqa (item 5)", pin_iqa, ()), ("ftfy (item 6)", pin_ftfy, ())):
+                           ("open_clip (item 4)", pin_clip, ()), ("pyiqa (item 5)", pin_iqa, ()), ("ftfy (item 6)", pin_ftfy, ()), ("lpips (item 7)", pin_lpips, ())):
         print(name)
         try:
             verdict[name] = fn(out, *args)
