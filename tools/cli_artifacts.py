@@ -15,23 +15,9 @@ import os
 import numpy as np
 import torch
 
-SWINIR_YAML = """target: diffusion.model.swinir.SwinIR
-params:
-  img_size: 64
-  patch_size: 1
-  in_chans: 3
-  embed_dim: 180
-  depths: [6, 6, 6, 6, 6, 6, 6, 6]
-  num_heads: [6, 6, 6, 6, 6, 6, 6, 6]
-  window_size: 8
-  mlp_ratio: 2
-  sf: 8
-  img_range: 1.0
-  upsampler: "nearest+conv"
-  resi_connection: "1conv"
-  unshuffle: True
-  unshuffle_scale: 8
-"""
+# the released general SwinIR's constructor arguments (the architecture bench.py times; the reference keeps them in configs/swinir.yaml)
+SWINIR_PARAMS = dict(img_size=64, patch_size=1, in_chans=3, embed_dim=180, depths=[6] * 8, num_heads=[6] * 8, window_size=8, mlp_ratio=2, sf=8, img_range=1.0,
+                     upsampler="nearest+conv", resi_connection="1conv", unshuffle=True, unshuffle_scale=8)
 
 
 def write_full_artifacts(d, sds=None):
@@ -50,7 +36,8 @@ def write_full_artifacts(d, sds=None):
     torch.save(sds["dit"], os.path.join(d, "weights", "InstaRevive_v1.ckpt"))
     torch.save({"state_dict": {"module." + k: v for k, v in sds["swin"].items()}}, os.path.join(d, "weights", "general_swinir_v1.ckpt"))
     with open(os.path.join(d, "configs", "swinir.yaml"), "w") as f:
-        f.write(SWINIR_YAML)
+        import yaml
+        yaml.safe_dump({"target": "diffusion.model.swinir.SwinIR", "params": SWINIR_PARAMS}, f)
     with open(os.path.join(d, "vae", "config.json"), "w") as f:
         json.dump({"_class_name": "AutoencoderKL", "in_channels": 3, "out_channels": 3, "latent_channels": 4, "block_out_channels": [128, 256, 512, 512],
                    "layers_per_block": 2, "norm_num_groups": 32, "scaling_factor": 0.18215, "act_fn": "silu", "sample_size": 256}, f)
