@@ -402,7 +402,7 @@ def main():
         fp8_words = ", fp8 MFMA operands (MX-scaled e4m3) in " + " and ".join(
             w for bit, w, on in ((1, conv_words, bool(fmask & conv_bits)), (2, "the DiT self-attention products", bool(fmask & 1)),
                                  (4, "the VAE mid-block attention products", bool(fmask & 6))) if (feats & bit) and on)
-        fp8_words += {"default": " [operand set chosen by the 0.1 dB tolerance: >= 46.3 dB vs the fp32 oracle at 2048 x 2048]",
+        fp8_words += {"default": " [operand set chosen by the 0.1 dB tolerance ON THESE SEEDED, FLAT-SOFTMAX WEIGHTS: >= 46.3 dB vs the fp32 oracle at 2048 x 2048 - parity_2048; on weights with heavy-tailed channels and peaky attention fp8 does not hold that tolerance: 37 dB, tests/test_headline_gpu.py::test_stress_weights_vs_oracle]",
                       "all": " [ALL parts: OUT OF TOLERANCE above a 25.8 dB reference (42.1 dB vs the oracle); opt-in]"}.get(args.fp8_parts, f" [--fp8_parts {args.fp8_parts}]")
         vae.enable_fp8(True)                                # packs + uploads the fp8 weight forms of the VAE resnet convs
         ctx.check(ctx.lib.ir_set_fp8(ctx.h, 0), "ir_set_fp8")  # ... the mode itself is switched per call by IR_FLAG_FP8
