@@ -70,6 +70,11 @@ def parse_args() -> Namespace:
     parser.add_argument("--batch_size", type=int, default=1, help="consecutive files of equal network-input size per process() call")
     parser.add_argument("--shard_tiles", action="store_true", help="with --tiled under torchrun: spread the TILES of each image over the "
                         "GPUs (one large image at a time) instead of spreading the files")
+    parser.add_argument("--fp8", type=str, default="off", choices=["off", "default", "all", "attention"], help="BASELINE.json configs[4]: fp8 (e4m3) MFMA operands. "
+                        "default = the operand set that keeps the result within 0.1 dB PSNR of the bf16 / reference path up to a 30 dB reference on flat-softmax "
+                        "weights (attention products + two decoder conv levels: about 15 %% faster); all = every part (about 22 %% faster, 42 dB against the "
+                        "reference path: out of that tolerance); attention = the attention products only. On weights with heavy-tailed channels / peaky attention "
+                        "fp8 costs more accuracy (DESIGN.md section 4): off is the default")
     parser.add_argument("--workers", type=int, default=-1, help="host threads that decode / resize the inputs and resize / PNG-encode the results "
                         "around the GPU (PIL releases the GIL there); -1 = this process's CPU share, 0 = everything on the main thread like the reference")
     return parser.parse_args()
@@ -264,6 +269,14 @@ def main() -> None:
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     m = load_models(args, device)
+    if args.fp8 != "off":
+        from instarevive_amd import _lib as L
+        if args.shard_tiles:
+            raise SystemExit("--fp8 is not offered together with --shard_tiles (the sharded encode runs the bf16 attention)")
+        m.vae.enable_fp8(True)                                   # packs + uploads the fp8 weight forms ...
+        ctx = m.model.ctx
+        ctx.check(ctx.lib.ir_set_fp8(ctx.h, 0), "ir_set_fp8")    # ... the mode itself is switched per call (IR_FLAG_FP8)
+        ctx.check(ctx.lib.ir_set_fp8_mask(ctx.h, {"default": L.FP8_MASK_DEFAULT, "all": L.FP8_MASK_ALL, "attention": L.FP8_MASK_ATTENTION}[args.fp8]), "ir_set_fp8_mask")
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
     pools = HostPools(default_workers(local_world) if args.workers < 0 else args.workers)
     if not os.path.isdir(args.input):
@@ -299,7 +312,7 @@ def main() -> None:
 
     first = None    # (time, files) when the first result left the GPU: what follows is the steady state (no library / workspace warm-up in it)
     for preds, stage1 in process_stream(m.model, feed(), tiled=args.tiled, return_stage1=args.show_lq and not args.disable_preprocess_model,
-                                        **common):
+                                        fp8=args.fp8 != "off", **common):
         group = todo.pop(0)
         if first is None:
             first = (time.perf_counter(), len(group))

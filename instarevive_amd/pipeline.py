@@ -256,16 +256,19 @@ def process(model, control_imgs: List[np.ndarray], strength: float, color_fix_ty
 @torch.no_grad()
 def process_stream(model, batches: Iterable[Sequence[np.ndarray]], color_fix_type: str, disable_preprocess_model: bool, tiled: bool,
                    tile_size: int, tile_stride: int, preprocess_model=None, vae=None, y=None, y_mask=None, noise_scheduler=None,
-                   return_stage1: bool = True, graph: bool = False) -> Iterator[Tuple[List[np.ndarray], List[np.ndarray]]]:
+                   return_stage1: bool = True, graph: bool = False, fp8: bool = False) -> Iterator[Tuple[List[np.ndarray], List[np.ndarray]]]:
     """process() over a sequence of image batches with the transfers hidden: while batch i computes on the current stream, batch
     i+1 is uploaded and batch i-1 downloaded on a copy stream (two staging slots per batch shape). Yields process()'s result for
-    every batch, in order. Needs the fused form (all models instarevive_amd objects on one context)."""
+    every batch, in order. Needs the fused form (all models instarevive_amd objects on one context). fp8 as in process() (cfg-5:
+    vae.enable_fp8() first; the operand set is the context's ir_set_fp8_mask, by default the tolerance-chosen one)."""
     noise_scheduler = noise_scheduler or DDPMScheduler()
     if not _fused_ok(model, preprocess_model, vae, disable_preprocess_model):
         raise TypeError("process_stream needs instarevive_amd models sharing one context")
     ctx, device = model.ctx, model.device
     acp, sf = float(noise_scheduler.alphas_cumprod[400]), float(vae.config.scaling_factor)
-    base_flags = _pipeline_flags(model, color_fix_type, disable_preprocess_model, tiled) | (L.FLAG_GRAPH if graph else 0)
+    if fp8 and not vae.__dict__.get("_fp8_uploaded"):
+        raise RuntimeError("process_stream(fp8=True): call vae.enable_fp8() first - without the fp8 weight forms every layer would silently run in bf16")
+    base_flags = _pipeline_flags(model, color_fix_type, disable_preprocess_model, tiled) | (L.FLAG_GRAPH if graph else 0) | (L.FLAG_FP8 if fp8 else 0)
     main, copy = torch.cuda.current_stream(device), ctx.__dict__.setdefault("_copy_stream", torch.cuda.Stream(device))
     it = iter(batches)
 

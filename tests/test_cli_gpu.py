@@ -122,6 +122,30 @@ def test_cli_threaded_run_writes_the_single_thread_pixels(tmp_path):
         assert outs[0][k].shape == outs[4][k].shape and np.array_equal(outs[0][k], outs[4][k]), k
 
 
+def test_cli_fp8_flag(tmp_path):
+    """inference.py --fp8 (BASELINE.json configs[4] from the command line; default off): the flag is accepted, the fp8 weight forms are packed and
+    the run succeeds on the reduced test models - whose widths the fp8 kernels mostly do not take, so the result must stay within fp8's error of the
+    plain run (identical where no part was eligible) - and an unknown operand set is refused by the parser."""
+    d = tmp_path
+    _write_artifacts(d)
+    os.makedirs(d / "in", exist_ok=True)
+    for i in range(2):
+        Image.fromarray((det_input(400 + i, (64, 64, 3)) * 255).numpy().astype(np.uint8)).save(d / "in" / f"x{i}.png")
+    base = [sys.executable, os.path.join(ROOT, "inference.py"), "--ckpt", str(d / "weights" / "dit.ckpt"), "--input", str(d / "in"), "--swinir_ckpt",
+            str(d / "weights" / "swinir.ckpt"), "--swinir_config", str(d / "swinir.yaml"), "--vae", str(d / "vae"), "--dit_config", str(d / "pixart"),
+            "--prompt_embeds", str(d / "prompt.pth")]
+    outs = {}
+    for name, extra in (("plain", []), ("fp8", ["--fp8", "all"])):
+        r = subprocess.run(base + ["--output", str(d / name)] + extra, capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs[name] = [np.array(Image.open(d / name / f"x{i}_0.png")) for i in range(2)]
+    p = _psnr_u8(outs["fp8"], outs["plain"])
+    print(f"cli --fp8 all vs plain on the reduced models: {p:.2f} dB")
+    assert p >= 38.0
+    r = subprocess.run(base + ["--output", str(d / "bad"), "--fp8", "int4"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode != 0 and "invalid choice" in r.stderr
+
+
 def test_eval_batch_harness_matches_oracle(tmp_path):
     """the batched evaluation harness (eval_batch.py, the role of test_dmd_general.py:112-192) on five images of
     different sizes in batches of 2 — centre crop (center_crop_arr), B > 1 through process_stream, result + condition folders, .jpg -> .png —

@@ -731,3 +731,26 @@ def test_tiled_encode_force_fallback_path(full_models):
     print(f"forced fallback: attention rows vs the fixed-reference kernel's rel-L2 {rel_rows:.5f}, init latent vs the unsharded encode rel-L2 {rel:.5f}")
     assert 0 < rel_rows <= 0.01 and rel <= 0.01
     assert float(init_forced.abs().max()) > 0
+
+
+def test_process_stream_fp8_equals_process_fp8(full_models):
+    """cfg-5 from the streaming entry the command line uses (inference.py --fp8): process_stream(fp8=True) over three 512 x 512 images gives, image by
+    image, exactly what process(fp8=True) gives, differs from the bf16 stream, and refuses to run without the fp8 weight forms."""
+    import bench
+    from instarevive_amd.pipeline import process, process_stream
+    swin, vae, dit, sds, y, mask = full_models
+    imgs = [bench.synthetic_lq(1, 512, 512, 90 + i)[0].numpy() for i in range(3)]
+    kw = dict(preprocess_model=swin, vae=vae, y=full_models.y_cuda, y_mask=full_models.mask_cuda)
+    with pytest.raises(RuntimeError):
+        list(process_stream(dit, ([im] for im in imgs), "wavelet", False, False, 512, 448, fp8=True, **kw))
+    bf = [p[0] for p, _ in process_stream(dit, ([im] for im in imgs), "wavelet", False, False, 512, 448, **kw)]
+    vae.enable_fp8(True)
+    try:
+        dit.ctx.check(dit.ctx.lib.ir_set_fp8(dit.ctx.h, 0), "ir_set_fp8")   # the mode is switched per call
+        one = [process(dit, [im], 1, "wavelet", False, False, 512, 448, fp8=True, **kw)[0][0] for im in imgs]
+        st = [p[0] for p, _ in process_stream(dit, ([im] for im in imgs), "wavelet", False, False, 512, 448, fp8=True, **kw)]
+    finally:
+        vae.enable_fp8(False)
+    for a, b, c in zip(st, one, bf):
+        assert np.array_equal(a, b) and not np.array_equal(a, c)
+    print(f"process_stream fp8 vs bf16: {_psnr(np.stack(st), np.stack(bf)):.2f} dB")
