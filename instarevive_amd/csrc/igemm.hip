@@ -1266,7 +1266,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(IGemmParams p) {
                 unsigned char* base = smem + ((kt + 3) & 3) * G::B_BYTES;
                 const int ko = (kt + 3) * G::BK;
 #pragma unroll
-                for (int i = 0; i < 5; ++i) if (IR_GKO != 2) glds16(src[i] + ko, (lds_ptr_t)(base + dst[i]));
+                for (int i = 0; i < 5; ++i) if (IR_GKO != 2 && IR_GKO != 4) glds16(src[i] + ko, (lds_ptr_t)(base + dst[i]));   // (4: no B pieces only)
             }
             if (kt + 1 < KT && IR_GKO != 3) read_frags(sa1, (kt + 1) & 3);
             sa1 = sa1 == G::NSA - 1 ? 0 : sa1 + 1;
@@ -1281,7 +1281,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(IGemmParams p) {
                 unsigned char* base = smem + sa4 * G::A_BYTES;
                 const int ko = (kt + 4) * G::BK;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) if (IR_GKO != 2) glds16(src[i] + ko, (lds_ptr_t)(base + dst[i]));
+                for (int i = 0; i < 4; ++i) if (IR_GKO != 2 && IR_GKO != 5) glds16(src[i] + ko, (lds_ptr_t)(base + dst[i]));   // (5: no A pieces only)
             }
             if (IR_GKO != 3 || kt == 0) read_frags(sa, kt & 3);
             // A(kt+1) has landed; the batches of A(kt+2) .. A(kt+4) may be in flight (fewer at the end of the K loop)
