@@ -1236,6 +1236,11 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(IGemmParams p) {
     for (int i = 0; i < G::TM; ++i)
 #pragma unroll
         for (int j = 0; j < G::TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#ifndef IR_GEMM_PK_GELU
+#define IR_GEMM_PK_GELU 0   // 1: the packed-fp32 GELU of the epilogue below. Measured (profiles/r05_ab_gemm_pk_gelu.txt): the fc1 launch alone 221 -> 210 us,
+                            // but the kernel is at its 256-VGPR limit and the pair form makes hipcc spill 23 registers (80 B of scratch per lane): inside the
+                            // pipeline ALL 168 launches of the kernel pay for the scratch set-up and the kernel's total goes 18.13 -> 18.33 ms. Off.
+#endif
 #ifndef IR_GKO
 #define IR_GKO 0  // knock-out builds for timing only (-DIR_GKO=n, results wrong by design; never set in the library): 1 no MFMAs, 2 no
 #endif            // LDS-DMA in the K loop, 3 no fragment reads - DESIGN.md section 7 quotes the three timings
@@ -1317,12 +1322,32 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(IGemmParams p) {
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-            for (int j = 0; j < G::TN; ++j)
+            for (int j = 0; j < G::TN; ++j) {
+                if constexpr (ACT == IR_ACT_GELU_TANH && IR_GEMM_PK_GELU) {
+                    // Round 5: fc1's GELU (PixArt_blocks.py: approximate="tanh") costs 66 of the launch's 228 us as an epilogue nothing overlaps
+                    // (profiles/r05_gemm_knockouts.txt). Same formula as gelu_tanh(), x * rcp(1 + exp(-2 k0 (x + k1 x^3))), on PAIRS of accumulators:
+                    // the full-rate part as packed fp32 (v_pk_add / v_pk_mul / v_pk_fma: IEEE per lane, half the issue slots), the exponential and the
+                    // reciprocal one instruction per value.
+                    typedef float gf2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float a = hh == 0 ? acc[ii][j][q] : acc[2 + ii][j][q];
-                    slab[(ii * 16 + rq * 4 + q) * 144 + j * 16 + col] = apply_act<ACT>(a + cb[j], p.slope) * cm[j];
+                    for (int q = 0; q < 4; q += 2) {
+                        const gf2 a = hh == 0 ? gf2{acc[ii][j][q], acc[ii][j][q + 1]} : gf2{acc[2 + ii][j][q], acc[2 + ii][j][q + 1]};
+                        const gf2 x = a + cb[j];
+                        const gf2 t = x * x * 0.044715f + 1.0f;                                            // 1 + k1 x^2
+                        const gf2 e = x * t * (-2.0f * 0.7978845608028654f * 1.44269504088896340736f);     // -2 k0 (x + k1 x^3) log2 e
+                        const gf2 d = gf2{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])} + 1.0f;
+                        const gf2 y = x * gf2{fast_rcp(d[0]), fast_rcp(d[1])} * cm[j];
+                        slab[(ii * 16 + rq * 4 + q) * 144 + j * 16 + col] = y[0];
+                        slab[(ii * 16 + rq * 4 + q + 1) * 144 + j * 16 + col] = y[1];
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float a = hh == 0 ? acc[ii][j][q] : acc[2 + ii][j][q];
+                        slab[(ii * 16 + rq * 4 + q) * 144 + j * 16 + col] = apply_act<ACT>(a + cb[j], p.slope) * cm[j];
+                    }
                 }
+            }
     };
     // Row phase of one half. The forms the DiT uses are specialised so that no uniform condition sits inside the unrolled loops
     // (hipcc turns those into branches with a full vmcnt(0) per vector): KIND 0 = no residual, bf16 out; KIND 1 = fp32 residual, fp32
