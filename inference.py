@@ -278,6 +278,9 @@ def main() -> None:
         ctx.check(ctx.lib.ir_set_fp8(ctx.h, 0), "ir_set_fp8")    # ... the mode itself is switched per call (IR_FLAG_FP8)
         ctx.check(ctx.lib.ir_set_fp8_mask(ctx.h, {"default": L.FP8_MASK_DEFAULT, "all": L.FP8_MASK_ALL, "attention": L.FP8_MASK_ATTENTION}[args.fp8]), "ir_set_fp8_mask")
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+    if os.environ.get("IR_SWITCH_INTERVAL"):   # experiment knob: how long a worker thread may keep the GIL while the thread that feeds the GPU waits for it
+        import sys
+        sys.setswitchinterval(float(os.environ["IR_SWITCH_INTERVAL"]))
     pools = HostPools(default_workers(local_world) if args.workers < 0 else args.workers)
     if not os.path.isdir(args.input):
         raise SystemExit(f"--input {args.input} is not a directory")
