@@ -260,11 +260,13 @@ def cli_files_leg(k, sds, value, log):
         c = rates[0]
         log(f"cli leg: {c['files']} files in {c['seconds']:.2f}s = {c['files_per_s']:.2f} files/s; after the first result {c['steady_files_per_s']:.2f} files/s "
             f"({c['workers']} host threads) against {value:.2f} images/s device-resident")
-        return dict(files=k, files_per_s=c["files_per_s"], steady_files_per_s=c["steady_files_per_s"], host_threads=c["workers"],
+        return dict(files=k, files_per_s=c["files_per_s"], steady_files_per_s=c["steady_files_per_s"], result_rate=c.get("result_rate"), host_threads=c["workers"],
                     ratio_to_value=round(c["files_per_s"] / value, 3), steady_ratio_to_value=round(c["steady_files_per_s"] / value, 3),
                     command="inference.py --sr_scale 4 (child process; 512x512 PNG in, 2048x2048 PNG out, default --workers)",
                     note="files_per_s: first read submitted -> last PNG closed, including the child's library / workspace warm-up on its first image; "
-                         "steady_*: from the first finished result on. Model loading is excluded from both")
+                         "steady_*: from the first finished result on (the last files' PNG encoding - about 1 s of drain after the GPU has finished - is "
+                         "inside both: a longer folder amortises it); result_rate: finished results per second between the first and the last one, i.e. "
+                         "what the GPU side of the stream delivers. Model loading is excluded from all")
     except Exception as e:  # noqa: BLE001 - the headline line must still be printed
         return dict(error=repr(e)[:300])
     finally:

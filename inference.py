@@ -317,8 +317,9 @@ def main() -> None:
     for preds, stage1 in process_stream(m.model, feed(), tiled=args.tiled, return_stage1=args.show_lq and not args.disable_preprocess_model,
                                         fp8=args.fp8 != "off", **common):
         group = todo.pop(0)
+        last_result = time.perf_counter()
         if first is None:
-            first = (time.perf_counter(), len(group))
+            first = (last_result, len(group))
         for k, job in enumerate(group):
             pools.write_behind(write_job, job, preds[k], stage1[k] if stage1 else None, args)
     pools.drain()
@@ -327,7 +328,8 @@ def main() -> None:
         # first read submitted -> last PNG closed, model loading excluded (bench.py --cli_files parses this line)
         rest, dt_rest = pools.written - first[1], t1 - first[0]
         print(f"[rank {rank}] wrote {pools.written} files in {t1 - t0:.3f} s = {pools.written / (t1 - t0):.3f} files/s ({pools.workers} host threads); "
-              f"after the first result: {rest} files in {dt_rest:.3f} s = {rest / dt_rest:.3f} files/s")
+              f"after the first result: {rest} files in {dt_rest:.3f} s = {rest / dt_rest:.3f} files/s"
+              + (f"; results left the GPU at {rest / (last_result - first[0]):.3f} /s (the rest is the encoders' drain of the last files)" if rest and last_result > first[0] else ""))
 
 
 if __name__ == "__main__":

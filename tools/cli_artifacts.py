@@ -74,7 +74,9 @@ def parse_cli_rate(stdout):
     import re
     out = []
     for m in re.finditer(r"\[rank (\d+)\] wrote (\d+) files in ([0-9.]+) s = ([0-9.]+) files/s \((\d+) host threads\); after the first result: "
-                         r"(\d+) files in ([0-9.]+) s = ([0-9.]+) files/s", stdout):
+                         r"(\d+) files in ([0-9.]+) s = ([0-9.]+) files/s(?:; results left the GPU at ([0-9.]+) /s)?", stdout):
         out.append(dict(rank=int(m.group(1)), files=int(m.group(2)), seconds=float(m.group(3)), files_per_s=float(m.group(4)), workers=int(m.group(5)),
                         steady_files=int(m.group(6)), steady_seconds=float(m.group(7)), steady_files_per_s=float(m.group(8))))
+        if m.group(9):
+            out[-1]["result_rate"] = float(m.group(9))
     return out

@@ -40,7 +40,7 @@ def main():
                 print(cfg, "FAILED", r.stderr[-500:])
                 continue
             c = rate[0]
-            print(f"{cfg:22s} {c['files_per_s']:6.2f} files/s overall, {c['steady_files_per_s']:6.2f} after the first result ({c['workers']} threads; child wall {time.time() - t0:.1f} s)", flush=True)
+            print(f"{cfg:22s} {c['files_per_s']:6.2f} files/s overall, {c['steady_files_per_s']:6.2f} after the first result, results left the GPU at {c.get('result_rate', float('nan')):.2f} /s ({c['workers']} threads; child wall {time.time() - t0:.1f} s)", flush=True)
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
