@@ -314,7 +314,7 @@ def main():
                     "VAE mid blocks) times G - q and k projections scaled by sqrt(G), tests/support/stress_weights.py - and the same steps timed again, with the "
                     "number of attention launches that raised the fixed-reference overflow flag and took the rescaling fallback (the seeded weights give "
                     "near-uniform softmax rows: logit spread about 8)")
-    ap.add_argument("--cli_files", type=int, default=48, metavar="K", help="after the timed steps (N = 1, headline workload only): write K synthetic 512 x 512 PNGs and "
+    ap.add_argument("--cli_files", type=int, default=96, metavar="K", help="after the timed steps (N = 1, headline workload only): write K synthetic 512 x 512 PNGs and "
                     "the full-size artefacts, run `inference.py --sr_scale 4` on them as a fresh child process and report its files/s beside `value` (0 = skip)")
     ap.add_argument("--fp8", action="store_true", help="BASELINE configs[4]: fp8 (e4m3) MFMA operands in the parts ir_fp8_features() reports (the JSON line names them)")
     args = ap.parse_args()
