@@ -194,6 +194,26 @@ def test_bench_self_launches_its_ranks():
     assert "roofline" in line and line["roofline"]["per_kernel"]
 
 
+def test_bench_round5_legs_on_a_small_workload():
+    """bench.py's round-5 additions through the real script on a small workload (128 x 128 LQ, sr_scale 2): the clock / power trace object (its fields
+    are null on a box without readable hwmon nodes, never missing), `executed_frac` beside `frac` on every per-kernel row that has one, no `frac` above 1,
+    the --logit_gain leg (weights re-uploaded with every self-attention logit x 4, the attention-fallback counter read through the C ABI, weights restored)
+    and a `roofline.traffic_source` that is either a PMC file of THESE kernel sources or the reason why there is none."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--lq", "128", "--sr_scale", "2", "--steps", "2", "--warmup", "1", "--no_cpu_baseline", "--no_host_rate",
+           "--cli_files", "0", "--logit_gain", "4"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert "clock_mhz" in line and "power_w" in line and "power_trace" in line
+    rows = line["roofline"]["per_kernel"]
+    assert rows and all(("frac" not in v) or (v["frac"] <= 1.0 and "executed_frac" in v) for v in rows.values()), rows
+    pk = line["peaky_attention"]
+    assert len(pk) == 1 and pk[0]["logit_gain"] == 4 and pk[0]["fallback_launches_per_step"] >= 0 and pk[0]["ms_per_step"] > 0 and pk[0]["output_std"] > 1.0
+    assert line["verified"] is True and line["value"] > 0
+    assert line["roofline"]["traffic"] is None     # the PMC file describes the 2048 x 2048 workload only
+
+
 def test_make_prompt_writes_the_reference_prompt_file(tmp_path):
     """SURVEY.md section 8(f) N3, the producer of --prompt_embeds: tools/make_prompt.py (tokenizer from a local folder -> HIP T5 encoder ->
     {'caption_embeds', 'emb_mask'} as test_scripts/test_controlnet.py:389-395 saves them) on a folder in the DeepFloyd layout: a
