@@ -1163,6 +1163,22 @@ struct GemmPP {
     static constexpr int LDS = RING > 8 * SLAB ? RING : 8 * SLAB;
 };
 
+// Round 6: the epilogue forms the DiT uses are compiled as their own instantiations (ACT_T / KIND_T >= 0: the activation and the row phase
+// are compile-time constants; -1: decided at run time, the generic form every other caller gets). Before, ONE kernel carried every activation in
+// every row phase behind run-time switches inside its unrolled loops: the two halves of the accumulator tile were selected per ELEMENT by a
+// v_cndmask (the half index stayed a loop variable) and each half branched over the activation codes. UNIT: no per-column gate and out_scale == 1
+// (the launcher checks), so the multiply behind the activation disappears. In every form the bias now rides in as the accumulators' initial
+// value (one add per element less in the epilogue), and the tanh-GELU is x * rcp(1 + exp2(x * (c0 + c1 x^2))): five full-rate instructions and
+// two transcendentals per element instead of nine and two.
+#ifndef IR_GPP_KO
+#define IR_GPP_KO 0   // knock-outs of the fp32-residual row phase, timing only (results wrong by design; never set in the library): 1 no residual
+#endif                // read, 2 no bf16 copy, 3 no fp32 store
+IR_DEVINL float gelu_tanh_fused(float x) {   // == gelu_tanh(x) up to rounding; exp2 overflow (x << 0) gives rcp(inf) = 0 -> -0, underflow gives x
+    const float c0 = -2.0f * 0.7978845608028654f * 1.44269504088896340736f, c1 = c0 * 0.044715f;
+    const float t = __builtin_fmaf(x * x, c1, c0);
+    return x * fast_rcp(1.0f + __builtin_amdgcn_exp2f(x * t));
+}
+template <int ACT_T, int KIND_T, bool UNIT>
 __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(IGemmParams p) {
     typedef GemmPP G;
     typedef __attribute__((ext_vector_type(4))) float f32x4_t;
@@ -1232,15 +1248,15 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(IGemmParams p) {
         for (int j = 0; j < G::TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(gbase + sb * G::B_BYTES + j * 1024);
     };
     f32x4_t acc[G::TM][G::TN];
+    // the accumulators start at the bias of their column (lane l holds column 16 j + (l & 15) of its 144 for all four rows of a register quad)
 #pragma unroll
-    for (int i = 0; i < G::TM; ++i)
+    for (int j = 0; j < G::TN; ++j) {
+        const float b0 = p.bias ? p.bias[n0 + grp * 144 + j * 16 + (lane & 15)] : 0.f;
 #pragma unroll
-        for (int j = 0; j < G::TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#ifndef IR_GEMM_PK_GELU
-#define IR_GEMM_PK_GELU 0   // 1: the packed-fp32 GELU of the epilogue below. Measured (profiles/r05_ab_gemm_pk_gelu.txt): the fc1 launch alone 221 -> 210 us,
-                            // but the kernel is at its 256-VGPR limit and the pair form makes hipcc spill 23 registers (80 B of scratch per lane): inside the
-                            // pipeline ALL 168 launches of the kernel pay for the scratch set-up and the kernel's total goes 18.13 -> 18.33 ms. Off.
-#endif
+        for (int i = 0; i < G::TM; ++i) acc[i][j] = f32x4_t{b0, b0, b0, b0};
+    }
+    // (Round 5 tried the GELU as packed fp32 pairs - v_pk_add / v_pk_mul / v_pk_fma - on the slab-write side: the fc1 launch alone 221 -> 210 us, but
+    // at the kernel's 256-VGPR limit the pair form spilled 23 registers and every launch paid for the scratch set-up: profiles/r05_ab_gemm_pk_gelu.txt.)
 #ifndef IR_GKO
 #define IR_GKO 0  // knock-out builds for timing only (-DIR_GKO=n, results wrong by design; never set in the library): 1 no MFMAs, 2 no
 #endif            // LDS-DMA in the K loop, 3 no fragment reads - DESIGN.md section 7 quotes the three timings
@@ -1304,61 +1320,43 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(IGemmParams p) {
     }
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- epilogue: v = act(acc + bias) * out_scale * gate + res, through a wave-private fp32 slab (two 16-row tiles = 32 x 144
-    // at a time) so that residual reads and stores are row-contiguous 16-byte vectors. All loop reads were consumed before the last
+    // ---- epilogue: v = act(acc) * out_scale * gate + res (the bias is in acc already), through a wave-private fp32 slab (two 16-row tiles =
+    // 32 x 144 at a time) so that residual reads and stores are row-contiguous 16-byte vectors. All loop reads were consumed before the last
     // barrier, so the slabs may overlay the ring.
     float* slab = reinterpret_cast<float*>(smem) + wu * (G::SLAB / 4);
     const int col = lane & 15, rq = lane >> 4;
     const int nw = n0 + grp * 144;          // first column of this wave
-    float cb[G::TN], cm[G::TN];
+    const int act = ACT_T >= 0 ? ACT_T : p.act;
+    float cm[UNIT ? 1 : G::TN];
+    if constexpr (!UNIT) {
 #pragma unroll
-    for (int j = 0; j < G::TN; ++j) {
-        const int n = nw + j * 16 + col;
-        cb[j] = p.bias ? p.bias[n] : 0.f;
-        cm[j] = p.out_scale * (p.gate ? p.gate[n] : 1.f);
+        for (int j = 0; j < G::TN; ++j) cm[j] = p.out_scale * (p.gate ? p.gate[nw + j * 16 + col] : 1.f);
     }
-    auto half = [&](auto act_tag, int hh) __attribute__((always_inline)) {
-        constexpr int ACT = decltype(act_tag)::value;
+    auto half = [&](auto act_tag, auto hc) __attribute__((always_inline)) {
+        constexpr int ACT = decltype(act_tag)::value, HH = decltype(hc)::value;
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-            for (int j = 0; j < G::TN; ++j) {
-                if constexpr (ACT == IR_ACT_GELU_TANH && IR_GEMM_PK_GELU) {
-                    // Round 5: fc1's GELU (PixArt_blocks.py: approximate="tanh") costs 66 of the launch's 228 us as an epilogue nothing overlaps
-                    // (profiles/r05_gemm_knockouts.txt). Same formula as gelu_tanh(), x * rcp(1 + exp(-2 k0 (x + k1 x^3))), on PAIRS of accumulators:
-                    // the full-rate part as packed fp32 (v_pk_add / v_pk_mul / v_pk_fma: IEEE per lane, half the issue slots), the exponential and the
-                    // reciprocal one instruction per value.
-                    typedef float gf2 __attribute__((ext_vector_type(2)));
+            for (int j = 0; j < G::TN; ++j)
 #pragma unroll
-                    for (int q = 0; q < 4; q += 2) {
-                        const gf2 a = hh == 0 ? gf2{acc[ii][j][q], acc[ii][j][q + 1]} : gf2{acc[2 + ii][j][q], acc[2 + ii][j][q + 1]};
-                        const gf2 x = a + cb[j];
-                        const gf2 t = x * x * 0.044715f + 1.0f;                                            // 1 + k1 x^2
-                        const gf2 e = x * t * (-2.0f * 0.7978845608028654f * 1.44269504088896340736f);     // -2 k0 (x + k1 x^3) log2 e
-                        const gf2 d = gf2{__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])} + 1.0f;
-                        const gf2 y = x * gf2{fast_rcp(d[0]), fast_rcp(d[1])} * cm[j];
-                        slab[(ii * 16 + rq * 4 + q) * 144 + j * 16 + col] = y[0];
-                        slab[(ii * 16 + rq * 4 + q + 1) * 144 + j * 16 + col] = y[1];
-                    }
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float a = hh == 0 ? acc[ii][j][q] : acc[2 + ii][j][q];
-                        slab[(ii * 16 + rq * 4 + q) * 144 + j * 16 + col] = apply_act<ACT>(a + cb[j], p.slope) * cm[j];
-                    }
+                for (int q = 0; q < 4; ++q) {
+                    const float a = acc[2 * HH + ii][j][q];
+                    float y;
+                    if constexpr (ACT == IR_ACT_GELU_TANH) y = gelu_tanh_fused(a);
+                    else y = apply_act<ACT>(a, p.slope);
+                    if constexpr (!UNIT) y *= cm[j];
+                    slab[(ii * 16 + rq * 4 + q) * 144 + j * 16 + col] = y;
                 }
-            }
     };
-    // Row phase of one half. The forms the DiT uses are specialised so that no uniform condition sits inside the unrolled loops
-    // (hipcc turns those into branches with a full vmcnt(0) per vector): KIND 0 = no residual, bf16 out; KIND 1 = fp32 residual, fp32
-    // out (+ optional bf16 copy), whose 18 residual vectors are all requested back to back (one exposed latency per half); KIND 2 = anything else.
-    auto write_half = [&](int hh) __attribute__((always_inline)) {
-        switch (p.act) {
-            case IR_ACT_GELU_TANH: half(std::integral_constant<int, IR_ACT_GELU_TANH>{}, hh); break;
-            case IR_ACT_GELU_ERF: half(std::integral_constant<int, IR_ACT_GELU_ERF>{}, hh); break;
-            case IR_ACT_SILU: half(std::integral_constant<int, IR_ACT_SILU>{}, hh); break;
-            case IR_ACT_LRELU: half(std::integral_constant<int, IR_ACT_LRELU>{}, hh); break;
-            default: half(std::integral_constant<int, IR_ACT_NONE>{}, hh); break;
+    // Row phase of one half. KIND 0 = no residual, bf16 out; KIND 1 = fp32 residual, fp32 out (+ optional bf16 copy), whose 18 residual vectors
+    // are requested six at a time (one exposed latency per batch); KIND 2 = anything else.
+    auto write_half = [&](auto hc) __attribute__((always_inline)) {
+        switch (act) {
+            case IR_ACT_GELU_TANH: half(std::integral_constant<int, IR_ACT_GELU_TANH>{}, hc); break;
+            case IR_ACT_GELU_ERF: half(std::integral_constant<int, IR_ACT_GELU_ERF>{}, hc); break;
+            case IR_ACT_SILU: half(std::integral_constant<int, IR_ACT_SILU>{}, hc); break;
+            case IR_ACT_LRELU: half(std::integral_constant<int, IR_ACT_LRELU>{}, hc); break;
+            default: half(std::integral_constant<int, IR_ACT_NONE>{}, hc); break;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1369,15 +1367,25 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(IGemmParams p) {
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
-    const int kind = (!p.res && !p.out_f32 && !p.out2) ? 0 : (p.res && p.res_f32 && p.out_f32 && p.res_mod == 0) ? 1 : 2;
+    const int kind = KIND_T >= 0 ? KIND_T : ((!p.res && !p.out_f32 && !p.out2) ? 0 : (p.res && p.res_f32 && p.out_f32 && p.res_mod == 0) ? 1 : 2);
     const int mw = m0 + wq * 64;
     // fast forms address with 32-bit element offsets from the uniform base pointers (the launcher checks that they fit): one
     // address register per vector instead of two
-    if (kind == 0) {
+    auto rows_kind0 = [&](auto hc) __attribute__((always_inline)) {
+        constexpr int hh = decltype(hc)::value;
         bf16_t* outb = reinterpret_cast<bf16_t*>(p.out);
+        write_half(hc);
+        if (KIND_T == 0 && (p.out_cs & 7) == 0) {   // 16-byte stores: 18 lanes x 8 columns per row, 9 vectors per lane and half (the instantiated bf16 forms;
+                                                    // the launcher has checked the 16-byte alignment of p.out, nw is a multiple of 8)
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            write_half(hh);
+            for (int it = 0; it < 9; ++it) {
+                const int v = it * 64 + lane, row = v / 18, c8 = (v - row * 18) * 8;
+                const int m = mw + hh * 32 + row;
+                const f32x4_t o0 = *reinterpret_cast<const f32x4_t*>(&slab[row * 144 + c8]), o1 = *reinterpret_cast<const f32x4_t*>(&slab[row * 144 + c8 + 4]);
+                if (m < p.M) *reinterpret_cast<uint4*>(outb + (unsigned)(m * p.out_cs + nw + c8)) =
+                    make_uint4(pack2bf(o0[0], o0[1]), pack2bf(o0[2], o0[3]), pack2bf(o1[0], o1[1]), pack2bf(o1[2], o1[3]));
+            }
+        } else {
 #pragma unroll
             for (int it = 0; it < 18; ++it) {
                 const int v = it * 64 + lane, row = v / 36, c4 = (v - row * 36) * 4;
@@ -1385,83 +1393,88 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(IGemmParams p) {
                 const f32x4_t o = *reinterpret_cast<const f32x4_t*>(&slab[row * 144 + c4]);
                 if (m < p.M) *reinterpret_cast<uint2*>(outb + (unsigned)(m * p.out_cs + nw + c4)) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
             }
-            if (p.vt_out && nw >= p.vt_col0) {   // wave-uniform: this wave's 144 columns are two heads of V
-                // The slab holds 32 consecutive tokens x 144 columns: a lane takes a column (three passes over the 144) and writes its 32
-                // tokens as 64 contiguous bytes of the V^T row of that (head, d). Launcher: M % 256 == 0 and vt_T % 64 == 0, so the 32 tokens
-                // never straddle an image and the destination is 64-byte aligned.
-                const int tok0 = mw + hh * 32, bidx = tok0 / p.vt_T, t0 = tok0 - bidx * p.vt_T;
+        }
+        if (p.vt_out && nw >= p.vt_col0) {   // wave-uniform: this wave's 144 columns are two heads of V
+            // The slab holds 32 consecutive tokens x 144 columns: a lane takes a column (three passes over the 144) and writes its 32
+            // tokens as 64 contiguous bytes of the V^T row of that (head, d). Launcher: M % 256 == 0 and vt_T % 64 == 0, so the 32 tokens
+            // never straddle an image and the destination is 64-byte aligned.
+            const int tok0 = mw + hh * 32, bidx = tok0 / p.vt_T, t0 = tok0 - bidx * p.vt_T;
 #pragma unroll
-                for (int pass = 0; pass < 3; ++pass) {
-                    const int c = pass * 64 + lane;
-                    if (c < 144) {
-                        const int nn = nw + c - p.vt_col0, head = nn / p.vt_hd, d = nn - head * p.vt_hd;
-                        bf16_t* dst = p.vt_out + (long)bidx * p.vt_bs + ((long)head * p.vt_dv + d) * p.vt_ld + t0;
+            for (int pass = 0; pass < 3; ++pass) {
+                const int c = pass * 64 + lane;
+                if (c < 144) {
+                    const int nn = nw + c - p.vt_col0, head = nn / p.vt_hd, d = nn - head * p.vt_hd;
+                    bf16_t* dst = p.vt_out + (long)bidx * p.vt_bs + ((long)head * p.vt_dv + d) * p.vt_ld + t0;
 #pragma unroll
-                        for (int g4 = 0; g4 < 4; ++g4) {
-                            uint32_t w[4];
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        uint32_t w[4];
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) w[e] = pack2bf(slab[(g4 * 8 + 2 * e) * 144 + c], slab[(g4 * 8 + 2 * e + 1) * 144 + c]);
-                            *reinterpret_cast<uint4*>(dst + g4 * 8) = make_uint4(w[0], w[1], w[2], w[3]);
-                        }
+                        for (int e = 0; e < 4; ++e) w[e] = pack2bf(slab[(g4 * 8 + 2 * e) * 144 + c], slab[(g4 * 8 + 2 * e + 1) * 144 + c]);
+                        *reinterpret_cast<uint4*>(dst + g4 * 8) = make_uint4(w[0], w[1], w[2], w[3]);
                     }
                 }
             }
-            done_half();
         }
-    } else if (kind == 1) {
+        done_half();
+    };
+    auto rows_kind1 = [&](auto hc) __attribute__((always_inline)) {
+        constexpr int hh = decltype(hc)::value;
         const float* resf = reinterpret_cast<const float*>(p.res);
         float* outf = reinterpret_cast<float*>(p.out);
+        write_half(hc);   // first: this half's 72 accumulator registers die here and make room for the residual vectors
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            write_half(hh);   // first: this half's 72 accumulator registers die here and make room for the residual vectors
+        for (int bt = 0; bt < 3; ++bt) {   // three batches of 6 vectors: 6 residual requests back to back, then 6 add + stores
+            f32x4_t rr[6];
 #pragma unroll
-            for (int bt = 0; bt < 3; ++bt) {   // three batches of 6 vectors: 6 residual requests back to back, then 6 add + stores
-                f32x4_t rr[6];
-#pragma unroll
-                for (int it = 0; it < 6; ++it) {
-                    const int v = (bt * 6 + it) * 64 + lane, row = v / 36, c4 = (v - row * 36) * 4;
-                    const int m = min(mw + hh * 32 + row, p.M - 1);
-                    rr[it] = *reinterpret_cast<const f32x4_t*>(resf + (unsigned)(m * p.res_cs + nw + c4));
-                }
-#pragma unroll
-                for (int it = 0; it < 6; ++it) {
-                    const int v = (bt * 6 + it) * 64 + lane, row = v / 36, c4 = (v - row * 36) * 4;
-                    const int m = mw + hh * 32 + row;
-                    const f32x4_t o = *reinterpret_cast<const f32x4_t*>(&slab[row * 144 + c4]) + rr[it];
-                    if (m < p.M) {
-                        *reinterpret_cast<f32x4_t*>(outf + (unsigned)(m * p.out_cs + nw + c4)) = o;
-                        if (p.out2) *reinterpret_cast<uint2*>(p.out2 + (unsigned)(m * p.out2_cs + nw + c4)) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
-                    }
-                }
+            for (int it = 0; it < 6; ++it) {
+                const int v = (bt * 6 + it) * 64 + lane, row = v / 36, c4 = (v - row * 36) * 4;
+                const int m = min(mw + hh * 32 + row, p.M - 1);
+                if (IR_GPP_KO == 1) rr[it] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                else rr[it] = *reinterpret_cast<const f32x4_t*>(resf + (unsigned)(m * p.res_cs + nw + c4));
             }
-            done_half();
-        }
-    } else {
-        for (int hh = 0; hh < 2; ++hh) {
-            write_half(hh);
-            for (int it = 0; it < 18; ++it) {
-                const int v = it * 64 + lane, row = v / 36, c4 = (v - row * 36) * 4;
+#pragma unroll
+            for (int it = 0; it < 6; ++it) {
+                const int v = (bt * 6 + it) * 64 + lane, row = v / 36, c4 = (v - row * 36) * 4;
                 const int m = mw + hh * 32 + row;
-                f32x4_t o = *reinterpret_cast<const f32x4_t*>(&slab[row * 144 + c4]);
+                const f32x4_t o = *reinterpret_cast<const f32x4_t*>(&slab[row * 144 + c4]) + rr[it];
                 if (m < p.M) {
-                    const int n = nw + c4;
-                    if (p.res) {
-                        const long rm = p.res_mod > 0 ? (long)(m % p.res_mod) : (long)m;
-                        if (p.res_f32) o += *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(p.res) + rm * p.res_cs + n);
-                        else {
-                            const uint2 rb = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(p.res) + rm * p.res_cs + n);
-                            o += f32x4_t{bflo(rb.x), bfhi(rb.x), bflo(rb.y), bfhi(rb.y)};
-                        }
-                    }
-                    const uint2 pk = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
-                    if (p.out_f32) *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(p.out) + (long)m * p.out_cs + n) = o;
-                    else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (long)m * p.out_cs + n) = pk;
-                    if (p.out2) *reinterpret_cast<uint2*>(p.out2 + (long)m * p.out2_cs + n) = pk;
+                    if (IR_GPP_KO != 3) *reinterpret_cast<f32x4_t*>(outf + (unsigned)(m * p.out_cs + nw + c4)) = o;
+                    if (p.out2 && IR_GPP_KO != 2) *reinterpret_cast<uint2*>(p.out2 + (unsigned)(m * p.out2_cs + nw + c4)) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
                 }
             }
-            done_half();
         }
-    }
+        done_half();
+    };
+    auto rows_kind2 = [&](auto hc) __attribute__((always_inline)) {
+        constexpr int hh = decltype(hc)::value;
+        write_half(hc);
+        for (int it = 0; it < 18; ++it) {
+            const int v = it * 64 + lane, row = v / 36, c4 = (v - row * 36) * 4;
+            const int m = mw + hh * 32 + row;
+            f32x4_t o = *reinterpret_cast<const f32x4_t*>(&slab[row * 144 + c4]);
+            if (m < p.M) {
+                const int n = nw + c4;
+                if (p.res) {
+                    const long rm = p.res_mod > 0 ? (long)(m % p.res_mod) : (long)m;
+                    if (p.res_f32) o += *reinterpret_cast<const f32x4_t*>(reinterpret_cast<const float*>(p.res) + rm * p.res_cs + n);
+                    else {
+                        const uint2 rb = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(p.res) + rm * p.res_cs + n);
+                        o += f32x4_t{bflo(rb.x), bfhi(rb.x), bflo(rb.y), bfhi(rb.y)};
+                    }
+                }
+                const uint2 pk = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+                if (p.out_f32) *reinterpret_cast<f32x4_t*>(reinterpret_cast<float*>(p.out) + (long)m * p.out_cs + n) = o;
+                else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (long)m * p.out_cs + n) = pk;
+                if (p.out2) *reinterpret_cast<uint2*>(p.out2 + (long)m * p.out2_cs + n) = pk;
+            }
+        }
+        done_half();
+    };
+    using H0 = std::integral_constant<int, 0>;
+    using H1 = std::integral_constant<int, 1>;
+    if (kind == 0) { rows_kind0(H0{}); rows_kind0(H1{}); }
+    else if (kind == 1) { rows_kind1(H0{}); rows_kind1(H1{}); }
+    else { rows_kind2(H0{}); rows_kind2(H1{}); }
 }
 
 int g_ir_plain_kernels = 0;
@@ -1495,7 +1508,15 @@ int ir_igemm_writes_vt(const IGemmParams& pin) {
 }
 static int launch_gemm_pp(const IGemmParams& p, hipStream_t s) {
     const int MT = (p.M + GemmPP::BM - 1) / GemmPP::BM, NT = p.Cout / GemmPP::BN;
-    hipLaunchKernelGGL(gemm_pp_kernel, dim3(((MT + 7) / 8) * 8 * NT), dim3(512), 0, s, p);
+    const dim3 grid(((MT + 7) / 8) * 8 * NT);
+    static const bool generic = getenv("IR_GEMM_PP_GENERIC") != nullptr;   // experiment knob: the run-time form for every launch
+    const bool unit = !p.gate && p.out_scale == 1.f;
+    const int kind = (!p.res && !p.out_f32 && !p.out2) ? 0 : (p.res && p.res_f32 && p.out_f32 && p.res_mod == 0) ? 1 : 2;
+    if (generic) hipLaunchKernelGGL((gemm_pp_kernel<-1, -1, false>), grid, dim3(512), 0, s, p);
+    else if (kind == 0 && unit && p.act == IR_ACT_NONE) hipLaunchKernelGGL((gemm_pp_kernel<IR_ACT_NONE, 0, true>), grid, dim3(512), 0, s, p);
+    else if (kind == 0 && unit && p.act == IR_ACT_GELU_TANH) hipLaunchKernelGGL((gemm_pp_kernel<IR_ACT_GELU_TANH, 0, true>), grid, dim3(512), 0, s, p);
+    else if (kind == 1 && p.act == IR_ACT_NONE) hipLaunchKernelGGL((gemm_pp_kernel<IR_ACT_NONE, 1, false>), grid, dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((gemm_pp_kernel<-1, -1, false>), grid, dim3(512), 0, s, p);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 

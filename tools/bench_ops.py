@@ -9,16 +9,24 @@ ctx = Context(0)
 
 
 def timeit(fn, iters=5, warm=2):
+    """IR_BENCH_ITERS=n: n timed launches back to back (default 5); IR_BENCH_REPS=r: the best of r such windows (default 1) - short ops need both to
+    separate a few per cent on a box whose clock wanders."""
+    iters = int(os.environ.get("IR_BENCH_ITERS", iters))
+    reps = int(os.environ.get("IR_BENCH_REPS", 1))
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters
+    best = None
+    for _ in range(reps):
+        t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+        t0.record()
+        for _ in range(iters):
+            fn()
+        t1.record()
+        torch.cuda.synchronize()
+        ms = t0.elapsed_time(t1) / iters
+        best = ms if best is None else min(best, ms)
+    return best
 
 
 def conv(n, h, w, cin, cout, up=0, stride=1):
