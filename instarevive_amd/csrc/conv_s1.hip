@@ -90,7 +90,9 @@ IR_DEVINL void cs1_mfma(bf16x8 w, bf16x8 px) {
 // pixels (out-of-range buffer loads: zeros) are left alone - the zero padding applies to the NORMALISED tensor. The per-image scale / shift tables
 // of the current and the next tile live behind the weight ring. To make room in the arch register file (the 9-tap stream holds two full fragment
 // sets, 128 VGPRs) this form keeps two weight-fragment sets but streams the pixel fragments through a ring of three.
-template <int UP, int NTAP, bool NORM = false>
+// EFULL (round 6): every tile of the launch is a whole 16 x 32 patch inside the image and the launch writes GroupNorm statistics - the epilogue
+// then carries no validity tests and no per-store exec-mask juggling (conv_s1_epi.h). The launcher decides.
+template <int UP, int NTAP, bool NORM = false, bool EFULL = false>
 __global__ __launch_bounds__(256, 1) void conv_halo_s1_kernel(IGemmParams p, int tiles_y, int tiles_x, int total_vb) {
     static_assert(!NORM || (UP == 0 && NTAP == 9), "the in-kernel GroupNorm form exists for the plain 9-tap conv");
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub: the buffer-resource type of the body does not exist there, and with it in
@@ -509,11 +511,11 @@ __global__ __launch_bounds__(256, 1) void conv_halo_s1_kernel(IGemmParams p, int
         unsigned char* ebuf = smem + (hb3 == 0 ? 2 : hb3 - 1) * HALO_BYTES;   // every wave passed the last barrier after its last read of it
 #ifdef IR_S1_STAMPS
         unsigned long long st4v = 0;
-        cs1_epilogue<false>(p, ebuf, tid, lane, wid, c16, kq, cur.n0, cur.img, cur.oy0, cur.ox0, cur.trem, IR_KO_S1 != 1 && IR_KO_S1 != 3, IR_KO_S1 == 0, &st4v,
+        cs1_epilogue<false, EFULL>(p, ebuf, tid, lane, wid, c16, kq, cur.n0, cur.img, cur.oy0, cur.ox0, cur.trem, IR_KO_S1 != 1 && IR_KO_S1 != 3, IR_KO_S1 == 0, &st4v,
                             PH ? 2 : 1, cur.dy, cur.dx, PH ? p.H : p.Ho, PH ? p.W : p.Wo);
         const unsigned long long st4 = st4v;
 #else
-        cs1_epilogue<false>(p, ebuf, tid, lane, wid, c16, kq, cur.n0, cur.img, cur.oy0, cur.ox0, cur.trem, IR_KO_S1 != 1 && IR_KO_S1 != 3, IR_KO_S1 == 0, nullptr,
+        cs1_epilogue<false, EFULL>(p, ebuf, tid, lane, wid, c16, kq, cur.n0, cur.img, cur.oy0, cur.ox0, cur.trem, IR_KO_S1 != 1 && IR_KO_S1 != 3, IR_KO_S1 == 0, nullptr,
                             PH ? 2 : 1, cur.dy, cur.dx, PH ? p.H : p.Ho, PH ? p.W : p.Wo);
 #endif
         IR_S1_T(st5);
@@ -575,9 +577,15 @@ int ir_launch_conv_s1(const IGemmParams& p, hipStream_t s) {
     const long total = ((MT + 7) / 8) * 8 * NT;
     if (total > 0x7fffffffL) return -12;
     const long grid = total < cs1_cus() ? total : cs1_cus();
-    if (p.nrm_scale) hipLaunchKernelGGL((conv_halo_s1_kernel<0, 9, true>), dim3((unsigned)grid), dim3(256), 0, s, p, tiles_y, tiles_x, (int)total);
-    else if (p.up) hipLaunchKernelGGL((conv_halo_s1_kernel<1, 9>), dim3((unsigned)grid), dim3(256), 0, s, p, tiles_y, tiles_x, (int)total);
-    else hipLaunchKernelGGL((conv_halo_s1_kernel<0, 9>), dim3((unsigned)grid), dim3(256), 0, s, p, tiles_y, tiles_x, (int)total);
+    static const bool no_full = getenv("IR_S1_NO_EFULL") != nullptr;   // experiment knob: the general epilogue for every launch
+    const bool full = !no_full && p.gn_part && p.Ho % 16 == 0 && p.Wo % 32 == 0;
+    const dim3 g((unsigned)grid), b(256);
+    if (p.nrm_scale) {
+        if (full) hipLaunchKernelGGL((conv_halo_s1_kernel<0, 9, true, true>), g, b, 0, s, p, tiles_y, tiles_x, (int)total);
+        else hipLaunchKernelGGL((conv_halo_s1_kernel<0, 9, true>), g, b, 0, s, p, tiles_y, tiles_x, (int)total);
+    } else if (p.up) hipLaunchKernelGGL((conv_halo_s1_kernel<1, 9>), g, b, 0, s, p, tiles_y, tiles_x, (int)total);
+    else if (full) hipLaunchKernelGGL((conv_halo_s1_kernel<0, 9, false, true>), g, b, 0, s, p, tiles_y, tiles_x, (int)total);
+    else hipLaunchKernelGGL((conv_halo_s1_kernel<0, 9>), g, b, 0, s, p, tiles_y, tiles_x, (int)total);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
 
@@ -603,6 +611,8 @@ int ir_launch_conv_s1_up2x2(const IGemmParams& p, hipStream_t s) {
     const long total = ((MT + 7) / 8) * 8 * NT;
     if (total > 0x7fffffffL) return -12;
     const long grid = total < cs1_cus() ? total : cs1_cus();
-    hipLaunchKernelGGL((conv_halo_s1_kernel<0, 4>), dim3((unsigned)grid), dim3(256), 0, s, p, tiles_y, tiles_x, (int)total);
+    static const bool no_full = getenv("IR_S1_NO_EFULL") != nullptr;
+    if (!no_full && p.gn_part && p.H % 16 == 0 && p.W % 32 == 0) hipLaunchKernelGGL((conv_halo_s1_kernel<0, 4, false, true>), dim3((unsigned)grid), dim3(256), 0, s, p, tiles_y, tiles_x, (int)total);
+    else hipLaunchKernelGGL((conv_halo_s1_kernel<0, 4>), dim3((unsigned)grid), dim3(256), 0, s, p, tiles_y, tiles_x, (int)total);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -26,10 +26,15 @@ IR_DEVINL float cs1_acc_read() {
 // the image). do_passes / do_stats / mid_stamp: diagnostics of the callers' knock-out and stamp builds (true, true, nullptr in the product).
 // Output map (the sub-pixel phase form of conv_s1.hip): tile pixel (y, x) is stored at output pixel (omul * y + oyoff, omul * x + oxoff); tile
 // pixels are valid below (hlim, wlim). Identity map: omul = 1, offsets 0, limits = p.Ho, p.Wo. The residual (if any) uses the same map.
-template <bool GATE>
-IR_DEVINL void cs1_epilogue(const IGemmParams& p, unsigned char* ebuf, int tid, int lane, int wid, int c16, int kq, int t_n0, int t_img, int t_oy0,
-                            int t_ox0, int t_trem, bool do_passes, bool do_stats, unsigned long long* mid_stamp, int omul, int oyoff, int oxoff, int hlim,
-                            int wlim) {
+// FULL (round 6): the whole 16 x 32 patch lies inside the image - every tile of a 2048 x 2048 map and all but the last row / column of tiles
+// otherwise - so the row / column validity tests, the safe residual pixel and the exec-mask save / restore around every 16-byte store (a
+// saveexec + branch pair per store, plus the spilled scalars they dragged in) disappear, and store / residual addresses are one wave-uniform
+// 64-bit base plus a 32-bit lane offset. GN: the statistics are compiled in or out instead of branched over per store. Same arithmetic in the
+// same order as the general form: results are bit-identical.
+template <bool GATE, bool FULL>
+IR_DEVINL void cs1_epilogue_impl(const IGemmParams& p, unsigned char* ebuf, int tid, int lane, int wid, int c16, int kq, int t_n0, int t_img, int t_oy0,
+                                 int t_ox0, int t_trem, bool do_passes, bool do_stats, unsigned long long* mid_stamp, int omul, int oyoff, int oxoff, int hlim,
+                                 int wlim) {
     using namespace cs1e;
     float* slab = reinterpret_cast<float*>(ebuf + wid * SLAB);
     const int co8 = (lane & 15) * 8, xq = lane >> 4;
@@ -53,28 +58,49 @@ IR_DEVINL void cs1_epilogue(const IGemmParams& p, unsigned char* ebuf, int tid, 
     // Row it of a pass is pixel (oyw + A, oxl + 4 it): per-lane base pointers once per tile, uniform offsets per pass and row
     const int oyw = oy0 + 4 * wid, oxl = ox0 + xq;
     unsigned xm = 0;   // bit it: column oxl + 4 it lies inside the image
+    if constexpr (!FULL) {
 #pragma unroll
-    for (int it = 0; it < 8; ++it) xm |= (oxl + 4 * it < wlim ? 1u : 0u) << it;
+        for (int it = 0; it < 8; ++it) xm |= (oxl + 4 * it < wlim ? 1u : 0u) << it;
+    }
     const long pix0 = ((long)img * p.Ho + (long)omul * oyw + oyoff) * p.Wo + (long)omul * oxl + oxoff;
     bf16_t* obase = reinterpret_cast<bf16_t*>(p.out) + pix0 * p.out_cs + n0 + co8;
     const bf16_t* rbase = reinterpret_cast<const bf16_t*>(p.res) + pix0 * p.res_cs + n0 + co8;
     const bf16_t* rsafe = reinterpret_cast<const bf16_t*>(p.res) + (((long)img * p.Ho + (long)omul * oy0 + oyoff) * p.Wo + (long)omul * ox0 + oxoff) * p.res_cs + n0 + co8;   // always inside
     const long o_row = (long)omul * p.Wo * p.out_cs, r_row = (long)omul * p.Wo * p.res_cs;
     const long o_col = (long)omul * p.out_cs, r_col = (long)omul * p.res_cs;   // element step between tile columns
-    const bool do_gn = p.gn_part != nullptr;
+    // FULL: wave-uniform bases (the wave's first pixel, the tile's first channel) + 32-bit lane offsets; four rows of a patch span less than
+    // 2^31 elements for every tensor the launcher admits (4 x omul x Wo x cs)
+    const long upix = ((long)img * p.Ho + (long)omul * oyw + oyoff) * p.Wo + (long)omul * ox0 + oxoff;
+    bf16_t* const uo = reinterpret_cast<bf16_t*>(p.out) + upix * p.out_cs + n0;
+    const bf16_t* const ur = reinterpret_cast<const bf16_t*>(p.res) + upix * p.res_cs + n0;
+    // byte offsets, so that the address is "uniform 64-bit base + zero-extended 32-bit lane offset" - the saddr form of global_load / global_store.
+    // The empty asm makes the lane terms opaque per call: left visible, hipcc hoists all 64 (row, column) offsets of a tile out of the persistent
+    // tile loop as 64-bit values - 128 registers it then spills, each reloaded in front of the load or store that uses it
+    unsigned lo_o = (unsigned)(xq * (int)o_col + co8) * 2u, lo_r = (unsigned)(xq * (int)r_col + co8) * 2u;
+    if constexpr (FULL) asm volatile("" : "+v"(lo_o), "+v"(lo_r));
+    const unsigned uo_row = (unsigned)o_row * 2u, ur_row = (unsigned)r_row * 2u, uo_c4 = 8u * (unsigned)o_col, ur_c4 = 8u * (unsigned)r_col;
+    unsigned char* const uob = reinterpret_cast<unsigned char*>(uo);
+    const unsigned char* const urb = reinterpret_cast<const unsigned char*>(ur);
+    constexpr bool GN = FULL;                            // the FULL form exists with the statistics only (every VAE conv behind a GroupNorm has them)
+    const bool do_gn = FULL || p.gn_part != nullptr;
     uint4 rrb[2][8];   // residual rows of the pass being finished / of the next pass
     auto res_fetch = [&](int a) {   // rows outside the image read a safe pixel
-        const bool yok = oyw + a < hlim;
+        if constexpr (FULL) {
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const bool v = yok && ((xm >> it) & 1);
-            rrb[a & 1][it] = *reinterpret_cast<const uint4*>(v ? rbase + a * r_row + (long)(4 * it) * r_col : rsafe);
+            for (int it = 0; it < 8; ++it) rrb[a & 1][it] = *reinterpret_cast<const uint4*>(urb + (lo_r + (unsigned)a * ur_row + (unsigned)it * ur_c4));
+        } else {
+            const bool yok = oyw + a < hlim;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const bool v = yok && ((xm >> it) & 1);
+                rrb[a & 1][it] = *reinterpret_cast<const uint4*>(v ? rbase + a * r_row + (long)(4 * it) * r_col : rsafe);
+            }
         }
     };
     auto pass = [&](auto ac, auto resc) {
         constexpr int A = decltype(ac)::value;
         constexpr bool RES = decltype(resc)::value;
-        const bool yok = oyw + A < hlim;
+        const bool yok = FULL || oyw + A < hlim;
         uint4 (&rr)[8] = rrb[A & 1];
         if constexpr (RES && A < 3) res_fetch(A + 1);   // the next pass's residual rows fly during this pass
         [&]<int... MXS>(std::integer_sequence<int, MXS...>) {
@@ -88,6 +114,7 @@ IR_DEVINL void cs1_epilogue(const IGemmParams& p, unsigned char* ebuf, int tid, 
                         *reinterpret_cast<f32x4*>(&slab[c16 * SROW + 16 * CT + 4 * kq]) = v;
                     }(), ...);
                 }(std::make_integer_sequence<int, 8>{});
+                if constexpr (FULL) __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -107,7 +134,15 @@ IR_DEVINL void cs1_epilogue(const IGemmParams& p, unsigned char* ebuf, int tid, 
                         b += f32x4{bflo(rr[it].z), bfhi(rr[it].z), bflo(rr[it].w), bfhi(rr[it].w)};
                     }
                     const uint4 pk = make_uint4(pack2bf_valu(a[0], a[1]), pack2bf_valu(a[2], a[3]), pack2bf_valu(b[0], b[1]), pack2bf_valu(b[2], b[3]));
-                    if (yok && ((xm >> it) & 1)) {
+                    if constexpr (FULL) {
+                        *reinterpret_cast<uint4*>(uob + (lo_o + (unsigned)A * uo_row + (unsigned)it * uo_c4)) = pk;
+                        if constexpr (GN) {   // statistics of the values as stored (bf16-rounded)
+                            const f32x4 ar = {bflo(pk.x), bfhi(pk.x), bflo(pk.y), bfhi(pk.y)}, br = {bflo(pk.z), bfhi(pk.z), bflo(pk.w), bfhi(pk.w)};
+                            sA4 += ar; qA4 += ar * ar;
+                            sB4 += br; qB4 += br * br;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else if (yok && ((xm >> it) & 1)) {
                         *reinterpret_cast<uint4*>(obase + A * o_row + (long)(4 * it) * o_col) = pk;
                         if (do_gn) {   // statistics of the values as stored (bf16-rounded)
                             const f32x4 ar = {bflo(pk.x), bfhi(pk.x), bflo(pk.y), bfhi(pk.y)}, br = {bflo(pk.z), bfhi(pk.z), bflo(pk.w), bfhi(pk.w)};
@@ -119,6 +154,7 @@ IR_DEVINL void cs1_epilogue(const IGemmParams& p, unsigned char* ebuf, int tid, 
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if constexpr (FULL) __builtin_amdgcn_sched_barrier(0);   // straight-line code: without it hipcc interleaves the half passes until it spills
             }(), ...);
         }(std::make_integer_sequence<int, 2>{});
     };
@@ -137,7 +173,7 @@ IR_DEVINL void cs1_epilogue(const IGemmParams& p, unsigned char* ebuf, int tid, 
         }
     }
     if (mid_stamp) *mid_stamp = __builtin_amdgcn_s_memrealtime();
-    if (p.gn_part && do_stats) {
+    if (do_gn && do_stats) {
         // Fixed-order workgroup reduction (no atomics, bit-identical run to run). Unit u = 4 channels; lane (L = lane & 15) holds units 2L and
         // 2L+1 over the pixel columns xq, xq + 4, ...: first the four column classes of a wave (lanes L, L+16, L+32, L+48), then the four
         // waves through LDS, then the units of a group.
@@ -169,4 +205,14 @@ IR_DEVINL void cs1_epilogue(const IGemmParams& p, unsigned char* ebuf, int tid, 
             }
         }
     }
+}
+
+// FULL is the caller's promise (a kernel instantiation of its own, chosen by the launcher): EVERY tile of the launch is a whole patch inside the
+// image and the launch writes statistics. (Chosen per tile inside one kernel - both forms inlined side by side - hipcc's register allocation
+// of the 512-register kernels fell apart: 145 spilled VGPRs and conv_halo_s1_kernel 40.6 -> 46.3 ms per image, profiles/r06_ab_s1_epi_pertile.txt.)
+template <bool GATE, bool FULL = false>
+IR_DEVINL void cs1_epilogue(const IGemmParams& p, unsigned char* ebuf, int tid, int lane, int wid, int c16, int kq, int t_n0, int t_img, int t_oy0,
+                            int t_ox0, int t_trem, bool do_passes, bool do_stats, unsigned long long* mid_stamp, int omul, int oyoff, int oxoff, int hlim,
+                            int wlim) {
+    cs1_epilogue_impl<GATE, FULL>(p, ebuf, tid, lane, wid, c16, kq, t_n0, t_img, t_oy0, t_ox0, t_trem, do_passes, do_stats, mid_stamp, omul, oyoff, oxoff, hlim, wlim);
 }
