@@ -69,7 +69,7 @@ template <class T>
 IR_DEVINL void c8_keep(const T& x) { asm volatile("" ::"v"(x)); }
 
 // UP = 1: the conv runs on the nearest-2x upsampled input (2H x 2W), folded into the halo's source addresses (as conv_halo_s1_kernel<1>)
-template <int UP>
+template <int UP, bool EFULL = false>   // EFULL: whole-patch launch with statistics (conv_s1_epi.h, round 6)
 __global__ __launch_bounds__(256, 1) void conv_halo_s1_fp8_kernel(IGemmParams p, int tiles_y, int tiles_x, int total_vb) {
     using namespace c8;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES];   // halo[0..1] | W ring of 6 ; epilogue: slabs + red in halo[1]
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256, 1) void conv_halo_s1_fp8_kernel(IGemmParams p,
         // ---- epilogue through slabs in halo buffer 1 (the last chunk's: every wave passed the last barrier after its last read of it;
         // the next tile's chunk 0 is landing in buffer 0, its chunk 1 is fetched during its own first steps)
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMA results -> v_accvgpr_read
-        cs1_epilogue<true>(p, smem + HALO_BYTES, tid, lane, wid, c16, kq, cur.n0, cur.img, cur.oy0, cur.ox0, cur.trem, true, true, nullptr, 1, 0, 0, p.Ho, p.Wo);
+        cs1_epilogue<true, EFULL>(p, smem + HALO_BYTES, tid, lane, wid, c16, kq, cur.n0, cur.img, cur.oy0, cur.ox0, cur.trem, true, true, nullptr, 1, 0, 0, p.Ho, p.Wo);
         if (!more) break;
         bid = nbid;
         cur = nxt;
@@ -302,7 +302,9 @@ int ir_launch_conv_s1_fp8(const IGemmParams& p, hipStream_t s) {
         return n & ~7;
     }();
     const long grid = total < cus ? total : cus;
+    static const bool no_full = getenv("IR_S1_NO_EFULL") != nullptr;   // experiment knob (shared with conv_s1.hip)
     if (p.up) hipLaunchKernelGGL(conv_halo_s1_fp8_kernel<1>, dim3((unsigned)grid), dim3(256), 0, s, p, tiles_y, tiles_x, (int)total);
+    else if (!no_full && p.gn_part && p.Ho % 16 == 0 && p.Wo % 32 == 0) hipLaunchKernelGGL((conv_halo_s1_fp8_kernel<0, true>), dim3((unsigned)grid), dim3(256), 0, s, p, tiles_y, tiles_x, (int)total);
     else hipLaunchKernelGGL(conv_halo_s1_fp8_kernel<0>, dim3((unsigned)grid), dim3(256), 0, s, p, tiles_y, tiles_x, (int)total);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
