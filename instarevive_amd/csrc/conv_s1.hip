@@ -90,9 +90,9 @@ IR_DEVINL void cs1_mfma(bf16x8 w, bf16x8 px) {
 // pixels (out-of-range buffer loads: zeros) are left alone - the zero padding applies to the NORMALISED tensor. The per-image scale / shift tables
 // of the current and the next tile live behind the weight ring. To make room in the arch register file (the 9-tap stream holds two full fragment
 // sets, 128 VGPRs) this form keeps two weight-fragment sets but streams the pixel fragments through a ring of three.
-// EFULL (round 6): every tile of the launch is a whole 16 x 32 patch inside the image and the launch writes GroupNorm statistics - the epilogue
-// then carries no validity tests and no per-store exec-mask juggling (conv_s1_epi.h). The launcher decides.
-template <int UP, int NTAP, bool NORM = false, bool EFULL = false>
+// EFULL (round 6; 1: with GroupNorm statistics, 2: without): every tile of the launch is a whole 16 x 32 patch inside the image - the epilogue then
+// carries no validity tests and no per-store exec-mask juggling, and the bias rides in the accumulators (conv_s1_epi.h). The launcher decides.
+template <int UP, int NTAP, bool NORM = false, int EFULL = 0>
 __global__ __launch_bounds__(256, 1) void conv_halo_s1_kernel(IGemmParams p, int tiles_y, int tiles_x, int total_vb) {
     static_assert(!NORM || (UP == 0 && NTAP == 9), "the in-kernel GroupNorm form exists for the plain 9-tap conv");
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub: the buffer-resource type of the body does not exist there, and with it in
@@ -458,7 +458,25 @@ __global__ __launch_bounds__(256, 1) void conv_halo_s1_kernel(IGemmParams p, int
             if (first_tile) load_tab(tpar, cur.img);
             load_tab(tpar ^ 1, nxt.img);   // (the slot of the tile before this one: its last reader passed the barrier that ended that tile's stream)
         }
-        asm volatile(".set ir_cs1_i, 0\n\t.rept 256\n\tv_accvgpr_write_b32 a[ir_cs1_i], 0\n\t.set ir_cs1_i, ir_cs1_i + 1\n\t.endr" ::: IR_AGPR256_CLOBBERS);
+        if constexpr (EFULL != 0) {
+            // the accumulators start at the bias of their channel (tile (pixel fragment PT, channel fragment CT) at a[4 (8 PT + CT) ..+3], a lane holding channels
+            // 16 CT + 4 kq .. +3): the epilogue then stores the accumulators as they are (out_scale == 1: launcher)
+            [&]<int... CT>(std::integer_sequence<int, CT...>) {
+                ([&] {
+                    const f32x4 b4 = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + cur.n0 + 16 * CT + 4 * kq) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    if constexpr (CT == 0)
+                        asm volatile(".set ir_cs1_i, 0\n\t.rept 8\n\tv_accvgpr_write_b32 a[ir_cs1_i], %0\n\tv_accvgpr_write_b32 a[ir_cs1_i + 1], %1\n\t"
+                                     "v_accvgpr_write_b32 a[ir_cs1_i + 2], %2\n\tv_accvgpr_write_b32 a[ir_cs1_i + 3], %3\n\t.set ir_cs1_i, ir_cs1_i + 32\n\t.endr"
+                                     ::"v"(b4[0]), "v"(b4[1]), "v"(b4[2]), "v"(b4[3]) : IR_AGPR256_CLOBBERS);
+                    else
+                        asm volatile(".set ir_cs1_i, %c4\n\t.rept 8\n\tv_accvgpr_write_b32 a[ir_cs1_i], %0\n\tv_accvgpr_write_b32 a[ir_cs1_i + 1], %1\n\t"
+                                     "v_accvgpr_write_b32 a[ir_cs1_i + 2], %2\n\tv_accvgpr_write_b32 a[ir_cs1_i + 3], %3\n\t.set ir_cs1_i, ir_cs1_i + 32\n\t.endr"
+                                     ::"v"(b4[0]), "v"(b4[1]), "v"(b4[2]), "v"(b4[3]), "n"(4 * CT));
+                }(), ...);
+            }(std::make_integer_sequence<int, 8>{});
+        } else {
+            asm volatile(".set ir_cs1_i, 0\n\t.rept 256\n\tv_accvgpr_write_b32 a[ir_cs1_i], 0\n\t.set ir_cs1_i, ir_cs1_i + 1\n\t.endr" ::: IR_AGPR256_CLOBBERS);
+        }
         // everything in flight has landed (first tile: the prologue; later: the pieces fetched through the tile boundary and the previous
         // epilogue's stores) - chunk 1's halo included, which costs nothing after an epilogue and ~1 us once per workgroup
         wait_dma();
@@ -593,13 +611,15 @@ int ir_launch_conv_s1(const IGemmParams& p, hipStream_t s) {
     if (total > 0x7fffffffL) return -12;
     const long grid = total < cs1_cus() ? total : cs1_cus();
     static const bool no_full = getenv("IR_S1_NO_EFULL") != nullptr;   // experiment knob: the general epilogue for every launch
-    const bool full = !no_full && p.gn_part && p.Ho % 16 == 0 && p.Wo % 32 == 0;
+    const int full = (!no_full && p.Ho % 16 == 0 && p.Wo % 32 == 0 && p.out_scale == 1.f) ? (p.gn_part ? 1 : 2) : 0;
     const dim3 g((unsigned)grid), b(256);
     if (p.nrm_scale) {
-        if (full) hipLaunchKernelGGL((conv_halo_s1_kernel<0, 9, true, true>), g, b, 0, s, p, tiles_y, tiles_x, (int)total);
+        if (full == 1) hipLaunchKernelGGL((conv_halo_s1_kernel<0, 9, true, 1>), g, b, 0, s, p, tiles_y, tiles_x, (int)total);
+        else if (full == 2) hipLaunchKernelGGL((conv_halo_s1_kernel<0, 9, true, 2>), g, b, 0, s, p, tiles_y, tiles_x, (int)total);
         else hipLaunchKernelGGL((conv_halo_s1_kernel<0, 9, true>), g, b, 0, s, p, tiles_y, tiles_x, (int)total);
     } else if (p.up) hipLaunchKernelGGL((conv_halo_s1_kernel<1, 9>), g, b, 0, s, p, tiles_y, tiles_x, (int)total);
-    else if (full) hipLaunchKernelGGL((conv_halo_s1_kernel<0, 9, false, true>), g, b, 0, s, p, tiles_y, tiles_x, (int)total);
+    else if (full == 1) hipLaunchKernelGGL((conv_halo_s1_kernel<0, 9, false, 1>), g, b, 0, s, p, tiles_y, tiles_x, (int)total);
+    else if (full == 2) hipLaunchKernelGGL((conv_halo_s1_kernel<0, 9, false, 2>), g, b, 0, s, p, tiles_y, tiles_x, (int)total);
     else hipLaunchKernelGGL((conv_halo_s1_kernel<0, 9>), g, b, 0, s, p, tiles_y, tiles_x, (int)total);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
@@ -627,7 +647,7 @@ int ir_launch_conv_s1_up2x2(const IGemmParams& p, hipStream_t s) {
     if (total > 0x7fffffffL) return -12;
     const long grid = total < cs1_cus() ? total : cs1_cus();
     static const bool no_full = getenv("IR_S1_NO_EFULL") != nullptr;
-    if (!no_full && p.gn_part && p.H % 16 == 0 && p.W % 32 == 0) hipLaunchKernelGGL((conv_halo_s1_kernel<0, 4, false, true>), dim3((unsigned)grid), dim3(256), 0, s, p, tiles_y, tiles_x, (int)total);
+    if (!no_full && p.gn_part && p.H % 16 == 0 && p.W % 32 == 0 && p.out_scale == 1.f) hipLaunchKernelGGL((conv_halo_s1_kernel<0, 4, false, 1>), dim3((unsigned)grid), dim3(256), 0, s, p, tiles_y, tiles_x, (int)total);
     else hipLaunchKernelGGL((conv_halo_s1_kernel<0, 4>), dim3((unsigned)grid), dim3(256), 0, s, p, tiles_y, tiles_x, (int)total);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

@@ -31,7 +31,7 @@ IR_DEVINL float cs1_acc_read() {
 // saveexec + branch pair per store, plus the spilled scalars they dragged in) disappear, and store / residual addresses are one wave-uniform
 // 64-bit base plus a 32-bit lane offset. GN: the statistics are compiled in or out instead of branched over per store. Same arithmetic in the
 // same order as the general form: results are bit-identical.
-template <bool GATE, bool FULL>
+template <bool GATE, bool FULL, bool FGN>
 IR_DEVINL void cs1_epilogue_impl(const IGemmParams& p, unsigned char* ebuf, int tid, int lane, int wid, int c16, int kq, int t_n0, int t_img, int t_oy0,
                                  int t_ox0, int t_trem, bool do_passes, bool do_stats, unsigned long long* mid_stamp, int omul, int oyoff, int oxoff, int hlim,
                                  int wlim) {
@@ -43,8 +43,12 @@ IR_DEVINL void cs1_epilogue_impl(const IGemmParams& p, unsigned char* ebuf, int 
     // plain: bias * out_scale per accumulator tile, the slab write is one fused multiply-add per value. GATE: the accumulators go to the
     // slab as they are and gate / bias are applied on the read-back side, where a lane keeps the same 8 channels for the whole tile
     // (16 registers instead of 64)
-    f32x4 bias4[GATE ? 1 : 8], g_lo, g_hi, b_lo, b_hi;
-    if constexpr (GATE) {
+    // FULL && !GATE: the caller started the accumulators at the bias (out_scale == 1, launcher) - the slab write is the accumulator itself, and the 32
+    // bias registers do not sit in the epilogue's register budget (with them the NORM kernel spilled 39 registers that every tile's prologue reloaded)
+    constexpr bool BIAS_IN_ACC = FULL && !GATE;
+    f32x4 bias4[(GATE || BIAS_IN_ACC) ? 1 : 8], g_lo, g_hi, b_lo, b_hi;
+    if constexpr (BIAS_IN_ACC) {
+    } else if constexpr (GATE) {
         g_lo = *reinterpret_cast<const f32x4*>(p.gate + n0 + co8);
         g_hi = *reinterpret_cast<const f32x4*>(p.gate + n0 + co8 + 4);
         b_lo = (p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n0 + co8) : f32x4{0.f, 0.f, 0.f, 0.f}) * g_lo;
@@ -81,8 +85,8 @@ IR_DEVINL void cs1_epilogue_impl(const IGemmParams& p, unsigned char* ebuf, int 
     const unsigned uo_row = (unsigned)o_row * 2u, ur_row = (unsigned)r_row * 2u, uo_c4 = 8u * (unsigned)o_col, ur_c4 = 8u * (unsigned)r_col;
     unsigned char* const uob = reinterpret_cast<unsigned char*>(uo);
     const unsigned char* const urb = reinterpret_cast<const unsigned char*>(ur);
-    constexpr bool GN = FULL;                            // the FULL form exists with the statistics only (every VAE conv behind a GroupNorm has them)
-    const bool do_gn = FULL || p.gn_part != nullptr;
+    constexpr bool GN = FULL && FGN;                     // FULL: the statistics are compiled in (FGN) or out
+    const bool do_gn = FULL ? FGN : p.gn_part != nullptr;
     uint4 rrb[2][8];   // residual rows of the pass being finished / of the next pass
     auto res_fetch = [&](int a) {   // rows outside the image read a safe pixel
         if constexpr (FULL) {
@@ -110,7 +114,7 @@ IR_DEVINL void cs1_epilogue_impl(const IGemmParams& p, unsigned char* ebuf, int 
                     ([&] {
                         constexpr int CT = CTS, LO = 4 * ((A * 2 + MX) * 8 + CT);
                         f32x4 v = f32x4{cs1_acc_read<LO>(), cs1_acc_read<LO + 1>(), cs1_acc_read<LO + 2>(), cs1_acc_read<LO + 3>()};
-                        if constexpr (!GATE) v = v * osc + bias4[CT];
+                        if constexpr (!GATE && !BIAS_IN_ACC) v = v * osc + bias4[CT];
                         *reinterpret_cast<f32x4*>(&slab[c16 * SROW + 16 * CT + 4 * kq]) = v;
                     }(), ...);
                 }(std::make_integer_sequence<int, 8>{});
@@ -208,11 +212,11 @@ IR_DEVINL void cs1_epilogue_impl(const IGemmParams& p, unsigned char* ebuf, int 
 }
 
 // FULL is the caller's promise (a kernel instantiation of its own, chosen by the launcher): EVERY tile of the launch is a whole patch inside the
-// image and the launch writes statistics. (Chosen per tile inside one kernel - both forms inlined side by side - hipcc's register allocation
+// image; whether the launch writes statistics is part of the instantiation too. (Chosen per tile inside one kernel - both forms inlined side by side - hipcc's register allocation
 // of the 512-register kernels fell apart: 145 spilled VGPRs and conv_halo_s1_kernel 40.6 -> 46.3 ms per image, profiles/r06_ab_s1_epi_pertile.txt.)
-template <bool GATE, bool FULL = false>
+template <bool GATE, int EMODE = 0>   // EMODE 0: general; 1: FULL with statistics; 2: FULL without (the launch has no gn_part)
 IR_DEVINL void cs1_epilogue(const IGemmParams& p, unsigned char* ebuf, int tid, int lane, int wid, int c16, int kq, int t_n0, int t_img, int t_oy0,
                             int t_ox0, int t_trem, bool do_passes, bool do_stats, unsigned long long* mid_stamp, int omul, int oyoff, int oxoff, int hlim,
                             int wlim) {
-    cs1_epilogue_impl<GATE, FULL>(p, ebuf, tid, lane, wid, c16, kq, t_n0, t_img, t_oy0, t_ox0, t_trem, do_passes, do_stats, mid_stamp, omul, oyoff, oxoff, hlim, wlim);
+    cs1_epilogue_impl<GATE, EMODE != 0, EMODE == 1>(p, ebuf, tid, lane, wid, c16, kq, t_n0, t_img, t_oy0, t_ox0, t_trem, do_passes, do_stats, mid_stamp, omul, oyoff, oxoff, hlim, wlim);
 }

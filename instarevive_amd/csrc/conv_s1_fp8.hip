@@ -69,7 +69,7 @@ template <class T>
 IR_DEVINL void c8_keep(const T& x) { asm volatile("" ::"v"(x)); }
 
 // UP = 1: the conv runs on the nearest-2x upsampled input (2H x 2W), folded into the halo's source addresses (as conv_halo_s1_kernel<1>)
-template <int UP, bool EFULL = false>   // EFULL: whole-patch launch with statistics (conv_s1_epi.h, round 6)
+template <int UP, int EFULL = 0>   // EFULL: whole-patch launch with statistics (conv_s1_epi.h, round 6)
 __global__ __launch_bounds__(256, 1) void conv_halo_s1_fp8_kernel(IGemmParams p, int tiles_y, int tiles_x, int total_vb) {
     using namespace c8;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES];   // halo[0..1] | W ring of 6 ; epilogue: slabs + red in halo[1]
@@ -304,7 +304,7 @@ int ir_launch_conv_s1_fp8(const IGemmParams& p, hipStream_t s) {
     const long grid = total < cus ? total : cus;
     static const bool no_full = getenv("IR_S1_NO_EFULL") != nullptr;   // experiment knob (shared with conv_s1.hip)
     if (p.up) hipLaunchKernelGGL(conv_halo_s1_fp8_kernel<1>, dim3((unsigned)grid), dim3(256), 0, s, p, tiles_y, tiles_x, (int)total);
-    else if (!no_full && p.gn_part && p.Ho % 16 == 0 && p.Wo % 32 == 0) hipLaunchKernelGGL((conv_halo_s1_fp8_kernel<0, true>), dim3((unsigned)grid), dim3(256), 0, s, p, tiles_y, tiles_x, (int)total);
+    else if (!no_full && p.gn_part && p.Ho % 16 == 0 && p.Wo % 32 == 0) hipLaunchKernelGGL((conv_halo_s1_fp8_kernel<0, 1>), dim3((unsigned)grid), dim3(256), 0, s, p, tiles_y, tiles_x, (int)total);
     else hipLaunchKernelGGL(conv_halo_s1_fp8_kernel<0>, dim3((unsigned)grid), dim3(256), 0, s, p, tiles_y, tiles_x, (int)total);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
