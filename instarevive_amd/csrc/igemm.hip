@@ -1417,31 +1417,60 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(IGemmParams p) {
         }
         done_half();
     };
-    auto rows_kind1 = [&](auto hc) __attribute__((always_inline)) {
-        constexpr int hh = decltype(hc)::value;
+    // KIND 1 (the DiT's residual stream: fp32 in, fp32 out in place, optional bf16 copy). The residual vectors come in FOUR batches of nine (two per
+    // half), each requested one batch ahead of its use - the first before the slab of half 0 is written, the third (half 1's first) while half 0's
+    // second is processed - so that one memory latency is exposed per launch instead of six (round 5: three batches of six per half, each requested
+    // after the previous one's stores; the knock-out without the reads was 13 us of a 68 us launch shorter, profiles/r06_gemm_ab_ops.txt). A lane
+    // reads and writes the same elements and the batches are disjoint, so the in-place form (res == out) stays exact.
+    auto k1_load = [&](auto hc, auto i0c, auto nc, f32x4_t* rr) __attribute__((always_inline)) {   // vectors it0 .. it0 + n - 1 of half hh
+        constexpr int hh = decltype(hc)::value, it0 = decltype(i0c)::value, n = decltype(nc)::value;
         const float* resf = reinterpret_cast<const float*>(p.res);
+#pragma unroll
+        for (int it = 0; it < n; ++it) {
+            const int v = (it0 + it) * 64 + lane, row = v / 36, c4 = (v - row * 36) * 4;
+            const int m = min(mw + hh * 32 + row, p.M - 1);
+            if (IR_GPP_KO == 1) rr[it] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            else rr[it] = *reinterpret_cast<const f32x4_t*>(resf + (unsigned)(m * p.res_cs + nw + c4));
+        }
+    };
+    auto k1_rows = [&](auto hc, auto i0c, auto nc, const f32x4_t* rr) __attribute__((always_inline)) {
+        constexpr int hh = decltype(hc)::value, it0 = decltype(i0c)::value, n = decltype(nc)::value;
         float* outf = reinterpret_cast<float*>(p.out);
-        write_half(hc);   // first: this half's 72 accumulator registers die here and make room for the residual vectors
 #pragma unroll
-        for (int bt = 0; bt < 3; ++bt) {   // three batches of 6 vectors: 6 residual requests back to back, then 6 add + stores
+        for (int it = 0; it < n; ++it) {
+            const int v = (it0 + it) * 64 + lane, row = v / 36, c4 = (v - row * 36) * 4;
+            const int m = mw + hh * 32 + row;
+            const f32x4_t o = *reinterpret_cast<const f32x4_t*>(&slab[row * 144 + c4]) + rr[it];
+            if (m < p.M) {
+                if (IR_GPP_KO != 3) *reinterpret_cast<f32x4_t*>(outf + (unsigned)(m * p.out_cs + nw + c4)) = o;
+                if (p.out2 && IR_GPP_KO != 2) *reinterpret_cast<uint2*>(p.out2 + (unsigned)(m * p.out2_cs + nw + c4)) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
+            }
+        }
+    };
+#ifndef IR_GPP_K1
+#define IR_GPP_K1 0   // residual request schedule of the instantiated KIND 1 form: 0 = three batches of six per half, each after the previous one's stores;
+#endif                // 1 = IR_GPP_K1_NA vectors of a half requested BEFORE its slab is written, the rest behind it. Measured in round 6 (6 + 12, 9 + 9, 12 + 6
+#ifndef IR_GPP_K1_NA  // against 0, profiles/r06_gemm_k1_schedules.txt): 55 us per 1152 -> 1152 launch and 150 us per 4608 -> 1152 launch whatever the schedule -
+#define IR_GPP_K1_NA 9   // the row phase is bound by the memory system's burst (189 MB in and out per launch while every CU is in its epilogue), not by the
+#endif                   // latency of the requests. 0 stays.
+    auto run_kind1 = [&](auto hc) __attribute__((always_inline)) {
+        constexpr int hh = decltype(hc)::value;
+        using I0 = std::integral_constant<int, 0>;
+        if constexpr (KIND_T == 1 && IR_GPP_K1 == 1) {
+            constexpr int NA = IR_GPP_K1_NA;
+            f32x4_t ra[NA], rb[18 - NA > 0 ? 18 - NA : 1];
+            k1_load(hc, I0{}, std::integral_constant<int, NA>{}, ra);
+            write_half(hc);   // this half's 72 accumulator registers die here
+            if constexpr (NA < 18) k1_load(hc, std::integral_constant<int, NA>{}, std::integral_constant<int, 18 - NA>{}, rb);
+            k1_rows(hc, I0{}, std::integral_constant<int, NA>{}, ra);
+            if constexpr (NA < 18) k1_rows(hc, std::integral_constant<int, NA>{}, std::integral_constant<int, 18 - NA>{}, rb);
+        } else {
+            write_half(hc);
             f32x4_t rr[6];
-#pragma unroll
-            for (int it = 0; it < 6; ++it) {
-                const int v = (bt * 6 + it) * 64 + lane, row = v / 36, c4 = (v - row * 36) * 4;
-                const int m = min(mw + hh * 32 + row, p.M - 1);
-                if (IR_GPP_KO == 1) rr[it] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-                else rr[it] = *reinterpret_cast<const f32x4_t*>(resf + (unsigned)(m * p.res_cs + nw + c4));
-            }
-#pragma unroll
-            for (int it = 0; it < 6; ++it) {
-                const int v = (bt * 6 + it) * 64 + lane, row = v / 36, c4 = (v - row * 36) * 4;
-                const int m = mw + hh * 32 + row;
-                const f32x4_t o = *reinterpret_cast<const f32x4_t*>(&slab[row * 144 + c4]) + rr[it];
-                if (m < p.M) {
-                    if (IR_GPP_KO != 3) *reinterpret_cast<f32x4_t*>(outf + (unsigned)(m * p.out_cs + nw + c4)) = o;
-                    if (p.out2 && IR_GPP_KO != 2) *reinterpret_cast<uint2*>(p.out2 + (unsigned)(m * p.out2_cs + nw + c4)) = make_uint2(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]));
-                }
-            }
+            [&]<int... BT>(std::integer_sequence<int, BT...>) {
+                ((k1_load(hc, std::integral_constant<int, 6 * BT>{}, std::integral_constant<int, 6>{}, rr),
+                  k1_rows(hc, std::integral_constant<int, 6 * BT>{}, std::integral_constant<int, 6>{}, rr)), ...);
+            }(std::make_integer_sequence<int, 3>{});
         }
         done_half();
     };
@@ -1473,7 +1502,7 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(IGemmParams p) {
     using H0 = std::integral_constant<int, 0>;
     using H1 = std::integral_constant<int, 1>;
     if (kind == 0) { rows_kind0(H0{}); rows_kind0(H1{}); }
-    else if (kind == 1) { rows_kind1(H0{}); rows_kind1(H1{}); }
+    else if (kind == 1) { run_kind1(H0{}); run_kind1(H1{}); }
     else { rows_kind2(H0{}); rows_kind2(H1{}); }
 }
 
