@@ -75,6 +75,9 @@ def parse_args() -> Namespace:
                         "weights (attention products + two decoder conv levels: about 15 %% faster); all = every part (about 22 %% faster, 42 dB against the "
                         "reference path: out of that tolerance); attention = the attention products only. On weights with heavy-tailed channels / peaky attention "
                         "fp8 costs more accuracy (DESIGN.md section 4): off is the default")
+    parser.add_argument("--png_compress_level", type=int, default=None, choices=range(0, 10), metavar="0..9", help="zlib level of the saved PNGs; default: PIL's own "
+                        "(6, what the reference writes). The pixels are the same at every level; 1 costs about a third of the encoder time - for ranks whose CPU share "
+                        "cannot keep up with the GPU (the CLI says so at start-up)")
     parser.add_argument("--workers", type=int, default=-1, help="host threads that decode / resize the inputs and resize / PNG-encode the results "
                         "around the GPU (PIL releases the GIL there); -1 = this process's CPU share, 0 = everything on the main thread like the reference")
     return parser.parse_args()
@@ -104,11 +107,33 @@ def cpu_share() -> int:
 
 
 def default_workers(local_world: int = 1) -> int:
-    """Host threads for this rank: its part of the CPU share, less two cores for the thread that feeds the GPU and the copy engine's callbacks, at
-    most 16 (one MI355X produces ~8 results of 2048 x 2048 a second and a PNG of that size costs 0.8 - 1.7 core-seconds; $IR_WORKERS overrides)."""
+    """Host threads for this rank: its part of the CPU share, less the cores kept for the thread that feeds the GPU and the copy engine's callbacks
+    (two; one when the rank's part is 8 cores or fewer - 8 ranks on a 64-core host - where the feeding thread, asleep in stream waits most of the time,
+    shares a core with an encoder rather than take a quarter of the rank's budget), at most 16 (one MI355X produces ~8 results of 2048 x 2048 a second and
+    a PNG of that size costs 0.8 - 1.7 core-seconds; $IR_WORKERS overrides)."""
     if os.environ.get("IR_WORKERS"):
         return max(0, int(os.environ["IR_WORKERS"]))
-    return max(1, min(16, cpu_share() // max(local_world, 1) - 2))
+    part = cpu_share() // max(local_world, 1)
+    return max(1, min(16, part - (2 if part > 8 else 1)))
+
+
+PNG_CORE_SECONDS_2048 = 1.25   # PIL's default encoder (compress_level 6) on one 2048 x 2048 RGB result: 0.8 - 1.7 core-seconds by content (profiles/r05_cli_rate_ab.txt)
+GPU_FILES_PER_SECOND_2048 = 8.4   # what one MI355X delivers at 2048 x 2048 (bench.py `value`)
+
+
+def host_keeps_up(workers: int, out_pixels: int, compress_level) -> str:
+    """'' when `workers` encoder threads keep ahead of one GPU for results of out_pixels pixels, else the sentence the CLI prints: the rank is then
+    host-bound (8 ranks on a 64-core host: 7 threads encode ~5.6 files/s of 2048 x 2048 at PIL's default level against ~8.4 from the GPU). The estimate
+    scales the measured level-6 cost by the pixel count; level 1 costs about a third of it (larger files, the same pixels)."""
+    if workers <= 0 or out_pixels <= 0:
+        return ""
+    scale = out_pixels / float(2048 * 2048)
+    cost = PNG_CORE_SECONDS_2048 * scale * (1.0 if compress_level is None or compress_level >= 6 else (0.35 if compress_level <= 1 else 0.6))
+    host_rate, gpu_rate = workers / cost, GPU_FILES_PER_SECOND_2048 / scale
+    if host_rate >= gpu_rate:
+        return ""
+    return (f"host-bound: {workers} encoder threads write ~{host_rate:.1f} files/s of {out_pixels / 1e6:.1f} Mpixel against ~{gpu_rate:.1f} from the GPU - give the rank more "
+            f"cores (--workers / $IR_WORKERS), or trade file size for speed with --png_compress_level 1 (same pixels, lossless)")
 
 
 def check_device(device: str) -> str:
@@ -163,7 +188,11 @@ def write_job(job: Job, pred: np.ndarray, stage1_pred, args: Namespace) -> None:
         if not args.disable_preprocess_model:
             panels.append(back_to_lq(stage1_pred))
         result = np.concatenate(panels + [result], axis=1)
-    Image.fromarray(result).save(job.save_path)
+    lvl = getattr(args, "png_compress_level", None)
+    if lvl is None:
+        Image.fromarray(result).save(job.save_path)
+    else:
+        Image.fromarray(result).save(job.save_path, compress_level=lvl)
     print(f"save to {job.save_path}")
 
 
@@ -282,6 +311,9 @@ def main() -> None:
         import sys
         sys.setswitchinterval(float(os.environ["IR_SWITCH_INTERVAL"]))
     pools = HostPools(default_workers(local_world) if args.workers < 0 else args.workers)
+    note = host_keeps_up(pools.workers, int(512 * 512 * max(args.sr_scale, 1.0) ** 2), args.png_compress_level)   # priced on a 512 x 512 LQ file at this --sr_scale
+    if note:
+        print(f"[rank {rank}] {note}")
     if not os.path.isdir(args.input):
         raise SystemExit(f"--input {args.input} is not a directory")
     # os.walk order, like the reference (no sorting) for one process. With several ranks the list is what decides which rank owns

@@ -185,6 +185,8 @@ def sharded_encode(engine, control_imgs, rank: int, world: int):
         return engine.encode(control_imgs)             # replicated: SwinIR and the VAE encoder are untiled in the reference
     h, w = control_imgs[0].shape[:2]
     T = (h // 8) * (w // 8)
+    if T // 128 < world:   # fewer 128-row blocks than ranks (a frame below 8 x 128 latent pixels on 8 ranks): a rank would hold no rows - every rank
+        return engine.encode(control_imgs)   # sees the same shape and takes the replicated encode
     shards = row_shards(T, world)
     r0, r1 = shards[rank]
     control, attn_o, attn_res = engine.encode_part0(control_imgs, r0, r1)

@@ -592,6 +592,30 @@ def test_host_pools_order_bounds_and_errors(tmp_path):
         outs[workers] = {p.name: np.array(Image.open(p)) for p in sorted((tmp_path / f"out{workers}").iterdir())}
     assert list(outs[0]) == list(outs[3]) and len(outs[0]) == 6
     assert all(np.array_equal(outs[0][k], outs[3][k]) for k in outs[0])
+    # --png_compress_level changes the file, not the pixels
+    a1 = Namespace(**{**vars(a), "output": str(tmp_path / "out_l1"), "png_compress_level": 1})
+    for job in inf.HostPools(0).read_ahead(lambda f: inf.read_job(f, 0, a1), files):
+        inf.write_job(job, 255 - job.net_in, job.net_in, a1)
+    l1 = {p.name: np.array(Image.open(p)) for p in sorted((tmp_path / "out_l1").iterdir())}
+    assert list(l1) == list(outs[0]) and all(np.array_equal(l1[k], outs[0][k]) for k in l1)
+
+
+def test_default_workers_on_a_shared_host(monkeypatch):
+    """8 ranks on a 64-core host. Each rank's part is 8 cores: one is kept for the feeding thread (two from 9 cores up), and the CLI
+    says at start-up when that many encoders cannot keep ahead of one GPU at the output size - and what to do about it."""
+    import importlib
+    inf = importlib.import_module("inference")
+    monkeypatch.delenv("IR_WORKERS", raising=False)
+    monkeypatch.setattr(inf, "cpu_share", lambda: 64)
+    assert inf.default_workers(8) == 7 and inf.default_workers(4) == 14 and inf.default_workers(1) == 16 and inf.default_workers(64) == 1
+    monkeypatch.setattr(inf, "cpu_share", lambda: 16)   # the one-GPU box of this pool
+    assert inf.default_workers(1) == 14
+    note = inf.host_keeps_up(7, 2048 * 2048, None)
+    assert note.startswith("host-bound") and "--png_compress_level" in note
+    assert inf.host_keeps_up(14, 2048 * 2048, None) == "" and inf.host_keeps_up(7, 2048 * 2048, 1) == ""
+    assert inf.host_keeps_up(0, 2048 * 2048, None) == ""   # inline mode: the reference's behaviour, nothing to size
+    monkeypatch.setenv("IR_WORKERS", "3")
+    assert inf.default_workers(8) == 3
 
 
 def test_hub_ids_resolve_through_the_hf_cache(tmp_path, monkeypatch):
