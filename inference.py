@@ -70,11 +70,13 @@ def parse_args() -> Namespace:
     parser.add_argument("--batch_size", type=int, default=1, help="consecutive files of equal network-input size per process() call")
     parser.add_argument("--shard_tiles", action="store_true", help="with --tiled under torchrun: spread the TILES of each image over the "
                         "GPUs (one large image at a time) instead of spreading the files")
-    parser.add_argument("--fp8", type=str, default="off", choices=["off", "default", "all", "attention"], help="BASELINE.json configs[4]: fp8 (e4m3) MFMA operands. "
-                        "default = the operand set that keeps the result within 0.1 dB PSNR of the bf16 / reference path up to a 30 dB reference on flat-softmax "
-                        "weights (attention products + two decoder conv levels: about 15 %% faster); all = every part (about 22 %% faster, 42 dB against the "
-                        "reference path: out of that tolerance); attention = the attention products only. On weights with heavy-tailed channels / peaky attention "
-                        "fp8 costs more accuracy (DESIGN.md section 4): off is the default")
+    parser.add_argument("--fp8", type=str, default="off", choices=["off", "default", "auto", "qualified", "all", "attention"], help="BASELINE.json configs[4]: fp8 (e4m3) MFMA "
+                        "operands. default (= auto): the operand set is chosen ON THE LOADED WEIGHTS at start-up - one 512 x 512 calibration image, every part alone "
+                        "against the bf16 pass (about a second; cached per weight set) - so that the result stays within 0.1 dB PSNR of the bf16 / reference path up to a "
+                        "30 dB reference: on flat-softmax weights that is the attention products + two decoder conv levels (about 15 %% faster), on weights with "
+                        "heavy-tailed channels / peaky attention fewer parts or none (instarevive_amd/fp8_select.py). qualified = that flat-softmax set without "
+                        "calibration; attention = the attention products only; all = every part (about 22 %% faster, 42 dB against the reference path: out of the "
+                        "tolerance). off is the default")
     parser.add_argument("--png_compress_level", type=int, default=None, choices=range(0, 10), metavar="0..9", help="zlib level of the saved PNGs; default: PIL's own "
                         "(6, what the reference writes). The pixels are the same at every level; 1 costs about a third of the encoder time - for ranks whose CPU share "
                         "cannot keep up with the GPU (the CLI says so at start-up)")
@@ -305,7 +307,16 @@ def main() -> None:
         m.vae.enable_fp8(True)                                   # packs + uploads the fp8 weight forms ...
         ctx = m.model.ctx
         ctx.check(ctx.lib.ir_set_fp8(ctx.h, 0), "ir_set_fp8")    # ... the mode itself is switched per call (IR_FLAG_FP8)
-        ctx.check(ctx.lib.ir_set_fp8_mask(ctx.h, {"default": L.FP8_MASK_DEFAULT, "all": L.FP8_MASK_ALL, "attention": L.FP8_MASK_ATTENTION}[args.fp8]), "ir_set_fp8_mask")
+        if args.fp8 in ("default", "auto"):   # the operand set these weights allow (calibrated once per weight set, cached)
+            from instarevive_amd import fp8_select
+            fmask = fp8_select.auto_mask(m.preprocess_model, m.vae, m.model, m.y, m.y_mask, log=lambda t: print(f"[rank {rank}] {t}"))
+            m.vae.enable_fp8(True)
+            ctx.check(ctx.lib.ir_set_fp8(ctx.h, 0), "ir_set_fp8")
+        else:
+            fmask = {"qualified": L.FP8_MASK_QUALIFIED, "all": L.FP8_MASK_ALL, "attention": L.FP8_MASK_ATTENTION}[args.fp8]
+        ctx.check(ctx.lib.ir_set_fp8_mask(ctx.h, fmask), "ir_set_fp8_mask")
+        if fmask == 0:
+            print(f"[rank {rank}] fp8: no operand part holds the tolerance on these weights - running bf16 throughout")
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
     if os.environ.get("IR_SWITCH_INTERVAL"):   # experiment knob: how long a worker thread may keep the GIL while the thread that feeds the GPU waits for it
         import sys

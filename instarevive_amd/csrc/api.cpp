@@ -1606,7 +1606,7 @@ int check_size(ir_ctx* c, int n, int h, int w, int mult) {
 // ================================================================ exported C ABI
 extern "C" {
 
-int ir_abi_version(void) { return 2; }   // 2: ir_tiled_encode_part callers must read + MAX-reduce the overflow flag; the default fp8 operand set is IR_FP8_MASK_DEFAULT
+int ir_abi_version(void) { return 3; }   // 2: ir_tiled_encode_part callers must read + MAX-reduce the overflow flag; 3: the context's default fp8 operand set (IR_FP8_MASK_DEFAULT) no longer contains the DiT self-attention (IR_FP8_MASK_QUALIFIED is round 5's set)
 
 int ir_init(int device, ir_ctx** out) {
     if (!out) return -1;

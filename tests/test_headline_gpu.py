@@ -651,6 +651,7 @@ def test_stress_weights_vs_oracle(full_models):
     st = stress_state_dicts(sds, float(z["frac"]), float(z["gain"]), gains)
     img = bench.synthetic_lq(1, 512, 512, int(z["lq_seed"]))[0].numpy()
     kw = dict(preprocess_model=swin, vae=vae, y=full_models.y_cuda, y_mask=full_models.mask_cuda)
+    seeded, _ = process(dit, [img], 1, "wavelet", False, False, 512, 448, **kw)   # the session's weights, before anything is swapped
     try:
         vae.load_state_dict(st["vae"])
         dit.load_state_dict(st["dit"])
@@ -665,7 +666,7 @@ def test_stress_weights_vs_oracle(full_models):
         vae.enable_fp8(True)
         f8 = {}
         try:   # cfg-5 under the same stress, part by part: REPORTED (north_star's tolerance is stated on the bf16 path; see the assertion below)
-            for name, m8 in (("default set", L.FP8_MASK_DEFAULT), ("DiT self-attention only", 1), ("VAE mid-block attention only", 0b110), ("decoder level-0 / level-2 convs only", 0x5000)):
+            for name, m8 in (("default set", L.FP8_MASK_DEFAULT), ("qualified set", L.FP8_MASK_QUALIFIED), ("DiT self-attention only", 1), ("VAE mid-block attention only", 0b110), ("decoder level-0 / level-2 convs only", 0x5000)):
                 ctx.check(ctx.lib.ir_set_fp8_mask(ctx.h, m8), "ir_set_fp8_mask")
                 f8[name] = process(dit, [img], 1, "wavelet", False, False, 512, 448, fp8=True, **kw)[0][0]
         finally:
@@ -682,7 +683,7 @@ def test_stress_weights_vs_oracle(full_models):
     print(f"stress weights (1 % channels x{float(z['gain']):.0f}, every attention's median logit spread {float(z['spread_median'].min()):.0f}-{float(z['spread_median'].max()):.0f}) "
           f"at 512 x 512 vs the fp32 oracle: bf16 {p:.2f} dB (stage-1 {p1:.2f} dB), x0 latent relative L2 {rel * 100:.3f} %; "
           f"{fallbacks} of 30 attention launches raised the overflow flag and took the rescaling fallback; fp8: " + ", ".join(f"{k} {v:.2f} dB" for k, v in p8.items()))
-    assert fallbacks >= 0
+    assert fallbacks == 0, "the fixture's logit spread (median 34) stays below the fixed references' head room: no launch takes the rescaling fallback (profiles/r05_stress_parity.txt: 0 of 30)"
     assert p >= 45.0 and p1 >= 50.0 and rel <= 0.015
     # fp8 under such weights (REPORTED; profiles/r05_stress_parity.txt): an e4m3 q . k carries 3.7 % of the logit's size as error -
     # at a logit spread of 34 that is a factor e^0.6 on a softmax weight - and a row dominated by one or two keys no longer averages the P . V rounding
@@ -690,9 +691,87 @@ def test_stress_weights_vs_oracle(full_models):
     # the channels carry 30x the scale. cfg-5's tolerance claim therefore holds for the flat-softmax seeded weights it was chosen on, not for these.
     # Asserted only: nothing breaks (every operand set still produces the picture), the conv parts stay within 4 dB of bf16.
     assert p8["decoder level-0 / level-2 convs only"] >= p - 4.0 and min(p8.values()) >= 33.0
-    # and the session's weights are back: the seeded-weight result is what it was
+    # the context's DEFAULT set (ABI v3: without the DiT self-attention) is gated here too - it stays within 5 dB of the bf16 path on these
+    # weights (measured 4.4: its VAE attention parts cost 2.2 dB, its two decoder conv levels 3.1), where round 5's constant set (now
+    # IR_FP8_MASK_QUALIFIED) loses 9.8. Neither holds north_star's tolerance here; the calibrated choice (test_fp8_auto_...) does
+    assert p8["default set"] >= p - 5.0 and p8["qualified set"] < p8["default set"] - 3.0
+    # and the session's weights are back: the seeded-weight result is EXACTLY what it was before the swap
     again, _ = process(dit, [img], 1, "wavelet", False, False, 512, 448, **kw)
-    assert not np.array_equal(again[0], bf[0])
+    assert np.array_equal(again[0], seeded[0]) and not np.array_equal(again[0], bf[0])
+
+
+def test_fp8_auto_operand_set_on_seeded_and_stress_weights(full_models):
+    """the fp8 operand set is chosen ON THE LOADED WEIGHTS (instarevive_amd/fp8_select.py: one 512 x 512 calibration image, every
+    part alone against the bf16 pass, a part keeps its qualified cost only while it deviates as it did when it was qualified). Gates, against the fp32
+    oracle's fixtures: on the seeded weights the chosen set is round 5's qualified set and holds >= 46.3 dB on the 2048 x 2048 crops (north_star's 0.1 dB
+    at a 30 dB reference); on the stress weights (heavy-tailed channels, peaky attention: where that constant set lost 9 dB) the chosen set stays
+    within 1.3 dB of the bf16 path. A D_REF that no longer describes the kernels (deviation of a part on the seeded weights off by more than 12 %) fails
+    here, before it can skew a choice."""
+    import bench
+    from instarevive_amd import _lib as L
+    from instarevive_amd import fp8_select as F
+    from instarevive_amd.pipeline import process
+    from tests.golden.make_headline_crops import CROP, inputs_for
+    from tests.support.stress_weights import stress_state_dicts
+    swin, vae, dit, sds, y, mask = full_models
+    ctx = dit.ctx
+    yc, mc = full_models.y_cuda, full_models.mask_cuda
+    kw = dict(preprocess_model=swin, vae=vae, y=yc, y_mask=mc)
+    logs = []
+    # ---- seeded weights
+    dev = F.measure_parts(swin, vae, dit, yc, mc)
+    worst = max(abs(dev[b] / F.D_REF[b] - 1.0) for b in F.D_REF)
+    print("fp8 auto, seeded weights: deviation / D_REF per part: " + ", ".join(f"{n} {dev[b] / F.D_REF[b]:.3f}" for b, n, _ in F.PARTS))
+    assert worst <= 0.12, "fp8_select.D_REF is stale: re-run tools/fp8_auto_calib.py and update the constants"
+    m_seed = F.auto_mask(swin, vae, dit, yc, mc, log=logs.append, use_cache=False)
+    key_seed = F.weights_key(dit, vae)
+    assert m_seed == L.FP8_MASK_QUALIFIED, hex(m_seed)
+    z = np.load(os.path.join(G, "headline_crops.npz"))
+    img = inputs_for(2048)
+    pos, want = z["pos_2048"], z["crops_2048"]
+    take = lambda a: np.stack([a[yy:yy + CROP, xx:xx + CROP] for yy, xx in pos])
+    vae.enable_fp8(True)
+    try:
+        ctx.check(ctx.lib.ir_set_fp8_mask(ctx.h, m_seed), "ir_set_fp8_mask")
+        f8, _ = process(dit, [img], 1, "wavelet", False, False, 512, 448, fp8=True, **kw)
+    finally:
+        ctx.check(ctx.lib.ir_set_fp8_mask(ctx.h, L.FP8_MASK_DEFAULT), "ir_set_fp8_mask")
+        vae.enable_fp8(False)
+    p_seed = _psnr(take(f8[0]), want)
+    # ---- stress weights
+    zs = np.load(os.path.join(G, "stress_512.npz"))
+    gains = {"dit": [float(v) for v in zs["logit_gain_dit"]], "vae_encoder": float(zs["logit_gain_vae"][0]), "vae_decoder": float(zs["logit_gain_vae"][1])}
+    st = stress_state_dicts(sds, float(zs["frac"]), float(zs["gain"]), gains)
+    simg = bench.synthetic_lq(1, 512, 512, int(zs["lq_seed"]))[0].numpy()
+    try:
+        vae.load_state_dict(st["vae"])
+        dit.load_state_dict(st["dit"])
+        dit.invalidate_prompt()
+        assert F.weights_key(dit, vae) != key_seed, "the cache key must tell the two weight sets apart"
+        m_stress = F.auto_mask(swin, vae, dit, yc, mc, log=logs.append, use_cache=False)
+        bf, _ = process(dit, [simg], 1, "wavelet", False, False, 512, 448, **kw)
+        if m_stress:
+            vae.enable_fp8(True)
+            try:
+                ctx.check(ctx.lib.ir_set_fp8_mask(ctx.h, m_stress), "ir_set_fp8_mask")
+                s8, _ = process(dit, [simg], 1, "wavelet", False, False, 512, 448, fp8=True, **kw)
+            finally:
+                ctx.check(ctx.lib.ir_set_fp8_mask(ctx.h, L.FP8_MASK_DEFAULT), "ir_set_fp8_mask")
+                vae.enable_fp8(False)
+        else:
+            s8 = bf   # nothing qualifies: --fp8 default runs bf16 throughout on these weights
+    finally:
+        vae.enable_fp8(False)
+        vae.load_state_dict(sds["vae"])
+        dit.load_state_dict(sds["dit"])
+        dit.invalidate_prompt()
+    p_bf, p_s8 = _psnr(bf[0], zs["pred"]), _psnr(s8[0], zs["pred"])
+    for line in logs:
+        print(line)
+    print(f"fp8 auto: seeded weights -> {m_seed:#x}, {p_seed:.2f} dB on the 2048 x 2048 oracle crops (gate 46.3); stress weights -> {m_stress:#x}, "
+          f"{p_s8:.2f} dB against the oracle at 512 x 512 (bf16 {p_bf:.2f}, gate bf16 - 1.3)")
+    assert p_seed >= 46.3
+    assert p_s8 >= p_bf - 1.3 and not (m_stress & 1), "the DiT self-attention must not be chosen on peaky weights"
 
 
 def test_tiled_encode_force_fallback_path(full_models):
@@ -741,6 +820,9 @@ def test_process_stream_fp8_equals_process_fp8(full_models):
     swin, vae, dit, sds, y, mask = full_models
     imgs = [bench.synthetic_lq(1, 512, 512, 90 + i)[0].numpy() for i in range(3)]
     kw = dict(preprocess_model=swin, vae=vae, y=full_models.y_cuda, y_mask=full_models.mask_cuda)
+    vae.enable_fp8(False)
+    vae.load_state_dict(sds["vae"])   # the precondition of the guard below, made explicit: a VAE whose fp8 weight forms are NOT uploaded,
+    assert not vae.__dict__.get("_fp8_uploaded")   # whatever ran before in this session (the fixture is session-scoped; enable_fp8(False) keeps the forms)
     with pytest.raises(RuntimeError):
         list(process_stream(dit, ([im] for im in imgs), "wavelet", False, False, 512, 448, fp8=True, **kw))
     bf = [p[0] for p, _ in process_stream(dit, ([im] for im in imgs), "wavelet", False, False, 512, 448, **kw)]

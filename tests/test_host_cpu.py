@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for s in declared:
         assert hasattr(lib, s), s
-    assert lib.ir_abi_version() == 2
+    assert lib.ir_abi_version() == 3
 
 
 def test_no_cpu_fallback():

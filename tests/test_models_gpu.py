@@ -17,6 +17,7 @@ from oracle import dit as odit
 from oracle import glue as oglue
 from oracle import swinir as oswin
 from oracle import vae as ovae
+from instarevive_amd import _lib as L
 from tests.golden._det import det_input, det_state_dict
 
 pytestmark = pytest.mark.gpu
@@ -543,7 +544,7 @@ def test_vae_fp8_resnet_convs(full_models):
     try:
         f_e, f_d = vae.encode(x.cuda()).latent_dist.mode().cpu(), vae.decode(z.cuda()).sample.cpu()
     finally:
-        ctx.check(ctx.lib.ir_set_fp8_mask(ctx.h, 0x5007), "ir_set_fp8_mask")
+        ctx.check(ctx.lib.ir_set_fp8_mask(ctx.h, L.FP8_MASK_DEFAULT), "ir_set_fp8_mask")
         vae.enable_fp8(False)
     again = vae.decode(z.cuda()).sample.cpu()
     assert torch.equal(again, b_d), "switching fp8 off must restore the bf16 path bit for bit"
@@ -598,7 +599,7 @@ def test_psnr_guard_bites_at_realistic_reference_quality(full_models):
 
 def test_fp8_mask_selects_the_operand_set(full_models):
     """ir_set_fp8_mask: with every part switched off the fp8 call IS the bf16 path (bit for bit); the unmasked call runs the default set
-    (IR_FP8_MASK_DEFAULT = 0x5007: attention parts + decoder level-0 / level-2 convs); the attention parts alone (DiT self-attention +
+    (IR_FP8_MASK_DEFAULT = 0x5006: the VAE attention parts + decoder level-0 / level-2 convs; IR_FP8_MASK_QUALIFIED adds the DiT self-attention); the attention parts alone (DiT self-attention +
     both VAE mid blocks) stay within 0.3 dB of the bf16 path's PSNR against the oracle - tools/fp8_attribution.py: the e4m3 conv activations
     carry cfg-5's error, the attention products do not - and the full set is what the unmasked call runs."""
     import bench
@@ -615,12 +616,13 @@ def test_fp8_mask_selects_the_operand_set(full_models):
     try:
         full, _ = process(dit, imgs, 1, "wavelet", False, False, 512, 448, fp8=True, **kw)          # the context's default: IR_FP8_MASK_DEFAULT
         out = {}
-        for name, m in (("none", 0), ("attention", 0b111), ("default", 0x5007), ("all", 0xffffffff)):
+        for name, m in (("none", 0), ("attention", 0b111), ("default", L.FP8_MASK_DEFAULT), ("qualified", L.FP8_MASK_QUALIFIED), ("all", 0xffffffff)):
             ctx.check(ctx.lib.ir_set_fp8_mask(ctx.h, m), "ir_set_fp8_mask")
             out[name], _ = process(dit, imgs, 1, "wavelet", False, False, 512, 448, fp8=True, **kw)
     finally:
-        ctx.check(ctx.lib.ir_set_fp8_mask(ctx.h, 0x5007), "ir_set_fp8_mask")
+        ctx.check(ctx.lib.ir_set_fp8_mask(ctx.h, L.FP8_MASK_DEFAULT), "ir_set_fp8_mask")
         vae.enable_fp8(False)
+    assert L.FP8_MASK_DEFAULT == 0x5006 and L.FP8_MASK_QUALIFIED == 0x5007 and not np.array_equal(out["qualified"][0], full[0])
     assert np.array_equal(out["none"][0], bf[0]), "an empty operand set must be the bf16 path"
     assert np.array_equal(out["default"][0], full[0]) and not np.array_equal(full[0], bf[0]), "the unmasked call runs IR_FP8_MASK_DEFAULT"
     assert not np.array_equal(out["all"][0], full[0])

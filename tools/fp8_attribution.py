@@ -71,7 +71,7 @@ def main():
             p, q = run(m)
             print(f"{label:52s} {p:14.2f} / {q:6.2f} dB   (within 0.1 dB up to {p - 16.33:.1f} dB)", flush=True)
     finally:
-        ctx.check(ctx.lib.ir_set_fp8_mask(ctx.h, 0x5007), "ir_set_fp8_mask")   # back to IR_FP8_MASK_DEFAULT
+        ctx.check(ctx.lib.ir_set_fp8_mask(ctx.h, 0x5006), "ir_set_fp8_mask")   # back to IR_FP8_MASK_DEFAULT
         vae.enable_fp8(False)
 
 

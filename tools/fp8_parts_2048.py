@@ -88,7 +88,7 @@ def main():
             t, n = run(m)
             print(f"{label:30s} mask {m:#8x}: {t:7.2f} ms ({t_bf - t:5.2f} saved), {db(n):.2f} dB vs oracle crops -> within 0.1 dB up to a {db(n) - 16.33:.1f} dB reference", flush=True)
     finally:
-        ctx.check(ctx.lib.ir_set_fp8_mask(ctx.h, 0x5007), "ir_set_fp8_mask")   # back to IR_FP8_MASK_DEFAULT
+        ctx.check(ctx.lib.ir_set_fp8_mask(ctx.h, 0x5006), "ir_set_fp8_mask")   # back to IR_FP8_MASK_DEFAULT
         vae.enable_fp8(False)
 
 
