@@ -997,6 +997,7 @@ struct DitBufs {
     uint8_t* f8tiles;   // e4m3 K / V^T tile images of the fp8 self-attention (attn_fp8.hip), or null
     bool vt_ready = false;   // vt's ones row / padding were written for this run (ir_launch_vt_pad_init): qkv epilogues may write rows d < hd
     int* attn_flag;
+    int attn_map = 0;   // ints behind attn_flag[0]: the per-workgroup overflow map (AttnParams::ovf_map)
     int n, Tpad, DV;
     long T;
 };
@@ -1040,6 +1041,7 @@ void dit_block(Run& r, const DitLayer& Lw, const float* mod, float* x, const Dit
         p.q_rs = p.k_rs = 3 * C; p.o_rs = C; p.q_hs = p.k_hs = p.o_hs = hd;
         p.B = n; p.Hh = Hh; p.Tq = (int)T; p.Tk = (int)T; p.Tk_pad = Tpad; p.D = hd; p.scale_log2 = sl2;
         p.ovf_flag = b.attn_flag;
+        p.ovf_map = b.attn_map;
         const bool pp2 = ir_flash_attn_is_pp2(p);
         LAUNCHK(r, pp2 ? PK_ATTN_SELF : PK_ATTN_OTHER, 4.0 * n * Hh * (double)T * T * hd, 0.0, ir_launch_flash_attn(p, r.s), "self_attn");
         if (pp2 && r.c->count_fb) LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_count_flag(b.attn_flag, r.c->attn_fb, r.s), "count_flag");
@@ -1082,7 +1084,8 @@ float* dit_tokens_run(Run& r, const float* lat, int n, int h, int w, float times
     b.xn = r.a.alloc<bf16_t>(BT * C);
     b.qkv = r.a.alloc<bf16_t>(BT * 3 * C);
     b.vt = r.a.alloc<bf16_t>((long)n * Hh * b.DV * b.Tpad);
-    b.attn_flag = r.a.alloc<int>(16);  // 4 bytes used: overflow flag of the ping-pong self-attention kernel
+    b.attn_map = (int)((long)n * Hh * ((T + 255) / 256));   // one int per 256-query workgroup of the self-attention behind the flag itself
+    b.attn_flag = r.a.alloc<int>(16 + b.attn_map);  // [0]: overflow flag of the fixed-reference self-attention kernel; [1 ..]: which of its workgroups overflowed
     b.f8tiles = (hd == 72 && (T & 63) == 0) ? r.a.alloc<uint8_t>(ir_attn_fp8_tile_bytes(n, Hh, (int)T)) : nullptr;
     b.att = r.a.alloc<bf16_t>(BT * C);
     b.cq = r.a.alloc<bf16_t>(BT * C);
@@ -3009,7 +3012,11 @@ int ir_op_attention(ir_ctx* c, void* stream, const uint16_t* q, const uint16_t* 
     AttnParams p;
     memset(&p, 0, sizeof p);
     p.q = q; p.k = k; p.vt = (const bf16_t*)ws; p.o = o;
-    if (ws_bytes >= need + 64) p.ovf_flag = (int*)((char*)ws + ((need + 15) & ~(size_t)15));
+    if (ws_bytes >= need + 64) {
+        const size_t off = (need + 15) & ~(size_t)15;
+        p.ovf_flag = (int*)((char*)ws + off);
+        p.ovf_map = (int)std::min<size_t>((ws_bytes - off) / 4 - 1, (size_t)1 << 24);   // what is left behind the flag word: the per-workgroup overflow map if it fits
+    }
     p.q_bs = (long)tq * heads * d; p.k_bs = (long)tk * heads * d; p.o_bs = p.q_bs; p.vt_bs = (long)heads * DV * tkp;
     p.q_rs = p.k_rs = p.o_rs = heads * d; p.q_hs = p.k_hs = p.o_hs = d;
     p.B = b; p.Hh = heads; p.Tq = tq; p.Tk = tk; p.Tk_pad = tkp; p.D = d;

@@ -76,6 +76,9 @@ __global__ __launch_bounds__(256, 2) void flash_attn_kernel(AttnParams p) {
     const int q0 = blockIdx.x * 128, head = blockIdx.y, b = blockIdx.z;
     // launched behind flash_attn_pp_kernel as its fallback: nothing to do unless that kernel flagged a query it could not handle
     if (p.ovf_flag && *reinterpret_cast<volatile const int*>(p.ovf_flag) == 0) return;
+    // ... and, when the flagging kernel kept a map of its 256-query workgroups, nothing unless THIS block's queries belong to one that overflowed
+    if (p.ovf_flag && p.ovf_map > 0 &&
+        reinterpret_cast<volatile const int*>(p.ovf_flag)[1 + ((long)b * p.Hh + head) * ((p.Tq + 255) >> 8) + (q0 >> 8)] == 0) return;
 
     const bf16_t* qp = p.q + (long)b * p.q_bs + (long)head * p.q_hs;
     const bf16_t* kp = p.k + (long)b * p.k_bs + (long)head * p.k_hs;
@@ -616,13 +619,17 @@ int ir_launch_flash_attn(const AttnParams& p, hipStream_t s) {
     const bool general = p.key_bias != nullptr || (p.Tk & 63);
     static const bool no_pp = getenv("IR_NO_PINGPONG") != nullptr;  // experiment knob
     if (p.D == 72 && !general && p.Tq >= 256 && p.ovf_flag && !no_pp && !g_ir_plain_kernels) {  // the DiT self-attention: ping-pong kernel, 256 queries per workgroup
-        if (ir_launch_zero_f32(reinterpret_cast<float*>(p.ovf_flag), 1, s)) return -1;
+        static const bool pp1e = getenv("IR_ATTN_PP1") != nullptr, no_map = getenv("IR_ATTN_NO_OVF_MAP") != nullptr;   // (no_map: experiment knob - the whole-launch fallback of rounds 2-5)
+        const long need = (long)p.B * p.Hh * ((p.Tq + 255) / 256);
+        AttnParams pm = p;
+        if (pp1e || no_map || p.ovf_map < need) pm.ovf_map = 0;   // the two-waves-per-SIMD kernel keeps no map; a short scratch means the caller did not size one
+        if (ir_launch_zero_f32(reinterpret_cast<float*>(p.ovf_flag), 1 + (pm.ovf_map ? need : 0), s)) return -1;
         static const bool pp1 = getenv("IR_ATTN_PP1") != nullptr;  // experiment knob: the two-waves-per-SIMD ping-pong kernel
         if (!pp1) {
-            if (ir_launch_flash_attn_pp2(p, s)) return -1;
+            if (ir_launch_flash_attn_pp2(pm, s)) return -1;
         } else
-        hipLaunchKernelGGL((flash_attn_pp_kernel<72>), dim3((p.Tq + 255) / 256, p.Hh, p.B), dim3(512), 0, s, p);
-        hipLaunchKernelGGL((flash_attn_kernel<72, false>), grid, dim3(256), 0, s, p);  // fallback: returns at once unless flagged
+        hipLaunchKernelGGL((flash_attn_pp_kernel<72>), dim3((p.Tq + 255) / 256, p.Hh, p.B), dim3(512), 0, s, pm);
+        hipLaunchKernelGGL((flash_attn_kernel<72, false>), grid, dim3(256), 0, s, pm);  // fallback: returns at once unless flagged (per 256-query workgroup with the map)
         return hipGetLastError() == hipSuccess ? 0 : -1;
     }
     AttnParams q = p;

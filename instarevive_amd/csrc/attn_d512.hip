@@ -745,7 +745,10 @@ __global__ __launch_bounds__(256, 1) void flash_attn_pp2_kernel(AttnParams p) {
             }
         }(), ...);
     }(std::make_integer_sequence<int, 2 * NDT>{});
-    if (__any(bad) && lane == 0) atomicOr(p.ovf_flag, 1);
+    if (__any(bad) && lane == 0) {
+        atomicOr(p.ovf_flag, 1);
+        if (p.ovf_map > 0) p.ovf_flag[1 + ((long)b * p.Hh + head) * ((p.Tq + 255) >> 8) + qt] = 1;   // this workgroup's 256 queries: what the rescaling kernel recomputes
+    }
     __syncthreads();
     bf16_t* op = p.o + (long)b * p.o_bs + (long)head * p.o_hs;
     for (int c = lane; c < 64 * RCH; c += 64) {

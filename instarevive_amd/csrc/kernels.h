@@ -126,6 +126,9 @@ struct AttnParams {
     const float* key_bias;     // optional additive bias per key [B][kb_bs] (natural-log domain)
     long kb_bs;
     int* ovf_flag;             // optional 4 bytes of device scratch: enables the fixed-reference ping-pong kernel (see attention.hip)
+    int ovf_map;               // ints available BEHIND ovf_flag[0] (0: none). With B * Hh * ceil(Tq / 256) of them (round 6) flash_attn_pp2_kernel marks the
+                               // 256-query workgroups whose fixed reference was outgrown, and the rescaling kernel behind it recomputes only those
+                               // instead of the whole launch (one peaky row among 16384 x 16 used to cost 28 x 1.7 ms per image)
 };
 int ir_launch_flash_attn(const AttnParams& p, hipStream_t s);
 bool ir_flash_attn_is_pp2(const AttnParams& p);   // ir_launch_flash_attn routes p to flash_attn_pp2_kernel (profiler rows)

