@@ -700,6 +700,55 @@ def test_stress_weights_vs_oracle(full_models):
     assert np.array_equal(again[0], seeded[0]) and not np.array_equal(again[0], bf[0])
 
 
+@pytest.mark.parametrize("case", ["tiled1024", "2048"])
+def test_stress_weights_at_headline_size_and_tiled(full_models, case):
+    """the stress weights (1 % channels x30, peaky attention: tests/support/stress_weights.py with stress_512.npz's gains) where the
+    headline kernels run - 2048 x 2048 untiled (16384 DiT tokens through flash_attn_pp2_kernel / gemm_pp_kernel, 65536 VAE tokens) and 1024 x 1024
+    --tiled (9 tiles + wavelet fix) - against the fp32 oracle's crops of tests/golden/stress_headline.npz (make_stress_headline.py; the oracle saw a
+    median DiT logit spread of 30-42 and top-1 softmass 0.11 at 16384 keys). Gates: bf16 >= 44.5 dB on the crops, the one-step latent within 1.5 %,
+    no attention launch on the rescaling fallback (the sweep of tools/spread_sweep.py puts the first one at a median spread of 56)."""
+    from instarevive_amd.models import DDPMScheduler
+    from instarevive_amd.pipeline import process
+    from tests.golden.make_headline_crops import CROP, inputs_for
+    from tests.support.stress_weights import stress_state_dicts
+    swin, vae, dit, sds, y, mask = full_models
+    ctx = dit.ctx
+    z5, z = np.load(os.path.join(G, "stress_512.npz")), np.load(os.path.join(G, "stress_headline.npz"))
+    gains = {"dit": [float(v) for v in z5["logit_gain_dit"]], "vae_encoder": float(z5["logit_gain_vae"][0]), "vae_decoder": float(z5["logit_gain_vae"][1])}
+    st = stress_state_dicts(sds, float(z5["frac"]), float(z5["gain"]), gains)
+    size, tiled = (2048, False) if case == "2048" else (1024, True)
+    img = inputs_for(size)
+    kw = dict(preprocess_model=swin, vae=vae, y=full_models.y_cuda, y_mask=full_models.mask_cuda)
+    try:
+        vae.load_state_dict(st["vae"])
+        dit.load_state_dict(st["dit"])
+        dit.invalidate_prompt()
+        ctx.check(ctx.lib.ir_attn_fallback_count(ctx.h, ctx.stream(), 1), "ir_attn_fallback_count")
+        got, _ = process(dit, [img], 1, "wavelet", False, tiled, 512, 448, **kw)
+        fallbacks = ctx.lib.ir_attn_fallback_count(ctx.h, ctx.stream(), 0)
+        ctx.check(ctx.lib.ir_attn_fallback_count(ctx.h, ctx.stream(), -1), "ir_attn_fallback_count")
+        rel = None
+        if not tiled:
+            x = torch.from_numpy(img).cuda().permute(2, 0, 1)[None].float() / 255.0
+            lat = vae.encode(swin(x) * 2 - 1).latent_dist.mode() * float(vae.config.scaling_factor)
+            x0 = dit.step(lat, 400.0, float(DDPMScheduler().alphas_cumprod[400]), full_models.y_cuda, full_models.mask_cuda)
+            ref0 = torch.from_numpy(z[f"x0_{case}"].astype(np.float32)).cuda()[None]
+            rel = float((x0 - ref0).norm() / ref0.norm())
+    finally:
+        vae.load_state_dict(sds["vae"])
+        dit.load_state_dict(sds["dit"])
+        dit.invalidate_prompt()
+    pos, want = z[f"pos_{case}"], z[f"crops_{case}"]
+    crops = np.stack([got[0][yy:yy + CROP, xx:xx + CROP] for yy, xx in pos])
+    per = [_psnr(g, w) for g, w in zip(crops, want)]
+    p = _psnr(crops, want)
+    print(f"stress weights, {case}: bf16 {p:.2f} dB on the oracle's crops (worst crop {min(per):.2f}), x0 relative L2 {'-' if rel is None else f'{rel * 100:.3f} %'}, "
+          f"{fallbacks} attention launches on the fallback; oracle-side median DiT logit spread {np.nanmin(z[f'spread_median_{case}'][:28]):.0f}-{np.nanmax(z[f'spread_median_{case}'][:28]):.0f}, "
+          f"byte sum {int(got[0].astype(np.int64).sum())} vs {int(z[f'sum_{case}'])}")
+    assert p >= 44.5 and min(per) >= 41.0 and fallbacks == 0 and (rel is None or rel <= 0.015)
+    assert abs(int(got[0].astype(np.int64).sum()) - int(z[f"sum_{case}"])) <= 0.002 * int(z[f"sum_{case}"])
+
+
 def test_fp8_auto_operand_set_on_seeded_and_stress_weights(full_models):
     """the fp8 operand set is chosen ON THE LOADED WEIGHTS (instarevive_amd/fp8_select.py: one 512 x 512 calibration image, every
     part alone against the bf16 pass, a part keeps its qualified cost only while it deviates as it did when it was qualified). Gates, against the fp32
