@@ -118,6 +118,14 @@ struct DitModel {
     float cached_t = -1e30f;
     float *tsin = nullptr, *th = nullptr, *emb = nullptr, *semb = nullptr, *t6 = nullptr, *modtab = nullptr, *fmod = nullptr;
     float* ctrl_modtab = nullptr;
+    // Micro-conditioning (round 6; scripts/DMD/transformer_train/generate.py:56-62 builds `resolution` / `aspect_ratio` when config.sample_size == 128;
+    // diffusers' PixArtAlphaCombinedTimestepSizeEmbeddings, whose in-tree twin is SizeEmbedder, PixArt_blocks.py:366-399, wired as in
+    // diffusion/model/nets/controlnet.py:189-191): S = C / 3 > 0 when the host uploaded the two embedders (dit.res1 / dit.res2 / dit.ar1 / dit.ar2). The
+    // conditioning vector is then emb(t) + [size_emb(h) | size_emb(w) | ar_emb(h / w)] of the LATENT's height and width, so the tables also depend on them.
+    int S = 0;
+    const float *rs1w = nullptr, *rs1b = nullptr, *rs2w = nullptr, *ar1w = nullptr, *ar1b = nullptr, *ar2w = nullptr;
+    float *tsin2 = nullptr, *th2 = nullptr;
+    int cached_h = -1, cached_w = -1;
 };
 
 // T5 v1.1 encoder (prompt producer, diffusion/model/t5.py:82-101)
@@ -969,14 +977,23 @@ void vae_decode_run(Run& r, const float* lat, float in_scale, float* out_nhwc4, 
 }
 
 // ================================================================ PixArt DiT (diffusers Transformer2DModel == PixArtMS.py:165-211)
-int dit_update_timestep(Run& r, float t) {
+int dit_update_timestep(Run& r, float t, int lat_h, int lat_w) {
     DitModel& m = r.c->dit;
     if (!r.live()) return 0;
-    if (m.cached_t == t) return 0;
+    if (m.cached_t == t && (m.S == 0 || (m.cached_h == lat_h && m.cached_w == lat_w))) return 0;
     const int C = m.C;
     r.chk(ir_launch_timestep_embed(m.tsin, t, 256, r.s), "timestep_embed");
     r.chk(ir_launch_gemv_f32(m.t1w, m.tsin, m.t1b, m.th, C, 256, ACT_SILU, r.s), "temb1");
     r.chk(ir_launch_gemv_f32(m.t2w, m.th, m.t2b, m.emb, C, C, ACT_NONE, r.s), "temb2");
+    if (m.S > 0) {   // emb += [size_emb(h) | size_emb(w) | ar_emb(h / w)]: the second linear of each embedder accumulates onto its slice of emb (its bias
+                     // was folded into dit.temb2.b by the host, weights.pack_dit)
+        const float vals[3] = {(float)lat_h, (float)lat_w, (float)lat_h / (float)lat_w};
+        for (int k = 0; k < 3; ++k) {
+            r.chk(ir_launch_timestep_embed(m.tsin2, vals[k], 256, r.s), "size_embed");
+            r.chk(ir_launch_gemv_f32(k < 2 ? m.rs1w : m.ar1w, m.tsin2, k < 2 ? m.rs1b : m.ar1b, m.th2, m.S, 256, ACT_SILU, r.s), "size_emb1");
+            r.chk(ir_launch_gemv_f32(k < 2 ? m.rs2w : m.ar2w, m.th2, m.emb + k * m.S, m.emb + k * m.S, m.S, m.S, ACT_NONE, r.s), "size_emb2");
+        }
+    }
     r.chk(ir_launch_silu_f32(m.emb, m.semb, C, r.s), "silu");
     r.chk(ir_launch_gemv_f32(m.tbw, m.semb, m.tbb, m.t6, 6 * C, C, ACT_NONE, r.s), "t_block");
     // per-layer tables: rows shift_msa, 1+scale_msa, gate_msa, shift_mlp, 1+scale_mlp, gate_mlp
@@ -987,7 +1004,7 @@ int dit_update_timestep(Run& r, float t) {
     // final layer: rows shift, 1+scale from scale_shift_table + embedded_timestep
     r.chk(ir_launch_modtab(m.emb, m.fsst, m.fmod, 1, 2, C, 0, 0x2, r.s), "fmod");
     r.chain = nullptr;  // these launches are not profiled: the next profiled launch records its own start event
-    if (r.rc == 0) m.cached_t = t;
+    if (r.rc == 0) { m.cached_t = t; m.cached_h = lat_h; m.cached_w = lat_w; }
     return r.rc;
 }
 
@@ -1075,7 +1092,7 @@ float* dit_tokens_run(Run& r, const float* lat, int n, int h, int w, float times
     DitBufs b;
     b.n = n; b.T = T;
     b.Tpad = (int)((T + 63) & ~63L) + 64; b.DV = ir_attn_dv(hd);  // +64: no power-of-two row stride (channel conflicts)
-    dit_update_timestep(r, timestep);
+    dit_update_timestep(r, timestep, h, w);
     float* tok = r.a.alloc<float>(BT * 32);
     const size_t mk = r.a.mark();
     bf16_t* tokp = r.a.alloc<bf16_t>(BT * 32);
@@ -1665,7 +1682,8 @@ int ir_drop_optional(ir_ctx* c, const char* prefix) {
     for (auto it = c->t.begin(); it != c->t.end();) {
         const std::string& k = it->first;
         auto ends = [&](const char* suf) { const size_t l = strlen(suf); return k.size() >= l && k.compare(k.size() - l, l, suf) == 0; };
-        if (k.compare(0, pre.size(), pre) == 0 && (ends(".wup") || ends(".w8") || ends(".g8") || ends(".b8") || ends(".qkv_t") || ends(".biasM") || ends(".mlp_t") || ends(".mlp_v") || ends(".proj_t"))) {
+        const bool micro = k.compare(0, 9, "dit.res1.") == 0 || k.compare(0, 9, "dit.res2.") == 0 || k.compare(0, 8, "dit.ar1.") == 0 || k.compare(0, 8, "dit.ar2.") == 0;   // the DiT's size embedders (micro-conditioning): present only for sample_size 128 models
+        if (k.compare(0, pre.size(), pre) == 0 && (micro || ends(".kvc_w") || ends(".kvc_b") || ends(".kvc_g") || ends(".kvc_beta") || ends(".wup") || ends(".w8") || ends(".g8") || ends(".b8") || ends(".qkv_t") || ends(".biasM") || ends(".mlp_t") || ends(".mlp_v") || ends(".proj_t"))) {
             if (it->second.p) (void)hipFree(it->second.p);
             it = c->t.erase(it);
             ++c->generation;
@@ -1889,6 +1907,13 @@ int ir_dit_configure(ir_ctx* c, int n_layers, int heads, int head_dim, int mlp_h
     m.tbw = b.f32("dit.tblock.w", (size_t)6 * C * C); m.tbb = b.f32("dit.tblock.b", (size_t)6 * C);
     m.fsst = b.f32("dit.final_sst", (size_t)2 * C);
     for (int l = 0; l < n_layers; ++l) m.layers.push_back(bind_dit_layer(b, fmt("dit.l%d", l), C, mlp_hidden));
+    if (c->t.count("dit.res1.w")) {   // micro-conditioning: both size embedders, hidden size C / 3 each
+        if (C % 3) return fail(c, -1, "ir_dit_configure: micro-conditioning needs a hidden size divisible by 3 (got %d)", C);
+        const int S = C / 3;
+        m.rs1w = b.f32("dit.res1.w", (size_t)S * 256); m.rs1b = b.f32("dit.res1.b", S); m.rs2w = b.f32("dit.res2.w", (size_t)S * S);
+        m.ar1w = b.f32("dit.ar1.w", (size_t)S * 256); m.ar1b = b.f32("dit.ar1.b", S); m.ar2w = b.f32("dit.ar2.w", (size_t)S * S);
+        m.S = S;
+    }
     if (!b.ok) return fail(c, -2, "ir_dit_configure: tensor %s", b.missing.c_str());
     // a re-bind (load_state_dict / .to again) replaces the previous model's tables, control branch and prompt caches
     release_list(c->dit_tabs);
@@ -1904,6 +1929,10 @@ int ir_dit_configure(ir_ctx* c, int n_layers, int heads, int head_dim, int mlp_h
     rc |= dev_alloc(c, c->dit_tabs, (void**)&m.t6, 6 * C * 4);
     rc |= dev_alloc(c, c->dit_tabs, (void**)&m.modtab, (size_t)n_layers * 6 * C * 4);
     rc |= dev_alloc(c, c->dit_tabs, (void**)&m.fmod, 2 * C * 4);
+    if (m.S > 0) {
+        rc |= dev_alloc(c, c->dit_tabs, (void**)&m.tsin2, 256 * 4);
+        rc |= dev_alloc(c, c->dit_tabs, (void**)&m.th2, m.S * 4);
+    }
     if (rc) return rc;
     m.ok = true;
     c->dit = m;

@@ -507,7 +507,7 @@ int ir_launch_layernorm(const float* x, bf16_t* y, float* yf, const float* a, co
 // out[n] = act(b[n] + sum_k w[n][k] * x[k]); one wave per output row. Used for the timestep MLP and adaLN-single
 // linear (PixArt_blocks.py:336-358, PixArtMS.py:134-137) where bf16 rounding of a [1,K] operand would bias every token.
 __global__ __launch_bounds__(256) void gemv_f32_kernel(const float* __restrict__ w, const float* __restrict__ x,
-                                                       const float* __restrict__ b, float* __restrict__ out, int N, int K, int act) {
+                                                       const float* b, float* out, int N, int K, int act) {   // b may alias out (out[row] = w[row] . x + out[row]: the size embedders of the DiT)
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= N) return;
     const float* wr = w + (long)row * K;

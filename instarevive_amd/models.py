@@ -377,9 +377,10 @@ class Transformer2DModel(_DeviceModule):
                 norm_elementwise_affine or not attention_bias or attention_head_dim not in (32, 64, 72) or cross_attention_dim not in (None, C_)):
             raise NotImplementedError("the MI355X path implements the PixArt-alpha Transformer2DModel configuration "
                                       "(tools/convert_pixart_to_diffusers.py:163-180)")
-        if sample_size == 128:
-            raise NotImplementedError("micro-conditioning (sample_size 128) is not used by the InstaRevive checkpoint")
-        self.cfg = dict(num_layers=num_layers, num_attention_heads=num_attention_heads, attention_head_dim=attention_head_dim,
+        # sample_size 128 (PixArt-alpha 1024): diffusers builds the model with use_additional_conditions - `resolution` / `aspect_ratio` embeddings on top
+        # of the timestep embedding (generate.py:56-62 passes them; in-tree twin: SizeEmbedder, PixArt_blocks.py:366-399). The library computes them from
+        # the latent's height and width, which is what forward_model passes.
+        self.cfg = dict(num_layers=num_layers, micro=sample_size == 128, num_attention_heads=num_attention_heads, attention_head_dim=attention_head_dim,
                         sample_size=sample_size, caption_channels=caption_channels, mlp=mlp_ratio * C_,
                         interpolation_scale=float(interpolation_scale) if interpolation_scale is not None else float(max(sample_size // 64, 1)))
         self.config = SimpleNamespace(sample_size=sample_size, out_channels=out_channels, in_channels=in_channels, patch_size=patch_size,
@@ -463,6 +464,22 @@ class Transformer2DModel(_DeviceModule):
         """Forget the cached prompt: the next call projects encoder_hidden_states again even if it is the same tensor object."""
         self._prompt_key = None
 
+    def _check_added_cond(self, added, h, w):
+        """added_cond_kwargs as generate.py:56-62 builds them: None entries for the 512 model, the latent's (height, width) and height / width for the
+        sample_size 128 one. The library derives exactly these from the latent it is given; anything else is a conditioning the path does not offer."""
+        res = None if added is None else added.get("resolution")
+        ar = None if added is None else added.get("aspect_ratio")
+        if not self.cfg["micro"]:
+            if res is not None or ar is not None:
+                raise NotImplementedError("added_cond_kwargs given to a model without micro-conditioning (sample_size != 128)")
+            return
+        if res is None and ar is None:
+            return   # the fused entry points (step / ir_pipeline) never pass them: the library computes them itself
+        r = torch.as_tensor(res, dtype=torch.float32).reshape(-1, 2).cpu()
+        a = torch.as_tensor(ar, dtype=torch.float32).reshape(-1).cpu()
+        if not (bool((r == torch.tensor([float(h), float(w)])).all()) and bool(((a - float(h) / float(w)).abs() <= 1e-6).all())):
+            raise NotImplementedError("micro-conditioning is computed from the latent's own height / width (generate.py:58-60); other values are not offered")
+
     @staticmethod
     def _scalar_timestep(timestep):
         t = torch.as_tensor(timestep).detach().reshape(-1).to("cpu", torch.float32)
@@ -479,6 +496,7 @@ class Transformer2DModel(_DeviceModule):
         n, ch, h, w = x.shape
         if ch != 4 or h % 2 or w % 2:
             raise ValueError(f"latents must be [B,4,h,w] with even h,w, got {tuple(x.shape)}")
+        self._check_added_cond(added_cond_kwargs, h, w)
         self.ensure_pos(h // 2, w // 2)
         out = torch.empty(n, 8, h, w, dtype=torch.float32, device=self.device)
         ws = self.ctx.workspace(self.ctx.ws_bytes(L.STAGE_DIT, n, h, w))

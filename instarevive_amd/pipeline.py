@@ -92,6 +92,10 @@ def eps_to_mu(scheduler, model_output, sample, timesteps):
 
 def forward_model(model, latents, timestep, prompt_embeds, prompt_attention_masks=None, c=None):
     added = {"resolution": None, "aspect_ratio": None}
+    if model.config.sample_size == 128:   # generate.py:56-62: micro-conditioning on the latent's height / width
+        bsz, _, height, width = latents.shape
+        added = {"resolution": torch.tensor([height, width]).repeat(bsz, 1).to(prompt_embeds.dtype),
+                 "aspect_ratio": torch.tensor([float(height / width)]).repeat(bsz, 1).to(prompt_embeds.dtype)}
     timestep = timestep.expand(latents.shape[0])
     if c is None:
         noise_pred = model(latents, timestep=timestep, encoder_hidden_states=prompt_embeds, encoder_attention_mask=prompt_attention_masks,

@@ -344,6 +344,10 @@ def dit_expected_keys(cfg):
                  "adaln_single.emb.timestep_embedder.linear_2", "adaln_single.linear", "proj_out"):
         keys += [base + ".weight", base + ".bias"]
     keys.append("scale_shift_table")
+    if cfg.get("micro"):
+        for e in ("resolution_embedder", "aspect_ratio_embedder"):
+            for l in ("linear_1", "linear_2"):
+                keys += [f"adaln_single.emb.{e}.{l}.weight", f"adaln_single.emb.{e}.{l}.bias"]
     for d in range(cfg["num_layers"]):
         keys += _dit_block_keys(f"transformer_blocks.{d}.")
     return keys
@@ -389,6 +393,15 @@ def pack_dit(sd, cfg):
                      ("dit.tblock", "adaln_single.linear")):
         out[dst + ".w"], out[dst + ".b"] = sd[src + ".weight"].float().contiguous(), sd[src + ".bias"].float().contiguous()
     out["dit.final_sst"] = sd["scale_shift_table"].float().contiguous()
+    if cfg.get("micro"):
+        # micro-conditioning (sample_size 128; diffusers PixArtAlphaCombinedTimestepSizeEmbeddings, in-tree SizeEmbedder PixArt_blocks.py:366-399): the two
+        # embedders' first linears and the weights of their second ones; the second linears' biases ride in the timestep embedder's (the library adds
+        # W2 h onto the slices [0:S), [S:2S) - the resolution embedder twice, for height and width - and [2S:3S) of emb = temb2(...))
+        r, a = "adaln_single.emb.resolution_embedder.", "adaln_single.emb.aspect_ratio_embedder."
+        for dst, src in (("dit.res1", r + "linear_1"), ("dit.ar1", a + "linear_1")):
+            out[dst + ".w"], out[dst + ".b"] = sd[src + ".weight"].float().contiguous(), sd[src + ".bias"].float().contiguous()
+        out["dit.res2.w"], out["dit.ar2.w"] = sd[r + "linear_2.weight"].float().contiguous(), sd[a + "linear_2.weight"].float().contiguous()
+        out["dit.temb2.b"] = (out["dit.temb2.b"] + torch.cat([sd[r + "linear_2.bias"], sd[r + "linear_2.bias"], sd[a + "linear_2.bias"]]).float()).contiguous()
     for d in range(cfg["num_layers"]):
         _pack_dit_block(out, sd, f"transformer_blocks.{d}.", f"dit.l{d}.")
     return out
@@ -539,6 +552,11 @@ def dit_shapes(cfg):
          "adaln_single.emb.timestep_embedder.linear_2.weight": (C, C), "adaln_single.emb.timestep_embedder.linear_2.bias": (C,),
          "adaln_single.linear.weight": (6 * C, C), "adaln_single.linear.bias": (6 * C,),
          "proj_out.weight": (32, C), "proj_out.bias": (32,), "scale_shift_table": (2, C)}
+    if cfg.get("micro"):   # use_additional_conditions (sample_size 128): two TimestepEmbedding(256 -> C / 3) stacks
+        S = C // 3
+        for e in ("resolution_embedder", "aspect_ratio_embedder"):
+            s[f"adaln_single.emb.{e}.linear_1.weight"], s[f"adaln_single.emb.{e}.linear_1.bias"] = (S, 256), (S,)
+            s[f"adaln_single.emb.{e}.linear_2.weight"], s[f"adaln_single.emb.{e}.linear_2.bias"] = (S, S), (S,)
     for d in range(cfg["num_layers"]):
         p = f"transformer_blocks.{d}."
         s[p + "scale_shift_table"] = (6, C)

@@ -49,6 +49,23 @@ def _lin(sd, p, x):
     return F.linear(x, sd[p + ".weight"], sd[p + ".bias"])
 
 
+def size_embedding(sd, p, s):
+    """SizeEmbedder.forward for ONE scalar per batch row (PixArt_blocks.py:384-396: sinusoid of the value, Linear -> SiLU -> Linear; the module
+    flattens a [B, dims] input to B * dims scalars and concatenates their embeddings per row - the caller concatenates here). `p`: key prefix of
+    the two linears in the diffusers layout (adaln_single.emb.resolution_embedder / aspect_ratio_embedder: TimestepEmbedding(256 -> C / 3))."""
+    return _lin(sd, p + ".linear_2", F.silu(_lin(sd, p + ".linear_1", timestep_embedding(torch.as_tensor(s, dtype=torch.float32).reshape(-1)))))
+
+
+def micro_condition(sd, B, H, W):
+    """What sample_size == 128 models add to the timestep embedding: generate.py:56-62 passes resolution = (height, width) of the LATENT and
+    aspect_ratio = height / width; diffusers' PixArtAlphaCombinedTimestepSizeEmbeddings (UNPINNED: diffusers is not in the tree) embeds the two
+    resolution scalars with ONE embedder and the ratio with another and concatenates [res(h) | res(w) | ar] - the wiring of the in-tree twin,
+    diffusion/model/nets/controlnet.py:189-191 (csize_embedder / ar_embedder, t = t + cat([csize, ar], dim=1)), which IS pinned (size_embedder.npz)."""
+    r, a = "adaln_single.emb.resolution_embedder", "adaln_single.emb.aspect_ratio_embedder"
+    parts = [size_embedding(sd, r, [float(H)] * B), size_embedding(sd, r, [float(W)] * B), size_embedding(sd, a, [float(H) / float(W)] * B)]
+    return torch.cat(parts, dim=1)
+
+
 def _heads(x, nh):
     B, T, C = x.shape
     return x.view(B, T, nh, C // nh).transpose(1, 2)
@@ -79,6 +96,8 @@ def dit_forward(sd, latents, timestep, encoder_hidden_states, encoder_attention_
     x = x + torch.from_numpy(pos).float().unsqueeze(0)
     t = torch.as_tensor(timestep, dtype=torch.float32).reshape(-1).expand(B)
     emb = _lin(sd, "adaln_single.emb.timestep_embedder.linear_2", F.silu(_lin(sd, "adaln_single.emb.timestep_embedder.linear_1", timestep_embedding(t))))
+    if cfg["sample_size"] == 128:   # use_additional_conditions
+        emb = emb + micro_condition(sd, B, H, W)
     t6 = _lin(sd, "adaln_single.linear", F.silu(emb))  # [B, 6C]
     y = _lin(sd, "caption_projection.linear_2", F.gelu(_lin(sd, "caption_projection.linear_1", encoder_hidden_states), approximate="tanh"))
     y = y.reshape(-1, y.shape[-2], C)
@@ -184,6 +203,10 @@ def state_dict_shapes(cfg=None, mlp_ratio=4):
          "adaln_single.emb.timestep_embedder.linear_2.weight": (C, C), "adaln_single.emb.timestep_embedder.linear_2.bias": (C,),
          "adaln_single.linear.weight": (6 * C, C), "adaln_single.linear.bias": (6 * C,),
          "proj_out.weight": (ps * ps * cfg["out_channels"], C), "proj_out.bias": (ps * ps * cfg["out_channels"],), "scale_shift_table": (2, C)}
+    if cfg["sample_size"] == 128:
+        for e in ("resolution_embedder", "aspect_ratio_embedder"):
+            s[f"adaln_single.emb.{e}.linear_1.weight"], s[f"adaln_single.emb.{e}.linear_1.bias"] = (C // 3, 256), (C // 3,)
+            s[f"adaln_single.emb.{e}.linear_2.weight"], s[f"adaln_single.emb.{e}.linear_2.bias"] = (C // 3, C // 3), (C // 3,)
     for d in range(cfg["num_layers"]):
         p = f"transformer_blocks.{d}."
         s[p + "scale_shift_table"] = (6, C)

@@ -112,6 +112,23 @@ def test_dit_matches_reference_wiring():
         torch.testing.assert_close(out, fx[k + "_mask2d"], rtol=2e-4, atol=2e-5)
 
 
+def test_micro_conditioning_matches_the_reference_size_embedders():
+    """sample_size-128 models (generate.py:56-62): what oracle.dit.micro_condition adds to the timestep embedding equals what the reference's two
+    SizeEmbedder modules produce, wired as controlnet.py:189-191 (fixture from the imported modules, tests/golden/make_golden_r6.py). The diffusers
+    class that the CLI would execute (PixArtAlphaCombinedTimestepSizeEmbeddings) is not in the tree: that equality is UNPINNED."""
+    fx = load("size_embedder.npz")
+    S = 96
+    shapes = {"mlp.0.weight": (S, 256), "mlp.0.bias": (S,), "mlp.2.weight": (S, S), "mlp.2.bias": (S,)}
+    sd_c, sd_a = det_state_dict(shapes, seed=611), det_state_dict(shapes, seed=612)
+    assert abs(checksum(sd_c) - float(fx["wsum_c"])) < 1e-6 * abs(float(fx["wsum_c"])) and abs(checksum(sd_a) - float(fx["wsum_a"])) < 1e-6 * abs(float(fx["wsum_a"]))
+    dsd = {}
+    for pre, sd in (("adaln_single.emb.resolution_embedder.", sd_c), ("adaln_single.emb.aspect_ratio_embedder.", sd_a)):
+        for a, b in (("linear_1", "mlp.0"), ("linear_2", "mlp.2")):
+            dsd[pre + a + ".weight"], dsd[pre + a + ".bias"] = sd[b + ".weight"], sd[b + ".bias"]
+    for name, (h, w) in (("16x24", (16, 24)), ("64x64", (64, 64)), ("128x96", (128, 96))):
+        torch.testing.assert_close(odit.micro_condition(dsd, 2, h, w), fx["add_" + name], rtol=1e-5, atol=1e-6)
+
+
 def test_dit_3d_mask_is_additive_not_dropping():
     """diffusers semantics the CLI triggers (inference.py:274-277): a [B,1,L] float mask is added to the logits."""
     fx = load("dit_small.npz")
