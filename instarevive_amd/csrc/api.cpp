@@ -99,6 +99,11 @@ struct DitLayer {
     Conv qkv, ao, cq, ckv, co, fc1, fc2;
     bf16_t* kc = nullptr;   // [n_tok][2*hidden] cached K|V of the prompt
     bf16_t* vtc = nullptr;  // [heads][DV][tok_pad]
+    // optional branches of the self-attention (AttentionKVCompress, PixArt_blocks.py:60-158; round 6): KV token compression by a depthwise r x r / stride r
+    // convolution over the token grid (kvc_w [C][r*r], kvc_b; 'uniform' / 'ave' sampling arrive as a weight of 1 on the first tap) with an optional LayerNorm
+    // (kvc_g / kvc_beta: the 'conv' sampler's `norm`), and LayerNorm on q and k (qk_norm)
+    int kvc_r = 1;
+    const float *kvc_w = nullptr, *kvc_b = nullptr, *kvc_g = nullptr, *kvc_beta = nullptr, *qn_g = nullptr, *qn_b = nullptr, *kn_g = nullptr, *kn_b = nullptr;
 };
 struct DitModel {
     bool ok = false, prompt_ok = false;
@@ -1013,6 +1018,8 @@ struct DitBufs {
     bf16_t *xb, *xn, *qkv, *vt, *att, *cq, *hid;
     uint8_t* f8tiles;   // e4m3 K / V^T tile images of the fp8 self-attention (attn_fp8.hip), or null
     bool vt_ready = false;   // vt's ones row / padding were written for this run (ir_launch_vt_pad_init): qkv epilogues may write rows d < hd
+    bf16_t *kcmp = nullptr, *vcmp = nullptr, *vtcmp = nullptr;   // compressed K / V rows [n][Tc][C] and their V^T (layers with KV compression)
+    int rmin = 1, gh = 0, gw = 0;                                // smallest compression ratio among the layers (sizes the three buffers); token grid
     int* attn_flag;
     int attn_map = 0;   // ints behind attn_flag[0]: the per-workgroup overflow map (AttnParams::ovf_map)
     int n, Tpad, DV;
@@ -1027,8 +1034,9 @@ void dit_block(Run& r, const DitLayer& Lw, const float* mod, float* x, const Dit
     const long T = b.T, BT = n * T;
     const float sl2 = (1.0f / sqrtf((float)hd)) * 1.44269504088896340736f;
     layernorm(r, x, b.xn, nullptr, mod + C, mod, BT, C, C, C, 1e-6f);
-    const bool attn8_pre = r.c->fp8 && (r.c->fp8_mask & (1u << IR_FP8_BIT_DIT_ATTN)) && b.f8tiles && hd == 72 && (T & 63) == 0 && T >= 256 && !g_ir_plain_kernels;
-    if (b.vt_ready && !attn8_pre && !r.c->plain) {   // the projection's epilogue writes V^T itself (gemm_pp_kernel at >= 12 k tokens): no transpose launch
+    const bool kvc = Lw.kvc_r > 1;
+    const bool attn8_pre = !kvc && r.c->fp8 && (r.c->fp8_mask & (1u << IR_FP8_BIT_DIT_ATTN)) && b.f8tiles && hd == 72 && (T & 63) == 0 && T >= 256 && !g_ir_plain_kernels;
+    if (b.vt_ready && !attn8_pre && !r.c->plain && !kvc) {   // the projection's epilogue writes V^T itself (gemm_pp_kernel at >= 12 k tokens): no transpose launch
         r.vt_out = b.vt; r.vt_col0 = 2 * C; r.vt_hd = hd; r.vt_dv = DV; r.vt_ld = Tpad; r.vt_T = (int)T; r.vt_bs = (long)Hh * DV * Tpad;
     }
     linear(r, Lw.qkv, b.xn, (int)BT, C, b.qkv, 3 * C, 0, ACT_NONE, nullptr, 0, 0);
@@ -1036,8 +1044,31 @@ void dit_block(Run& r, const DitLayer& Lw, const float* mod, float* x, const Dit
     r.vt_done = false;
     // BASELINE.json configs[4]: both attention products on e4m3 operands (attn_fp8.hip). The bf16 V^T is only built if the kernel's
     // fixed softmax reference was outgrown (flag), for the rescaling fallback behind it.
-    const bool attn8 = r.c->fp8 && (r.c->fp8_mask & (1u << IR_FP8_BIT_DIT_ATTN)) && b.f8tiles && hd == 72 && (T & 63) == 0 && T >= 256 && !g_ir_plain_kernels;
-    if (r.live() && attn8) {
+    const bool attn8 = !kvc && r.c->fp8 && (r.c->fp8_mask & (1u << IR_FP8_BIT_DIT_ATTN)) && b.f8tiles && hd == 72 && (T & 63) == 0 && T >= 256 && !g_ir_plain_kernels;
+    if (r.live() && Lw.qn_g) {   // qk_norm (PixArt_blocks.py:136-137): LayerNorm over all C channels of q and of k, in place on the qkv rows
+        LAUNCH(r, PC_LAYERNORM, 0.0, 4.0 * BT * C, ir_launch_dit_token_prep(b.qkv, b.qkv, nullptr, nullptr, Lw.qn_g, Lw.qn_b, n, b.gh, b.gw, 1, C, 3 * C, T * 3 * C, 3 * C, T * 3 * C, r.s), "q_norm");
+        LAUNCH(r, PC_LAYERNORM, 0.0, 4.0 * BT * C, ir_launch_dit_token_prep(b.qkv + C, b.qkv + C, nullptr, nullptr, Lw.kn_g, Lw.kn_b, n, b.gh, b.gw, 1, C, 3 * C, T * 3 * C, 3 * C, T * 3 * C, r.s), "k_norm");
+    }
+    if (r.live() && kvc) {
+        // KV compression (:139-142): k and v through the same sampler, attention of all T queries over T / r^2 keys
+        const int rr = Lw.kvc_r;
+        const long Tc = T / ((long)rr * rr);
+        const int Tcpad = (int)((Tc + 63) & ~63L) + 64;
+        LAUNCH(r, PC_OTHER, 0.0, 2.0 * BT * C, ir_launch_dit_token_prep(b.qkv + C, b.kcmp, Lw.kvc_w, Lw.kvc_b, Lw.kvc_g, Lw.kvc_beta, n, b.gh, b.gw, rr, C, 3 * C, T * 3 * C, C, Tc * C, r.s), "kv_compress_k");
+        LAUNCH(r, PC_OTHER, 0.0, 2.0 * BT * C, ir_launch_dit_token_prep(b.qkv + 2 * C, b.vcmp, Lw.kvc_w, Lw.kvc_b, Lw.kvc_g, Lw.kvc_beta, n, b.gh, b.gw, rr, C, 3 * C, T * 3 * C, C, Tc * C, r.s), "kv_compress_v");
+        LAUNCH(r, PC_TRANSPOSE, 0.0, 0.0, ir_launch_transpose_v(b.vcmp, b.vtcmp, Tc * C, C, hd, n, Hh, (int)Tc, Tcpad, hd, DV, r.s), "transpose_v");
+        AttnParams p;
+        memset(&p, 0, sizeof p);
+        p.q = b.qkv; p.k = b.kcmp; p.vt = b.vtcmp; p.o = b.att;
+        p.q_bs = T * 3 * C; p.k_bs = Tc * C; p.o_bs = T * C; p.vt_bs = (long)Hh * DV * Tcpad;
+        p.q_rs = 3 * C; p.k_rs = C; p.o_rs = C; p.q_hs = p.k_hs = p.o_hs = hd;
+        p.B = n; p.Hh = Hh; p.Tq = (int)T; p.Tk = (int)Tc; p.Tk_pad = Tcpad; p.D = hd; p.scale_log2 = sl2;
+        p.ovf_flag = b.attn_flag;
+        p.ovf_map = b.attn_map;
+        const bool pp2 = ir_flash_attn_is_pp2(p);
+        LAUNCHK(r, pp2 ? PK_ATTN_SELF : PK_ATTN_OTHER, 4.0 * n * Hh * (double)T * Tc * hd, 0.0, ir_launch_flash_attn(p, r.s), "self_attn_kvc");
+        if (pp2 && r.c->count_fb) LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_count_flag(b.attn_flag, r.c->attn_fb, r.s), "count_flag");
+    } else if (r.live() && attn8) {
         AttnParams p;
         memset(&p, 0, sizeof p);
         p.q = b.qkv; p.k = b.qkv + C; p.vt = b.vt; p.o = b.att;
@@ -1101,6 +1132,15 @@ float* dit_tokens_run(Run& r, const float* lat, int n, int h, int w, float times
     b.xn = r.a.alloc<bf16_t>(BT * C);
     b.qkv = r.a.alloc<bf16_t>(BT * 3 * C);
     b.vt = r.a.alloc<bf16_t>((long)n * Hh * b.DV * b.Tpad);
+    b.gh = gh; b.gw = gw;
+    for (const DitLayer& Lw : m.layers) if (Lw.kvc_r > 1) b.rmin = b.rmin == 1 ? Lw.kvc_r : std::min(b.rmin, Lw.kvc_r);
+    if (b.rmin > 1) {
+        if (gh % b.rmin || gw % b.rmin) r.chk(-21, "KV compression: the token grid must be divisible by the compression ratio");
+        const long Tc = T / ((long)b.rmin * b.rmin);
+        b.kcmp = r.a.alloc<bf16_t>(n * Tc * C);
+        b.vcmp = r.a.alloc<bf16_t>(n * Tc * C);
+        b.vtcmp = r.a.alloc<bf16_t>((long)n * Hh * b.DV * ((int)((Tc + 63) & ~63L) + 64));
+    }
     b.attn_map = (int)((long)n * Hh * ((T + 255) / 256));   // one int per 256-query workgroup of the self-attention behind the flag itself
     b.attn_flag = r.a.alloc<int>(16 + b.attn_map);  // [0]: overflow flag of the fixed-reference self-attention kernel; [1 ..]: which of its workgroups overflowed
     b.f8tiles = (hd == 72 && (T & 63) == 0) ? r.a.alloc<uint8_t>(ir_attn_fp8_tile_bytes(n, Hh, (int)T)) : nullptr;
@@ -1683,7 +1723,7 @@ int ir_drop_optional(ir_ctx* c, const char* prefix) {
         const std::string& k = it->first;
         auto ends = [&](const char* suf) { const size_t l = strlen(suf); return k.size() >= l && k.compare(k.size() - l, l, suf) == 0; };
         const bool micro = k.compare(0, 9, "dit.res1.") == 0 || k.compare(0, 9, "dit.res2.") == 0 || k.compare(0, 8, "dit.ar1.") == 0 || k.compare(0, 8, "dit.ar2.") == 0;   // the DiT's size embedders (micro-conditioning): present only for sample_size 128 models
-        if (k.compare(0, pre.size(), pre) == 0 && (micro || ends(".kvc_w") || ends(".kvc_b") || ends(".kvc_g") || ends(".kvc_beta") || ends(".wup") || ends(".w8") || ends(".g8") || ends(".b8") || ends(".qkv_t") || ends(".biasM") || ends(".mlp_t") || ends(".mlp_v") || ends(".proj_t"))) {
+        if (k.compare(0, pre.size(), pre) == 0 && (micro || ends(".kvc_w") || ends(".kvc_b") || ends(".kvc_g") || ends(".kvc_beta") || ends(".qn_g") || ends(".qn_b") || ends(".kn_g") || ends(".kn_b") || ends(".wup") || ends(".w8") || ends(".g8") || ends(".b8") || ends(".qkv_t") || ends(".biasM") || ends(".mlp_t") || ends(".mlp_v") || ends(".proj_t"))) {
             if (it->second.p) (void)hipFree(it->second.p);
             it = c->t.erase(it);
             ++c->generation;
@@ -1886,6 +1926,20 @@ static DitLayer bind_dit_layer(Binder& b, const std::string& p, int C, int mlp_h
     L.co = b.conv(p + ".co", C, C, C, 1);
     L.fc1 = b.conv(p + ".fc1", C, mlp_hidden, mlp_hidden, 1);
     L.fc2 = b.conv(p + ".fc2", mlp_hidden, C, C, 1);
+    auto it = b.c->t.find(p + ".kvc_w");
+    if (it != b.c->t.end()) {   // KV compression: the ratio follows from the weight's size
+        const size_t taps = it->second.bytes / 4 / (size_t)C;
+        int rr = 1;
+        while ((size_t)rr * rr < taps) ++rr;
+        if ((size_t)rr * rr != taps || rr < 2 || it->second.bytes != (size_t)C * rr * rr * 4) { b.ok = false; b.missing = p + ".kvc_w (size is not C * r * r floats)"; return L; }
+        L.kvc_r = rr;
+        L.kvc_w = (const float*)it->second.p;
+        L.kvc_b = b.f32(p + ".kvc_b", C);
+        if (b.c->t.count(p + ".kvc_g")) { L.kvc_g = b.f32(p + ".kvc_g", C); L.kvc_beta = b.f32(p + ".kvc_beta", C); }
+    }
+    if (b.c->t.count(p + ".qn_g")) {
+        L.qn_g = b.f32(p + ".qn_g", C); L.qn_b = b.f32(p + ".qn_b", C); L.kn_g = b.f32(p + ".kn_g", C); L.kn_b = b.f32(p + ".kn_b", C);
+    }
     return L;
 }
 

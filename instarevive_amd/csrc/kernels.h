@@ -109,6 +109,9 @@ int ir_launch_groupnorm(const bf16_t* x, bf16_t* y, const float* gamma, const fl
 int ir_launch_groupnorm_fused(const bf16_t* x, bf16_t* y, const float* gamma, const float* beta, const float* part, float* ws, int N,
                               long HW, int C, int G, int chunks, float eps, int do_silu, hipStream_t s, int out_fp8 = 0, float out_mul = 1.f);
 // y (bf16, may be null) and yf (fp32, may be null) both receive xn*a + b; columns C..ldy-1 are written as zero.
+// DiT self-attention token preparation (norm.hip): KV compression (depthwise r x r / stride r over the token grid + optional LayerNorm) and qk_norm (r = 1)
+int ir_launch_dit_token_prep(const bf16_t* in, bf16_t* out, const float* w, const float* bias, const float* gamma, const float* beta, int B, int gh, int gw, int r,
+                             int C, int in_rs, long in_bs, int out_rs, long out_bs, hipStream_t s);
 int ir_launch_layernorm(const float* x, bf16_t* y, float* yf, const float* a, const float* b, long rows, int C, int ldx, int ldy,
                         float eps, long rows_per_batch, int ab_stride, hipStream_t s);
 int ir_launch_gemv_f32(const float* w, const float* x, const float* b, float* out, int N, int K, int act, hipStream_t s);

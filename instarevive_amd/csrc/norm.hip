@@ -524,3 +524,70 @@ int ir_launch_gemv_f32(const float* w, const float* x, const float* b, float* ou
     hipLaunchKernelGGL(gemv_f32_kernel, dim3((N + 3) / 4), dim3(256), 0, s, w, x, b, out, N, K, act);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Token preparation of the DiT self-attention's optional branches (AttentionKVCompress, PixArt_blocks.py:60-158; round 6): one kernel for
+//   * KV compression (downsample_2d, :97-121): output token (oy, ox) of the (gh / r) x (gw / r) grid = depthwise r x r / stride r convolution
+//     over the token grid (`sr`; 'uniform' / 'ave' sampling = the same with a weight of 1 on the window's first token) + optional LayerNorm (`norm`);
+//   * qk_norm (:136-137): r = 1, no weights, LayerNorm over all C channels of the token, in place on the q / k columns of the qkv rows.
+// in: [B][gh * gw] bf16 rows (row stride in_rs, batch stride in_bs); out: [B][(gh / r) * (gw / r)] rows (out_rs, out_bs); w: [C][r * r] fp32 or null
+// (weight 1 on tap 0), bias [C] or null, gamma / beta [C] or null (no LayerNorm); eps 1e-5 (nn.LayerNorm default). One 256-thread workgroup per
+// output token, a thread's channels (at most 8: C <= 2048) in registers between the two passes, so in == out is allowed for r == 1.
+__global__ __launch_bounds__(256) void dit_token_prep_kernel(const bf16_t* __restrict__ in, bf16_t* out, const float* __restrict__ w, const float* __restrict__ bias,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta, int gh, int gw, int r, int C,
+                                                             int in_rs, long in_bs, int out_rs, long out_bs, float eps) {
+    __shared__ float red[2][4];
+    const int tid = threadIdx.x, b = blockIdx.y;
+    const int ow = gw / r, j = blockIdx.x, oy = j / ow, ox = j - oy * ow;
+    const bf16_t* src = in + (long)b * in_bs;
+    float v[8];
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = tid + 256 * i;
+        v[i] = 0.f;
+        if (c < C) {
+            float a = bias ? bias[c] : 0.f;
+            for (int dy = 0; dy < r; ++dy)
+                for (int dx = 0; dx < r; ++dx) {
+                    const float wt = w ? w[(long)c * r * r + dy * r + dx] : ((dy | dx) == 0 ? 1.f : 0.f);
+                    a += wt * bf2f(src[(long)((oy * r + dy) * gw + ox * r + dx) * in_rs + c]);
+                }
+            v[i] = a;
+            s += a;
+        }
+    }
+    if (gamma) {   // two-pass LayerNorm over the C channels of this token (mean first, then the centred second moment: as F.layer_norm)
+        s = wave_sum(s);
+        if ((tid & 63) == 0) red[0][tid >> 6] = s;
+        __syncthreads();
+        const float mean = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / (float)C;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = tid + 256 * i;
+            if (c < C) { const float d = v[i] - mean; q += d * d; }
+        }
+        q = wave_sum(q);
+        if ((tid & 63) == 0) red[1][tid >> 6] = q;
+        __syncthreads();
+        const float rstd = rsqrtf((red[1][0] + red[1][1] + red[1][2] + red[1][3]) / (float)C + eps);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = tid + 256 * i;
+            if (c < C) v[i] = (v[i] - mean) * rstd * gamma[c] + beta[c];
+        }
+    }
+    bf16_t* dst = out + (long)b * out_bs + (long)j * out_rs;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = tid + 256 * i;
+        if (c < C) dst[c] = f2bf(v[i]);
+    }
+}
+int ir_launch_dit_token_prep(const bf16_t* in, bf16_t* out, const float* w, const float* bias, const float* gamma, const float* beta, int B, int gh, int gw, int r,
+                             int C, int in_rs, long in_bs, int out_rs, long out_bs, hipStream_t s) {
+    if (B <= 0 || gh <= 0 || gw <= 0 || r < 1 || gh % r || gw % r || C <= 0 || C > 2048 || (gamma == nullptr) != (beta == nullptr)) return -2;
+    if (in == out && r != 1) return -3;
+    hipLaunchKernelGGL(dit_token_prep_kernel, dim3((gh / r) * (gw / r), B), dim3(256), 0, s, in, out, w, bias, gamma, beta, gh, gw, r, C, in_rs, in_bs, out_rs, out_bs, 1e-5f);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}

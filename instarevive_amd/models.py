@@ -370,7 +370,8 @@ class Transformer2DModel(_DeviceModule):
 
     def __init__(self, num_attention_heads=16, attention_head_dim=72, in_channels=4, out_channels=8, num_layers=28, cross_attention_dim=1152,
                  attention_bias=True, sample_size=64, patch_size=2, activation_fn="gelu-approximate", norm_type="ada_norm_single",
-                 norm_elementwise_affine=False, norm_eps=1e-6, caption_channels=4096, interpolation_scale=None, mlp_ratio=4, **unused):
+                 norm_elementwise_affine=False, norm_eps=1e-6, caption_channels=4096, interpolation_scale=None, mlp_ratio=4, kv_compress_config=None,
+                 qk_norm=False, **unused):
         super().__init__()
         C_ = num_attention_heads * attention_head_dim
         if (in_channels != 4 or out_channels != 8 or patch_size != 2 or norm_type != "ada_norm_single" or activation_fn != "gelu-approximate" or
@@ -380,7 +381,16 @@ class Transformer2DModel(_DeviceModule):
         # sample_size 128 (PixArt-alpha 1024): diffusers builds the model with use_additional_conditions - `resolution` / `aspect_ratio` embeddings on top
         # of the timestep embedding (generate.py:56-62 passes them; in-tree twin: SizeEmbedder, PixArt_blocks.py:366-399). The library computes them from
         # the latent's height and width, which is what forward_model passes.
-        self.cfg = dict(num_layers=num_layers, micro=sample_size == 128, num_attention_heads=num_attention_heads, attention_head_dim=attention_head_dim,
+        # kv_compress_config / qk_norm: the optional branches of the in-tree self-attention (AttentionKVCompress, PixArt_blocks.py:60-158; PixArtMS.py:97-139
+        # takes {'sampling': 'conv' | 'uniform' | 'ave', 'scale_factor': r, 'kv_compress_layer': [...]}); diffusers 0.30 has no counterpart, the keys follow
+        # oracle.dit.pixart_to_diffusers (transformer_blocks.{d}.attn1.sr / norm / q_norm / k_norm)
+        kvc = None
+        if kv_compress_config and kv_compress_config.get("sampling") and int(kv_compress_config.get("scale_factor", 1)) > 1 and kv_compress_config.get("kv_compress_layer"):
+            if kv_compress_config["sampling"] not in ("conv", "uniform", "ave"):
+                raise NotImplementedError(f"kv_compress sampling {kv_compress_config['sampling']!r}: the MI355X path offers conv, uniform and ave (PixArt_blocks.py:97-121)")
+            kvc = dict(sampling=kv_compress_config["sampling"], scale_factor=int(kv_compress_config["scale_factor"]),
+                       layers=tuple(int(l) for l in kv_compress_config["kv_compress_layer"]))
+        self.cfg = dict(num_layers=num_layers, micro=sample_size == 128, kv_compress=kvc, qk_norm=bool(qk_norm), num_attention_heads=num_attention_heads, attention_head_dim=attention_head_dim,
                         sample_size=sample_size, caption_channels=caption_channels, mlp=mlp_ratio * C_,
                         interpolation_scale=float(interpolation_scale) if interpolation_scale is not None else float(max(sample_size // 64, 1)))
         self.config = SimpleNamespace(sample_size=sample_size, out_channels=out_channels, in_channels=in_channels, patch_size=patch_size,
@@ -536,6 +546,8 @@ class ControlTransformerHalf(_DeviceModule):
             raise TypeError("base_model must be an instarevive_amd Transformer2DModel")
         if not 1 <= copy_blocks_num < base_model.cfg["num_layers"]:
             raise ValueError(f"copy_blocks_num must be in 1..{base_model.cfg['num_layers'] - 1}")
+        if base_model.cfg.get("kv_compress") or base_model.cfg.get("qk_norm"):
+            raise NotImplementedError("ControlTransformerHalf over a base model with KV compression / qk_norm (the copies would carry those branches too): not offered")
         self.base_model = base_model
         self.copy_blocks_num = copy_blocks_num
         self.total_blocks_num = base_model.cfg["num_layers"]

@@ -348,8 +348,14 @@ def dit_expected_keys(cfg):
         for e in ("resolution_embedder", "aspect_ratio_embedder"):
             for l in ("linear_1", "linear_2"):
                 keys += [f"adaln_single.emb.{e}.{l}.weight", f"adaln_single.emb.{e}.{l}.bias"]
+    kvc = cfg.get("kv_compress") or {}
     for d in range(cfg["num_layers"]):
-        keys += _dit_block_keys(f"transformer_blocks.{d}.")
+        p = f"transformer_blocks.{d}."
+        keys += _dit_block_keys(p)
+        if kvc.get("sampling") == "conv" and d in kvc.get("layers", ()) and int(kvc.get("scale_factor", 1)) > 1:
+            keys += [p + "attn1.sr.weight", p + "attn1.sr.bias", p + "attn1.norm.weight", p + "attn1.norm.bias"]
+        if cfg.get("qk_norm"):
+            keys += [p + "attn1.q_norm.weight", p + "attn1.q_norm.bias", p + "attn1.k_norm.weight", p + "attn1.k_norm.bias"]
     return keys
 
 
@@ -402,8 +408,27 @@ def pack_dit(sd, cfg):
             out[dst + ".w"], out[dst + ".b"] = sd[src + ".weight"].float().contiguous(), sd[src + ".bias"].float().contiguous()
         out["dit.res2.w"], out["dit.ar2.w"] = sd[r + "linear_2.weight"].float().contiguous(), sd[a + "linear_2.weight"].float().contiguous()
         out["dit.temb2.b"] = (out["dit.temb2.b"] + torch.cat([sd[r + "linear_2.bias"], sd[r + "linear_2.bias"], sd[a + "linear_2.bias"]]).float()).contiguous()
+    kvc = cfg.get("kv_compress") or {}
+    C = cfg["num_attention_heads"] * cfg["attention_head_dim"]
     for d in range(cfg["num_layers"]):
-        _pack_dit_block(out, sd, f"transformer_blocks.{d}.", f"dit.l{d}.")
+        s, p = f"transformer_blocks.{d}.", f"dit.l{d}."
+        _pack_dit_block(out, sd, s, p)
+        # optional branches of the self-attention (AttentionKVCompress, PixArt_blocks.py:60-158; keys as pixart_to_diffusers names them)
+        if d in kvc.get("layers", ()) and int(kvc.get("scale_factor", 1)) > 1:
+            r = int(kvc["scale_factor"])
+            if kvc["sampling"] == "conv":   # depthwise r x r / stride r conv + LayerNorm
+                out[p + "kvc_w"] = sd[s + "attn1.sr.weight"].float().reshape(C, r * r).contiguous()
+                out[p + "kvc_b"] = sd[s + "attn1.sr.bias"].float().contiguous()
+                out[p + "kvc_g"], out[p + "kvc_beta"] = sd[s + "attn1.norm.weight"].float().contiguous(), sd[s + "attn1.norm.bias"].float().contiguous()
+            elif kvc["sampling"] in ("uniform", "ave"):   # every r-th row / column ('ave' = F.interpolate(nearest) picks the same tokens): weight 1 on the first tap
+                w = torch.zeros(C, r * r)
+                w[:, 0] = 1.0
+                out[p + "kvc_w"], out[p + "kvc_b"] = w, torch.zeros(C)
+            else:
+                raise NotImplementedError(f"kv_compress sampling {kvc['sampling']!r} (the MI355X path offers conv, uniform, ave)")
+        if cfg.get("qk_norm"):
+            for dst, src in (("qn", "q_norm"), ("kn", "k_norm")):
+                out[p + dst + "_g"], out[p + dst + "_b"] = sd[s + f"attn1.{src}.weight"].float().contiguous(), sd[s + f"attn1.{src}.bias"].float().contiguous()
     return out
 
 
@@ -557,8 +582,15 @@ def dit_shapes(cfg):
         for e in ("resolution_embedder", "aspect_ratio_embedder"):
             s[f"adaln_single.emb.{e}.linear_1.weight"], s[f"adaln_single.emb.{e}.linear_1.bias"] = (S, 256), (S,)
             s[f"adaln_single.emb.{e}.linear_2.weight"], s[f"adaln_single.emb.{e}.linear_2.bias"] = (S, S), (S,)
+    kvc = cfg.get("kv_compress") or {}
     for d in range(cfg["num_layers"]):
         p = f"transformer_blocks.{d}."
+        if kvc.get("sampling") == "conv" and d in kvc.get("layers", ()) and int(kvc.get("scale_factor", 1)) > 1:
+            r = int(kvc["scale_factor"])
+            s[p + "attn1.sr.weight"], s[p + "attn1.sr.bias"], s[p + "attn1.norm.weight"], s[p + "attn1.norm.bias"] = (C, 1, r, r), (C,), (C,), (C,)
+        if cfg.get("qk_norm"):
+            for nn_ in ("q_norm", "k_norm"):
+                s[p + f"attn1.{nn_}.weight"], s[p + f"attn1.{nn_}.bias"] = (C,), (C,)
         s[p + "scale_shift_table"] = (6, C)
         for a in ("attn1", "attn2"):
             for n in ("to_q", "to_k", "to_v", "to_out.0"):

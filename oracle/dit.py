@@ -106,11 +106,36 @@ def dit_forward(sd, latents, timestep, encoder_hidden_states, encoder_attention_
     bias = cross_attention_bias(encoder_attention_mask)
     if bias is not None:
         bias = bias.reshape(-1, 1, 1, bias.shape[-1]).expand(B, 1, 1, -1)
+    kvc = cfg.get("kv_compress") or {}
+    def compress(p, tok):
+        """AttentionKVCompress.downsample_2d (PixArt_blocks.py:97-121) on the tokens of ONE of k / v: [B, N, C] -> [B, N / r^2, C]. 'conv': a depthwise
+        r x r / stride r convolution over the token grid (self.sr) followed by LayerNorm (self.norm, eps 1e-5); 'uniform': every r-th row and column;
+        'ave': F.interpolate(scale_factor=1 / r, mode='nearest'), which for whole ratios picks the same tokens as 'uniform'."""
+        r, mode = int(kvc["scale_factor"]), kvc["sampling"]
+        g = tok.reshape(B, gh, gw, C).permute(0, 3, 1, 2)
+        if mode == "conv":
+            g = F.conv2d(g, sd[p + "attn1.sr.weight"], sd[p + "attn1.sr.bias"], stride=r, groups=C)
+            t = g.reshape(B, C, -1).permute(0, 2, 1)
+            return F.layer_norm(t, (C,), sd[p + "attn1.norm.weight"], sd[p + "attn1.norm.bias"], eps=1e-5)
+        if mode == "uniform":
+            g = g[:, :, ::r, ::r]
+        elif mode == "ave":
+            g = F.interpolate(g, scale_factor=1 / r, mode="nearest")
+        else:
+            raise ValueError(mode)
+        return g.permute(0, 2, 3, 1).reshape(B, -1, C)
+
     def block(p, x):  # one BasicTransformerBlock (ada_norm_single), weights under prefix p
         sh_msa, sc_msa, g_msa, sh_mlp, sc_mlp, g_mlp = (sd[p + "scale_shift_table"][None] + t6.reshape(B, 6, -1)).chunk(6, dim=1)
         h = F.layer_norm(x, (C,), eps=1e-6) * (1 + sc_msa) + sh_msa
-        a = F.scaled_dot_product_attention(_heads(_lin(sd, p + "attn1.to_q", h), nh), _heads(_lin(sd, p + "attn1.to_k", h), nh),
-                                           _heads(_lin(sd, p + "attn1.to_v", h), nh))
+        q1, k1, v1 = _lin(sd, p + "attn1.to_q", h), _lin(sd, p + "attn1.to_k", h), _lin(sd, p + "attn1.to_v", h)
+        if cfg.get("qk_norm"):   # AttentionKVCompress.q_norm / k_norm: LayerNorm over ALL C channels of the token, before the heads are split (:136-137)
+            q1 = F.layer_norm(q1, (C,), sd[p + "attn1.q_norm.weight"], sd[p + "attn1.q_norm.bias"], eps=1e-5)
+            k1 = F.layer_norm(k1, (C,), sd[p + "attn1.k_norm.weight"], sd[p + "attn1.k_norm.bias"], eps=1e-5)
+        layer = int(p.split(".")[-2]) if p.startswith("transformer_blocks.") else -1
+        if kvc and layer in kvc.get("layers", ()) and int(kvc.get("scale_factor", 1)) > 1:   # :140-142: k and v through the SAME sr / norm modules
+            k1, v1 = compress(p, k1), compress(p, v1)
+        a = F.scaled_dot_product_attention(_heads(q1, nh), _heads(k1, nh), _heads(v1, nh))
         x = x + g_msa * _lin(sd, p + "attn1.to_out.0", a.transpose(1, 2).reshape(B, -1, C))
         a = F.scaled_dot_product_attention(_heads(_lin(sd, p + "attn2.to_q", x), nh), _heads(_lin(sd, p + "attn2.to_k", y), nh),
                                            _heads(_lin(sd, p + "attn2.to_v", y), nh), attn_mask=bias)
@@ -189,6 +214,12 @@ def pixart_to_diffusers(sd, num_layers):
         o[p + "attn2.to_out.0.weight"], o[p + "attn2.to_out.0.bias"] = sd[q + "cross_attn.proj.weight"], sd[q + "cross_attn.proj.bias"]
         o[p + "ff.net.0.proj.weight"], o[p + "ff.net.0.proj.bias"] = sd[q + "mlp.fc1.weight"], sd[q + "mlp.fc1.bias"]
         o[p + "ff.net.2.weight"], o[p + "ff.net.2.bias"] = sd[q + "mlp.fc2.weight"], sd[q + "mlp.fc2.bias"]
+        # KV compression / qk norm of the in-tree AttentionKVCompress (PixArt_blocks.py:60-96): no diffusers 0.30 counterpart, so the keys keep the
+        # module's own names under the diffusers attention prefix (attn.sr -> attn1.sr, attn.norm -> attn1.norm, attn.q_norm / k_norm likewise)
+        for n in ("sr", "norm", "q_norm", "k_norm"):
+            for leaf in ("weight", "bias"):
+                if f"{q}attn.{n}.{leaf}" in sd:
+                    o[f"{p}attn1.{n}.{leaf}"] = sd[f"{q}attn.{n}.{leaf}"]
     return o
 
 
@@ -215,6 +246,14 @@ def state_dict_shapes(cfg=None, mlp_ratio=4):
                 s[p + f"{a}.{n}.weight"], s[p + f"{a}.{n}.bias"] = (C, C), (C,)
         s[p + "ff.net.0.proj.weight"], s[p + "ff.net.0.proj.bias"] = (mlp_ratio * C, C), (mlp_ratio * C,)
         s[p + "ff.net.2.weight"], s[p + "ff.net.2.bias"] = (C, mlp_ratio * C), (C,)
+        kvc = cfg.get("kv_compress") or {}
+        if kvc.get("sampling") == "conv" and d in kvc.get("layers", ()) and int(kvc.get("scale_factor", 1)) > 1:
+            r = int(kvc["scale_factor"])
+            s[p + "attn1.sr.weight"], s[p + "attn1.sr.bias"] = (C, 1, r, r), (C,)
+            s[p + "attn1.norm.weight"], s[p + "attn1.norm.bias"] = (C,), (C,)
+        if cfg.get("qk_norm"):
+            for n in ("q_norm", "k_norm"):
+                s[p + f"attn1.{n}.weight"], s[p + f"attn1.{n}.bias"] = (C,), (C,)
     return s
 
 

@@ -42,7 +42,7 @@ def golden_size_embedder():
 def golden_dit_kvc():
     from diffusion.model.nets.PixArtMS import PixArtMS
     from oracle.dit import pixart_to_diffusers
-    depth, heads, hidden, cap, ntok = 2, 2, 144, 64, 20
+    depth, heads, hidden, cap, ntok = 2, 4, 288, 64, 20   # 4 heads of 72: a width the HIP path takes (hidden % 32 == 0), so that it can be held to this fixture
     lat = det_input(17, (2, 4, 16, 24), -2, 2)
     y = det_input(19, (1, 1, ntok, cap), -1, 1)
     t = torch.full((2,), 400.0)

@@ -129,6 +129,47 @@ def test_micro_conditioning_matches_the_reference_size_embedders():
         torch.testing.assert_close(odit.micro_condition(dsd, 2, h, w), fx["add_" + name], rtol=1e-5, atol=1e-6)
 
 
+KVC_VARIANTS = {   # name -> (kv_compress_config of the reference's PixArtMS, qk_norm)
+    "conv": ({"sampling": "conv", "scale_factor": 2, "kv_compress_layer": [1]}, False),
+    "uniform_qknorm": ({"sampling": "uniform", "scale_factor": 2, "kv_compress_layer": [0, 1]}, True),
+    "ave": ({"sampling": "ave", "scale_factor": 2, "kv_compress_layer": [0]}, False)}
+
+
+def _dit_kvc_small(name):
+    """The seeded in-tree state dict make_golden_r6.py::golden_dit_kvc built for variant `name`, its diffusers-keyed form and the oracle's config."""
+    depth, heads, hidden, cap = 2, 4, 288, 64
+    kvc, qkn = KVC_VARIANTS[name]
+    shapes = _pixart_shapes(depth, hidden, cap)
+    for d in range(depth):
+        q = f"blocks.{d}.attn."
+        if kvc["sampling"] == "conv" and d in kvc["kv_compress_layer"]:
+            shapes.update({q + "sr.weight": (hidden, 1, 2, 2), q + "sr.bias": (hidden,), q + "norm.weight": (hidden,), q + "norm.bias": (hidden,)})
+        if qkn:
+            shapes.update({q + "q_norm.weight": (hidden,), q + "q_norm.bias": (hidden,), q + "k_norm.weight": (hidden,), q + "k_norm.bias": (hidden,)})
+    sd = det_state_dict(shapes, seed=909)
+    for k in sd:
+        if k.endswith(("attn.norm.weight", "attn.q_norm.weight", "attn.k_norm.weight")):
+            sd[k] = sd[k] + 1.0
+    cfg = dict(num_layers=depth, num_attention_heads=heads, attention_head_dim=hidden // heads, sample_size=16, caption_channels=cap, qk_norm=qkn,
+               kv_compress=dict(sampling=kvc["sampling"], scale_factor=kvc["scale_factor"], layers=tuple(kvc["kv_compress_layer"])))
+    return sd, odit.pixart_to_diffusers(sd, depth), cfg
+
+
+def test_dit_kv_compression_and_qk_norm_match_the_reference():
+    """AttentionKVCompress (PixArt_blocks.py:60-158) inside the reference's PixArtMS: KV token compression by the depthwise 'conv' sampler + LayerNorm
+    in one block, by 'uniform' picking with LayerNorm on q and k (qk_norm) in both blocks, by 'ave' in the first block - the oracle against the
+    outputs of the imported model (dit_kvc_small.npz). VERDICT r05 missing 3."""
+    fx = load("dit_kvc_small.npz")
+    for name in KVC_VARIANTS:
+        sd, dsd, cfg = _dit_kvc_small(name)
+        assert abs(checksum(sd) - float(fx["wsum_" + name])) < 1e-6 * float(fx["wsum_" + name]), name
+        assert abs(checksum(dsd) - float(fx["wsum_diffusers_" + name])) < 1e-6 * float(fx["wsum_diffusers_" + name]), name
+        out = odit.dit_forward(dsd, fx["lat"], 400.0, fx["y"], None, cfg)
+        torch.testing.assert_close(out, fx["out_" + name], rtol=2e-4, atol=2e-5)
+        plain = odit.dit_forward(dsd, fx["lat"], 400.0, fx["y"], None, dict(cfg, kv_compress=None, qk_norm=False))
+        assert (out - plain).abs().max() > 1e-2, name   # the branch really changes the result in the fixture
+
+
 def test_dit_3d_mask_is_additive_not_dropping():
     """diffusers semantics the CLI triggers (inference.py:274-277): a [B,1,L] float mask is added to the logits."""
     fx = load("dit_small.npz")
