@@ -80,9 +80,14 @@ IR_DEVINL float fast_erf(float z) {
     return copysignf(e, z);
 }
 IR_DEVINL float gelu_erf(float x) { return 0.5f * x * (1.0f + fast_erf(x * 0.70710678118654752440f)); }
-IR_DEVINL float gelu_tanh(float x) {  // 0.5*(1 + tanh(u)) == sigmoid(2u)
-    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-    return x * fast_sigmoid(2.0f * k0 * (x + k1 * x * x * x));
+// tanh-GELU as x * rcp(1 + exp2(x * (c0 + c1 x^2))), c0 = -2 sqrt(2 / pi) log2(e), c1 = c0 * 0.044715: 0.5 (1 + tanh(u)) == sigmoid(2u), five full-rate
+// instructions and two transcendentals (round 6; before: nine and two). ONE definition for every kernel: which GEMM kernel runs a linear depends on its row
+// count (gemm_pp_kernel from 192 workgroups on), and a tile-sharded frame must not differ from the unsharded one in the last bit.
+// exp2 overflow (x << 0) gives rcp(inf) = 0 -> -0, underflow gives x.
+IR_DEVINL float gelu_tanh(float x) {
+    const float c0 = -2.0f * 0.7978845608028654f * 1.44269504088896340736f, c1 = c0 * 0.044715f;
+    const float t = __builtin_fmaf(x * x, c1, c0);
+    return x * fast_rcp(1.0f + __builtin_amdgcn_exp2f(x * t));
 }
 IR_DEVINL float silu(float x) { return x * fast_sigmoid(x); }
 

@@ -1167,17 +1167,13 @@ struct GemmPP {
 // are compile-time constants; -1: decided at run time, the generic form every other caller gets). Before, ONE kernel carried every activation in
 // every row phase behind run-time switches inside its unrolled loops: the two halves of the accumulator tile were selected per ELEMENT by a
 // v_cndmask (the half index stayed a loop variable) and each half branched over the activation codes. UNIT: no per-column gate and out_scale == 1
-// (the launcher checks), so the multiply behind the activation disappears. In every form the bias now rides in as the accumulators' initial
-// value (one add per element less in the epilogue), and the tanh-GELU is x * rcp(1 + exp2(x * (c0 + c1 x^2))): five full-rate instructions and
-// two transcendentals per element instead of nine and two.
+// (the launcher checks), so the multiply behind the activation disappears. The tanh-GELU is common.h's five-instruction form. (The bias stays an
+// add in the epilogue: started in the accumulators it saved one instruction per element, but bias + sum rounds differently from sum + bias, and the
+// 128 x 128 kernel that takes the same linear at smaller row counts adds it last - a tile-sharded frame then differed from the unsharded one by
+// up to 4 grey levels, tests/test_cli_gpu.py::test_tile_sharding_two_ranks_on_one_gpu.)
 #ifndef IR_GPP_KO
 #define IR_GPP_KO 0   // knock-outs of the fp32-residual row phase, timing only (results wrong by design; never set in the library): 1 no residual
 #endif                // read, 2 no bf16 copy, 3 no fp32 store
-IR_DEVINL float gelu_tanh_fused(float x) {   // == gelu_tanh(x) up to rounding; exp2 overflow (x << 0) gives rcp(inf) = 0 -> -0, underflow gives x
-    const float c0 = -2.0f * 0.7978845608028654f * 1.44269504088896340736f, c1 = c0 * 0.044715f;
-    const float t = __builtin_fmaf(x * x, c1, c0);
-    return x * fast_rcp(1.0f + __builtin_amdgcn_exp2f(x * t));
-}
 template <int ACT_T, int KIND_T, bool UNIT>
 __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(IGemmParams p) {
     typedef GemmPP G;
@@ -1248,13 +1244,10 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(IGemmParams p) {
         for (int j = 0; j < G::TN; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(gbase + sb * G::B_BYTES + j * 1024);
     };
     f32x4_t acc[G::TM][G::TN];
-    // the accumulators start at the bias of their column (lane l holds column 16 j + (l & 15) of its 144 for all four rows of a register quad)
 #pragma unroll
-    for (int j = 0; j < G::TN; ++j) {
-        const float b0 = p.bias ? p.bias[n0 + grp * 144 + j * 16 + (lane & 15)] : 0.f;
+    for (int i = 0; i < G::TM; ++i)
 #pragma unroll
-        for (int i = 0; i < G::TM; ++i) acc[i][j] = f32x4_t{b0, b0, b0, b0};
-    }
+        for (int j = 0; j < G::TN; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     // (Round 5 tried the GELU as packed fp32 pairs - v_pk_add / v_pk_mul / v_pk_fma - on the slab-write side: the fc1 launch alone 221 -> 210 us, but
     // at the kernel's 256-VGPR limit the pair form spilled 23 registers and every launch paid for the scratch set-up: profiles/r05_ab_gemm_pk_gelu.txt.)
 #ifndef IR_GKO
@@ -1320,14 +1313,19 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(IGemmParams p) {
     }
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- epilogue: v = act(acc) * out_scale * gate + res (the bias is in acc already), through a wave-private fp32 slab (two 16-row tiles =
+    // ---- epilogue: v = act(acc + bias) * out_scale * gate + res, through a wave-private fp32 slab (two 16-row tiles =
     // 32 x 144 at a time) so that residual reads and stores are row-contiguous 16-byte vectors. All loop reads were consumed before the last
     // barrier, so the slabs may overlay the ring.
     float* slab = reinterpret_cast<float*>(smem) + wu * (G::SLAB / 4);
     const int col = lane & 15, rq = lane >> 4;
     const int nw = n0 + grp * 144;          // first column of this wave
     const int act = ACT_T >= 0 ? ACT_T : p.act;
-    float cm[UNIT ? 1 : G::TN];
+    constexpr bool CB_REGS = ACT_T >= 0;   // the instantiated forms keep the nine bias values in registers; the run-time form (at its register limit) re-reads them
+    float cb[CB_REGS ? G::TN : 1], cm[UNIT ? 1 : G::TN];
+    if constexpr (CB_REGS) {
+#pragma unroll
+        for (int j = 0; j < G::TN; ++j) cb[j] = p.bias ? p.bias[nw + j * 16 + col] : 0.f;
+    }
     if constexpr (!UNIT) {
 #pragma unroll
         for (int j = 0; j < G::TN; ++j) cm[j] = p.out_scale * (p.gate ? p.gate[nw + j * 16 + col] : 1.f);
@@ -1340,10 +1338,10 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(IGemmParams p) {
             for (int j = 0; j < G::TN; ++j)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float a = acc[2 * HH + ii][j][q];
-                    float y;
-                    if constexpr (ACT == IR_ACT_GELU_TANH) y = gelu_tanh_fused(a);
-                    else y = apply_act<ACT>(a, p.slope);
+                    float bj;
+                    if constexpr (CB_REGS) bj = cb[j];
+                    else bj = p.bias ? p.bias[nw + j * 16 + col] : 0.f;
+                    float y = apply_act<ACT>(acc[2 * HH + ii][j][q] + bj, p.slope);
                     if constexpr (!UNIT) y *= cm[j];
                     slab[(ii * 16 + rq * 4 + q) * 144 + j * 16 + col] = y;
                 }
