@@ -49,7 +49,7 @@ def pmc_file_for_this_tree():
         if sha == cur:
             return f, None
         seen.append(f"{os.path.basename(f)} ({sha or 'no hash'})")
-    return None, f"no PMC file for kernel sources {cur}: {', '.join(seen[:2]) or 'none found'} - stale, refused; run tools/r05_evidence.sh"
+    return None, f"no PMC file for kernel sources {cur}: {', '.join(seen[:2]) or 'none found'} - stale, refused; run tools/r06_evidence.sh"
 
 
 # ---------------------------------------------------------------- algorithmic FLOP model (BASELINE.md section 2, 2*MAC, matmul/conv only)
