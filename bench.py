@@ -31,6 +31,10 @@ sys.path.insert(0, ROOT)
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA peak (/opt/skills/guides/MI355X_MICROARCH.md, chip-level table)
 PEAK_FP8_TFLOPS = 5000.0   # dense fp8 (MX-scaled f8f6f4 MFMA), same table
 PEAK_HBM_GBS = 8000.0
+# What a BARE bf16 MFMA loop on random operands delivers on this pool's chips once the card sits at its power-limited clock (tools/mfma_power_probe.hip,
+# profiles/r06_mfma_power_probe.txt: 1.70-1.72 PFLOP/s whatever the MFMA shape - 32x32x16 at 1.71 GHz, 16x16x32 at 2.12 GHz and a lower issue rate). NOT the
+# roofline's peak (that stays the guide's 2.5 PFLOP/s): a second yardstick in the line, `frac_of_power_limited_mfma`, for MFMA-bound bf16 kernels.
+POWER_LIMITED_BF16_TFLOPS = 1700.0
 
 
 def pmc_file_for_this_tree():
@@ -790,6 +794,10 @@ def main():
                     avg_launch_ms=round(d["ms"] / max(d["launches"], 1), 4), share_of_gpu_time=round(d["ms"] / total_ms, 3),
                     algorithmic_tflop_per_step=drow.get("tflop_per_step"),
                     algorithmic_bytes_per_launch=round(d["bytes"] / max(d["launches"], 1)))
+        if roof["bound"] == "mfma" and not args.fp8 and roof.get("achieved"):
+            roof["frac_of_power_limited_mfma"] = round(roof["achieved"] / POWER_LIMITED_BF16_TFLOPS, 4)
+            roof["power_limited_mfma_note"] = ("achieved / 1700 TFLOP/s = what a bare bf16 MFMA loop on random operands sustains on this pool's chips at the power-limited clock "
+                                                "(profiles/r06_mfma_power_probe.txt); `frac` stays on the guide's 2500 TFLOP/s peak")
         if dominant is not None:
             roof["timing"] = ("live: HIP events around this kernel's launches only, in the timed loop; per_kernel's other rows, per_class_ms and roofline_family come from a "
                               "second pass of the same steps with every launch bracketed")
