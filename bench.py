@@ -717,7 +717,14 @@ def main():
     # reader / writer threads; the rate is the child's own clock from the first read to the last closed PNG (model loading excluded)
     cli = None
     if world == 1 and args.cli_files > 0 and not (args.control or args.fp8 or args.tiled or args.net_hw) and (h, w, n) == (2048, 2048, 1):
+        # (the leg loads a second copy of the models in a child process and writes K PNGs + the artefacts to $TMPDIR - about 25-30 s and
+        # 3.5 GB of scratch disk, both released afterwards; the parent's workspace goes first, and a failure is said on stderr, not only inside the line)
+        ws = None
+        ctx._ws = None
+        torch.cuda.empty_cache()
         cli = cli_files_leg(args.cli_files, sds, value, log)
+        if cli.get("error"):
+            print(f"[bench] CLI LEG FAILED: {cli['error']} {cli.get('tail', '')[-400:]}", file=sys.stderr, flush=True)
 
     if rank == 0:
         fm = flops_model_tiled(h, w, tile_size, tile_stride, copies=args.control) if args.tiled else flops_model(h, w, copies=args.control)
