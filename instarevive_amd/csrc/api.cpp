@@ -346,6 +346,7 @@ struct Run {
     long vt_bs = 0;
     bool vt_done = false;
     bool splitk = false;         // conv() / linear() may split K over extra workgroups (IGemmParams::allow_splitk): set by the UNet path
+    int s1_min_tiles = 0;        // IGemmParams::s1_min_tiles of every conv this run launches: set by the ControlLDM pipeline (one small image per launch)
     bool live() const { return !a.dry && rc == 0 && !a.overflow; }
     void chk(int r, const char* w) {
         if (r != 0 && rc == 0) { rc = r; where = w; }
@@ -411,6 +412,7 @@ void conv(Run& r, const Conv& cw, const bf16_t* in, int N, int H, int W, int in_
     p.res = res; p.res_f32 = res_f32; p.res_cs = res_cs; p.res_mod = res_mod;
     p.out = out; p.out_f32 = out_f32; p.out_cs = out_cs; p.out2 = out2; p.out2_cs = out2_cs;
     size_t ks_mark = 0;
+    p.s1_min_tiles = r.s1_min_tiles;
     if (r.splitk) {   // small-M launches of the UNet path: K split over extra workgroups, partial sums in arena scratch (sized in dry runs too)
         p.allow_splitk = 1;
         if (const int ks = ir_igemm_splitk(p); ks > 1) {
@@ -474,6 +476,7 @@ bool norm_conv_fused(Run& r, const Norm& n, const Conv& cw, const bf16_t* x, flo
     p.Ho = H; p.Wo = W; p.M = N * H * W; p.wgt = cw.w; p.wgt_rs = 9L * cw.cin; p.Cout = cw.cout; p.Cout_pad = cw.cout_pad; p.bias = cw.b;
     p.act = ACT_NONE; p.out_scale = 1.f; p.rows_per_batch = 1 << 30; p.out = out; p.out_cs = cw.cout; p.res = res; p.res_cs = cw.cout;
     p.nrm_scale = ws; p.nrm_shift = ws + (long)N * cw.cin;
+    p.s1_min_tiles = r.s1_min_tiles;
     if (cw.taps != 9 || !ir_conv_s1_norm_takes(p)) return false;
     const int chunks = r.gn_chunks;
     r.gn_x = nullptr;
@@ -1441,6 +1444,9 @@ void cldm_pipeline_run(Run& r, const float* lq, const float* zT, float* samples,
                        float sf) {
     const size_t mk = r.a.mark();
     const int lh = h / 8, lw = w / 8;
+    static const int s1_min = getenv("IR_CLDM_S1_MIN_TILES") ? atoi(getenv("IR_CLDM_S1_MIN_TILES")) : 256;   // experiment knob (32: the DiT path's rule)
+    const int s1_before = r.s1_min_tiles;
+    r.s1_min_tiles = s1_min;   // this path runs single 512 x 512 images: the big-tile persistent conv only where it has a tile per CU
     float* control = control_out ? control_out : r.a.alloc<float>((long)n * 3 * h * w);
     const float* cimg = lq;
     if (!(flags & IR_FLAG_NO_PREPROCESS)) {
@@ -1455,6 +1461,7 @@ void cldm_pipeline_run(Run& r, const float* lq, const float* zT, float* samples,
     vae_decode_run(r, z, 1.f / sf, px, n, lh, lw);
     LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_nhwc_to_nchw(px, 4, samples, n, 3, (long)h * w, 0.5f, 0.5f, 0, r.s), "nhwc_to_nchw");
     r.a.release(mk);
+    r.s1_min_tiles = s1_before;
 }
 
 const float* dit_pos(ir_ctx* c, int gh, int gw, bool dry) {

@@ -581,9 +581,13 @@ bool ir_conv_s1_takes(const IGemmParams& p) {
     if (p.res && (p.res_f32 || p.res_mod > 0 || (p.res_cs & 7) || (reinterpret_cast<uintptr_t>(p.res) & 15))) return false;
     if ((p.out_cs & 7) || (reinterpret_cast<uintptr_t>(p.out) & 15)) return false;
     if (p.bias && (reinterpret_cast<uintptr_t>(p.bias) & 15)) return false;
-    // per IMAGE, not per launch: which kernel runs (and with it the summation order) must not depend on an image's batch neighbours
+    // per IMAGE, not per launch: which kernel runs (and with it the summation order) must not depend on an image's batch neighbours.
+    // 32: a 64 x 64 map at 512 channels and up - batched tiles (--tiled) fill the chip. A caller whose launches are never batched that way (the
+    // ControlLDM pipeline at 512 x 512) asks for one tile per CU instead (IGemmParams::s1_min_tiles = 256): below that the persistent 16 x 32 x 128
+    // tiles leave CUs idle and the 16 x 16 ping-pong kernel, with four times the workgroups, is faster - 64 x 64 x 512 -> 512 runs 80 us here
+    // against 54 us there, 128 x 128 x 512 -> 512 86 against 68 (256 x 256 x 256 -> 256, 256 tiles: 59 against 72); tools/bench_small.py vae.
     const long tiles = (long)((p.Ho + 15) / 16) * ((p.Wo + 31) / 32) * (p.Cout_pad / 128);
-    return tiles >= 32;   // a 64 x 64 map at 512 channels and up: batched tiles (--tiled) fill the chip; one such image is a single round either way
+    return tiles >= (p.s1_min_tiles > 32 ? p.s1_min_tiles : 32);
 }
 int ir_conv_s1_tiles(const IGemmParams& p) { return ((p.Ho + 15) / 16) * ((p.Wo + 31) / 32); }
 

@@ -237,8 +237,28 @@ IR_DEVINL void igemm_epilogue(const IGemmParams& p, f32x16 (&acc)[TM][TN], unsig
     }
 }
 
-template <int BM, int BN, int WM, int WN, int TAPS, int BK, bool M16 = false>
-__global__ __launch_bounds__(256, 2) void igemm_kernel(IGemmParams p) {
+// Block -> (row tile, column tile). Large launches: XCD-aware order - blocks b and b+8 share an XCD (and its L2); one XCD gets the n-tiles of the
+// same m-tile back to back so the A tile is re-read from that L2 (the grid is padded to a multiple of 8 row tiles; padding blocks exit). Speed
+// only, never correctness. SMALL launches (tile_grid: fewer than 64 row tiles, not a multiple of 8) get one block per tile in plain order: under
+// the XCD order a launch with MT row tiles uses min(MT, 8) of the 8 XCDs - the ControlLDM path's 8 x 8 and 16 x 16 levels (MT = 1, 2) ran on 32
+// and 64 of the 256 CUs.
+IR_DEVINL bool tile_of_block(int bid, int MT, int NT, int& mt, int& nt) {
+    if ((MT & 7) && (int)gridDim.x == MT * NT) {
+        mt = bid / NT;
+        nt = bid - mt * NT;
+        return true;
+    }
+    const int xcd = bid & 7, j = bid >> 3;
+    mt = (j / NT) * 8 + xcd;
+    nt = j % NT;
+    return mt < MT;
+}
+// NST: k-tiles resident in LDS (a ring of NST A | NST B slots). 2 is the form every large launch runs (two workgroups per CU cover each other's
+// waits). NST = 4 is for the SMALL launches of the ControlLDM path (a handful of row tiles, the reduction split over blockIdx.y: <= 2 workgroups per
+// CU): there every k-tile exposed the latency of its weight fetch (issued one 0.25 us tile earlier) - about 1 us per k-tile; with four tiles
+// resident the fetch of tile kt+3 is issued when tile kt retires. Same accumulation order, bit-identical results.
+template <int BM, int BN, int WM, int WN, int TAPS, int BK, bool M16 = false, int NST = 2>
+__global__ __launch_bounds__(256, NST == 2 ? 2 : 1) void igemm_kernel(IGemmParams p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int SP = BK / 8;            // 16-byte slots per tile row
     constexpr int ROWB = BK * 2;          // bytes per tile row in LDS (unpadded: LDS-DMA writes base + lane*16)
@@ -247,7 +267,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IGemmParams p) {
     constexpr int A_Q = BM / RPI, B_Q = BN / RPI;           // DMA instructions per A / B tile
     constexpr int A_I = (A_Q + 3) / 4, B_I = (B_Q + 3) / 4;  // per wave (instruction q = wave + 4*i)
     constexpr int COLS = TN * 32;
-    constexpr int LDS_AB = 2 * (BM + BN) * ROWB;
+    constexpr int LDS_AB = NST * (BM + BN) * ROWB;
+    static_assert(NST == 2 || (A_Q % 4 == 0 && B_Q % 4 == 0), "the ring's partial waits count A_I + B_I pieces per wave and tile");
     constexpr int LDS_EP = TM * 4 * 32 * COLS * 4;  // one wave-private fp32 slab per 32-row tile of every wave
     constexpr int LDS_BYTES = LDS_AB > LDS_EP ? LDS_AB : LDS_EP;
     __shared__ __attribute__((aligned(256))) unsigned char smem[LDS_BYTES];  // the ONLY LDS object of the kernel
@@ -265,10 +286,8 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IGemmParams p) {
     // same m-tile back to back so the A tile is re-read from that L2. Speed only, never correctness.
     const int NT = p.Cout_pad / BN;
     const int MT = (p.M + BM - 1) / BM;
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, j = bid >> 3;
-    const int mt = (j / NT) * 8 + xcd, nt = j % NT;
-    if (mt >= MT) return;
+    int mt, nt;
+    if (!tile_of_block(blockIdx.x, MT, NT, mt, nt)) return;
     const int m0 = mt * BM, n0 = nt * BN;
 
     const int cchunks = p.Cin / BK;
@@ -335,7 +354,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IGemmParams p) {
         for (int i = 0; i < B_I; ++i) {
             const int q = wu + 4 * i;
             if (B_Q % 4 == 0 || q < B_Q)
-                glds16(b_ptr[i], (lds_ptr_t)(smem + 2 * BM * ROWB + buf * BN * ROWB + q * RPI * ROWB));
+                glds16(b_ptr[i], (lds_ptr_t)(smem + NST * BM * ROWB + buf * BN * ROWB + q * RPI * ROWB));
             b_ptr[i] += BK;
         }
     };
@@ -358,7 +377,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IGemmParams p) {
 #pragma unroll
     for (int jn = 0; jn < TN; ++jn) {
         const int R = wn * (BN / WN) + jn * 32 + r;
-        fb_base[jn] = 2 * BM * ROWB + R * ROWB; fb_sw[jn] = (R / RB) % SP;
+        fb_base[jn] = NST * BM * ROWB + R * ROWB; fb_sw[jn] = (R / RB) % SP;
     }
 
     // Main loop. Two k-tiles are resident (double-buffered LDS) and the fragments are double-buffered in registers. Per k-step the
@@ -375,9 +394,23 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IGemmParams p) {
         for (int i = 0; i < A_I; ++i) a_ptr[i] += cc * BK;
     }
     stage(0);
-    if (KT > 1) { advance(); stage(1); }
-    wait_dma();
-    __syncthreads();  // both tiles landed and published to all waves
+#pragma unroll
+    for (int st = 1; st < NST; ++st)
+        if (KT > st) { advance(); stage(st); }
+    // ring form: wait until tile kt + 1 has landed while the younger tiles (at most NST - 2 of them, A_I + B_I pieces per wave each, in order) stay in flight
+    auto wait_younger = [&](int after) {   // returns when at most `after` of this wave's youngest tiles are still in flight
+        constexpr int PW = A_I + B_I;
+        if (NST == 2 || after <= 0) wait_dma();
+        else if (after == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
+        else if (after == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PW) : "memory");
+    };
+    // at the end of tile kt the tiles up to kt + NST - 1 have been issued; tile kt + 1 is needed, the younger ones may fly
+    auto wait_next = [&](int kt) { wait_younger(min(KT - 1, kt + NST - 1) - (kt + 1)); };
+    static_assert(NST == 2 || NST == 4, "wait_younger covers up to three younger tiles");
+    static_assert(3 * (A_I + B_I) < 64, "vmcnt is a 6-bit counter");
+    wait_younger(min(KT, NST) - 1);
+    __syncthreads();  // tile 0 (NST == 2: both tiles) landed and published to all waves
     if constexpr (M16) {
         // v_mfma_f32_16x16x32_bf16 form of the same loop (BK = 64 = two k-steps of 32): a 32-row tile is two 16-row fragments, lane l
         // holds row (l & 15) and the 8 k-values of 16-byte chunk 4*ks + (l >> 4). Same LDS image, same bytes read per FLOP, same
@@ -398,7 +431,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IGemmParams p) {
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
                 const int R = wn * (BN / WN) + jn * 32 + b * 16 + r16;
-                b_off[jn][b] = 2 * BM * ROWB + R * ROWB; b_swz[jn][b] = (R / RB) % SP;
+                b_off[jn][b] = NST * BM * ROWB + R * ROWB; b_swz[jn][b] = (R / RB) % SP;
             }
         f32x4_t c16[TM][TN][4];
 #pragma unroll
@@ -429,7 +462,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IGemmParams p) {
         };
         load16(0, 0, 0);
         for (int kt = 0; kt < KT; ++kt) {
-            const int cur = kt & 1;
+            const int cur = kt & (NST - 1), nxt = (kt + 1) & (NST - 1);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 __builtin_amdgcn_sched_barrier(0);
@@ -438,10 +471,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IGemmParams p) {
                 if (ks == 0) {
                     load16(cur, 1, 1);
                 } else {
-                    wait_dma();
+                    wait_next(kt);
                     __syncthreads();
-                    if (kt + 2 < KT) { advance(); stage(cur); }
-                    if (kt + 1 < KT) load16(cur ^ 1, 0, 0);
+                    if (kt + NST < KT) { advance(); stage(cur); }
+                    if (kt + 1 < KT) load16(nxt, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 mfma16s(ks, 2, TM * TN * 4);
@@ -478,7 +511,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IGemmParams p) {
     };
     load_frags(0, 0, 0);
     for (int kt = 0; kt < KT; ++kt) {
-        const int cur = kt & 1;
+        const int cur = kt & (NST - 1), nxt = (kt + 1) & (NST - 1);
 #pragma unroll
         for (int ks = 0; ks < NK; ++ks) {
             __builtin_amdgcn_sched_barrier(0);
@@ -487,10 +520,10 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IGemmParams p) {
             if (ks + 1 < NK) {
                 load_frags(cur, ks + 1, (ks + 1) & 1);
             } else {
-                wait_dma();
+                wait_next(kt);
                 __syncthreads();  // tile kt+1 has landed (issued a whole tile ago); every wave has read the last fragment of tile kt
-                if (kt + 2 < KT) { advance(); stage(cur); }
-                if (kt + 1 < KT) load_frags(cur ^ 1, 0, 0);
+                if (kt + NST < KT) { advance(); stage(cur); }
+                if (kt + 1 < KT) load_frags(nxt, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
             mfmas(ks & 1, 1, TM * TN);
@@ -548,10 +581,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo_kernel(IGemmParams p, int ti
 
     const int NT = p.Cout_pad / BN;
     const int MT = p.NB * tiles_y * tiles_x * (PH ? 4 : 1);
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, j = bid >> 3;
-    const int mt = (j / NT) * 8 + xcd, nt = j % NT;
-    if (mt >= MT) return;
+    int mt, nt;
+    if (!tile_of_block(blockIdx.x, MT, NT, mt, nt)) return;
     const int n0 = nt * BN;
     const int per_img = tiles_y * tiles_x * (PH ? 4 : 1);
     const int img = mt / per_img, trem_ph = mt - img * per_img;
@@ -878,10 +909,8 @@ __global__ __launch_bounds__(512, 1) void conv_halo_pp_kernel(IGemmParams p, int
 
     const int NT = p.Cout_pad / BN;
     const int MT = p.NB * tiles_y * tiles_x;
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, j = bid >> 3;
-    const int mt = (j / NT) * 8 + xcd, nt = j % NT;
-    if (mt >= MT) return;
+    int mt, nt;
+    if (!tile_of_block(blockIdx.x, MT, NT, mt, nt)) return;
     const int n0 = nt * BN;
     const int img = mt / (tiles_y * tiles_x), trem = mt - img * tiles_y * tiles_x;
     const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
@@ -1506,6 +1535,12 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(IGemmParams p) {
 
 int g_ir_plain_kernels = 0;
 
+// Grid of a tiled launch (see tile_of_block): one block per tile for small launches, the XCD-padded order otherwise. IR_NO_TILE_LIN: experiment knob.
+static long tile_grid(long MT, long NT) {
+    static const bool no_lin = getenv("IR_NO_TILE_LIN") != nullptr;
+    return ((MT & 7) && MT < 64 && !no_lin) ? MT * NT : ((MT + 7) / 8) * 8 * NT;
+}
+
 // Shortest reduction gemm_pp_kernel takes: 8 k-tiles. (Its prologue needs 4; with the limit at 6 SwinIR's qkv projection - K = 192, N = 576 =
 // 2 x 288 - runs here: measured in round 4 at 36 us per launch, exactly what igemm_kernel<128, 64> needs for it: no gain, limit left at 8.
 // IR_GEMM_PP_MIN_K: experiment knob.)
@@ -1550,7 +1585,7 @@ static int launch_gemm_pp(const IGemmParams& p, hipStream_t s) {
 static int launch_halo_pp(const IGemmParams& p, hipStream_t s) {
     const int tiles_y = (p.Ho + 15) / 16, tiles_x = (p.Wo + 15) / 16;
     const long MT = (long)p.NB * tiles_y * tiles_x, NT = p.Cout_pad / 128;
-    const long grid = ((MT + 7) / 8) * 8 * NT;
+    const long grid = tile_grid(MT, NT);
     if (grid > 0x7fffffffL) return -12;
     static const bool m16 = getenv("IR_NO_MFMA16") == nullptr;  // 16x16x32 MFMA form by default (knob: A/B against 32x32x16)
     if (m16 && p.up) hipLaunchKernelGGL((conv_halo_pp_kernel<1, true>), dim3((unsigned)grid), dim3(512), 0, s, p, tiles_y, tiles_x);
@@ -1564,7 +1599,7 @@ template <int BN>
 static int launch_halo(const IGemmParams& p, hipStream_t s) {
     const int tiles_y = (p.Ho + 7) / 8, tiles_x = (p.Wo + 15) / 16;
     const long MT = (long)p.NB * tiles_y * tiles_x, NT = p.Cout_pad / BN;
-    const long grid = ((MT + 7) / 8) * 8 * NT;
+    const long grid = tile_grid(MT, NT);
     if (grid > 0x7fffffffL) return -12;
     if (p.fp8) {
         if (p.up) hipLaunchKernelGGL((conv_halo_kernel<BN, 1, false, true>), dim3((unsigned)grid), dim3(256), 0, s, p, tiles_y, tiles_x);
@@ -1592,7 +1627,7 @@ static int launch_halo_up2x2(const IGemmParams& pin, hipStream_t s) {
     if (p.wgt_rs != 4L * p.Cin) return -3;
     const int tiles_y = (p.H + 7) / 8, tiles_x = (p.W + 15) / 16;
     const long MT = (long)p.NB * 4 * tiles_y * tiles_x, NT = p.Cout_pad / (p.Cout_pad % 128 == 0 ? 128 : 64);
-    const long grid = ((MT + 7) / 8) * 8 * NT;
+    const long grid = tile_grid(MT, NT);
     if (grid > 0x7fffffffL) return -12;
     if (p.Cout_pad % 128 == 0) hipLaunchKernelGGL((conv_halo_kernel<128, 0, true, false, true>), dim3((unsigned)grid), dim3(256), 0, s, p, tiles_y, tiles_x);
     else hipLaunchKernelGGL((conv_halo_kernel<64, 0, true, false, true>), dim3((unsigned)grid), dim3(256), 0, s, p, tiles_y, tiles_x);
@@ -1641,7 +1676,7 @@ int ir_igemm_splitk(const IGemmParams& p) {
     // experiment knobs (defaults = the shipped heuristic): most tiles a split launch may have, fewest k-tiles it must have, workgroups aimed at,
     // fewest k-tiles per split
     static const int max_tiles = getenv("IR_SPLITK_TILES") ? atoi(getenv("IR_SPLITK_TILES")) : 48, min_kt = getenv("IR_SPLITK_KT") ? atoi(getenv("IR_SPLITK_KT")) : 24;
-    static const int target = getenv("IR_SPLITK_TARGET") ? atoi(getenv("IR_SPLITK_TARGET")) : 384, per_min = getenv("IR_SPLITK_PER") ? atoi(getenv("IR_SPLITK_PER")) : 6;
+    static const int target = getenv("IR_SPLITK_TARGET") ? atoi(getenv("IR_SPLITK_TARGET")) : 256, per_min = getenv("IR_SPLITK_PER") ? atoi(getenv("IR_SPLITK_PER")) : 8;
     if (tiles > max_tiles || KT < min_kt) return 0;
     int ks = std::min(target / tiles, KT / std::max(per_min, 1));
     if (ks < 2) return 0;
@@ -1653,7 +1688,7 @@ template <int BM, int BN, int WM, int WN>
 static int launch_cfg(const IGemmParams& pin, hipStream_t s) {
     IGemmParams p = pin;
     const int MT = (p.M + BM - 1) / BM, NT = p.Cout_pad / BN;
-    const int tiles = ((MT + 7) / 8) * 8 * NT;
+    const int tiles = (int)tile_grid(MT, NT);
     const int ks = p.ks_ws ? ir_igemm_splitk(pin) : 0;
     const dim3 grid(tiles, ks > 1 ? ks : 1);
     if (ks > 1) {   // partial tiles into the workspace; bias / activation / residual in splitk_finish_kernel
@@ -1666,7 +1701,15 @@ static int launch_cfg(const IGemmParams& pin, hipStream_t s) {
     }
     static const bool force32 = getenv("IR_IGEMM_BK32") != nullptr;  // experiment knob
     const bool k64 = (p.Cin & 63) == 0 && !force32;
-    if (p.taps == 9) {
+    // the four-tile ring (igemm_kernel's NST): launches of at most one workgroup per CU with at least eight k-tiles per workgroup (with more
+    // workgroups the two-tile form's second workgroup per CU covers the waits better: 16384 x 640 -> 5120 at M = 1024 ran 17 against 25 us)
+    static const int ring_max = getenv("IR_IGEMM_RING_MAX") ? atoi(getenv("IR_IGEMM_RING_MAX")) : 256;   // experiment knob (0: never)
+    static const bool m16r = getenv("IR_NO_MFMA16") == nullptr;
+    const int kt_all = p.taps * (p.Cin / 64), kt_per = ks > 1 ? (kt_all + ks - 1) / ks : kt_all;
+    if (k64 && m16r && !g_ir_plain_kernels && (long)tiles * (ks > 1 ? ks : 1) <= ring_max && kt_per >= 8) {
+        if (p.taps == 9) hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, 9, 64, true, 4>), dim3(grid), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, 1, 64, true, 4>), dim3(grid), dim3(256), 0, s, p);
+    } else if (p.taps == 9) {
         static const bool m16t = getenv("IR_NO_MFMA16") == nullptr;
         if (k64 && m16t) hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, 9, 64, true>), dim3(grid), dim3(256), 0, s, p);
         else if (k64) hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, 9, 64>), dim3(grid), dim3(256), 0, s, p);

@@ -50,6 +50,7 @@ struct IGemmParams {
     // floats of scratch); ksplit is set by the launcher. Each split stores its partial tile in its own slice; a second kernel adds the
     // slices in order and applies the epilogue (deterministic).
     int allow_splitk, ksplit;
+    int s1_min_tiles;   // > 32: conv_halo_s1_kernel only takes images with at least that many patch tiles (callers that never batch small images)
     float* ks_ws;
     // Optional second, TRANSPOSED copy of the output columns >= vt_col0 (gemm_pp_kernel's bf16 form only; M % 256 == 0, vt_T % 64 == 0): column
     // vt_col0 + head * vt_hd + d of row m = batch * vt_T + t goes to vt_out[batch * vt_bs + (head * vt_dv + d) * vt_ld + t] - the V^T operand of

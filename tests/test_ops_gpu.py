@@ -723,6 +723,16 @@ def test_conv_splitk(ctx, n, h, w, cin, cout, taps, res):
         outs.append(out)
     assert (splits.value > 1) == (h < 64), f"split count {splits.value}"
     assert torch.equal(outs[0], outs[1]), "split-K must be deterministic"
+    # the four-tile ring these small launches take (igemm_kernel's NST = 4) accumulates in the order of the two-tile form: plain-kernel mode runs that
+    ctx.check(ctx.lib.ir_set_plain_kernels(ctx.h, 1), "plain on")
+    try:
+        out2 = torch.empty(n, h, w, cout, dtype=torch.int16, device="cuda")
+        ctx.check(ctx.lib.ir_op_conv_splitk(ctx.h, ctx.stream(), P(xin), P(wp), P(b.cuda()), P(out2), n, h, w, cin, cout, taps, L.ACT_SILU, P(rd), 1, 0,
+                                            P(ws), ws.numel(), ctypes.byref(splits)), "conv_splitk plain")
+        torch.cuda.synchronize()
+    finally:
+        ctx.check(ctx.lib.ir_set_plain_kernels(ctx.h, 0), "plain off")
+    assert torch.equal(outs[0], out2), "ring form and two-tile form must agree bit for bit"
     close(L.from_bf16_bits(outs[0]).cpu().permute(0, 3, 1, 2), ref, 2 ** -7, 4e-3, f"conv split-K x{splits.value}")
 
 

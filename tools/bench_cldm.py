@@ -64,6 +64,15 @@ def main():
     ap.add_argument("--verify", action="store_true", help="compare the last output with the fp32 CPU oracle")
     ap.add_argument("--graph", action="store_true", help="replay the step as one hipGraph (IR_FLAG_GRAPH); no per-kernel rows")
     args = ap.parse_args()
+    # clock / power trace (tools/power_sampler.py: a child that only reads sysfs), started before this process's first GPU call
+    import subprocess
+    import tempfile
+    sampler_file = os.path.join(tempfile.gettempdir(), f"ir_power_cldm_{os.getpid()}.txt")
+    try:
+        sampler = subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "power_sampler.py"), "--out", sampler_file, "--card", "0"], stdin=subprocess.PIPE,
+                                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    except OSError:
+        sampler = None
     if not torch.cuda.is_available():
         raise SystemExit("bench_cldm.py needs an MI355X GPU; the product path has no CPU fallback")
     device = torch.device("cuda", 0)
@@ -94,11 +103,25 @@ def main():
     torch.cuda.synchronize()
     if not args.graph:
         ctx.profile_begin()
+    wall0 = time.time()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
+    power = None
+    if sampler is not None:
+        from tools.power_sampler import summarise
+        time.sleep(0.05)
+        power = summarise(sampler_file, wall0, wall0 + dt * args.steps)
+        try:
+            sampler.stdin.close()
+            sampler.wait(timeout=2)
+        except Exception:
+            pass
+        if power is not None:
+            log(f"timed loop: gfx clock {power.get('clock_mhz')} MHz (min {power.get('clock_mhz_min')}, max {power.get('clock_mhz_max')}), socket power "
+                f"{power.get('power_w')} W, {power.get('samples')} samples")
     kprof = ctx.profile_end_kernels() if not args.graph else {}
     total_ms = sum(v["ms"] for v in kprof.values())
     flops = sum(v["flops"] for v in kprof.values()) / args.steps
@@ -143,7 +166,8 @@ def main():
             "config": {"workload": f"{h}x{w} LQ -> SwinIR -> condition encoder -> ControlNet + SD-2.1 UNet (t=999, 77x1024 context) -> decoder, batch {n}",
                        "weights": "seeded random, configs/cldm.yaml widths"},
             "algorithmic_tflop_per_step": round(flops / 1e12, 3), "path_tflops": round(flops / dt / 1e12, 1),
-            "roofline": dict(per_kernel[dom], kernel=dom, per_kernel=per_kernel) if dom else None, "graph": bool(args.graph)}
+            "roofline": dict(per_kernel[dom], kernel=dom, per_kernel=per_kernel) if dom else None, "graph": bool(args.graph),
+            "clock_mhz": power.get("clock_mhz") if power else None, "power_w": power.get("power_w") if power else None}
     if verify:
         line.update(verify)
     print(json.dumps(line), flush=True)

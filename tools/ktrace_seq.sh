@@ -17,7 +17,7 @@ def short(n):
     return n.replace("void ", "")
 # the last pass: from the last u8_to_nchw / swin_prep dispatch on
 names = [short(r["Kernel_Name"]) for r in rows]
-starts = [i for i, n in enumerate(names) if n.startswith("vae_conv_in_kernel")]
+starts = [i for i, n in enumerate(names) if n.startswith(__import__("os").environ.get("KTS_ANCHOR", "vae_conv_in_kernel"))]
 i0 = starts[-1] if starts else 0
 # back up to the beginning of that image's SwinIR stage (first dispatch after the previous image's last kernel is unknowable: take 700 before)
 with open(sys.argv[2], "w") as f:
