@@ -258,18 +258,20 @@ IR_DEVINL bool tile_of_block(int bid, int MT, int NT, int& mt, int& nt) {
 // CU): there every k-tile exposed the latency of its weight fetch (issued one 0.25 us tile earlier) - about 1 us per k-tile; with four tiles
 // resident the fetch of tile kt+3 is issued when tile kt retires. Same accumulation order, bit-identical results.
 template <int BM, int BN, int WM, int WN, int TAPS, int BK, bool M16 = false, int NST = 2>
-__global__ __launch_bounds__(256, NST == 2 ? 2 : 1) void igemm_kernel(IGemmParams p) {
+__global__ __launch_bounds__(64 * WM * WN, NST == 2 ? 2 : 1) void igemm_kernel(IGemmParams p) {
+    constexpr int NW = WM * WN;   // waves per workgroup: 4, or 8 for the small-launch form (two waves per SIMD, see launch_cfg)
+    static_assert(NW == 4 || NW == 8, "four or eight waves");
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int SP = BK / 8;            // 16-byte slots per tile row
     constexpr int ROWB = BK * 2;          // bytes per tile row in LDS (unpadded: LDS-DMA writes base + lane*16)
     constexpr int RB = 256 / ROWB;        // tile rows per 256-byte LDS bank row
     constexpr int RPI = 64 / SP;          // tile rows written by one wave-wide LDS-DMA instruction
     constexpr int A_Q = BM / RPI, B_Q = BN / RPI;           // DMA instructions per A / B tile
-    constexpr int A_I = (A_Q + 3) / 4, B_I = (B_Q + 3) / 4;  // per wave (instruction q = wave + 4*i)
+    constexpr int A_I = (A_Q + NW - 1) / NW, B_I = (B_Q + NW - 1) / NW;  // per wave (instruction q = wave + NW*i)
     constexpr int COLS = TN * 32;
     constexpr int LDS_AB = NST * (BM + BN) * ROWB;
-    static_assert(NST == 2 || (A_Q % 4 == 0 && B_Q % 4 == 0), "the ring's partial waits count A_I + B_I pieces per wave and tile");
-    constexpr int LDS_EP = TM * 4 * 32 * COLS * 4;  // one wave-private fp32 slab per 32-row tile of every wave
+    static_assert(NST == 2 || (A_Q % NW == 0 && B_Q % NW == 0), "the ring's partial waits count A_I + B_I pieces per wave and tile");
+    constexpr int LDS_EP = TM * NW * 32 * COLS * 4;  // one wave-private fp32 slab per 32-row tile of every wave
     constexpr int LDS_BYTES = LDS_AB > LDS_EP ? LDS_AB : LDS_EP;
     __shared__ __attribute__((aligned(256))) unsigned char smem[LDS_BYTES];  // the ONLY LDS object of the kernel
     // layout: A[0] | A[1] | B[0] | B[1]; element (row, 16-byte chunk c) of a tile lives at row*ROWB + ((c ^ swz(row)) * 16),
@@ -309,7 +311,7 @@ __global__ __launch_bounds__(256, NST == 2 ? 2 : 1) void igemm_kernel(IGemmParam
     int a_n[A_I], a_oy[A_I], a_ox[A_I], a_sw[A_I];
 #pragma unroll
     for (int i = 0; i < A_I; ++i) {
-        const int row = min((wid + 4 * i) * RPI + lrow, BM - 1);
+        const int row = min((wid + NW * i) * RPI + lrow, BM - 1);
         const int m = min(m0 + row, p.M - 1);
         a_sw[i] = (lslot ^ ((row / RB) % SP)) * 8;
         if (TAPS == 1) {
@@ -338,22 +340,22 @@ __global__ __launch_bounds__(256, NST == 2 ? 2 : 1) void igemm_kernel(IGemmParam
     const bf16_t* b_ptr[B_I];
 #pragma unroll
     for (int i = 0; i < B_I; ++i) {
-        const int row = min((wid + 4 * i) * RPI + lrow, BN - 1);
+        const int row = min((wid + NW * i) * RPI + lrow, BN - 1);
         b_ptr[i] = p.wgt + (long)(n0 + row) * p.wgt_rs + (lslot ^ ((row / RB) % SP)) * 8 + (long)kbeg * BK;
     }
     int cc = TAPS > 1 ? kbeg % cchunks : 0, tap = TAPS > 1 ? kbeg / cchunks : 0;
     auto stage = [&](int buf) {  // asynchronous global -> LDS copy of the k-tile the pointers address; then advance them
 #pragma unroll
         for (int i = 0; i < A_I; ++i) {
-            const int q = wu + 4 * i;
-            if (A_Q % 4 == 0 || q < A_Q)
+            const int q = wu + NW * i;
+            if (A_Q % NW == 0 || q < A_Q)
                 glds16(a_ptr[i], (lds_ptr_t)(smem + buf * BM * ROWB + q * RPI * ROWB));
             a_ptr[i] += BK;
         }
 #pragma unroll
         for (int i = 0; i < B_I; ++i) {
-            const int q = wu + 4 * i;
-            if (B_Q % 4 == 0 || q < B_Q)
+            const int q = wu + NW * i;
+            if (B_Q % NW == 0 || q < B_Q)
                 glds16(b_ptr[i], (lds_ptr_t)(smem + NST * BM * ROWB + buf * BN * ROWB + q * RPI * ROWB));
             b_ptr[i] += BK;
         }
@@ -488,7 +490,7 @@ __global__ __launch_bounds__(256, NST == 2 ? 2 : 1) void igemm_kernel(IGemmParam
 #pragma unroll
                 for (int g = 0; g < 16; ++g) acc[i][jn][g] = c16[i][jn][g >> 2][g & 3];
         const int gn_hw16 = !p.gn_part ? 1 : (p.taps == 9 ? p.Ho * p.Wo : p.M / p.NB);
-        igemm_epilogue<TM, TN, WN, 4, true>(p, acc, smem, wid, lane, n0 + wn * (BN / WN), n0, m0 / gn_hw16, (m0 % gn_hw16) / BM, [&](int i, int row) {
+        igemm_epilogue<TM, TN, WN, NW, true>(p, acc, smem, wid, lane, n0 + wn * (BN / WN), n0, m0 / gn_hw16, (m0 % gn_hw16) / BM, [&](int i, int row) {
             const int m = m0 + wm * (BM / WM) + i * 32 + row;
             return m < p.M ? m : -1;
         });
@@ -532,7 +534,7 @@ __global__ __launch_bounds__(256, NST == 2 ? 2 : 1) void igemm_kernel(IGemmParam
     __builtin_amdgcn_sched_barrier(0);
 
     const int gn_hw = !p.gn_part ? 1 : (p.taps == 9 ? p.Ho * p.Wo : p.M / p.NB);  // rows per image (fused GroupNorm statistics only)
-    igemm_epilogue<TM, TN, WN>(p, acc, smem, wid, lane, n0 + wn * (BN / WN), n0, m0 / gn_hw, (m0 % gn_hw) / BM, [&](int i, int row) {
+    igemm_epilogue<TM, TN, WN, NW>(p, acc, smem, wid, lane, n0 + wn * (BN / WN), n0, m0 / gn_hw, (m0 % gn_hw) / BM, [&](int i, int row) {
         const int m = m0 + wm * (BM / WM) + i * 32 + row;
         return m < p.M ? m : -1;
     });
@@ -1707,6 +1709,17 @@ static int launch_cfg(const IGemmParams& pin, hipStream_t s) {
     static const bool m16r = getenv("IR_NO_MFMA16") == nullptr;
     const int kt_all = p.taps * (p.Cin / 64), kt_per = ks > 1 ? (kt_all + ks - 1) / ks : kt_all;
     if (k64 && m16r && !g_ir_plain_kernels && (long)tiles * (ks > 1 ? ks : 1) <= ring_max && kt_per >= 8) {
+        // ... and with EIGHT waves (two per SIMD, each a 32-row slice of the tile) where the tile is 2 x 2 waves: alone on its SIMD a wave pays the
+        // issue of its LDS-DMA pieces (about 64 cycles each, 8 per k-tile = as long as its 32 MFMAs) with the matrix pipe idle; the second wave's
+        // MFMAs run under them. Not with fused GroupNorm statistics (their block reduction sums per wave row: another order).
+        static const bool no_w8 = getenv("IR_IGEMM_NO_W8") != nullptr;   // experiment knob
+        if constexpr (WM == 2 && WN == 2) {
+            if (!no_w8 && !p.gn_part) {
+                if (p.taps == 9) hipLaunchKernelGGL((igemm_kernel<BM, BN, 4, 2, 9, 64, true, 4>), dim3(grid), dim3(512), 0, s, p);
+                else hipLaunchKernelGGL((igemm_kernel<BM, BN, 4, 2, 1, 64, true, 4>), dim3(grid), dim3(512), 0, s, p);
+                goto launched;
+            }
+        }
         if (p.taps == 9) hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, 9, 64, true, 4>), dim3(grid), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, 1, 64, true, 4>), dim3(grid), dim3(256), 0, s, p);
     } else if (p.taps == 9) {
@@ -1720,6 +1733,7 @@ static int launch_cfg(const IGemmParams& pin, hipStream_t s) {
         else if (k64) hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, 1, 64>), dim3(grid), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, 1, 32>), dim3(grid), dim3(256), 0, s, p);
     }
+launched:
     if (ks > 1) {
         const long nv = (long)pin.M * (pin.Cout_pad / 4);
         const unsigned fg = (unsigned)std::min<long>((nv + 255) / 256, 4096);

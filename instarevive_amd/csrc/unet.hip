@@ -94,6 +94,51 @@ __global__ __launch_bounds__(256) void gn_any_apply_kernel(const bf16_t* __restr
     }
 }
 
+// ---- stages 2 + 3 in one launch (round 6: the ControlLDM step is bound by its launch count - 61 of these per step): every workgroup finalises the
+// statistics of all N x G groups itself (a few hundred partials, the arithmetic of gn_any_finalize_kernel in the same order) and applies. The
+// per-channel scale / shift are formed per element with the expressions of stage 2, so the result is that of the three-launch form bit for bit.
+constexpr int GN_ANY_MAX_GROUPS = 2048;
+__global__ __launch_bounds__(256) void gn_any_finalize_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, const float* __restrict__ part,
+                                                                    const float* __restrict__ gamma, const float* __restrict__ beta, long HW, int C, int cpg,
+                                                                    int chunks, int NG, float eps, int do_silu, long total_vec) {
+    __shared__ float mean_s[GN_ANY_MAX_GROUPS], rstd_s[GN_ANY_MAX_GROUPS];
+    for (int i = threadIdx.x; i < NG; i += 256) {
+        const float* p = part + (long)i * chunks * 2;
+        double s = 0.0, q = 0.0;
+        for (int k = 0; k < chunks; ++k) { s += p[2 * k]; q += p[2 * k + 1]; }
+        const double cnt = (double)HW * cpg, m = s / cnt;
+        double var = q / cnt - m * m;
+        if (var < 0.0) var = 0.0;
+        mean_s[i] = (float)m;
+        rstd_s[i] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    const int vpp = C >> 3, G = C / cpg;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total_vec; i += (long)gridDim.x * 256) {
+        const long pix = i / vpp;
+        const int c0 = (int)(i - pix * vpp) * 8;
+        const int n = (int)(pix / HW);
+        const uint4 u = *reinterpret_cast<const uint4*>(x + pix * C + c0);
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + c0), g1 = *reinterpret_cast<const f32x4*>(gamma + c0 + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + c0), b1 = *reinterpret_cast<const f32x4*>(beta + c0 + 4);
+        float v[8] = {bflo(u.x), bfhi(u.x), bflo(u.y), bfhi(u.y), bflo(u.z), bfhi(u.z), bflo(u.w), bfhi(u.w)};
+        int g = c0 / cpg, rem = c0 - g * cpg;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float ga = j < 4 ? g0[j & 3] : g1[j & 3], be = j < 4 ? b0[j & 3] : b1[j & 3];
+            const float sc = ga * rstd_s[n * G + g];
+            const float sh = be - mean_s[n * G + g] * sc;
+            v[j] = v[j] * sc + sh;
+            if (++rem == cpg) { rem = 0; ++g; }
+        }
+        if (do_silu) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = silu(v[j]);
+        }
+        *reinterpret_cast<uint4*>(y + pix * C + c0) = make_uint4(pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7]));
+    }
+}
+
 // ---- GEGLU: out[r][c] = ag[r][c] * gelu_erf(ag[r][F + c]); ag: [rows][2F] bf16 (value half | gate half), out: [rows][F]
 __global__ __launch_bounds__(256) void geglu_kernel(const bf16_t* __restrict__ ag, bf16_t* __restrict__ out, long rows, int F) {
     const int vpr = F >> 3;
@@ -180,8 +225,13 @@ int ir_launch_groupnorm_any(const bf16_t* x, bf16_t* y, const float* gamma, cons
     float* scale = ws + (long)N * G * chunks * 2;   // [N][C]
     float* shift = scale + (long)N * C;             // [N][C]
     hipLaunchKernelGGL(gn_any_partial_kernel, dim3(chunks, G, N), dim3(256), 0, s, x, part, HW, C, cpg, chunks, ppc);
-    hipLaunchKernelGGL(gn_any_finalize_kernel, dim3(N), dim3(256), 0, s, part, gamma, beta, scale, shift, HW, C, cpg, chunks, eps);
     const long nv = (long)N * HW * (C / 8);
+    static const bool three = getenv("IR_GN_ANY_3") != nullptr;   // experiment knob: finalise as a launch of its own
+    if (!three && (long)N * G <= GN_ANY_MAX_GROUPS && !(reinterpret_cast<uintptr_t>(gamma) & 15) && !(reinterpret_cast<uintptr_t>(beta) & 15)) {
+        hipLaunchKernelGGL(gn_any_finalize_apply_kernel, dim3(grid1d(nv)), dim3(256), 0, s, x, y, part, gamma, beta, HW, C, cpg, chunks, N * G, eps, do_silu, nv);
+        return LAUNCH_OK();
+    }
+    hipLaunchKernelGGL(gn_any_finalize_kernel, dim3(N), dim3(256), 0, s, part, gamma, beta, scale, shift, HW, C, cpg, chunks, eps);
     hipLaunchKernelGGL(gn_any_apply_kernel, dim3(grid1d(nv)), dim3(256), 0, s, x, y, scale, shift, HW, C, do_silu, nv);
     return LAUNCH_OK();
 }
