@@ -1191,6 +1191,8 @@ struct GemmPP {
     static constexpr int RING = B_BASE + NSB * B_BYTES;                   // 155648
     static constexpr int TM = 4, TN = 9;                                  // 16 x 16 tiles per wave
     static constexpr int SLAB = 32 * 144 * 4;                             // epilogue: two 16-row tiles of a wave at a time (fp32)
+    static constexpr int PF_OFF = RING;                                   // (-DIR_GPP_PF builds only) 1 KB nobody reads: landing area of the A operand's prefetch touches
+    static constexpr int LDS_PF = RING + 1024 > 8 * SLAB ? RING + 1024 : 8 * SLAB;
     static constexpr int LDS = RING > 8 * SLAB ? RING : 8 * SLAB;
 };
 
@@ -1202,6 +1204,14 @@ struct GemmPP {
 // add in the epilogue: started in the accumulators it saved one instruction per element, but bias + sum rounds differently from sum + bias, and the
 // 128 x 128 kernel that takes the same linear at smaller row counts adds it last - a tile-sharded frame then differed from the unsharded one by
 // up to 4 grey levels, tests/test_cli_gpu.py::test_tile_sharding_two_ranks_on_one_gpu.)
+// Experiment knob (-DIR_GPP_PF=d, d > 0; never set in the library): every A-issuing wave also touches, per k-tile, the rows of its four pieces d
+// k-tiles AHEAD of the tile it stages (one LDS-DMA piece of 64 rows x 16 B into a landing area nobody reads), to turn the A fetch - a miss for all
+// four column-tile workgroups of a row tile, which run in lockstep on one XCD - into an L2 hit. Measured SLOWER whatever d (2, 4, 8): the kernel
+// 17.4 -> 19.6 ms per image, every shape -12 to -16 % (profiles/r06_ab_gemm_l2_prefetch.txt). One more piece per four is +12 % of the bytes this
+// loop moves through LDS-DMA and it costs +13 %: the loop's time follows the LDS-DMA volume (34 KB per k-tile and CU), not the A operand's latency.
+#ifndef IR_GPP_PF
+#define IR_GPP_PF 0
+#endif
 #ifndef IR_GPP_KO
 #define IR_GPP_KO 0   // knock-outs of the fp32-residual row phase, timing only (results wrong by design; never set in the library): 1 no residual
 #endif                // read, 2 no bf16 copy, 3 no fp32 store
@@ -1209,7 +1219,7 @@ template <int ACT_T, int KIND_T, bool UNIT>
 __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(IGemmParams p) {
     typedef GemmPP G;
     typedef __attribute__((ext_vector_type(4))) float f32x4_t;
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[G::LDS];  // the ONLY LDS object of the kernel
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[IR_GPP_PF > 0 ? G::LDS_PF : G::LDS];  // the ONLY LDS object of the kernel
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wu = __builtin_amdgcn_readfirstlane(wid);
     const int grp = wu >> 2, wq = wu & 3;   // half (column group) and row quarter of this wave
@@ -1243,6 +1253,8 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(IGemmParams p) {
             dst[i] = G::B_BASE + q * 1024;
         }
     }
+    // L2 prefetch touch (IR_GPP_PF): lane l of A-issuing wave wq touches row 64 * wq + l (16 bytes of the k-tile's half line)
+    const bf16_t* pf_src = p.in + (long)min(m0 + wq * 64 + lane, p.M - 1) * p.in_cs;
     // prologue: A tiles 0..3 and B tiles 0..2 by all 8 waves (A piece q = wu + 8*i, i < 2; B piece q = wu + 8*i, i < 3, q < 18)
     auto issue_prologue = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -1327,11 +1339,13 @@ __global__ __launch_bounds__(512, 1) void gemm_pp_kernel(IGemmParams p) {
                 const int ko = (kt + 4) * G::BK;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) if (IR_GKO != 2 && IR_GKO != 5) glds16(src[i] + ko, (lds_ptr_t)(base + dst[i]));   // (5: no A pieces only)
+                if (IR_GPP_PF > 0) glds16(pf_src + min(kt + 4 + IR_GPP_PF, KT - 1) * G::BK, (lds_ptr_t)(smem + G::PF_OFF));   // part of the batch: BATCH pieces
             }
             if (IR_GKO != 3 || kt == 0) read_frags(sa, kt & 3);
             // A(kt+1) has landed; the batches of A(kt+2) .. A(kt+4) may be in flight (fewer at the end of the K loop)
             const int rem = KT - 2 - kt;
-            if (rem >= 3) wait_vm<12>(); else if (rem == 2) wait_vm<8>(); else if (rem == 1) wait_vm<4>(); else wait_dma();
+            constexpr int BATCH = IR_GPP_PF > 0 ? 5 : 4;
+            if (rem >= 3) wait_vm<3 * BATCH>(); else if (rem == 2) wait_vm<2 * BATCH>(); else if (rem == 1) wait_vm<BATCH>(); else wait_dma();
             sa = sa == G::NSA - 1 ? 0 : sa + 1;
             sa4 = sa4 == G::NSA - 1 ? 0 : sa4 + 1;
             __builtin_amdgcn_sched_barrier(0);
