@@ -30,6 +30,7 @@ IR_NO_POWER_TRACE=1 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES S
 python tools/pmc_sum.py $O/pmc_sq > $O/pmc_sq_summary.txt 2>&1
 rm -rf $O/pmc_sq
 echo "[7] sq counters done"
-python tools/bench_cldm.py > $O/bench_cldm.log 2>&1 || echo "cldm bench failed"
+python tools/bench_cldm.py --steps 20 --warmup 3 > $O/bench_cldm.log 2>&1 || echo "cldm bench failed"
+python tools/bench_cldm.py --steps 40 --warmup 5 --graph > $O/bench_cldm_graph.log 2>&1 || echo "cldm graph bench failed"
 echo "[8] cldm done"
 ls -la $O
