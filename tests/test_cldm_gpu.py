@@ -212,6 +212,12 @@ def test_log_images_pipeline_vs_oracle(small):
     cond = {"c_concat": [got["control"]], "c_crossattn": [ctxt.expand(B, -1, -1).contiguous()], "c_latent": [m.apply_condition_encoder(got["control"])]}
     staged = (m.decode_first_stage(m.sample_log(cond, zT=zT)) + 1) / 2
     check(staged, got["samples"], "staged vs fused", l2=1e-3, worst=2e-3)
+    # recorded as a hipGraph (capture on the first call, replay on the second, on other inputs in between): the same bits
+    g1 = m.log_images({"hint": lq}, zT=zT, c_crossattn=ctxt[0], graph=True)
+    m.log_images({"hint": det_input(83, (B, H, W, 3))}, zT=det_input(84, (B, 4, H // 8, W // 8), -2.0, 2.0), c_crossattn=ctxt[0], graph=True)
+    g2 = m.log_images({"hint": lq}, zT=zT, c_crossattn=ctxt[0], graph=True)
+    for k in ("control", "samples"):
+        assert torch.equal(g1[k], got[k]) and torch.equal(g2[k], got[k]), f"graph form differs in {k}"
 
 
 def test_full_width_unet_vs_oracle():
