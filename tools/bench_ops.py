@@ -164,6 +164,9 @@ if __name__ == "__main__":
         conv(1, 256, 256, 512, 512)
         conv(1, 2048, 2048, 64, 64)
         conv(1, 256, 256, 192, 192)
+    if "swinconv" in which:   # SwinIR's 180 (padded 192)-channel convs at the headline's and the ControlLDM path's token grids
+        conv(1, 256, 256, 192, 192)
+        conv(1, 64, 64, 192, 192)
     if "convnorm" in which:
         for shp in ((1, 2048, 2048, 128, 128), (1, 2048, 2048, 256, 128), (1, 1024, 1024, 256, 256), (1, 1024, 1024, 512, 512), (1, 512, 512, 512, 512)):
             conv(*shp)
