@@ -210,7 +210,7 @@ enum { PC_CONV3X3 = 0, PC_LINEAR, PC_FLASH_ATTN, PC_SWIN_ATTN, PC_GROUPNORM, PC_
 // each with the algorithmic FLOPs (un-padded dims) / bytes of its launches. Keep KERNEL_NAMES and KERNEL_CLASS in step.
 enum { PK_CONV_S1 = 0, PK_CONV_HALO_PP, PK_CONV_HALO, PK_CONV_S1_FP8, PK_CONV_FP8, PK_CONV_IGEMM, PK_GEMM_PP, PK_LINEAR_IGEMM, PK_SWIN_MLP, PK_ATTN_SELF, PK_ATTN_SELF_FP8, PK_ATTN_D512_FP8,
        PK_ATTN_D512, PK_ATTN_CROSS, PK_ATTN_OTHER, PK_SWIN_ATTN_PROJ, PK_SWIN_ATTN, PK_GN_APPLY, PK_GN_FULL, PK_LAYERNORM, PK_SOFTMAX, PK_TRANSPOSE, PK_OTHER, PK_VAE_CONV_IN, PK_VAE_CONV_OUT,
-       PK_SWIN_BLOCK, PK_COUNT };
+       PK_SWIN_BLOCK, PK_CONV_TO3, PK_CONV64, PK_COUNT };
 static const char* const KERNEL_NAMES[PK_COUNT] = {
     "conv3x3/conv_halo_s1_kernel", "conv3x3/conv_halo_pp_kernel", "conv3x3/conv_halo_kernel", "conv3x3/conv_halo_s1_fp8_kernel",
     "conv3x3/conv_halo_kernel<.., fp8>", "conv3x3/igemm_kernel<taps=9>",
@@ -221,10 +221,11 @@ static const char* const KERNEL_NAMES[PK_COUNT] = {
     "groupnorm/gn_finalize_groups+gn_apply (statistics from the conv epilogue)", "groupnorm/gn_partial+gn_finalize+gn_apply", "layernorm/layernorm_*_kernel",
     "softmax_rows/softmax_rows_kernel", "transpose/transpose_v*", "other/layout+glue",
     "conv3x3/vae_conv_in_kernel (3->128, store-bound)", "conv3x3/vae_norm_conv_out_kernel (GroupNorm+SiLU+128->3, read-bound)",
-    "linear/swin_block_kernel (window attention + proj + MLP + the next block's norm1 / qkv)"};
+    "linear/swin_block_kernel (window attention + proj + MLP + the next block's norm1 / qkv)",
+    "conv3x3/vae_norm_conv_out_kernel<1, false> (SwinIR conv_last 64->3, read-bound)", "conv3x3/conv64_kernel (SwinIR conv_hr 64->64 at full resolution)"};
 static const int KERNEL_CLASS[PK_COUNT] = {PC_CONV3X3, PC_CONV3X3, PC_CONV3X3, PC_CONV3X3, PC_CONV3X3, PC_CONV3X3, PC_LINEAR, PC_LINEAR, PC_LINEAR, PC_FLASH_ATTN, PC_FLASH_ATTN,
                                            PC_FLASH_ATTN, PC_FLASH_ATTN, PC_FLASH_ATTN, PC_FLASH_ATTN, PC_SWIN_ATTN, PC_SWIN_ATTN, PC_GROUPNORM, PC_GROUPNORM, PC_LAYERNORM,
-                                           PC_SOFTMAX, PC_TRANSPOSE, PC_OTHER, PC_CONV3X3, PC_CONV3X3, PC_LINEAR};
+                                           PC_SOFTMAX, PC_TRANSPOSE, PC_OTHER, PC_CONV3X3, PC_CONV3X3, PC_LINEAR, PC_CONV3X3, PC_CONV3X3};
 static const int CLASS_DEFAULT_KERNEL[PC_COUNT] = {PK_CONV_IGEMM, PK_LINEAR_IGEMM, PK_ATTN_OTHER, PK_SWIN_ATTN, PK_GN_FULL, PK_LAYERNORM, PK_SOFTMAX, PK_TRANSPOSE, PK_OTHER};
 struct ProfRec {
     int cls, kid;
@@ -448,7 +449,7 @@ void conv(Run& r, const Conv& cw, const bf16_t* in, int N, int H, int W, int in_
         r.vt_done = ir_igemm_writes_vt(p) != 0;
         if (!r.vt_done) p.vt_out = nullptr;
     }
-    static const int kid_of[5] = {PK_CONV_S1, PK_CONV_HALO_PP, PK_GEMM_PP, PK_CONV_HALO, -1};
+    static const int kid_of[6] = {PK_CONV_S1, PK_CONV_HALO_PP, PK_GEMM_PP, PK_CONV_HALO, -1, PK_CONV64};
     int kid = kid_of[ir_igemm_kernel_id(p)];
     if (kid < 0) kid = cw.taps == 9 ? PK_CONV_IGEMM : PK_LINEAR_IGEMM;
     const double cin_r = cw.cin_r ? cw.cin_r : cw.cin, cout_r = cw.cout_r ? cw.cout_r : cw.cout;
@@ -679,7 +680,13 @@ void swinir_run(Run& r, const float* in, float* out, int n, int h, int w) {
     conv(r, m.up3, u2, n, 4 * gh, 4 * gw, nf, u3, nf, 0, 1, 1, 1, ACT_LRELU, 0.2f, nullptr, 0, 0);
     conv(r, m.hr, u3, n, h, w, nf, u4, nf, 0, 1, 1, 0, ACT_LRELU, 0.2f, nullptr, 0, 0);
     // conv_last with x/img_range + mean folded into its weights (swinir.py:896,903)
-    conv(r, m.last, u4, n, h, w, nf, o4, 4, 1, 1, 1, 0, ACT_NONE, 0.f, nullptr, 0, 0);
+    static const bool no_to3 = getenv("IR_NO_SWIN_TO3") != nullptr;   // experiment knob: the generic implicit GEMM again
+    if (!r.c->plain && !no_to3 && nf == 64 && m.last.cin == 64 && m.last.cout_pad == 32 && m.last.taps == 9) {
+        const double px = (double)n * h * w;
+        LAUNCHK(r, PK_CONV_TO3, 2.0 * px * 3 * 9 * 64, px * (64 * 2 + 16), ir_launch_conv64_to3(u4, m.last.w, m.last.b, o4, n, h, w, r.s), "swin_conv_last");
+    } else {
+        conv(r, m.last, u4, n, h, w, nf, o4, 4, 1, 1, 1, 0, ACT_NONE, 0.f, nullptr, 0, 0);
+    }
     LAUNCH(r, PC_OTHER, 0.0, 0.0, ir_launch_nhwc_to_nchw(o4, 4, out, n, 3, (long)h * w, 1.f, 0.f, 0, r.s), "nhwc_to_nchw");
     r.a.release(mk);
 }

@@ -1788,6 +1788,7 @@ int ir_igemm_kernel_id(const IGemmParams& pin) {
     p.vec = igemm_vec(p);
     if (p.up2x2) return ir_conv_s1_up2x2_takes(p) ? 0 : 3;
     if (p.ks_ws && ir_igemm_splitk(p) > 1) return 4;
+    if (ir_conv64_takes(p)) return 5;
     if (ir_conv_s1_takes(p) || ir_conv_s1_fp8_takes(p)) return 0;
     if (takes_halo_pp(p)) return 1;
     if (takes_gemm_pp(p)) return 2;
@@ -1828,6 +1829,7 @@ int ir_launch_igemm(const IGemmParams& pin, hipStream_t s) {
         if (p.Cout_pad % 64 == 0) return launch_cfg<128, 64, 2, 2>(p, s);
         return launch_cfg<128, 32, 4, 1>(p, s);
     }
+    if (ir_conv64_takes(p)) return ir_launch_conv64(p, s);
     if (ir_conv_s1_takes(p)) return ir_launch_conv_s1(p, s);
     if (ir_conv_s1_fp8_takes(p)) return ir_launch_conv_s1_fp8(p, s);
     if (takes_halo_pp(p)) return launch_halo_pp(p, s);

@@ -80,6 +80,8 @@ int ir_igemm_splitk(const IGemmParams& p);
 
 // conv_s1.hip: the one-wave-per-SIMD 3x3 convolution (16 x 32 patches x 128 channels); ir_launch_igemm routes eligible launches to it
 bool ir_conv_s1_takes(const IGemmParams& p);
+bool ir_conv64_takes(const IGemmParams& p);   // vae_io.hip: 64 -> 64 at full resolution (SwinIR conv_hr)
+int ir_launch_conv64(const IGemmParams& p, hipStream_t s);
 // "nearest-2x upsample + 3 x 3 conv" as four 2 x 2 convs on the low-resolution tensor (conv_s1.hip); p.up2x2 = 1, p.wgt = the phase matrices
 bool ir_conv_s1_up2x2_takes(const IGemmParams& p);
 int ir_conv_s1_up2x2_tiles(const IGemmParams& p);
@@ -215,6 +217,7 @@ int ir_launch_vae_conv_in(const float* in, const bf16_t* wgt, const float* bias,
                           float in_shift, hipStream_t s);
 int ir_launch_vae_norm_conv_out(const bf16_t* x, const float* scale, const float* shift, const bf16_t* wgt, const float* bias, float* out, int N, int H,
                                 int W, hipStream_t s);
+int ir_launch_conv64_to3(const bf16_t* x, const bf16_t* wgt, const float* bias, float* out, int N, int H, int W, hipStream_t s);   // SwinIR conv_last (64 -> 3), same kernel family
 int ir_launch_fill_u32(uint32_t* p, long n, uint32_t v, hipStream_t s);
 int ir_launch_count_flag(const int* flag, int* counter, hipStream_t s);   // *counter += 1 if *flag != 0 (diagnostic: ir_attn_fallback_count)
 int ir_launch_tile_add(float* dst, const float* src, int N, int C, int H, int W, int th, int tw, int y0, int x0, hipStream_t s);

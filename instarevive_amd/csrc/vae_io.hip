@@ -156,25 +156,28 @@ namespace vco {
 constexpr int TH = 8, TW = 32, HWD = TW + 2, HP = (TH + 2) * HWD;   // 340 halo pixels
 constexpr int ROWB = 128;                                            // 64 channels of a half per halo pixel
 constexpr int HALO_BYTES = HP * ROWB;                                // 43 520
-constexpr int KS = 36;                                               // k-steps: 2 halves x 9 taps x 2 (32 channels each)
 constexpr int W_OFF = HALO_BYTES;                                    // weights [KS][4 rows: out channel 0, 1, 2, zeros][64 B]
-constexpr int LDS_BYTES = W_OFF + KS * 256;                          // 52 736: three workgroups per CU
 constexpr int NV = (HP * 8 + 255) / 256;                             // 11 16-byte vectors per thread and half
 }  // namespace vco
 
+// HALVES x 64 input channels, KS = HALVES x 9 taps x 2 k-steps of 32 channels. <2, true>: the VAE's norm_out + SiLU + conv_out (52 736 B of LDS: three
+// workgroups per CU). <1, false> (round 6): SwinIR's conv_last (swinir.py:896, 64 -> 3 at full resolution, no normalisation; `x / img_range + mean` is
+// folded into its weights and bias by weights.py) - the generic implicit GEMM spent 0.49 ms on the 0.5 GB it reads at 2048 x 2048.
+template <int HALVES, bool NORM>
 __global__ __launch_bounds__(256) void vae_norm_conv_out_kernel(const bf16_t* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
                                                                 const bf16_t* __restrict__ wgt, const float* __restrict__ bias, float* __restrict__ out,
                                                                 int N, int H, int W, int tiles_x, int tiles_per_img, int total_tiles) {
     using namespace vco;
+    constexpr int C = HALVES * 64, KS = HALVES * 18, LDS_BYTES = W_OFF + KS * 256;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int n16 = lane & 15, q = lane >> 4;
-    // ---- weights: wgt [32][9][128] bf16 (rows 0..2 real). k-step ks = (half * 9 + tap) * 2 + s covers channels half * 64 + s * 32 .. + 31.
+    // ---- weights: wgt [32][9][C] bf16 (rows 0..2 real). k-step ks = (half * 9 + tap) * 2 + s covers channels half * 64 + s * 32 .. + 31.
     for (int e = tid; e < KS * 16; e += 256) {   // 16-byte pieces: [ks][row 0..3][4 pieces]
         const int ks = e >> 4, row = (e >> 2) & 3, pc = e & 3;
         const int half = ks / 18, tap = (ks % 18) >> 1, s = ks & 1;
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (row < 3) v = *reinterpret_cast<const uint4*>(wgt + ((long)row * 9 + tap) * 128 + half * 64 + s * 32 + pc * 8);
+        if (row < 3) v = *reinterpret_cast<const uint4*>(wgt + ((long)row * 9 + tap) * C + half * 64 + s * 32 + pc * 8);
         *reinterpret_cast<uint4*>(smem + W_OFF + ks * 256 + row * 64 + pc * 16) = v;
     }
     const uint32_t lds0 = lds_addr(smem);
@@ -202,14 +205,14 @@ __global__ __launch_bounds__(256) void vae_norm_conv_out_kernel(const bf16_t* __
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i] = bsel;
 #pragma unroll 1
-        for (int half = 0; half < 2; ++half) {
+        for (int half = 0; half < HALVES; ++half) {
             // ---- the half's halo: load, GroupNorm scale / shift + SiLU, round to bf16, into LDS (zeros outside the image: the conv pads the
             // ACTIVATED tensor)
             float sc[8], sh[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                sc[e] = scale[(long)img * 128 + half * 64 + cv * 8 + e];
-                sh[e] = shift[(long)img * 128 + half * 64 + cv * 8 + e];
+                sc[e] = NORM ? scale[(long)img * C + half * 64 + cv * 8 + e] : 1.f;
+                sh[e] = NORM ? shift[(long)img * C + half * 64 + cv * 8 + e] : 0.f;
             }
             uint4 v[NV];
             bool ok[NV];
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(256) void vae_norm_conv_out_kernel(const bf16_t* __
                 const int y = oy0 + hy - 1, xx = ox0 + hx - 1;
                 ok[i] = hp < HP && y >= 0 && y < H && xx >= 0 && xx < W;
                 const long pix = ((long)img * H + min(max(y, 0), H - 1)) * W + min(max(xx, 0), W - 1);
-                v[i] = *reinterpret_cast<const uint4*>(x + pix * 128 + half * 64 + cv * 8);
+                v[i] = *reinterpret_cast<const uint4*>(x + pix * C + half * 64 + cv * 8);
             }
             __syncthreads();   // every wave has finished the MFMAs of the previous half / tile (and the weight fill, first time)
 #pragma unroll
@@ -231,9 +234,13 @@ __global__ __launch_bounds__(256) void vae_norm_conv_out_kernel(const bf16_t* __
                 uint32_t o4[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float a = silu(bflo(w4[e]) * sc[2 * e] + sh[2 * e]);
-                    const float b = silu(bfhi(w4[e]) * sc[2 * e + 1] + sh[2 * e + 1]);
-                    o4[e] = ok[i] ? pack2bf(a, b) : 0u;
+                    if constexpr (NORM) {
+                        const float a = silu(bflo(w4[e]) * sc[2 * e] + sh[2 * e]);
+                        const float b = silu(bfhi(w4[e]) * sc[2 * e + 1] + sh[2 * e + 1]);
+                        o4[e] = ok[i] ? pack2bf(a, b) : 0u;
+                    } else {
+                        o4[e] = ok[i] ? w4[e] : 0u;
+                    }
                 }
                 if (hp < HP) *reinterpret_cast<uint4*>(smem + hp * ROWB + ((cv ^ ((hx >> 1) & 7)) << 4)) = make_uint4(o4[0], o4[1], o4[2], o4[3]);
             }
@@ -272,6 +279,231 @@ int ir_launch_vae_norm_conv_out(const bf16_t* x, const float* scale, const float
     const long total = (long)N * per;
     if (total > 0x7fffffffL) return -12;
     const long grid = total < 768 * 8 ? total : 768 * 8;   // three workgroups per CU resident, eight rounds of them
-    hipLaunchKernelGGL(vae_norm_conv_out_kernel, dim3((unsigned)grid), dim3(256), 0, s, x, scale, shift, wgt, bias, out, N, H, W, tiles_x, per, (int)total);
+    hipLaunchKernelGGL((vae_norm_conv_out_kernel<2, true>), dim3((unsigned)grid), dim3(256), 0, s, x, scale, shift, wgt, bias, out, N, H, W, tiles_x, per, (int)total);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// 3 x 3 conv 64 -> 3 (output [pixel][4] fp32, like the VAE's): x [N][H][W][64] bf16, wgt [32][9][64] bf16 (rows 0..2 real), bias[3]
+int ir_launch_conv64_to3(const bf16_t* x, const bf16_t* wgt, const float* bias, float* out, int N, int H, int W, hipStream_t s) {
+    if (N <= 0 || H <= 0 || W <= 0 || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(out) & 15) || (reinterpret_cast<uintptr_t>(wgt) & 15)) return -2;
+    const int tiles_x = (W + vco::TW - 1) / vco::TW, per = ((H + vco::TH - 1) / vco::TH) * tiles_x;
+    const long total = (long)N * per;
+    if (total > 0x7fffffffL) return -12;
+    const long grid = total < 768 * 8 ? total : 768 * 8;
+    hipLaunchKernelGGL((vae_norm_conv_out_kernel<1, false>), dim3((unsigned)grid), dim3(256), 0, s, x, nullptr, nullptr, wgt, bias, out, N, H, W, tiles_x, per, (int)total);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+// ================================================================================================ 64 -> 64 at full resolution (SwinIR conv_hr)
+// SwinIR's conv_hr (swinir.py:895, 64 -> 64 + LeakyReLU at the OUTPUT resolution: 2048 x 2048 on the headline path) moves 0.54 GB in and 0.54 GB out
+// for 0.31 TFLOP, and as conv_halo_kernel<64> (8 x 16 patches, nine k-steps per workgroup, prologue and epilogue of 32 768 workgroups) it took
+// 0.56 ms inside the pipeline (0.67 alone). Here: vae_norm_conv_out_kernel's read side (8 x 32 patch, its 10 x 34 x 64-channel halo in LDS, each wave
+// two patch rows) with all 64 output channels (four 16-row weight tiles per k-step, the whole 72 KB weight image resident in LDS: one persistent
+// workgroup per CU) and vae_conv_in_kernel's store side (weight rows ordered so that a lane's accumulators of tiles 2j, 2j+1 are 8 consecutive
+// channels: 16-byte stores, 64 contiguous bytes per pixel and instruction). The halo travels through registers two tiles ahead.
+// 0.38 ms inside the pipeline, 0.45 alone (2.4 TB/s). Knock-outs (-DIR_C64_KO, alone): without MFMAs 0.23 ms, without stores 0.36, without the halo
+// loads / staging 0.34 - the parts add up instead of overlapping: per k-step a wave reads 8 KB of fragments for 16 MFMAs, so the four waves keep
+// the LDS pipe as busy as the matrix pipe (576 KB per tile at 128 B per clock = the 4 600 cycles of its 288 MFMAs) and one wave per SIMD has
+// nothing to hide the rest behind. What did NOT matter (each built and timed): pinning the fragment reads a k-step ahead, the halo two tiles
+// instead of one ahead, precomputed per-lane offsets, inline-asm loads with hand-counted waits (hipcc's own waits did sit in front of every
+// tile's loads). The next step would be the weights in registers (half the LDS traffic) - not built.
+#ifndef IR_C64_KO
+#define IR_C64_KO 0   // knock-out builds, timing only (results wrong by design; never set in the library): 1 no MFMAs, 2 no stores, 3 halo fetched once, 4 no LDS staging
+#endif
+typedef unsigned int c64_u32x4 __attribute__((ext_vector_type(4)));
+namespace c64 {
+using namespace vco;                                   // TH, TW, HWD, HP, ROWB, HALO_BYTES, NV
+constexpr int KS = 18;                                  // 9 taps x 2 k-steps of 32 channels
+constexpr int WT_OFF = HALO_BYTES;                      // weights [KS][4 tiles][16 rows][64 B], chunk-swizzled by the row
+constexpr int LDS_BYTES = WT_OFF + KS * 4096;           // 117 248
+}  // namespace c64
+
+__global__ __launch_bounds__(256) void conv64_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wgt, const float* __restrict__ bias,
+                                                      bf16_t* __restrict__ out, int N, int H, int W, int act, float slope, int tiles_x,
+                                                      int tiles_per_img, int total_tiles) {
+    using namespace c64;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[LDS_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int n16 = lane & 15, q = lane >> 4;
+    // ---- weights: wgt [64][9][64] bf16. LDS row (tile f, row m) holds output channel vci_channel(f, m); k-step ks = tap * 2 + s covers input channels
+    // 32 s .. 32 s + 31; the 16-byte chunk c of a row sits at slot c ^ ((m >> 2) & 3) (16 rows x 64 B: rows m and m + 4 would share banks)
+    for (int e = tid; e < KS * 64 * 4; e += 256) {
+        const int pc = e & 3, m = (e >> 2) & 15, f = (e >> 6) & 3, ks = e >> 8;
+        const int tap = ks >> 1, sh = ks & 1;
+        const uint4 v = *reinterpret_cast<const uint4*>(wgt + ((long)vci_channel(f, m) * 9 + tap) * 64 + sh * 32 + pc * 8);
+        *reinterpret_cast<uint4*>(smem + WT_OFF + ks * 4096 + f * 1024 + m * 64 + ((pc ^ ((m >> 2) & 3)) << 4)) = v;
+    }
+    const uint32_t lds0 = lds_addr(smem);
+    const uint32_t wrd = WT_OFF + n16 * 64 + ((q ^ ((n16 >> 2) & 3)) << 4);   // A fragment of tile f, k-step ks: + ks * 4096 + f * 1024
+    uint32_t prd[3][2][2];                                                     // B fragments: as vae_norm_conv_out_kernel
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int xf = 0; xf < 2; ++xf)
+#pragma unroll
+            for (int sh = 0; sh < 2; ++sh) {
+                const int hx = 16 * xf + kx + n16;
+                prd[kx][xf][sh] = hx * ROWB + (((4 * sh + q) ^ ((hx >> 1) & 7)) << 4);
+            }
+    const int cv = tid & 7;
+    // bias of this lane's 4 channels of tile f: channels vci_channel(f, 4 q .. 4 q + 3) = 32 (f >> 1) + 8 q + 4 (f & 1) + 0..3
+    f32x4_v bsel[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const int c0 = 32 * (f >> 1) + 8 * q + 4 * (f & 1);
+        bsel[f] = bias ? f32x4_v{bias[c0], bias[c0 + 1], bias[c0 + 2], bias[c0 + 3]} : f32x4_v{0.f, 0.f, 0.f, 0.f};
+    }
+    // the bias loads must have LANDED before the tile loop: hipcc's wait-count pass carries "a load into these registers is pending" around the
+    // loop and put an s_waitcnt vmcnt(0) in front of the first MFMA of every other tile - behind the halo loads just issued. An empty asm that
+    // reads them forces the wait here.
+#pragma unroll
+    for (int f = 0; f < 4; ++f) asm volatile("" ::"v"(bsel[f][0]), "v"(bsel[f][1]), "v"(bsel[f][2]), "v"(bsel[f][3]));
+    // per-thread constants of the halo staging (tile-independent): halo pixel hp_i = (tid >> 3) + 32 i -> its element offset from the halo's first
+    // pixel, its LDS address, whether it exists; an INTERIOR tile (the whole halo inside the image) then needs one add per load and no clamps
+    // (unsigned 32-bit BYTE offsets from a wave-uniform base: the loads take the `saddr + voffset` form, no per-lane 64-bit address arithmetic)
+    uint32_t soff[NV];
+    int ldst[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int hp = (tid >> 3) + 32 * i;
+        const int hy = hp / HWD, hx = hp - hy * HWD;
+        soff[i] = (uint32_t)((hy * W + hx) * 64 + cv * 8) * 2u;
+        ldst[i] = hp < HP ? hp * ROWB + ((cv ^ ((hx >> 1) & 7)) << 4) : -1;
+    }
+    // the halo travels through registers TWO tiles ahead (sets A and B, alternating)
+    c64_u32x4 vA[NV], vB[NV];
+    bool okA[NV], okB[NV];
+    auto fetch = [&](c64_u32x4 (&v)[NV], bool (&ok)[NV], int t) {
+        const int img = t / tiles_per_img, trem = t - img * tiles_per_img;
+        const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+        const int y0 = ty * TH - 1, x0 = tx * TW - 1;
+        if (y0 >= 0 && x0 >= 0 && y0 + TH + 2 <= H && x0 + TW + 2 <= W) {   // (uniform)
+            const unsigned char* base = reinterpret_cast<const unsigned char*>(x + (((long)img * H + y0) * W + x0) * 64);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                ok[i] = true;
+                v[i] = *reinterpret_cast<const c64_u32x4*>(base + (ldst[i] >= 0 ? soff[i] : soff[0]));
+            }
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int hp = (tid >> 3) + 32 * i;
+            const int hy = hp / HWD, hx = hp - hy * HWD;
+            const int y = y0 + hy, xx = x0 + hx;
+            ok[i] = hp < HP && y >= 0 && y < H && xx >= 0 && xx < W;
+            const long pix = ((long)img * H + min(max(y, 0), H - 1)) * W + min(max(xx, 0), W - 1);
+            v[i] = *reinterpret_cast<const c64_u32x4*>(x + pix * 64 + cv * 8);
+        }
+    };
+    auto stage = [&](c64_u32x4 (&v)[NV], bool (&ok)[NV]) {   // the fetched halo (registers) into LDS, zeros outside the image
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (ldst[i] >= 0) *reinterpret_cast<c64_u32x4*>(smem + ldst[i]) = ok[i] ? v[i] : c64_u32x4{0u, 0u, 0u, 0u};
+    };
+    int sto[4];   // element offset of this lane's pixel of fragment fr from the tile's first pixel
+#pragma unroll
+    for (int fr = 0; fr < 4; ++fr) sto[fr] = ((2 * wid + (fr >> 1)) * W + 16 * (fr & 1) + n16) * 64 + 8 * q;
+    const int G = gridDim.x;
+    int t = blockIdx.x;
+    if (t < total_tiles) fetch(vA, okA, t);
+    if (t + G < total_tiles) fetch(vB, okB, t + G);
+    __syncthreads();   // the weight fill
+    if (t < total_tiles) stage(vA, okA);
+    // Per tile: [barrier: halo visible] request the halo two tiles ahead into the register set just staged - 288 MFMAs - [barrier: every wave is done
+    // with the halo] the NEXT tile's halo (requested one tile ago) into LDS - this tile's stores (last: vmcnt counts loads and stores in issue order).
+    auto tile = [&](c64_u32x4 (&vcur)[NV], bool (&okcur)[NV], c64_u32x4 (&vnxt)[NV], bool (&oknxt)[NV], int tt) __attribute__((always_inline)) {
+        const int img = tt / tiles_per_img, trem = tt - img * tiles_per_img;
+        const int ty = trem / tiles_x, tx = trem - ty * tiles_x;
+        const int oy0 = ty * TH, ox0 = tx * TW;
+        __syncthreads();
+        if (tt + 2 * G < total_tiles && IR_C64_KO != 3) fetch(vcur, okcur, tt + 2 * G);   // (its previous content is in LDS)
+        f32x4_v acc[4][4];   // [weight tile f][pixel fragment fr = 2 * (row of the wave) + x half]
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int fr = 0; fr < 4; ++fr) acc[f][fr] = bsel[f];
+        // fragments double-buffered in registers, the order pinned (hipcc otherwise reads a k-step's eight fragments right in front of its MFMAs
+        // and waits for them - with one wave per SIMD the LDS latency was exposed 18 times per tile): first two MFMAs of step ks, then the reads of
+        // step ks + 1, then the other fourteen MFMAs
+        bf16x8 a[2][4], b[2][4];
+        auto load = [&](auto ksc, int set) __attribute__((always_inline)) {
+            constexpr int ks = decltype(ksc)::value, tap = ks >> 1, sh = ks & 1, ky = tap / 3, kx = tap - 3 * ky;
+#pragma unroll
+            for (int f = 0; f < 4; ++f) a[set][f] = *reinterpret_cast<const bf16x8*>(smem + wrd + ks * 4096 + f * 1024);
+#pragma unroll
+            for (int fr = 0; fr < 4; ++fr) {
+                const int r = 2 * wid + (fr >> 1), xf = fr & 1;
+                b[set][fr] = *reinterpret_cast<const bf16x8*>(smem + prd[kx][xf][sh] + (r + ky) * HWD * ROWB);
+            }
+        };
+        auto mfmas = [&](int set, int first, int last) __attribute__((always_inline)) {
+#pragma unroll
+            for (int e = first; e < last; ++e)
+                if (IR_C64_KO != 1 || e == first) acc[e >> 2][e & 3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[set][e >> 2], b[set][e & 3], acc[e >> 2][e & 3], 0, 0, 0);
+        };
+        load(std::integral_constant<int, 0>{}, 0);
+        [&]<int... KSI>(std::integer_sequence<int, KSI...>) {
+            ([&] {
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas(KSI & 1, 0, 2);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (KSI + 1 < KS) load(std::integral_constant<int, KSI + 1>{}, (KSI + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas(KSI & 1, 2, 16);
+            }(), ...);
+        }(std::make_integer_sequence<int, KS>{});
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        if (tt + G < total_tiles && IR_C64_KO != 4) stage(vnxt, oknxt);
+        // ---- store: per pixel fragment and tile pair j the lane's 8 consecutive channels 32 j + 8 q .. + 7
+#pragma unroll
+        for (int fr = 0; fr < 4; ++fr) {
+            const int y = oy0 + 2 * wid + (fr >> 1), xx = ox0 + 16 * (fr & 1) + n16;
+            if (y < H && xx < W && (IR_C64_KO != 2 || acc[0][fr][0] == 1234.5f)) {
+                bf16_t* dst = out + (((long)img * H + oy0) * W + ox0) * 64 + sto[fr];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    float o[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { o[e] = acc[2 * j][fr][e]; o[4 + e] = acc[2 * j + 1][fr][e]; }
+                    if (act == IR_ACT_LRELU) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = o[e] > 0.f ? o[e] : o[e] * slope;
+                    }
+                    *reinterpret_cast<uint4*>(dst + 32 * j) = make_uint4(pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7]));
+                }
+            }
+        }
+    };
+    for (; t < total_tiles; t += 2 * G) {
+        tile(vA, okA, vB, okB, t);
+        if (t + G < total_tiles) tile(vB, okB, vA, okA, t + G);
+    }
+}
+
+bool ir_conv64_takes(const IGemmParams& p) {
+    static const bool off = getenv("IR_NO_CONV64") != nullptr;   // experiment knob
+    if (off || g_ir_plain_kernels || p.fp8 || p.force_generic || p.up || p.up2x2 || p.gn_part || p.nrm_scale) return false;
+    if (p.taps != 9 || p.stride != 1 || p.pad != 1 || p.Cin != 64 || p.in_cs != 64 || p.Cout != 64 || p.Cout_pad != 64 || p.out_cs != 64) return false;
+    if (p.res || p.out_f32 || p.out2 || p.gate || p.out_scale != 1.f || p.wgt_rs != 9 * 64) return false;
+    if (p.act != IR_ACT_NONE && p.act != IR_ACT_LRELU) return false;
+    if ((reinterpret_cast<uintptr_t>(p.in) & 15) || (reinterpret_cast<uintptr_t>(p.out) & 15) || (reinterpret_cast<uintptr_t>(p.wgt) & 15)) return false;
+    return (long)p.Ho * p.Wo >= 256L * 256;   // per IMAGE: a tile (8 x 32 pixels) per CU at least; smaller maps stay on conv_halo_kernel
+}
+int ir_launch_conv64(const IGemmParams& p, hipStream_t s) {
+    if (!ir_conv64_takes(p)) return -2;
+    const int tiles_x = (p.Wo + vco::TW - 1) / vco::TW, per = ((p.Ho + vco::TH - 1) / vco::TH) * tiles_x;
+    const long total = (long)p.NB * per;
+    if (total > 0x7fffffffL) return -12;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+        cus = n;
+    }
+    const long grid = total < cus ? total : cus;   // persistent: one workgroup per CU (117 KB of LDS) fills its weight image once and walks its tiles
+    hipLaunchKernelGGL(conv64_kernel, dim3((unsigned)grid), dim3(256), 0, s, p.in, p.wgt, p.bias, reinterpret_cast<bf16_t*>(p.out), p.NB, p.Ho, p.Wo, p.act, p.slope,
+                       tiles_x, per, (int)total);
     return hipGetLastError() == hipSuccess ? 0 : -1;
 }

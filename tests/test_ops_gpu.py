@@ -159,6 +159,35 @@ def test_conv3x3(ctx, case):
     close(out.cpu().permute(0, 3, 1, 2), ref, 1e-4, 1e-3, f"conv {case}")
 
 
+@pytest.mark.parametrize("n,h,w,act", [(1, 256, 256, "lrelu"), (2, 260, 300, "lrelu"), (1, 264, 288, "none")])
+def test_conv64_full_resolution(ctx, n, h, w, act):
+    """conv64_kernel (vae_io.hip): SwinIR's conv_hr form - 3x3, 64 -> 64, bf16 NHWC in and out, bias + LeakyReLU(0.2) - on whole and ragged 8 x 32
+    tiles and two images, against F.conv2d on the same bf16 operands; and that the launcher really took it (plain-kernel mode runs conv_halo_kernel:
+    the two agree to bf16 rounding, not bit for bit - another summation order)."""
+    g = torch.Generator().manual_seed(h + w)
+    x = rb(torch.randn(n, 64, h, w, generator=g))
+    wt = rb(torch.randn(64, 64, 3, 3, generator=g) / math.sqrt(9 * 64))
+    b = torch.randn(64, generator=g)
+    ref = F.conv2d(x, wt, b, padding=1)
+    code = L.ACT_NONE
+    if act == "lrelu":
+        ref, code = F.leaky_relu(ref, 0.2), L.ACT_LRELU
+    xd = dev_bf16(x.permute(0, 2, 3, 1).contiguous())
+    wp = dev_bf16(pack_conv(wt, 64, 64))
+    outs = []
+    for plain in (0, 1):
+        ctx.check(ctx.lib.ir_set_plain_kernels(ctx.h, plain), "plain")
+        try:
+            out = torch.empty(n, h, w, 64, dtype=torch.int16, device="cuda")
+            ctx.check(ctx.lib.ir_op_conv(ctx.h, ctx.stream(), P(xd), P(wp), P(b.cuda()), P(out), n, h, w, 64, 64, 64, 9, 1, 1, 0, code, 0.2, None, 0, 0), "conv64")
+            torch.cuda.synchronize()
+        finally:
+            ctx.check(ctx.lib.ir_set_plain_kernels(ctx.h, 0), "plain off")
+        outs.append(L.from_bf16_bits(out).cpu().permute(0, 3, 1, 2))
+        close(outs[-1], ref, 2 ** -7, 2e-3, f"conv64 {n}x{h}x{w} {act} plain={plain}")
+    assert float((outs[0] - outs[1]).abs().max()) <= 2 ** -6 * float(ref.abs().max()), "conv64_kernel against conv_halo_kernel"
+
+
 @pytest.mark.parametrize("n,h,w,cin,cout,res,s1", [
     (1, 16, 16, 128, 128, False, False), (2, 24, 40, 256, 128, True, False), (1, 20, 28, 512, 64, False, False),   # conv_halo_kernel<.., FP8>
     (1, 128, 256, 128, 128, True, True),     # conv_halo_s1_fp8_kernel: one period of 9 MFMA steps, whole patches, residual
