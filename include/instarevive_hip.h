@@ -284,6 +284,13 @@ int ir_op_vae_conv_in(ir_ctx* ctx, void* stream, const float* in, const uint16_t
                       int w, float in_scale, float in_shift, int* tiles);
 int ir_op_vae_norm_conv_out(ir_ctx* ctx, void* stream, const uint16_t* x, const float* scale, const float* shift, const uint16_t* wgt, const float* bias,
                             float* out, int n, int h, int w);
+/* Per-kernel test entry of conv64_kernel (vae_io.hip): 3x3 stride-1 conv 64 -> 64 on bf16 NHWC, bias, act = IR_ACT_NONE or IR_ACT_LRELU(slope) - the shape
+ * of SwinIR's conv_hr (diffusion/model/swinir.py:895); h * w >= 65536. The pipeline takes this kernel only under IR_CONV64=1 (see vae_io.hip). */
+int ir_op_conv64(ir_ctx* ctx, void* stream, const uint16_t* in, const uint16_t* wgt, const float* bias, uint16_t* out, int n, int h, int w, int act,
+                 float slope);
+/* Per-kernel test entry of vae_norm_conv_out_kernel<1, false>: 3x3 stride-1 conv 64 -> 3 on bf16 NHWC, wgt [32][9][64] bf16 (rows 0..2 used), bias[3],
+ * out [pixel][4] fp32 - SwinIR's conv_last (diffusion/model/swinir.py:896), which ir_swinir_forward runs on it from 1024 x 1024 pixels up. */
+int ir_op_conv64_to3(ir_ctx* ctx, void* stream, const uint16_t* in, const uint16_t* wgt, const float* bias, float* out, int n, int h, int w);
 /* 3x3 stride-1 conv on fp8 operands: in8 [n][h][w][cin] e4m3, wgt8 [cout][9][cin] e4m3, out = (acc + bias_div[co]) * dequant[co] (+ res) in bf16 */
 int ir_op_conv_fp8(ir_ctx* ctx, void* stream, const uint8_t* in8, const uint8_t* wgt8, const float* dequant, const float* bias_div, uint16_t* out,
                    int n, int h, int w, int cin, int cout, const uint16_t* res);

@@ -21,7 +21,7 @@ SYMBOLS = [
     "ir_profile_kernel_name",
     "ir_op_conv", "ir_op_conv_splitk", "ir_op_conv_groupnorm", "ir_op_linear", "ir_op_groupnorm", "ir_op_layernorm", "ir_op_attention", "ir_op_swin_attention",
     "ir_op_softmax_rows", "ir_op_nchw_to_nhwc", "ir_op_nhwc_to_nchw",
-    "ir_tiled_count", "ir_tiled_encode", "ir_tiled_encode_part", "ir_tiled_encode_overflow", "ir_op_conv_up2x2", "ir_op_conv_norm", "ir_op_vae_conv_in", "ir_op_vae_norm_conv_out", "ir_tiled_dit", "ir_tiled_blend_latent", "ir_tiled_decode", "ir_tiled_blend_pixels", "ir_set_plain_kernels", "ir_set_fp8", "ir_set_fp8_mask", "ir_attn_fallback_count", "ir_op_conv_fp8", "ir_op_conv_fp8_up", "ir_op_conv_fp8_route", "ir_fp8_features", "ir_op_attention_fp8", "ir_op_attention_d512_fp8",
+    "ir_tiled_count", "ir_tiled_encode", "ir_tiled_encode_part", "ir_tiled_encode_overflow", "ir_op_conv_up2x2", "ir_op_conv_norm", "ir_op_vae_conv_in", "ir_op_vae_norm_conv_out", "ir_op_conv64", "ir_op_conv64_to3", "ir_tiled_dit", "ir_tiled_blend_latent", "ir_tiled_decode", "ir_tiled_blend_pixels", "ir_set_plain_kernels", "ir_set_fp8", "ir_set_fp8_mask", "ir_attn_fallback_count", "ir_op_conv_fp8", "ir_op_conv_fp8_up", "ir_op_conv_fp8_route", "ir_fp8_features", "ir_op_attention_fp8", "ir_op_attention_d512_fp8",
     "ir_unet_configure", "ir_unet_set_context", "ir_cldm_sample", "ir_cldm_pipeline", "ir_clip_text_configure", "ir_clip_text_encode", "ir_op_groupnorm_any", "ir_op_geglu",
 ]
 
@@ -108,6 +108,8 @@ def load_library():
     lib.ir_op_conv_norm.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, i, i, i, i, i]
     lib.ir_op_vae_conv_in.argtypes = [vp, vp, vp, vp, vp, vp, vp, i, i, i, f, f, vp]
     lib.ir_op_vae_norm_conv_out.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i, i, i]
+    lib.ir_op_conv64.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i, i, f]
+    lib.ir_op_conv64_to3.argtypes = [vp, vp, vp, vp, vp, vp, i, i, i]
     lib.ir_tiled_dit.argtypes = [vp, vp, vp, vp, i, i, i, i, i, i, i, f, f, i, vp, sz]
     lib.ir_tiled_blend_latent.argtypes = [vp, vp, vp, vp, i, i, i, i, i]
     lib.ir_tiled_decode.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, i, i, f, vp, sz]

@@ -81,7 +81,7 @@ int ir_igemm_splitk(const IGemmParams& p);
 // conv_s1.hip: the one-wave-per-SIMD 3x3 convolution (16 x 32 patches x 128 channels); ir_launch_igemm routes eligible launches to it
 bool ir_conv_s1_takes(const IGemmParams& p);
 bool ir_conv64_takes(const IGemmParams& p);   // vae_io.hip: 64 -> 64 at full resolution (SwinIR conv_hr)
-int ir_launch_conv64(const IGemmParams& p, hipStream_t s);
+int ir_launch_conv64(const IGemmParams& p, hipStream_t s, bool force = false);   // force: take the shape whatever IR_CONV64 says (ir_op_conv64)
 // "nearest-2x upsample + 3 x 3 conv" as four 2 x 2 convs on the low-resolution tensor (conv_s1.hip); p.up2x2 = 1, p.wgt = the phase matrices
 bool ir_conv_s1_up2x2_takes(const IGemmParams& p);
 int ir_conv_s1_up2x2_tiles(const IGemmParams& p);

@@ -482,17 +482,24 @@ __global__ __launch_bounds__(256) void conv64_kernel(const bf16_t* __restrict__ 
     }
 }
 
+// Opt-in (IR_CONV64=1): on the stress fixture at 2048 x 2048 the bf16 path's PSNR against the oracle moves by +- 0.7 dB with the summation ORDER of
+// this one conv (four combinations of this kernel and conv_last's: 44.30 / 44.46 / 45.10 / 45.71 dB, profiles/r06_stress_sensitivity.txt) and this
+// kernel's order lands at the low end; for 0.18 ms per image the default keeps conv_halo_kernel. ir_launch_conv64(p, s, true) (the op test) skips the switch.
+static bool conv64_shape(const IGemmParams& p);
 bool ir_conv64_takes(const IGemmParams& p) {
-    static const bool off = getenv("IR_NO_CONV64") != nullptr;   // experiment knob
-    if (off || g_ir_plain_kernels || p.fp8 || p.force_generic || p.up || p.up2x2 || p.gn_part || p.nrm_scale) return false;
+    static const bool on = getenv("IR_CONV64") != nullptr;
+    return on && conv64_shape(p);
+}
+static bool conv64_shape(const IGemmParams& p) {
+    if (g_ir_plain_kernels || p.fp8 || p.force_generic || p.up || p.up2x2 || p.gn_part || p.nrm_scale) return false;
     if (p.taps != 9 || p.stride != 1 || p.pad != 1 || p.Cin != 64 || p.in_cs != 64 || p.Cout != 64 || p.Cout_pad != 64 || p.out_cs != 64) return false;
     if (p.res || p.out_f32 || p.out2 || p.gate || p.out_scale != 1.f || p.wgt_rs != 9 * 64) return false;
     if (p.act != IR_ACT_NONE && p.act != IR_ACT_LRELU) return false;
     if ((reinterpret_cast<uintptr_t>(p.in) & 15) || (reinterpret_cast<uintptr_t>(p.out) & 15) || (reinterpret_cast<uintptr_t>(p.wgt) & 15)) return false;
     return (long)p.Ho * p.Wo >= 256L * 256;   // per IMAGE: a tile (8 x 32 pixels) per CU at least; smaller maps stay on conv_halo_kernel
 }
-int ir_launch_conv64(const IGemmParams& p, hipStream_t s) {
-    if (!ir_conv64_takes(p)) return -2;
+int ir_launch_conv64(const IGemmParams& p, hipStream_t s, bool force) {
+    if (!(force ? conv64_shape(p) : ir_conv64_takes(p))) return -2;
     const int tiles_x = (p.Wo + vco::TW - 1) / vco::TW, per = ((p.Ho + vco::TH - 1) / vco::TH) * tiles_x;
     const long total = (long)p.NB * per;
     if (total > 0x7fffffffL) return -12;
